@@ -1,0 +1,237 @@
+/*
+ * wdgan.h — C-ABI of libwdgan.so: the MI355X (gfx950) native operator library beneath the
+ * `downscaling` generator / discriminator / GAN train step.
+ *
+ * The reference (OpheliaMiralles/wind-downscaling-gan) has no FFI: its hot path sits behind the
+ * Keras layer API and bottoms out in TensorFlow 2.4.3 kernels.  Every entry point below therefore
+ * replaces a *Keras layer call site* of the reference; the citation after each declaration names
+ * the call sites (file:line under /root/reference/src/downscaling) whose arithmetic it performs.
+ *
+ * Conventions
+ *   - all tensors fp32, channels-last; an activation is addressed as
+ *         base + img * img_stride + (h * W + w) * ld + c        (elements, not bytes)
+ *     so channel-concatenations are zero-copy views (ld > C) of one wider buffer;
+ *   - every activation view handed to a conv entry point has ld % 4 == 0, a 16-byte aligned base,
+ *     and zero-filled pad channels up to the next multiple of 4;
+ *   - raw device pointers + sizes, caller-owned buffers, no torch types, no hidden allocation on
+ *     the launch path (plans allocate their small index tables at creation time);
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - return value: 0 on success, a negative wdg_status otherwise.  Nothing falls back to the CPU.
+ */
+#ifndef WDGAN_H
+#define WDGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wdg_stream;
+
+enum wdg_status {
+    WDG_OK = 0,
+    WDG_ERR_ARG = -1,      /* bad geometry / alignment / null pointer */
+    WDG_ERR_WORKSPACE = -2,/* workspace too small: call wdg_conv_ws_bytes */
+    WDG_ERR_HIP = -3       /* a HIP runtime call failed: see wdg_last_error */
+};
+
+/* Human-readable text of the last failure on the calling thread. */
+const char* wdg_last_error(void);
+/* Library version / target string, e.g. "wdgan 0.1 gfx950". */
+const char* wdg_version(void);
+/* Number of compute units of the current device (used by the host-side split-K heuristic). */
+int wdg_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family (implicit GEMM on v_mfma_f32_16x16x4_f32, exact fp32).
+ *
+ * One geometry describes the Keras Conv2D   y = conv(x, w; stride, pad)          [models.py:33,39,
+ * 49,70,95,103,114,123,134; tf_utils.py:20,29] with x:(n_img,H,W,Cin), y:(n_img,Ho,Wo,Cout),
+ * master weights HWIO [kh][kw][Cin][Cout] (the TF checkpoint layout).  The same three kernels
+ * serve Conv2DTranspose [models.py:55,64] whose TF kernel (kh,kw,out,in) is the HWIO kernel of the
+ * conv it is the adjoint of:  convT forward = wdg_conv_dgrad (+bias/activation epilogue),
+ * convT input-gradient = wdg_conv_fwd, convT weight-gradient = wdg_conv_wgrad with x/dy swapped.
+ * ConvLSTM2D input and recurrent convolutions [models.py:45,93,101] are plain 3x3 same convs.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_img;               /* B*T (TimeDistributed flattens the time axis) */
+    int32_t H, W, Cin;           /* conv-input spatial size and logical channel count */
+    int32_t ldx;                 /* pixel stride of the conv-input view (elements, %4==0) */
+    int64_t img_stride_x;        /* image stride of the conv-input view (elements) */
+    int32_t Ho, Wo, Cout;        /* conv-output spatial size and logical channel count */
+    int32_t ldy;                 /* pixel stride of the conv-output view */
+    int64_t img_stride_y;        /* image stride of the conv-output view */
+    int32_t kh, kw, stride;      /* kernel size and stride (same in both directions) */
+    int32_t pad_h, pad_w;        /* symmetric zero padding (ZeroPadding2D / 'same') */
+} wdg_conv_geom;
+
+typedef struct wdg_conv_plan wdg_conv_plan;
+
+/* Builds the device-side index tables (tap/channel offsets, dgrad phases). Not on the launch path. */
+int wdg_conv_plan_create(wdg_conv_plan** plan, const wdg_conv_geom* geom);
+int wdg_conv_plan_destroy(wdg_conv_plan* plan);
+/* Bytes of split-K scratch the plan may use (max over fwd/dgrad/wgrad). */
+size_t wdg_conv_ws_bytes(const wdg_conv_plan* plan);
+
+/* y = act(conv(x, wF) + bias) [+ y if accumulate].
+ *   wF: forward-packed weights [Cout][kh*kw][roundup4(Cin)] (see wdg_weight_pack).
+ *   bias may be NULL; act: 0 linear, 1 LeakyReLU(slope).                     models.py:33,39,49,70,95,103,114 */
+int wdg_conv_fwd(const wdg_conv_plan* plan, const float* x, const float* wF, const float* bias,
+                 float* y, int act, float slope, int accumulate,
+                 void* ws, size_t ws_bytes, wdg_stream stream);
+
+/* dx = act(conv_transpose(dy, wD) + bias) [+ dx if accumulate]   (gradient w.r.t. the conv input;
+ * also the *forward* of Conv2DTranspose, where bias/act are used).
+ *   wD: data-gradient-packed weights [kh*kw][Cin][roundup4(Cout)] (== master when Cout%4==0).
+ *                                                                            models.py:55,64; ganbase.py:35,60 */
+int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, const float* bias,
+                   float* dx, int act, float slope, int accumulate,
+                   void* ws, size_t ws_bytes, wdg_stream stream);
+
+/* dw[kh][kw][Cin][Cout] (+)= sum_pixels x (*) dy  — HWIO, the master layout.   ganbase.py:46,60 */
+int wdg_conv_wgrad(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw,
+                   int accumulate, void* ws, size_t ws_bytes, wdg_stream stream);
+
+/* Repack master HWIO weights into the two kernel layouts.
+ * wD may be NULL when Cout%4==0 (the master is then used directly as wD). */
+int wdg_weight_pack(const float* w_hwio, float* wF, float* wD, int taps, int Cin, int Cout,
+                    wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tfa.layers.SpectralNormalization — one power iteration, in place.          models.py:33,39,49,55,
+ * W = reshape(w, [rows, cols]) (cols = last kernel axis);                    95,103,114,123,134
+ *   v = l2n(u W^T); u' = l2n(v W); sigma = v W u'^T; w <- w / sigma; u <- u'
+ * scratch: >= wdg_sn_scratch_floats(rows, cols) floats.  All reductions run in a fixed order so
+ * that replicated weights stay bit-identical across data-parallel ranks.
+ * ------------------------------------------------------------------------------------------ */
+size_t wdg_sn_scratch_floats(int rows, int cols);
+int wdg_sn_power_iter(float* w, float* u, int rows, int cols, float* scratch, wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNormalization (axis -1, eps 1e-3, momentum 0.99) over P = B*T*H*W pixels.   models.py:34,40,50,56,69
+ * Statistics are accumulated in fp64 so the SyncBN all-reduce can be inserted between
+ * wdg_bn_stats and wdg_bn_finalize by the host.
+ * ------------------------------------------------------------------------------------------ */
+/* stats[0:C] += sum_p x, stats[C:2C] += sum_p x^2   (fp64; caller zeroes `stats` first) */
+int wdg_bn_stats(const float* x, int64_t P, int C, int ldx, double* stats, wdg_stream stream);
+/* training: mean/var from stats over `count` pixels -> scale/shift, saved mean/invstd, moving
+ * stats update (moving = momentum*moving + (1-momentum)*batch).  scale_shift: [2*C]; saved: [2*C]. */
+int wdg_bn_finalize_train(const double* stats, double count, const float* gamma, const float* beta,
+                          float* moving_mean, float* moving_var, float momentum, float eps,
+                          float* scale_shift, float* saved_mean_invstd, int C, wdg_stream stream);
+/* inference: scale/shift from the moving statistics. */
+int wdg_bn_finalize_infer(const float* gamma, const float* beta, const float* moving_mean,
+                          const float* moving_var, float eps, float* scale_shift, int C,
+                          wdg_stream stream);
+/* z = x*scale + shift */
+int wdg_bn_apply(const float* x, int ldx, const float* scale_shift, float* z, int ldz,
+                 int64_t P, int C, wdg_stream stream);
+/* backward, pass 1: red[0:C] += sum dz, red[C:2C] += sum dz*xhat  (fp64, caller zeroes) */
+int wdg_bn_bwd_reduce(const float* dz, int lddz, const float* y, int ldy,
+                      const float* saved_mean_invstd, int64_t P, int C, double* red,
+                      wdg_stream stream);
+/* backward, pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) with the means taken
+ * from red_mean/count (the SyncBN-all-reduced sums); dgamma += red_param[C:2C], dbeta +=
+ * red_param[0:C] (this rank's own sums, so the later gradient all-reduce does not double count;
+ * NULL skips them); if act_slope >= 0 the LeakyReLU derivative (sign of y) is fused:
+ * dpre = dy * (y > 0 ? 1 : slope) and dbias += colsum(dpre).  dpre may alias dz. */
+int wdg_bn_bwd_apply(const float* dz, int lddz, const float* y, int ldy,
+                     const float* saved_mean_invstd, const float* gamma, const double* red_mean,
+                     const double* red_param, double count, float act_slope, float* dpre,
+                     int lddpre, float* dgamma, float* dbeta, float* dbias, int64_t P, int C,
+                     wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNormalization (axis -1 only, eps 1e-3) per pixel.            models.py:97,105,116,125,136
+ * ------------------------------------------------------------------------------------------ */
+int wdg_ln_fwd(const float* y, int ldy, const float* gamma, const float* beta, float eps,
+               float* z, int ldz, float* mean_rstd /* [P][2] or NULL */, int64_t P, int C,
+               wdg_stream stream);
+/* dpre = LN-backward(dz) * lrelu'(y) (act_slope < 0: no activation); dgamma/dbeta/dbias
+ * accumulate (+=).  */
+int wdg_ln_bwd(const float* dz, int lddz, const float* y, int ldy, const float* mean_rstd,
+               const float* gamma, float act_slope, float* dpre, int lddpre,
+               float* dgamma, float* dbeta, float* dbias, int64_t P, int C, wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ConvLSTM2D cell pointwise part, Keras gate order i,f,c,o, hard_sigmoid = clip(0.2x+0.5,0,1).
+ * gates: [P][4F] pre-activations (x-conv + bias + h-conv).                   models.py:45,93,101
+ * c_prev may be NULL (t = 0: c_0 = 0).
+ * ------------------------------------------------------------------------------------------ */
+int wdg_lstm_fwd(const float* gates, int ldg, const float* c_prev, int ldcp, float* c, int ldc,
+                 float* h, int ldh, int64_t P, int F, wdg_stream stream);
+/* Given dh (total gradient w.r.t. h_t) and dc_in (gradient flowing into c_t from t+1, may be
+ * NULL), produce dgates [P][4F] and dc_prev (gradient w.r.t. c_{t-1}; may be NULL at t = 0). */
+int wdg_lstm_bwd(const float* gates, int ldg, const float* c_prev, int ldcp, const float* c,
+                 int ldc, const float* dh, int lddh, const float* dc_in, int lddci,
+                 float* dgates, int lddg, float* dc_prev, int lddcp, int64_t P, int F,
+                 wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * UpSampling2D(2, 'bilinear'): half-pixel centres, edge clamp.                     models.py:62
+ * ------------------------------------------------------------------------------------------ */
+int wdg_upsample2x_fwd(const float* x, int ldx, int64_t img_stride_x, float* y, int ldy,
+                       int64_t img_stride_y, int n_img, int H, int W, int C, wdg_stream stream);
+int wdg_upsample2x_bwd(const float* dy, int lddy, int64_t img_stride_dy, float* dx, int lddx,
+                       int64_t img_stride_dx, int n_img, int H, int W, int C, int accumulate,
+                       wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flatten + Dense(1) per timestep + GlobalAveragePooling1D over T.             models.py:137-140
+ * x: [T*B][K] rows, time-major (row = t*B + b, ld = K), w: [K], b: [1], score: [B].
+ * ------------------------------------------------------------------------------------------ */
+int wdg_dense_gap_fwd(const float* x, const float* w, const float* b, float* score, int B, int T,
+                      int K, wdg_stream stream);
+/* dscore: [B]; dx[(t,b)][k] = dscore[b]/T * w[k]; dw += sum x*dscore/T; db += sum dscore.
+ * dw/db may be NULL (input-gradient-only pass, ganbase.py:35,60). */
+int wdg_dense_gap_bwd(const float* x, const float* w, const float* dscore, float* dx, float* dw,
+                      float* db, int B, int T, int K, wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / reductions used by GAN.train_step.
+ * ------------------------------------------------------------------------------------------ */
+/* dst[img][q][c] (+)= src[img][q][c], c < C, q < pixels_per_img  (channel pack/unpack and
+ * batch<->time-major permutation between strided views; any alignment) */
+int wdg_copy_channels(const float* src, int lds, int64_t img_stride_src, float* dst, int ldd,
+                      int64_t img_stride_dst, int n_img, int64_t pixels_per_img, int C,
+                      int accumulate, wdg_stream stream);
+/* out[c] (+)= sum_p x[p][c]                                      (bias gradients) */
+int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out, int accumulate,
+               wdg_stream stream);
+/* Internal activations are TIME-MAJOR: image index = t*B + b (ConvLSTM steps then touch
+ * contiguous slabs).  out = eps[b]*a + (1-eps[b])*b_, b = (p / pixels_per_img) % B   ganbase.py:30-31 */
+int wdg_lerp_batch(const float* a, int lda, const float* b_, int ldb, const float* eps,
+                   float* out, int ldo, int64_t P, int64_t pixels_per_img, int B, int C,
+                   wdg_stream stream);
+/* out[b][c] = sum over t and the pixels of batch element b of x^2          ganbase.py:36 */
+int wdg_sumsq_batch_ch(const float* x, int ldx, int64_t pixels_per_img, int T, int B, int C,
+                       float* out, wdg_stream stream);
+/* out[i] = mean(x[off[i]:off[i+1]]^2)     (g_gradient_param / d_gradient_param, ganbase.py:80-81) */
+int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out,
+                       wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FlexibleNoiseGenerator: N(0, std^2) from Philox4x32-10 + Box-Muller.   data_generator.py:319-335
+ * Element e of the (dense, row-major) logical tensor [P][C] uses counter (offset + e/4), lane e%4.
+ * out[p*ldo + c] = (add ? add[p*lda + c] : 0) + std * z       (instance noise: ganbase.py:40,42)
+ * ------------------------------------------------------------------------------------------ */
+int wdg_philox_normal(float* out, int ldo, const float* add, int lda, int64_t P, int C,
+                      uint64_t seed, uint64_t offset, float std, wdg_stream stream);
+/* U[0,1) for the interpolation coefficients eps (ganbase.py:30). */
+int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * tf.keras.optimizers.Adam update, TF form (epsilon outside the bias correction):   train.py:34-35,57-58
+ *   m += (1-b1)(g-m); v += (1-b2)(g^2-v); p -= lr_t * m / (sqrt(v) + eps),
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host.  g is pre-scaled by grad_scale
+ *   (1/world_size after an RCCL sum all-reduce).
+ * ------------------------------------------------------------------------------------------ */
+int wdg_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                float beta2, float eps, float grad_scale, wdg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDGAN_H */

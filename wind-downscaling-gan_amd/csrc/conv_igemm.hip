@@ -1,0 +1,789 @@
+// conv_igemm.hip — im2col-free implicit-GEMM convolution on v_mfma_f32_16x16x4_f32 (gfx950).
+//
+// One kernel template serves the forward convolution and (phase-decomposed) data gradient /
+// transposed convolution; a second one serves the weight gradient.  Replaces the TF conv kernels
+// behind every kl.Conv2D / kl.Conv2DTranspose / kl.ConvLSTM2D call of
+// /root/reference/src/downscaling/gan/models.py:33-140.
+//
+// GEMM view:   Out[m][n] = sum_k A[m][k] * B[n][k]
+//   m : output pixel of one phase (img, pa, pb)           -> rows
+//   n : output channel                                    -> cols
+//   k : (tap, input-channel) flattened in groups of 4 channels ("k4 groups"); a per-plan device
+//       table gives, for every k4 group, the A element offset relative to the pixel base, the tap
+//       displacement (for the zero-padding test) and the B element offset.
+//
+// LDS tile layout: [kg][row] float4 slots, slot = kg*ROWS + (row ^ kg)  (kg = 0..7).
+//   * a lane's float4 holds 4 consecutive k of one row, so one ds_read_b128 feeds 4 MFMAs;
+//   * staging writes (8 consecutive lanes = 8 kg of one row = 128 contiguous global bytes) and
+//     fragment reads (16 rows x 4 kg per wave instruction) are both bank-conflict free under the
+//     XOR (guide: cdna_hip_programming.md section 2 / T2).
+// MFMA operand map (16x16x4 f32): lane l supplies A[row l&15][k l>>4], B[k l>>4][col l&15];
+// accumulator reg r of lane l is C[row (l>>4)*4 + r][col l&15].
+#include "common.h"
+#include <vector>
+#include <algorithm>
+
+struct WdgPhase {
+    int Pa, Pb;            // output sub-grid of this phase (rows, cols per image)
+    int a_off_h, a_off_w;  // A coord = pa * a_mul + a_off + tap displacement
+    int o_off_h, o_off_w;  // Out coord = pa * o_mul + o_off
+    int K4;                // k4 groups (padded to a multiple of 8 with invalid entries)
+    int tab_off;           // first table entry of this phase
+};
+
+struct WdgIgemm {
+    const float* A;
+    const float* B;
+    float* Out;
+    const float* bias;
+    const int4* ktab;  // {a_off, dh, dw, b_off}; b_off < 0 marks a padding entry
+    float* partial;    // split-K slabs [phase][split][Mmax][Ncols]
+    long long imgStrideA, imgStrideO;
+    int n_img, H, W, ldA;  // A tensor
+    int Ho, Wo, ldO;       // Out tensor
+    int Ncols, ldB;
+    int a_mul, o_mul;
+    int act, accumulate;
+    float slope;
+    int splitk, k4_per_split;
+    int Mmax, nphase;
+    WdgPhase ph[9];
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
+    constexpr int MT = BM / WGM / 16;
+    constexpr int NT = BN / WGN / 16;
+    constexpr int A_LOADS = BM / 32;
+    constexpr int B_LOADS = (BN + 31) / 32;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(MT >= 1 && NT >= 1, "tile");
+
+    __shared__ f32x4 ldsA[8 * BM];
+    __shared__ f32x4 ldsB[8 * BN];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int kg = t & 7;
+    const int lrow = t >> 3;  // 0..31
+
+    const WdgPhase ph = p.ph[blockIdx.z];
+    const int tiles_m = (p.Mmax + BM - 1) / BM;
+    const int tm = blockIdx.x % tiles_m;
+    const int tn = blockIdx.x / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int PaPb = ph.Pa * ph.Pb;
+    const int Mph = p.n_img * PaPb;
+    if (m0 >= Mph) return;
+
+    const int k4_begin = blockIdx.y * p.k4_per_split;
+    int k4_end = k4_begin + p.k4_per_split;
+    if (k4_end > ph.K4) k4_end = ph.K4;
+    const int nk = k4_end > k4_begin ? (k4_end - k4_begin) >> 3 : 0;
+
+    // ---- per-thread A row state
+    long long a_base[A_LOADS];
+    int a_ih0[A_LOADS], a_iw0[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < Mph) {
+            const int img = m / PaPb;
+            const int rem = m - img * PaPb;
+            const int pa = rem / ph.Pb;
+            const int pb = rem - pa * ph.Pb;
+            const int ih0 = pa * p.a_mul + ph.a_off_h;
+            const int iw0 = pb * p.a_mul + ph.a_off_w;
+            a_ih0[i] = ih0;
+            a_iw0[i] = iw0;
+            a_base[i] = (long long)img * p.imgStrideA + ((long long)ih0 * p.W + iw0) * p.ldA;
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
+        }
+    }
+    // ---- per-thread B row state
+    long long b_base[B_LOADS];
+    bool b_ok[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int nl = lrow + 32 * i;
+        const int n = n0 + nl;
+        b_ok[i] = (nl < BN) && (n < p.Ncols);
+        b_base[i] = (long long)n * p.ldB;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    const int4* tab = p.ktab + ph.tab_off + k4_begin + kg;
+
+    auto load_tile = [&](int kt) {
+        const int4 e = tab[kt * 8];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int ih = a_ih0[i] + e.y, iw = a_iw0[i] + e.z;
+            const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (e.w >= 0);
+            ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + e.x)
+                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const bool ok = b_ok[i] && (e.w >= 0);
+            rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.B + b_base[i] + e.w)
+                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage registers -> LDS
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int row = lrow + 32 * i;
+            ldsA[kg * BM + (row ^ kg)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int row = lrow + 32 * i;
+            if (row < BN) ldsB[kg * BN + (row ^ kg)] = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);  // in flight under the MFMAs below
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kgr = 4 * h + (lane >> 4);
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                af[a] = ldsA[kgr * BM + ((wm * (BM / WGM) + a * 16 + (lane & 15)) ^ kgr)];
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                bf[b] = ldsB[kgr * BN + ((wn * (BN / WGN) + b * 16 + (lane & 15)) ^ kgr)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const int col = lane & 15;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * (BM / WGM) + a * 16 + (lane >> 4) * 4 + r;
+            if (m >= Mph) continue;
+            if (p.splitk > 1) {
+                float* dst = p.partial +
+                             (((long long)blockIdx.z * p.splitk + blockIdx.y) * p.Mmax + m) * p.Ncols;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
+                    if (n < p.Ncols) dst[n] = acc[a][b][r];
+                }
+            } else {
+                const int img = m / PaPb;
+                const int rem = m - img * PaPb;
+                const int pa = rem / ph.Pb;
+                const int pb = rem - pa * ph.Pb;
+                const int oh = pa * p.o_mul + ph.o_off_h;
+                const int ow = pb * p.o_mul + ph.o_off_w;
+                float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
+                    if (n < p.Ncols) {
+                        float v = acc[a][b][r];
+                        if (p.bias) v += p.bias[n];
+                        if (p.act) v = wdg_lrelu(v, p.slope);
+                        if (p.accumulate) v += dst[n];
+                        dst[n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K second stage: sum the slabs, apply the epilogue, scatter to the output view.
+__global__ void __launch_bounds__(256) wdg_igemm_reduce_kernel(const WdgIgemm p) {
+    const WdgPhase ph = p.ph[blockIdx.z];
+    const int PaPb = ph.Pa * ph.Pb;
+    const int Mph = p.n_img * PaPb;
+    const long long total = (long long)Mph * p.Ncols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx / p.Ncols);
+        const int n = (int)(idx - (long long)m * p.Ncols);
+        const float* src = p.partial + (((long long)blockIdx.z * p.splitk) * p.Mmax + m) * p.Ncols + n;
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; ++s) v += src[(long long)s * p.Mmax * p.Ncols];
+        const int img = m / PaPb;
+        const int rem = m - img * PaPb;
+        const int pa = rem / ph.Pb;
+        const int pb = rem - pa * ph.Pb;
+        const int oh = pa * p.o_mul + ph.o_off_h;
+        const int ow = pb * p.o_mul + ph.o_off_w;
+        float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO + n;
+        if (p.bias) v += p.bias[n];
+        if (p.act) v = wdg_lrelu(v, p.slope);
+        if (p.accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[(tap,ci)][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co].
+// Rows are the k4 groups of the forward table (4 channels each); the reduction runs over output
+// pixels, 32 per step.  LDS tiles are pixel-major ([pixel][row], row stride = ROWS + 16 floats so
+// the two 16-lane halves of a ds_read_b32 hit disjoint banks).
+// ------------------------------------------------------------------------------------------
+struct WdgWgrad {
+    const float* X;
+    const float* DY;
+    float* dW;
+    float* partial;     // [split][rows][Cout]
+    const int4* ktab;   // forward table (a_off, dh, dw, valid>=0)
+    const int2* wrow;   // per k4 group: {dW element offset of its first row, valid rows (0..4)}
+    long long imgStrideX, imgStrideY;
+    int n_img, H, W, ldx;
+    int Ho, Wo, ldy;
+    int stride, pad_h, pad_w;
+    int K4;             // row groups (padded to a multiple of 8; padding has valid rows = 0)
+    int Cout, Cout_p;
+    int accumulate;
+    int splitk;
+    long long pix_per_split, Ptot;
+};
+
+template <int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
+    constexpr int BM = 128;
+    constexpr int MT = BM / WGM / 16;
+    constexpr int NT = BN / WGN / 16;
+    constexpr int RSA = BM + 16;
+    constexpr int RSB = BN + 16;
+    static_assert(WGM * WGN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float ldsA[32 * RSA];
+    __shared__ __attribute__((aligned(16))) float ldsB[32 * RSB];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int g4 = t & 31;   // row group (A) / column group (B) handled by this thread
+    const int ps = t >> 5;   // pixel slot 0..7
+
+    const int tiles_m = (p.K4 * 4 + BM - 1) / BM;
+    const int tm = blockIdx.x % tiles_m;
+    const int tn = blockIdx.x / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int r4 = (m0 >> 2) + g4;
+    int4 e = (int4){0, 0, 0, -1};
+    if (r4 < p.K4) e = p.ktab[r4];
+    const bool a_row_ok = e.w >= 0;
+    const int nb = n0 + 4 * g4;
+    const bool b_col_ok = (4 * g4 < BN) && (nb < p.Cout_p);
+
+    const long long pix_begin = (long long)blockIdx.y * p.pix_per_split;
+    long long pix_end = pix_begin + p.pix_per_split;
+    if (pix_end > p.Ptot) pix_end = p.Ptot;
+    const int nk = pix_end > pix_begin ? (int)((pix_end - pix_begin + 31) >> 5) : 0;
+    const int HoWo = p.Ho * p.Wo;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long q = pix_begin + (long long)kt * 32 + ps + 8 * i;
+            f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
+            if (q < pix_end) {
+                const int img = (int)(q / HoWo);
+                const int rem = (int)(q - (long long)img * HoWo);
+                const int oh = rem / p.Wo;
+                const int ow = rem - oh * p.Wo;
+                if (a_row_ok) {
+                    const int ih0 = oh * p.stride - p.pad_h, iw0 = ow * p.stride - p.pad_w;
+                    const int ih = ih0 + e.y, iw = iw0 + e.z;
+                    if (((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))
+                        va = *reinterpret_cast<const f32x4*>(
+                            p.X + (long long)img * p.imgStrideX + ((long long)ih0 * p.W + iw0) * p.ldx + e.x);
+                }
+                if (b_col_ok)
+                    vb = *reinterpret_cast<const f32x4*>(
+                        p.DY + (long long)img * p.imgStrideY + ((long long)oh * p.Wo + ow) * p.ldy + nb);
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = ps + 8 * i;
+            *reinterpret_cast<f32x4*>(&ldsA[px * RSA + 4 * g4]) = ra[i];
+            if (4 * g4 < BN) *reinterpret_cast<f32x4*>(&ldsB[px * RSB + 4 * g4]) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int px = 4 * s + (lane >> 4);
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = ldsA[px * RSA + wm * (BM / WGM) + a * 16 + (lane & 15)];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bf[b] = ldsB[px * RSB + wn * (BN / WGN) + b * 16 + (lane & 15)];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int col = lane & 15;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int rg = ((m0 + wm * (BM / WGM) + a * 16) >> 2) + (lane >> 4);  // k4 group of this lane's 4 rows
+        if (rg >= p.K4) continue;
+        if (p.splitk > 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* dst = p.partial + ((long long)blockIdx.y * p.K4 * 4 + rg * 4 + r) * p.Cout;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
+                    if (n < p.Cout) dst[n] = acc[a][b][r];
+                }
+            }
+        } else {
+            const int2 wr = p.wrow[rg];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r >= wr.y) continue;
+                float* dst = p.dW + wr.x + (long long)r * p.Cout;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
+                    if (n < p.Cout) {
+                        float v = acc[a][b][r];
+                        if (p.accumulate) v += dst[n];
+                        dst[n] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wdg_wgrad_reduce_kernel(const WdgWgrad p) {
+    const long long total = (long long)p.K4 * 4 * p.Cout;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int R = (int)(idx / p.Cout);
+        const int n = (int)(idx - (long long)R * p.Cout);
+        const int2 wr = p.wrow[R >> 2];
+        const int r = R & 3;
+        if (r >= wr.y) continue;
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; ++s) v += p.partial[((long long)s * p.K4 * 4 + R) * p.Cout + n];
+        float* dst = p.dW + wr.x + (long long)r * p.Cout + n;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+// repack master HWIO -> wF [Cout][taps][Cin_p] and wD [taps][Cin][Cout_p]
+__global__ void __launch_bounds__(256) wdg_weight_pack_kernel(const float* __restrict__ w, float* wF,
+                                                              float* wD, int taps, int Cin, int Cout,
+                                                              int Cin_p, int Cout_p) {
+    const long long nF = (long long)Cout * taps * Cin_p;
+    const long long nD = wD ? (long long)taps * Cin * Cout_p : 0;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nF + nD;
+         idx += (long long)gridDim.x * 256) {
+        if (idx < nF) {
+            const int ci = (int)(idx % Cin_p);
+            const long long r = idx / Cin_p;
+            const int tap = (int)(r % taps);
+            const int co = (int)(r / taps);
+            wF[idx] = ci < Cin ? w[((long long)tap * Cin + ci) * Cout + co] : 0.f;
+        } else {
+            const long long j = idx - nF;
+            const int co = (int)(j % Cout_p);
+            const long long r = j / Cout_p;  // tap*Cin + ci
+            wD[j] = co < Cout ? w[r * Cout + co] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side: plans
+// ------------------------------------------------------------------------------------------
+struct wdg_conv_plan {
+    wdg_conv_geom g;
+    int Cin_p, Cout_p, taps;
+    int cus;
+    // forward
+    int4* d_tab_fwd = nullptr;
+    int2* d_wrow = nullptr;
+    int K4_fwd = 0;  // padded to 8
+    // dgrad
+    int4* d_tab_dgrad = nullptr;
+    std::vector<WdgPhase> ph_dgrad;
+    int K4_dgrad_max = 0;
+    size_t ws_bytes = 0;
+    // launch configs (chosen at creation)
+    int fwd_split = 1, dgrad_split = 1, wgrad_split = 1;
+};
+
+static int g_cus = 0;
+extern "C" int wdg_device_cus(void) {
+    if (g_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_cus;
+}
+
+struct TileCfg {
+    int BM, BN;
+};
+static TileCfg pick_tile(int ncols) {
+    if (ncols <= 16) return {256, 16};
+    if (ncols <= 32) return {256, 32};
+    if (ncols <= 64) return {128, 64};
+    return {128, 128};
+}
+static int pick_wgrad_bn(int ncols) {
+    if (ncols <= 16) return 16;
+    if (ncols <= 32) return 32;
+    if (ncols <= 64) return 64;
+    return 128;
+}
+
+// choose a split-K factor so that roughly >= 2 blocks per CU exist, keeping >= 16 k4 groups per split
+static int pick_split(long long tiles, int K4, int cus) {
+    if (tiles >= 2LL * cus || K4 < 32) return 1;
+    long long want = (2LL * cus + tiles - 1) / tiles;
+    long long maxs = K4 / 16;
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want > 64) want = 64;
+    return (int)std::max<long long>(1, want);
+}
+
+extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g) {
+    WDG_CHECK_ARG(out && g, "null argument");
+    WDG_CHECK_ARG(g->n_img > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "bad sizes");
+    WDG_CHECK_ARG(g->kh > 0 && g->kw > 0 && g->stride > 0 && g->stride <= 3, "bad kernel/stride");
+    WDG_CHECK_ARG(g->ldx % 4 == 0 && g->ldy % 4 == 0, "pixel strides must be multiples of 4");
+    WDG_CHECK_ARG(g->ldx >= wdg_round_up(g->Cin, 4) && g->ldy >= wdg_round_up(g->Cout, 4), "ld < padded C");
+    const int Ho = (g->H + 2 * g->pad_h - g->kh) / g->stride + 1;
+    const int Wo = (g->W + 2 * g->pad_w - g->kw) / g->stride + 1;
+    WDG_CHECK_ARG(Ho == g->Ho && Wo == g->Wo, "Ho/Wo inconsistent with H,W,k,stride,pad");
+    WDG_CHECK_ARG((long long)g->n_img * g->Ho * g->Wo < (1LL << 31) && (long long)g->n_img * g->H * g->W < (1LL << 31),
+                  "pixel count overflows int32");
+
+    wdg_conv_plan* pl = new wdg_conv_plan();
+    pl->g = *g;
+    pl->Cin_p = wdg_round_up(g->Cin, 4);
+    pl->Cout_p = wdg_round_up(g->Cout, 4);
+    pl->taps = g->kh * g->kw;
+    pl->cus = wdg_device_cus();
+    const int s = g->stride;
+
+    // ---- forward table
+    std::vector<int4> tf;
+    std::vector<int2> wr;
+    for (int th = 0; th < g->kh; ++th)
+        for (int tw = 0; tw < g->kw; ++tw)
+            for (int c4 = 0; c4 < pl->Cin_p / 4; ++c4) {
+                const int tap = th * g->kw + tw;
+                int4 e;
+                e.x = (th * g->W + tw) * g->ldx + 4 * c4;
+                e.y = th;
+                e.z = tw;
+                e.w = tap * pl->Cin_p + 4 * c4;
+                tf.push_back(e);
+                int2 r;
+                r.x = (tap * g->Cin + 4 * c4) * g->Cout;
+                r.y = std::min(4, g->Cin - 4 * c4);
+                wr.push_back(r);
+            }
+    while (tf.size() % 8) {
+        tf.push_back((int4){0, -(1 << 28), -(1 << 28), -1});
+        wr.push_back((int2){0, 0});
+    }
+    pl->K4_fwd = (int)tf.size();
+
+    // ---- dgrad tables, one phase per (rh, rw) residue
+    std::vector<int4> td;
+    for (int rh = 0; rh < s; ++rh)
+        for (int rw = 0; rw < s; ++rw) {
+            WdgPhase ph;
+            ph.Pa = rh < g->H ? (g->H - rh + s - 1) / s : 0;
+            ph.Pb = rw < g->W ? (g->W - rw + s - 1) / s : 0;
+            ph.a_off_h = 0;
+            ph.a_off_w = 0;
+            ph.o_off_h = rh;
+            ph.o_off_w = rw;
+            ph.tab_off = (int)td.size();
+            int cnt = 0;
+            for (int th = (rh + g->pad_h) % s; th < g->kh; th += s)
+                for (int tw = (rw + g->pad_w) % s; tw < g->kw; tw += s) {
+                    const int dh = (rh + g->pad_h - th) / s;  // exact: numerator divisible by s
+                    const int dw = (rw + g->pad_w - tw) / s;
+                    const int tap = th * g->kw + tw;
+                    for (int c4 = 0; c4 < pl->Cout_p / 4; ++c4) {
+                        int4 e;
+                        e.x = (dh * g->Wo + dw) * g->ldy + 4 * c4;
+                        e.y = dh;
+                        e.z = dw;
+                        e.w = tap * g->Cin * pl->Cout_p + 4 * c4;
+                        td.push_back(e);
+                        ++cnt;
+                    }
+                }
+            while (cnt % 8) {
+                td.push_back((int4){0, -(1 << 28), -(1 << 28), -1});
+                ++cnt;
+            }
+            ph.K4 = cnt;
+            pl->K4_dgrad_max = std::max(pl->K4_dgrad_max, cnt);
+            pl->ph_dgrad.push_back(ph);
+        }
+
+    // ---- split-K choices and workspace
+    {
+        const long long M = (long long)g->n_img * g->Ho * g->Wo;
+        TileCfg tc = pick_tile(g->Cout);
+        long long tiles = ((M + tc.BM - 1) / tc.BM) * ((g->Cout + tc.BN - 1) / tc.BN);
+        pl->fwd_split = pick_split(tiles, pl->K4_fwd, pl->cus);
+        if (pl->fwd_split > 1) pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->fwd_split * M * g->Cout * 4));
+    }
+    {
+        long long Mmax = 0;
+        for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g->n_img * ph.Pa * ph.Pb);
+        TileCfg tc = pick_tile(g->Cin);
+        long long tiles = ((Mmax + tc.BM - 1) / tc.BM) * ((g->Cin + tc.BN - 1) / tc.BN) * (long long)pl->ph_dgrad.size();
+        pl->dgrad_split = pick_split(tiles, pl->K4_dgrad_max, pl->cus);
+        if (pl->dgrad_split > 1)
+            pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->dgrad_split * pl->ph_dgrad.size() * Mmax * g->Cin * 4));
+    }
+    {
+        const long long P = (long long)g->n_img * g->Ho * g->Wo;
+        const int bn = pick_wgrad_bn(g->Cout);
+        long long tiles = (long long)((pl->K4_fwd * 4 + 127) / 128) * ((g->Cout + bn - 1) / bn);
+        long long want = tiles >= 2LL * pl->cus ? 1 : (2LL * pl->cus + tiles - 1) / tiles;
+        long long maxs = std::max<long long>(1, P / 256);  // >= 256 pixels per split
+        want = std::min(want, maxs);
+        want = std::min<long long>(want, 256);
+        pl->wgrad_split = (int)std::max<long long>(1, want);
+        if (pl->wgrad_split > 1)
+            pl->ws_bytes = std::max(pl->ws_bytes, (size_t)pl->wgrad_split * pl->K4_fwd * 4 * g->Cout * 4);
+    }
+
+    auto upload = [&](const void* src, size_t bytes, void** dst) -> int {
+        WDG_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
+        if (bytes) WDG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return WDG_OK;
+    };
+    int rc;
+    if ((rc = upload(tf.data(), tf.size() * sizeof(int4), (void**)&pl->d_tab_fwd)) != WDG_OK) { delete pl; return rc; }
+    if ((rc = upload(wr.data(), wr.size() * sizeof(int2), (void**)&pl->d_wrow)) != WDG_OK) { delete pl; return rc; }
+    if ((rc = upload(td.data(), td.size() * sizeof(int4), (void**)&pl->d_tab_dgrad)) != WDG_OK) { delete pl; return rc; }
+    *out = pl;
+    return WDG_OK;
+}
+
+extern "C" int wdg_conv_plan_destroy(wdg_conv_plan* pl) {
+    if (!pl) return WDG_OK;
+    if (pl->d_tab_fwd) (void)hipFree(pl->d_tab_fwd);
+    if (pl->d_wrow) (void)hipFree(pl->d_wrow);
+    if (pl->d_tab_dgrad) (void)hipFree(pl->d_tab_dgrad);
+    delete pl;
+    return WDG_OK;
+}
+
+extern "C" size_t wdg_conv_ws_bytes(const wdg_conv_plan* pl) { return pl ? pl->ws_bytes : 0; }
+
+static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+    TileCfg tc = pick_tile(p.Ncols);
+    const int tiles_m = (p.Mmax + tc.BM - 1) / tc.BM;
+    const int tiles_n = (p.Ncols + tc.BN - 1) / tc.BN;
+    if (p.Mmax <= 0) return WDG_OK;
+    p.splitk = split;
+    p.nphase = nphase;
+    int per = (K4max + split - 1) / split;
+    per = wdg_round_up(per, 8);
+    p.k4_per_split = per;
+    // drop empty trailing splits
+    split = (K4max + per - 1) / per;
+    p.splitk = split;
+    if (split > 1) {
+        const size_t need = (size_t)split * nphase * p.Mmax * p.Ncols * sizeof(float);
+        if (!ws || ws_bytes < need) {
+            wdg_set_error("igemm: workspace too small (%zu < %zu)", ws_bytes, need);
+            return WDG_ERR_WORKSPACE;
+        }
+        p.partial = (float*)ws;
+    } else {
+        p.partial = nullptr;
+    }
+    dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
+    if (tc.BM == 128 && tc.BN == 128)
+        hipLaunchKernelGGL((wdg_igemm_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    else if (tc.BM == 128 && tc.BN == 64)
+        hipLaunchKernelGGL((wdg_igemm_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+    else if (tc.BM == 256 && tc.BN == 32)
+        hipLaunchKernelGGL((wdg_igemm_kernel<256, 32, 4, 1>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((wdg_igemm_kernel<256, 16, 4, 1>), grid, block, 0, st, p);
+    WDG_LAUNCH_CHECK();
+    if (split > 1) {
+        long long total = (long long)p.Mmax * p.Ncols;
+        int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(wdg_igemm_reduce_kernel, dim3(blocks, 1, nphase), block, 0, st, p);
+        WDG_LAUNCH_CHECK();
+    }
+    return WDG_OK;
+}
+
+extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias,
+                            float* y, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
+                            wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && wF && y, "null argument");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0, "x / wF must be 16-byte aligned");
+    const wdg_conv_geom& g = pl->g;
+    WdgIgemm p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
+    p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
+    p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
+    p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
+    p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p;
+    p.a_mul = g.stride; p.o_mul = 1;
+    p.act = act; p.slope = slope; p.accumulate = accumulate;
+    p.Mmax = g.n_img * g.Ho * g.Wo;
+    WdgPhase ph;
+    ph.Pa = g.Ho; ph.Pb = g.Wo; ph.a_off_h = -g.pad_h; ph.a_off_w = -g.pad_w;
+    ph.o_off_h = 0; ph.o_off_w = 0; ph.K4 = pl->K4_fwd; ph.tab_off = 0;
+    p.ph[0] = ph;
+    return launch_igemm(p, 1, pl->K4_fwd, pl->fwd_split, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const float* wD, const float* bias,
+                              float* dx, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
+                              wdg_stream stream) {
+    WDG_CHECK_ARG(pl && dy && wD && dx, "null argument");
+    WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0, "dy / wD must be 16-byte aligned");
+    const wdg_conv_geom& g = pl->g;
+    WdgIgemm p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.B = wD; p.Out = dx; p.bias = bias; p.ktab = pl->d_tab_dgrad;
+    p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
+    p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
+    p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
+    p.Ncols = g.Cin; p.ldB = pl->Cout_p;
+    p.a_mul = 1; p.o_mul = g.stride;
+    p.act = act; p.slope = slope; p.accumulate = accumulate;
+    int Mmax = 0;
+    const int np = (int)pl->ph_dgrad.size();
+    for (int i = 0; i < np; ++i) {
+        p.ph[i] = pl->ph_dgrad[i];
+        Mmax = std::max(Mmax, g.n_img * p.ph[i].Pa * p.ph[i].Pb);
+    }
+    p.Mmax = Mmax;
+    return launch_igemm(p, np, pl->K4_dgrad_max, pl->dgrad_split, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw,
+                              int accumulate, void* ws, size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && dy && dw, "null argument");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "x / dy must be 16-byte aligned");
+    const wdg_conv_geom& g = pl->g;
+    hipStream_t st = (hipStream_t)stream;
+    WdgWgrad p;
+    memset(&p, 0, sizeof(p));
+    p.X = x; p.DY = dy; p.dW = dw; p.ktab = pl->d_tab_fwd; p.wrow = pl->d_wrow;
+    p.imgStrideX = g.img_stride_x; p.imgStrideY = g.img_stride_y;
+    p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldx = g.ldx;
+    p.Ho = g.Ho; p.Wo = g.Wo; p.ldy = g.ldy;
+    p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
+    p.K4 = pl->K4_fwd; p.Cout = g.Cout; p.Cout_p = pl->Cout_p;
+    p.accumulate = accumulate;
+    p.Ptot = (long long)g.n_img * g.Ho * g.Wo;
+    int split = pl->wgrad_split;
+    long long per = (p.Ptot + split - 1) / split;
+    per = (per + 31) / 32 * 32;
+    split = (int)((p.Ptot + per - 1) / per);
+    p.splitk = split;
+    p.pix_per_split = per;
+    if (split > 1) {
+        const size_t need = (size_t)split * p.K4 * 4 * p.Cout * sizeof(float);
+        if (!ws || ws_bytes < need) {
+            wdg_set_error("wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+            return WDG_ERR_WORKSPACE;
+        }
+        p.partial = (float*)ws;
+    }
+    const int bn = pick_wgrad_bn(g.Cout);
+    const int tiles_m = (p.K4 * 4 + 127) / 128;
+    const int tiles_n = (g.Cout + bn - 1) / bn;
+    dim3 grid(tiles_m * tiles_n, split, 1), block(256);
+    if (bn == 128)
+        hipLaunchKernelGGL((wdg_wgrad_kernel<128, 2, 2>), grid, block, 0, st, p);
+    else if (bn == 64)
+        hipLaunchKernelGGL((wdg_wgrad_kernel<64, 2, 2>), grid, block, 0, st, p);
+    else if (bn == 32)
+        hipLaunchKernelGGL((wdg_wgrad_kernel<32, 4, 1>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((wdg_wgrad_kernel<16, 4, 1>), grid, block, 0, st, p);
+    WDG_LAUNCH_CHECK();
+    if (split > 1) {
+        long long total = (long long)p.K4 * 4 * p.Cout;
+        int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(wdg_wgrad_reduce_kernel, dim3(blocks), block, 0, st, p);
+        WDG_LAUNCH_CHECK();
+    }
+    return WDG_OK;
+}
+
+extern "C" int wdg_weight_pack(const float* w_hwio, float* wF, float* wD, int taps, int Cin, int Cout,
+                               wdg_stream stream) {
+    WDG_CHECK_ARG(w_hwio && wF, "null argument");
+    const int Cin_p = wdg_round_up(Cin, 4), Cout_p = wdg_round_up(Cout, 4);
+    long long total = (long long)Cout * taps * Cin_p + (wD ? (long long)taps * Cin * Cout_p : 0);
+    int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(wdg_weight_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, wF,
+                       wD, taps, Cin, Cout, Cin_p, Cout_p);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}

@@ -1,0 +1,463 @@
+// norms.hip — BatchNormalization / LayerNormalization forward + backward (HBM-bound kernels).
+// Reference call sites: /root/reference/src/downscaling/gan/models.py:34,40,50,56,69 (BatchNorm,
+// axis -1, eps 1e-3, momentum .99) and :97,105,116,125,136 (LayerNorm, axis -1, eps 1e-3).
+// The LeakyReLU(0.2) that precedes every norm (conv -> bias -> LReLU -> norm) has its derivative
+// fused into the norm-backward kernels (sign(y) == sign(pre-activation)).
+#include "common.h"
+#include <algorithm>
+
+// ---- block-level per-channel reduction helper -------------------------------------------------
+// Thread t owns channel group c4 = t % c4n for pixel row t / c4n.  Sums NV float4 values over the
+// rows of the block through LDS, then adds them to out[v*C + 4*c4 + j] with one atomic per value.
+template <int NV, typename OutT>
+__device__ __forceinline__ void wdg_block_colreduce(const float (&v)[NV][4], int c4, int c4n, int rows,
+                                                   bool active, OutT* out, int C, float* lds /*[NV*256*4]*/) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[(k * 256 + t) * 4 + j] = active ? v[k][j] : 0.f;
+    __syncthreads();
+    if (t < c4n) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                OutT s = 0;
+                for (int r = 0; r < rows; ++r) s += (OutT)lds[(k * 256 + r * c4n + t) * 4 + j];
+                atomicAdd(&out[(size_t)k * C + 4 * t + j], s);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct ColGeom {
+    int c4n, rows;  // channel groups, pixel rows per pass (rows * c4n <= 256)
+};
+static inline ColGeom col_geom(int C) {
+    ColGeom g;
+    g.c4n = C / 4;
+    g.rows = 256 / g.c4n;
+    if (g.rows < 1) g.rows = 1;
+    return g;
+}
+static inline int col_blocks(int64_t P, int rows) {
+    int64_t per_block = (int64_t)rows * 64;  // ~64 pixels per thread row
+    int64_t b = (P + per_block - 1) / per_block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, 4096));
+}
+
+// ---- BatchNorm ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wdg_bn_stats_kernel(const float* __restrict__ x, int64_t P, int C,
+                                                           int ldx, double* stats, int c4n, int rows) {
+    __shared__ float lds[2 * 256 * 4];
+    const int t = threadIdx.x;
+    const int c4 = t % c4n, prow = t / c4n;
+    const bool active = prow < rows;
+    float v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (active) {
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += (int64_t)gridDim.x * rows) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + p * ldx + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[0][j] += a[j];
+                v[1][j] += a[j] * a[j];
+            }
+        }
+    }
+    wdg_block_colreduce<2, double>(v, c4, c4n, rows, active, stats, C, lds);
+}
+
+extern "C" int wdg_bn_stats(const float* x, int64_t P, int C, int ldx, double* stats, wdg_stream stream) {
+    WDG_CHECK_ARG(x && stats && C % 4 == 0 && C <= 1024 && ldx % 4 == 0, "bad argument");
+    ColGeom g = col_geom(C);
+    // keep per-thread fp32 partial sums short: many blocks, each thread sees <= ~P/(blocks*rows) pixels
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 8192));
+    hipLaunchKernelGGL(wdg_bn_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ldx,
+                       stats, g.c4n, g.rows);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void wdg_bn_finalize_train_kernel(const double* stats, double count, const float* gamma,
+                                             const float* beta, float* mmean, float* mvar, float momentum,
+                                             float eps, float* ss, float* saved, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = stats[c] / count;
+    double var = stats[C + c] / count - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float scale = (float)((double)gamma[c] * invstd);
+    ss[c] = scale;
+    ss[C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+    saved[c] = (float)mean;
+    saved[C + c] = (float)invstd;
+    mmean[c] = mmean[c] * momentum + (float)mean * (1.f - momentum);
+    mvar[c] = mvar[c] * momentum + (float)var * (1.f - momentum);
+}
+
+extern "C" int wdg_bn_finalize_train(const double* stats, double count, const float* gamma, const float* beta,
+                                     float* moving_mean, float* moving_var, float momentum, float eps,
+                                     float* scale_shift, float* saved_mean_invstd, int C, wdg_stream stream) {
+    WDG_CHECK_ARG(stats && gamma && beta && moving_mean && moving_var && scale_shift && saved_mean_invstd,
+                  "null argument");
+    hipLaunchKernelGGL(wdg_bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       stats, count, gamma, beta, moving_mean, moving_var, momentum, eps, scale_shift,
+                       saved_mean_invstd, C);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void wdg_bn_finalize_infer_kernel(const float* gamma, const float* beta, const float* mmean,
+                                             const float* mvar, float eps, float* ss, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double invstd = 1.0 / sqrt((double)mvar[c] + (double)eps);
+    ss[c] = (float)((double)gamma[c] * invstd);
+    ss[C + c] = (float)((double)beta[c] - (double)mmean[c] * (double)gamma[c] * invstd);
+}
+
+extern "C" int wdg_bn_finalize_infer(const float* gamma, const float* beta, const float* moving_mean,
+                                     const float* moving_var, float eps, float* scale_shift, int C,
+                                     wdg_stream stream) {
+    WDG_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale_shift, "null argument");
+    hipLaunchKernelGGL(wdg_bn_finalize_infer_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       gamma, beta, moving_mean, moving_var, eps, scale_shift, C);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void __launch_bounds__(256) wdg_bn_apply_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ ss, float* z, int ldz,
+                                                           int64_t P, int C) {
+    const int c4n = C / 4;
+    const int64_t total = P * c4n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / c4n;
+        const int c = 4 * (int)(idx - p * c4n);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(ss + C + c);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = a[j] * sc[j] + sh[j];
+        *reinterpret_cast<f32x4*>(z + p * ldz + c) = r;
+    }
+}
+
+extern "C" int wdg_bn_apply(const float* x, int ldx, const float* scale_shift, float* z, int ldz, int64_t P,
+                            int C, wdg_stream stream) {
+    WDG_CHECK_ARG(x && scale_shift && z && C % 4 == 0 && ldx % 4 == 0 && ldz % 4 == 0, "bad argument");
+    const int64_t total = P * (C / 4);
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));
+    hipLaunchKernelGGL(wdg_bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       scale_shift, z, ldz, P, C);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void __launch_bounds__(256) wdg_bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
+                                                                const float* __restrict__ y, int ldy,
+                                                                const float* __restrict__ saved, int64_t P,
+                                                                int C, double* red, int c4n, int rows) {
+    __shared__ float lds[2 * 256 * 4];
+    const int t = threadIdx.x;
+    const int c4 = t % c4n, prow = t / c4n;
+    const bool active = prow < rows;
+    float v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (active) {
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(saved + 4 * c4);
+        const f32x4 inv = *reinterpret_cast<const f32x4*>(saved + C + 4 * c4);
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += (int64_t)gridDim.x * rows) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (a[j] - mean[j]) * inv[j];
+                v[0][j] += g[j];
+                v[1][j] += g[j] * xh;
+            }
+        }
+    }
+    wdg_block_colreduce<2, double>(v, c4, c4n, rows, active, red, C, lds);
+}
+
+extern "C" int wdg_bn_bwd_reduce(const float* dz, int lddz, const float* y, int ldy,
+                                 const float* saved_mean_invstd, int64_t P, int C, double* red,
+                                 wdg_stream stream) {
+    WDG_CHECK_ARG(dz && y && saved_mean_invstd && red && C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0,
+                  "bad argument");
+    ColGeom g = col_geom(C);
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 8192));
+    hipLaunchKernelGGL(wdg_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
+                       ldy, saved_mean_invstd, P, C, red, g.c4n, g.rows);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void __launch_bounds__(256) wdg_bn_bwd_apply_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ y, int ldy,
+    const float* __restrict__ saved, const float* __restrict__ gamma, const double* __restrict__ red_mean,
+    const double* __restrict__ red_param, double count, float act_slope, float* dpre, int lddpre, float* dgamma,
+    float* dbeta, float* dbias, int64_t P, int C, int c4n, int rows) {
+    __shared__ float lds[256 * 4];
+    const int t = threadIdx.x;
+    const int c4 = t % c4n, prow = t / c4n;
+    const bool active = prow < rows;
+    float v[1][4] = {{0, 0, 0, 0}};
+    if (active) {
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(saved + 4 * c4);
+        const f32x4 inv = *reinterpret_cast<const f32x4*>(saved + C + 4 * c4);
+        f32x4 k0, mdz, mdzx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k0[j] = gamma[4 * c4 + j] * inv[j];
+            mdz[j] = (float)(red_mean[4 * c4 + j] / count);
+            mdzx[j] = (float)(red_mean[C + 4 * c4 + j] / count);
+        }
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += (int64_t)gridDim.x * rows) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (a[j] - mean[j]) * inv[j];
+                float d = k0[j] * (g[j] - mdz[j] - xh * mdzx[j]);
+                if (act_slope >= 0.f) d *= (a[j] > 0.f ? 1.f : act_slope);
+                r[j] = d;
+                v[0][j] += d;
+            }
+            *reinterpret_cast<f32x4*>(dpre + p * lddpre + 4 * c4) = r;
+        }
+    }
+    if (dbias) wdg_block_colreduce<1, float>(v, c4, c4n, rows, active, dbias, C, lds);
+    if (blockIdx.x == 0 && t < C && red_param) {
+        if (dgamma) dgamma[t] += (float)red_param[C + t];
+        if (dbeta) dbeta[t] += (float)red_param[t];
+    }
+    if (blockIdx.x == 0 && red_param && C > 256) {
+        for (int c = 256 + t; c < C; c += 256) {
+            if (dgamma) dgamma[c] += (float)red_param[C + c];
+            if (dbeta) dbeta[c] += (float)red_param[c];
+        }
+    }
+}
+
+extern "C" int wdg_bn_bwd_apply(const float* dz, int lddz, const float* y, int ldy,
+                                const float* saved_mean_invstd, const float* gamma, const double* red_mean,
+                                const double* red_param, double count, float act_slope, float* dpre,
+                                int lddpre, float* dgamma, float* dbeta, float* dbias, int64_t P, int C,
+                                wdg_stream stream) {
+    WDG_CHECK_ARG(dz && y && saved_mean_invstd && gamma && red_mean && dpre, "null argument");
+    WDG_CHECK_ARG(C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0 && lddpre % 4 == 0, "bad sizes");
+    ColGeom g = col_geom(C);
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 16 - 1) / (g.rows * 16), 8192));
+    hipLaunchKernelGGL(wdg_bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
+                       ldy, saved_mean_invstd, gamma, red_mean, red_param, count, act_slope, dpre, lddpre,
+                       dgamma, dbeta, dbias, P, C, g.c4n, g.rows);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- LayerNorm ---------------------------------------------------------------------------------
+// L lanes (power of two <= 64) cooperate on one pixel; each lane owns channel groups sub, sub+L, ...
+template <int MAXCH>  // max float4 chunks per lane
+__global__ void __launch_bounds__(256) wdg_ln_fwd_kernel(const float* __restrict__ y, int ldy,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float* z,
+                                                         int ldz, float* mean_rstd, int64_t P, int C, int L) {
+    const int t = threadIdx.x;
+    const int sub = t % L;
+    const int ppb = 256 / L;
+    const int c4n = C / 4;
+    const float invC = 1.f / (float)C;
+    for (int64_t p = (int64_t)blockIdx.x * ppb + t / L; p < P; p += (int64_t)gridDim.x * ppb) {
+        f32x4 a[MAXCH];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int c4 = sub + k * L;
+            a[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < c4n) a[k] = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
+            s += a[k][0] + a[k][1] + a[k][2] + a[k][3];
+        }
+        for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int c4 = sub + k * L;
+            if (c4 < c4n) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = a[k][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = 1.f / sqrtf(q * invC + eps);
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int c4 = sub + k * L;
+            if (c4 < c4n) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = (a[k][j] - mean) * rstd * g[j] + b[j];
+                *reinterpret_cast<f32x4*>(z + p * ldz + 4 * c4) = r;
+            }
+        }
+        if (mean_rstd && sub == 0) {
+            mean_rstd[2 * p] = mean;
+            mean_rstd[2 * p + 1] = rstd;
+        }
+    }
+}
+
+static inline int ln_lanes(int C) {
+    int c4n = C / 4, L = 1;
+    while (L < c4n && L < 64) L <<= 1;
+    return L;
+}
+
+extern "C" int wdg_ln_fwd(const float* y, int ldy, const float* gamma, const float* beta, float eps, float* z,
+                          int ldz, float* mean_rstd, int64_t P, int C, wdg_stream stream) {
+    WDG_CHECK_ARG(y && gamma && beta && z, "null argument");
+    WDG_CHECK_ARG(C % 4 == 0 && C <= 1024 && ldy % 4 == 0 && ldz % 4 == 0, "bad sizes");
+    const int L = ln_lanes(C);
+    const int ppb = 256 / L;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + ppb - 1) / ppb, 16384));
+    const int chunks = (C / 4 + L - 1) / L;
+    if (chunks <= 1)
+        hipLaunchKernelGGL(wdg_ln_fwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, gamma,
+                           beta, eps, z, ldz, mean_rstd, P, C, L);
+    else
+        hipLaunchKernelGGL(wdg_ln_fwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, ldy, gamma,
+                           beta, eps, z, ldz, mean_rstd, P, C, L);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+template <int MAXCH>
+__global__ void __launch_bounds__(256) wdg_ln_bwd_kernel(const float* __restrict__ dz, int lddz,
+                                                         const float* __restrict__ y, int ldy,
+                                                         const float* __restrict__ mean_rstd,
+                                                         const float* __restrict__ gamma, float act_slope,
+                                                         float* dpre, int lddpre, float* dgamma, float* dbeta,
+                                                         float* dbias, int64_t P, int C, int L) {
+    __shared__ float lds[3 * MAXCH * 256 * 4];
+    const int t = threadIdx.x;
+    const int sub = t % L;
+    const int ppb = 256 / L;
+    const int c4n = C / 4;
+    const float invC = 1.f / (float)C;
+    float ag[MAXCH][4], ab[MAXCH][4], abias[MAXCH][4];
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ag[k][j] = ab[k][j] = abias[k][j] = 0.f;
+    f32x4 gm[MAXCH];
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int c4 = sub + k * L;
+        gm[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c4 < c4n) gm[k] = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+    }
+    for (int64_t p = (int64_t)blockIdx.x * ppb + t / L; p < P; p += (int64_t)gridDim.x * ppb) {
+        const float mean = mean_rstd[2 * p], rstd = mean_rstd[2 * p + 1];
+        f32x4 a[MAXCH], g[MAXCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int c4 = sub + k * L;
+            a[k] = g[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < c4n) {
+                a[k] = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
+                g[k] = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (a[k][j] - mean) * rstd;
+                    const float gg = g[k][j] * gm[k][j];
+                    s1 += gg;
+                    s2 += gg * xh;
+                    ag[k][j] += g[k][j] * xh;
+                    ab[k][j] += g[k][j];
+                }
+            }
+        }
+        for (int o = L >> 1; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        s1 *= invC;
+        s2 *= invC;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int c4 = sub + k * L;
+            if (c4 < c4n) {
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (a[k][j] - mean) * rstd;
+                    float d = rstd * (g[k][j] * gm[k][j] - s1 - xh * s2);
+                    if (act_slope >= 0.f) d *= (a[k][j] > 0.f ? 1.f : act_slope);
+                    r[j] = d;
+                    abias[k][j] += d;
+                }
+                *reinterpret_cast<f32x4*>(dpre + p * lddpre + 4 * c4) = r;
+            }
+        }
+    }
+    // reduce the three per-channel accumulators over the ppb pixel slots of the block
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lds[((0 * MAXCH + k) * 256 + t) * 4 + j] = ag[k][j];
+            lds[((1 * MAXCH + k) * 256 + t) * 4 + j] = ab[k][j];
+            lds[((2 * MAXCH + k) * 256 + t) * 4 + j] = abias[k][j];
+        }
+    __syncthreads();
+    if (t < L) {
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int c4 = t + k * L;
+            if (c4 >= c4n) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < ppb; ++r) {
+                    s0 += lds[((0 * MAXCH + k) * 256 + r * L + t) * 4 + j];
+                    s1 += lds[((1 * MAXCH + k) * 256 + r * L + t) * 4 + j];
+                    s2 += lds[((2 * MAXCH + k) * 256 + r * L + t) * 4 + j];
+                }
+                if (dgamma) atomicAdd(&dgamma[4 * c4 + j], s0);
+                if (dbeta) atomicAdd(&dbeta[4 * c4 + j], s1);
+                if (dbias) atomicAdd(&dbias[4 * c4 + j], s2);
+            }
+        }
+    }
+}
+
+extern "C" int wdg_ln_bwd(const float* dz, int lddz, const float* y, int ldy, const float* mean_rstd,
+                          const float* gamma, float act_slope, float* dpre, int lddpre, float* dgamma,
+                          float* dbeta, float* dbias, int64_t P, int C, wdg_stream stream) {
+    WDG_CHECK_ARG(dz && y && mean_rstd && gamma && dpre, "null argument");
+    WDG_CHECK_ARG(C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0 && lddpre % 4 == 0, "bad sizes");
+    const int L = ln_lanes(C);
+    const int ppb = 256 / L;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + ppb * 8 - 1) / (ppb * 8), 2048));
+    const int chunks = (C / 4 + L - 1) / L;
+    if (chunks <= 1)
+        hipLaunchKernelGGL(wdg_ln_bwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
+                           ldy, mean_rstd, gamma, act_slope, dpre, lddpre, dgamma, dbeta, dbias, P, C, L);
+    else
+        hipLaunchKernelGGL(wdg_ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
+                           ldy, mean_rstd, gamma, act_slope, dpre, lddpre, dgamma, dbeta, dbias, P, C, L);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}

@@ -1,0 +1,463 @@
+// pointwise.hip — ConvLSTM gate math, bilinear x2 resampling, Dense+GAP head, channel packing,
+// train-step elementwise ops and reductions, Philox noise.  All HBM-bound.
+// Reference call sites are cited per kernel (files under /root/reference/src/downscaling).
+#include "common.h"
+#include <algorithm>
+
+static inline int ew_blocks(int64_t total, int cap = 16384) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, cap));
+}
+
+// ---- ConvLSTM2D pointwise cell (gan/models.py:45,93,101; Keras gate order i,f,c,o) --------------
+__device__ __forceinline__ float wdg_hsig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float wdg_hsig_grad(float x) {
+    const float v = 0.2f * x + 0.5f;
+    return (v >= 0.f && v <= 1.f) ? 0.2f : 0.f;
+}
+
+__global__ void __launch_bounds__(256) wdg_lstm_fwd_kernel(const float* __restrict__ gates, int ldg,
+                                                           const float* __restrict__ c_prev, int ldcp, float* c,
+                                                           int ldc, float* h, int ldh, int64_t P, int F) {
+    const int64_t total = P * F;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / F;
+        const int f = (int)(idx - p * F);
+        const float* g = gates + p * ldg;
+        const float gi = wdg_hsig(g[f]);
+        const float gc = tanhf(g[2 * F + f]);
+        const float go = wdg_hsig(g[3 * F + f]);
+        float cn = gi * gc;
+        if (c_prev) cn += wdg_hsig(g[F + f]) * c_prev[p * ldcp + f];
+        c[p * ldc + f] = cn;
+        h[p * ldh + f] = go * tanhf(cn);
+    }
+}
+
+extern "C" int wdg_lstm_fwd(const float* gates, int ldg, const float* c_prev, int ldcp, float* c, int ldc,
+                            float* h, int ldh, int64_t P, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(gates && c && h && F > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_lstm_fwd_kernel, dim3(ew_blocks(P * F)), dim3(256), 0, (hipStream_t)stream, gates,
+                       ldg, c_prev, ldcp, c, ldc, h, ldh, P, F);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void __launch_bounds__(256) wdg_lstm_bwd_kernel(const float* __restrict__ gates, int ldg,
+                                                           const float* __restrict__ c_prev, int ldcp,
+                                                           const float* __restrict__ c, int ldc,
+                                                           const float* __restrict__ dh, int lddh,
+                                                           const float* __restrict__ dc_in, int lddci,
+                                                           float* dgates, int lddg, float* dc_prev, int lddcp,
+                                                           int64_t P, int F) {
+    const int64_t total = P * F;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / F;
+        const int f = (int)(idx - p * F);
+        const float* g = gates + p * ldg;
+        const float xi = g[f], xf = g[F + f], xc = g[2 * F + f], xo = g[3 * F + f];
+        const float gi = wdg_hsig(xi), gf = wdg_hsig(xf), gc = tanhf(xc), go = wdg_hsig(xo);
+        const float cp = c_prev ? c_prev[p * ldcp + f] : 0.f;
+        const float tc = tanhf(c[p * ldc + f]);
+        const float dhv = dh[p * lddh + f];
+        float dc = dhv * go * (1.f - tc * tc);
+        if (dc_in) dc += dc_in[p * lddci + f];
+        float* dg = dgates + p * lddg;
+        dg[f] = dc * gc * wdg_hsig_grad(xi);
+        dg[F + f] = dc * cp * wdg_hsig_grad(xf);
+        dg[2 * F + f] = dc * gi * (1.f - gc * gc);
+        dg[3 * F + f] = dhv * tc * wdg_hsig_grad(xo);
+        if (dc_prev) dc_prev[p * lddcp + f] = dc * gf;
+    }
+}
+
+extern "C" int wdg_lstm_bwd(const float* gates, int ldg, const float* c_prev, int ldcp, const float* c, int ldc,
+                            const float* dh, int lddh, const float* dc_in, int lddci, float* dgates, int lddg,
+                            float* dc_prev, int lddcp, int64_t P, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(gates && c && dh && dgates && F > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_lstm_bwd_kernel, dim3(ew_blocks(P * F)), dim3(256), 0, (hipStream_t)stream, gates,
+                       ldg, c_prev, ldcp, c, ldc, dh, lddh, dc_in, lddci, dgates, lddg, dc_prev, lddcp, P, F);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- UpSampling2D(2, bilinear), half-pixel centres + edge clamp (gan/models.py:62) --------------
+__global__ void __launch_bounds__(256) wdg_up2_fwd_kernel(const float* __restrict__ x, int ldx, int64_t isx,
+                                                          float* y, int ldy, int64_t isy, int n_img, int H,
+                                                          int W, int C) {
+    const int c4n = C / 4;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const int64_t total = (int64_t)n_img * H2 * W2 * c4n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = 4 * (int)(idx % c4n);
+        int64_t r = idx / c4n;
+        const int ow = (int)(r % W2);
+        r /= W2;
+        const int oh = (int)(r % H2);
+        const int img = (int)(r / H2);
+        // even output 2j: .25*x[j-1] + .75*x[j]; odd 2j+1: .75*x[j] + .25*x[j+1]  (indices clamped)
+        const int jh = oh >> 1, jw = ow >> 1;
+        const int h0 = (oh & 1) ? jh : max(jh - 1, 0), h1 = (oh & 1) ? min(jh + 1, H - 1) : jh;
+        const int w0 = (ow & 1) ? jw : max(jw - 1, 0), w1 = (ow & 1) ? min(jw + 1, W - 1) : jw;
+        const float fh = (oh & 1) ? 0.25f : 0.75f;  // weight of the upper index (h1)
+        const float fw = (ow & 1) ? 0.25f : 0.75f;
+        const float* xb = x + (int64_t)img * isx + c;
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)h0 * W + w0) * ldx);
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)h0 * W + w1) * ldx);
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)h1 * W + w0) * ldx);
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(xb + ((int64_t)h1 * W + w1) * ldx);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float top = a00[j] + (a01[j] - a00[j]) * fw;
+            const float bot = a10[j] + (a11[j] - a10[j]) * fw;
+            o[j] = top + (bot - top) * fh;
+        }
+        *reinterpret_cast<f32x4*>(y + (int64_t)img * isy + ((int64_t)oh * W2 + ow) * ldy + c) = o;
+    }
+}
+
+extern "C" int wdg_upsample2x_fwd(const float* x, int ldx, int64_t img_stride_x, float* y, int ldy,
+                                  int64_t img_stride_y, int n_img, int H, int W, int C, wdg_stream stream) {
+    WDG_CHECK_ARG(x && y && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "bad argument");
+    const int64_t total = (int64_t)n_img * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(wdg_up2_fwd_kernel, dim3(ew_blocks(total, 65536)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, img_stride_x, y, ldy, img_stride_y, n_img, H, W, C);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// adjoint as a gather: input pixel i collects outputs 2i-1, 2i, 2i+1, 2i+2 with weights
+// .25, .75(+.25 at i=0), .75(+.25 at i=n-1), .25
+__device__ __forceinline__ void wdg_up2_taps(int i, int n, int (&o)[4], float (&w)[4]) {
+    o[0] = 2 * i - 1; w[0] = (i >= 1) ? 0.25f : 0.f;
+    o[1] = 2 * i;     w[1] = (i == 0) ? 1.0f : 0.75f;
+    o[2] = 2 * i + 1; w[2] = (i == n - 1) ? 1.0f : 0.75f;
+    o[3] = 2 * i + 2; w[3] = (i <= n - 2) ? 0.25f : 0.f;
+}
+
+__global__ void __launch_bounds__(256) wdg_up2_bwd_kernel(const float* __restrict__ dy, int lddy, int64_t isdy,
+                                                          float* dx, int lddx, int64_t isdx, int n_img, int H,
+                                                          int W, int C, int accumulate) {
+    const int c4n = C / 4;
+    const int W2 = 2 * W;
+    const int64_t total = (int64_t)n_img * H * W * c4n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = 4 * (int)(idx % c4n);
+        int64_t r = idx / c4n;
+        const int iw = (int)(r % W);
+        r /= W;
+        const int ih = (int)(r % H);
+        const int img = (int)(r / H);
+        int oh[4], ow[4];
+        float wh[4], ww[4];
+        wdg_up2_taps(ih, H, oh, wh);
+        wdg_up2_taps(iw, W, ow, ww);
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* db = dy + (int64_t)img * isdy + c;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (wh[a] == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (ww[b] == 0.f) continue;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(db + ((int64_t)oh[a] * W2 + ow[b]) * lddy);
+                const float wgt = wh[a] * ww[b];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += wgt * g[j];
+            }
+        }
+        float* dst = dx + (int64_t)img * isdx + ((int64_t)ih * W + iw) * lddx + c;
+        if (accumulate) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += old[j];
+        }
+        *reinterpret_cast<f32x4*>(dst) = s;
+    }
+}
+
+extern "C" int wdg_upsample2x_bwd(const float* dy, int lddy, int64_t img_stride_dy, float* dx, int lddx,
+                                  int64_t img_stride_dx, int n_img, int H, int W, int C, int accumulate,
+                                  wdg_stream stream) {
+    WDG_CHECK_ARG(dy && dx && C % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "bad argument");
+    const int64_t total = (int64_t)n_img * H * W * (C / 4);
+    hipLaunchKernelGGL(wdg_up2_bwd_kernel, dim3(ew_blocks(total, 65536)), dim3(256), 0, (hipStream_t)stream, dy,
+                       lddy, img_stride_dy, dx, lddx, img_stride_dx, n_img, H, W, C, accumulate);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- Flatten + Dense(1) + GlobalAveragePooling1D (gan/models.py:137-140) ------------------------
+__global__ void __launch_bounds__(256) wdg_dense_gap_fwd_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* score, int B,
+                                                                int T, int K) {
+    __shared__ float red[4];
+    const int bi = blockIdx.x;
+    float s = 0.f;
+    const int64_t n = (int64_t)T * K;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int t = (int)(i / K), k = (int)(i % K);
+        s += x[((int64_t)t * B + bi) * K + k] * w[k];  // rows are time-major: row = t*B + b
+    }
+    s = wdg_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) score[bi] = (red[0] + red[1] + red[2] + red[3]) / (float)T + b[0];
+}
+
+extern "C" int wdg_dense_gap_fwd(const float* x, const float* w, const float* b, float* score, int B, int T,
+                                 int K, wdg_stream stream) {
+    WDG_CHECK_ARG(x && w && b && score && B > 0 && T > 0 && K > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_dense_gap_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, w, b, score, B, T, K);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void __launch_bounds__(256) wdg_dense_gap_bwd_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ dscore, float* dx,
+                                                                float* dw, float* db, int B, int T, int K) {
+    const float invT = 1.f / (float)T;
+    const int64_t total = (int64_t)B * T * K;
+    // dx
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int k = (int)(idx % K);
+        const int b = (int)((idx / K) % B);  // row = t*B + b
+        if (dx) dx[idx] = dscore[b] * invT * w[k];
+    }
+    // dw: one thread per k loops over rows
+    if (dw) {
+        for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+            float s = 0.f;
+            for (int r = 0; r < B * T; ++r) s += x[(int64_t)r * K + k] * dscore[r % B];
+            dw[k] += s * invT;
+        }
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dscore[b];
+        db[0] += s;
+    }
+}
+
+extern "C" int wdg_dense_gap_bwd(const float* x, const float* w, const float* dscore, float* dx, float* dw,
+                                 float* db, int B, int T, int K, wdg_stream stream) {
+    WDG_CHECK_ARG(x && w && dscore, "null argument");
+    const int64_t total = (int64_t)B * T * K;
+    hipLaunchKernelGGL(wdg_dense_gap_bwd_kernel, dim3(ew_blocks(total, 1024)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, dscore, dx, dw, db, B, T, K);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- channel pack / unpack between views ---------------------------------------------------------
+__global__ void __launch_bounds__(256) wdg_copy_channels_kernel(const float* __restrict__ src, int lds_,
+                                                                int64_t iss, float* dst, int ldd, int64_t isd,
+                                                                int n_img, int64_t ppi, int C, int accumulate) {
+    const int64_t total = (int64_t)n_img * ppi * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / C;
+        const int c = (int)(idx - p * C);
+        const int64_t img = p / ppi, q = p - img * ppi;
+        const float v = src[img * iss + q * lds_ + c];
+        float* d = dst + img * isd + q * ldd + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+extern "C" int wdg_copy_channels(const float* src, int lds_, int64_t img_stride_src, float* dst, int ldd,
+                                 int64_t img_stride_dst, int n_img, int64_t pixels_per_img, int C,
+                                 int accumulate, wdg_stream stream) {
+    WDG_CHECK_ARG(src && dst && C > 0 && n_img > 0 && pixels_per_img > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_copy_channels_kernel, dim3(ew_blocks((int64_t)n_img * pixels_per_img * C)), dim3(256),
+                       0, (hipStream_t)stream, src, lds_, img_stride_src, dst, ldd, img_stride_dst, n_img,
+                       pixels_per_img, C, accumulate);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- column sum (bias gradients): block = 64 channels x 4 pixel rows ----------------------------
+__global__ void __launch_bounds__(256) wdg_colsum_kernel(const float* __restrict__ x, int ldx, int64_t P, int C,
+                                                         float* out) {
+    __shared__ float red[256];
+    const int cx = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t p = (int64_t)blockIdx.x * 4 + pr; p < P; p += (int64_t)gridDim.x * 4) s += x[p * ldx + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pr == 0 && c < C) atomicAdd(&out[c], red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx]);
+}
+
+extern "C" int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out, int accumulate,
+                          wdg_stream stream) {
+    WDG_CHECK_ARG(x && out && C > 0, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) WDG_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+    int bx = (int)std::max<int64_t>(1, std::min<int64_t>((P + 255) / 256, 1024));
+    hipLaunchKernelGGL(wdg_colsum_kernel, dim3(bx, (C + 63) / 64), dim3(256), 0, st, x, ldx, P, C, out);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- combined = eps*real + (1-eps)*fake (gan/ganbase.py:30-31) ----------------------------------
+__global__ void __launch_bounds__(256) wdg_lerp_batch_kernel(const float* __restrict__ a, int lda,
+                                                             const float* __restrict__ b, int ldb,
+                                                             const float* __restrict__ eps, float* out, int ldo,
+                                                             int64_t P, int64_t ppi, int B, int C) {
+    const int64_t total = P * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / C;
+        const int c = (int)(idx - p * C);
+        const float e = eps[(p / ppi) % B];  // images are time-major: img = t*B + b
+        out[p * ldo + c] = e * a[p * lda + c] + (1.f - e) * b[p * ldb + c];
+    }
+}
+
+extern "C" int wdg_lerp_batch(const float* a, int lda, const float* b_, int ldb, const float* eps, float* out,
+                              int ldo, int64_t P, int64_t pixels_per_img, int B, int C, wdg_stream stream) {
+    WDG_CHECK_ARG(a && b_ && eps && out && pixels_per_img > 0 && B > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_lerp_batch_kernel, dim3(ew_blocks(P * C)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                       b_, ldb, eps, out, ldo, P, pixels_per_img, B, C);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- per-(batch, channel) sum of squares (gradient-penalty norm, gan/ganbase.py:36) -------------
+__global__ void __launch_bounds__(256) wdg_sumsq_batch_ch_kernel(const float* __restrict__ x, int ldx,
+                                                                 int64_t ppi, int T, int B, int C, float* out) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < ppi * T; q += (int64_t)gridDim.x * 256) {
+            const int64_t t = q / ppi, p = q - t * ppi;
+            const float v = x[((t * B + b) * ppi + p) * ldx + c];  // images are time-major
+            s += v * v;
+        }
+        s = wdg_wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&out[b * C + c], red[0] + red[1] + red[2] + red[3]);
+        __syncthreads();
+    }
+}
+
+extern "C" int wdg_sumsq_batch_ch(const float* x, int ldx, int64_t pixels_per_img, int T, int B, int C,
+                                  float* out, wdg_stream stream) {
+    WDG_CHECK_ARG(x && out && B > 0 && T > 0 && C > 0 && C <= 64, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    WDG_HIP(hipMemsetAsync(out, 0, (size_t)B * C * sizeof(float), st));
+    int bx = (int)std::max<int64_t>(1, std::min<int64_t>((pixels_per_img * T + 2047) / 2048, 256));
+    hipLaunchKernelGGL(wdg_sumsq_batch_ch_kernel, dim3(bx, B), dim3(256), 0, st, x, ldx, pixels_per_img, T, B, C,
+                       out);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- mean of squares per parameter segment (gan/ganbase.py:80-81) -------------------------------
+__global__ void __launch_bounds__(256) wdg_segment_meansq_kernel(const float* __restrict__ x,
+                                                                 const int64_t* __restrict__ off, float* out) {
+    __shared__ double red[4];
+    const int s = blockIdx.x;
+    const int64_t b = off[s], e = off[s + 1];
+    double acc = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) acc += (double)x[i] * (double)x[i];
+    acc = wdg_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)(e > b ? e - b : 1));
+}
+
+extern "C" int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out, wdg_stream stream) {
+    WDG_CHECK_ARG(x && off && out && nseg > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_segment_meansq_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, x, off, out);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- Philox4x32-10 (data/data_generator.py:319-335: FlexibleNoiseGenerator) ---------------------
+__device__ __forceinline__ void wdg_philox4x32_10(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ ctr[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ ctr[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        ctr[0] = n0; ctr[1] = n1; ctr[2] = n2; ctr[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+// uniform in (0, 1]: 24 random bits
+__device__ __forceinline__ float wdg_u01(uint32_t x) { return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f); }
+
+__global__ void __launch_bounds__(256) wdg_philox_normal_kernel(float* out, int ldo, const float* __restrict__ add,
+                                                                int lda, int64_t P, int C, uint64_t seed,
+                                                                uint64_t offset, float stdv) {
+    const int64_t total = P * C;
+    const int64_t groups = (total + 3) / 4;
+    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * 256) {
+        const uint64_t cnt = offset + (uint64_t)gi;
+        uint32_t ctr[4] = {(uint32_t)cnt, (uint32_t)(cnt >> 32), 0u, 0u};
+        wdg_philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u0 = wdg_u01(ctr[2 * h]), u1 = wdg_u01(ctr[2 * h + 1]);
+            const float rad = sqrtf(-2.f * logf(u0));
+            const float ang = 6.283185307179586f * u1;
+            z[2 * h] = rad * cosf(ang);
+            z[2 * h + 1] = rad * sinf(ang);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t e = gi * 4 + j;
+            if (e < total) {
+                const int64_t p = e / C;
+                const int c = (int)(e - p * C);
+                float v = stdv * z[j];
+                if (add) v += add[p * lda + c];
+                out[p * ldo + c] = v;
+            }
+        }
+    }
+}
+
+extern "C" int wdg_philox_normal(float* out, int ldo, const float* add, int lda, int64_t P, int C, uint64_t seed,
+                                 uint64_t offset, float std, wdg_stream stream) {
+    WDG_CHECK_ARG(out && P >= 0 && C > 0, "bad argument");
+    if (P == 0) return WDG_OK;
+    hipLaunchKernelGGL(wdg_philox_normal_kernel, dim3(ew_blocks((P * C + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, out, ldo, add, lda, P, C, seed, offset, std);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+__global__ void __launch_bounds__(256) wdg_philox_uniform_kernel(float* out, int64_t n, uint64_t seed,
+                                                                 uint64_t offset) {
+    const int64_t groups = (n + 3) / 4;
+    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * 256) {
+        const uint64_t cnt = offset + (uint64_t)gi;
+        uint32_t ctr[4] = {(uint32_t)cnt, (uint32_t)(cnt >> 32), 0u, 0u};
+        wdg_philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t e = gi * 4 + j;
+            if (e < n) out[e] = (float)(ctr[j] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+        }
+    }
+}
+
+extern "C" int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, wdg_stream stream) {
+    WDG_CHECK_ARG(out && n >= 0, "bad argument");
+    if (n == 0) return WDG_OK;
+    hipLaunchKernelGGL(wdg_philox_uniform_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, out, n, seed, offset);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
