@@ -1,0 +1,345 @@
+"""TEST INFRASTRUCTURE — CPU oracle of the operator interface (never imported by the product).
+
+`TorchOps` mirrors, method for method, `downscaling.engine.hipops.HipOps` (the HIP backend behind
+the C ABI of include/wdgan.h) using stock torch-CPU functional ops, by default in float64.  Each
+method restates the TF/Keras semantics of the reference layer it stands for (citations are to
+/root/reference/src/downscaling; the arithmetic itself lives in tensorflow==2.4.3 /
+tensorflow-addons==0.14.0, which are not vendored in the reference and not installed here):
+
+  Conv2D / Conv2DTranspose / ConvLSTM2D convolutions ....... gan/models.py:33,39,45,49,55,64,70,93-134
+  BatchNormalization (eps 1e-3, momentum .99, biased var) ... gan/models.py:34,40,50,56,69
+  LayerNormalization (axis -1, eps 1e-3) ..................... gan/models.py:97,105,116,125,136
+  LeakyReLU(0.2) as the conv activation ...................... gan/models.py:33 ff.
+  UpSampling2D(2,'bilinear') = half-pixel, edge clamp ........ gan/models.py:62
+  tfa SpectralNormalization, one power iteration ............. gan/models.py:33 ff.
+  Adam in TF form (epsilon outside the bias correction) ...... gan/train.py:34-35,57-58
+
+PARITY UNPINNED: the reference ships no tests, golden vectors or runnable TF, so nothing pins this
+oracle to TensorFlow output; it is pinned only by hand-computed known-answer tests
+(tests/test_oracle_known_answers.py) and by agreement with the independent numpy restatement
+(oracle/np_ops.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+
+
+class PackedWeights:
+    def __init__(self, ops, w):
+        kh, kw, cin, cout = w.shape
+        self.ops, self.w = ops, w
+        self.taps, self.cin, self.cout = kh * kw, cin, cout
+
+    def refresh(self):
+        pass
+
+
+def _lrelu(x, slope):
+    return torch.where(x > 0, x, x * slope)
+
+
+# ---- Philox4x32-10 (Salmon et al. 2011), vectorised over counters -------------------------------
+def philox4x32_10(counter_lo, counter_hi, seed):
+    """counter: uint64 arrays (lo 64 bits used as ctr[0:2]); returns uint32 array [..., 4]."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    c0 = (counter_lo & mask).astype(np.uint64)
+    c1 = (counter_lo >> np.uint64(32)).astype(np.uint64)
+    c2 = np.zeros_like(c0)
+    c3 = np.zeros_like(c0)
+    k0 = np.uint64(seed & 0xFFFFFFFF)
+    k1 = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & mask
+        n3 = p0 & mask
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def philox_normal_np(n, seed, offset):
+    """n standard normals exactly as wdg_philox_normal orders them (Box-Muller on 24-bit uniforms)."""
+    groups = (n + 3) // 4
+    ctr = np.arange(groups, dtype=np.uint64) + np.uint64(offset)
+    r = philox4x32_10(ctr, None, seed).astype(np.uint64)
+    u = ((r >> np.uint64(8)) + np.uint64(1)).astype(np.float64) / 16777216.0  # (0, 1]
+    z = np.empty((groups, 4), dtype=np.float64)
+    for h in range(2):
+        rad = np.sqrt(-2.0 * np.log(u[:, 2 * h]))
+        ang = 2.0 * np.pi * u[:, 2 * h + 1]
+        z[:, 2 * h] = rad * np.cos(ang)
+        z[:, 2 * h + 1] = rad * np.sin(ang)
+    return z.reshape(-1)[:n]
+
+
+def philox_uniform_np(n, seed, offset):
+    groups = (n + 3) // 4
+    ctr = np.arange(groups, dtype=np.uint64) + np.uint64(offset)
+    r = philox4x32_10(ctr, None, seed).astype(np.uint64)
+    return ((r >> np.uint64(8)).astype(np.float64) / 16777216.0).reshape(-1)[:n]
+
+
+class TorchOps:
+    name = "torch-oracle"
+
+    def __init__(self, dtype=torch.float64):
+        self.dtype = dtype
+        self.device = torch.device("cpu")
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def empty(self, *shape):
+        return torch.zeros(*shape, dtype=self.dtype)
+
+    def zeros(self, *shape, dtype=None):
+        if dtype in (torch.int64, torch.int32):
+            return torch.zeros(*shape, dtype=dtype)
+        return torch.zeros(*shape, dtype=self.dtype)  # stats buffers are "fp64" on HIP; oracle dtype here
+
+    def from_host(self, arr):
+        return torch.as_tensor(np.asarray(arr)).to(self.dtype)
+
+    def pack_weights(self, w):
+        return PackedWeights(self, w)
+
+    # ---- convolution family -----------------------------------------------------------------
+    @staticmethod
+    def _oihw(pk):
+        return pk.w.permute(3, 2, 0, 1)
+
+    def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2):
+        xin = x[..., :pk.cin].permute(0, 3, 1, 2)
+        out = F.conv2d(xin, self._oihw(pk), bias, stride=g.stride, padding=g.pad).permute(0, 2, 3, 1)
+        if act:
+            out = _lrelu(out, slope)
+        if accumulate:
+            out = out + y[..., :pk.cout]
+        y[..., :pk.cout] = out
+
+    def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2):
+        H, W = dx.shape[1], dx.shape[2]
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        oph = H - ((Ho - 1) * g.stride - 2 * g.pad + g.kh)
+        opw = W - ((Wo - 1) * g.stride - 2 * g.pad + g.kw)
+        out = F.conv_transpose2d(dy[..., :pk.cout].permute(0, 3, 1, 2), self._oihw(pk), bias, stride=g.stride,
+                                 padding=g.pad, output_padding=(oph, opw)).permute(0, 2, 3, 1)
+        if act:
+            out = _lrelu(out, slope)
+        if accumulate:
+            out = out + dx[..., :pk.cin]
+        dx[..., :pk.cin] = out
+
+    def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True):
+        xin = x[..., :pk.cin].permute(0, 3, 1, 2).contiguous()
+        gout = dy[..., :pk.cout].permute(0, 3, 1, 2).contiguous()
+        gw = torch.nn.grad.conv2d_weight(xin, (pk.cout, pk.cin, g.kh, g.kw), gout, stride=g.stride, padding=g.pad)
+        gw = gw.permute(2, 3, 1, 0)
+        if accumulate:
+            dw += gw
+        else:
+            dw.copy_(gw)
+
+    def sn_power_iter(self, w2d, u):
+        # tfa.layers.SpectralNormalization.normalize_weights, power_iterations=1
+        def l2n(v):
+            return v * torch.rsqrt(torch.clamp((v * v).sum(), min=1e-12))
+        uu = u.reshape(1, -1)
+        v = l2n(uu @ w2d.t())
+        un = l2n(v @ w2d)
+        sigma = (v @ w2d @ un.t()).reshape(())
+        w2d.div_(sigma)
+        u.copy_(un.reshape(-1))
+
+    # ---- batch norm -------------------------------------------------------------------------
+    def bn_stats(self, x, stats):
+        C = x.shape[1]
+        stats[:C] += x.sum(0).to(stats.dtype)
+        stats[C:] += (x * x).sum(0).to(stats.dtype)
+
+    def bn_finalize_train(self, stats, count, gamma, beta, mmean, mvar, momentum, eps, ss, saved):
+        C = gamma.numel()
+        mean = stats[:C] / count
+        var = torch.clamp(stats[C:] / count - mean * mean, min=0)
+        inv = 1.0 / torch.sqrt(var + eps)
+        ss[:C] = gamma * inv
+        ss[C:] = beta - mean * gamma * inv
+        saved[:C] = mean
+        saved[C:] = inv
+        mmean.mul_(momentum).add_(mean * (1 - momentum))
+        mvar.mul_(momentum).add_(var * (1 - momentum))
+
+    def bn_finalize_infer(self, gamma, beta, mmean, mvar, eps, ss):
+        C = gamma.numel()
+        inv = 1.0 / torch.sqrt(mvar + eps)
+        ss[:C] = gamma * inv
+        ss[C:] = beta - mmean * gamma * inv
+
+    def bn_apply(self, x, ss, z):
+        C = x.shape[1]
+        z.copy_(x * ss[:C] + ss[C:])
+
+    def bn_bwd_reduce(self, dz, y, saved, red):
+        C = dz.shape[1]
+        xh = (y - saved[:C]) * saved[C:]
+        red[:C] += dz.sum(0)
+        red[C:] += (dz * xh).sum(0)
+
+    def bn_bwd_apply(self, dz, y, saved, gamma, red_mean, red_param, count, act_slope, dpre, dgamma, dbeta, dbias):
+        C = dz.shape[1]
+        xh = (y - saved[:C]) * saved[C:]
+        d = gamma * saved[C:] * (dz - red_mean[:C] / count - xh * (red_mean[C:] / count))
+        if act_slope >= 0:
+            d = d * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, act_slope))
+        dpre.copy_(d)
+        if dbias is not None:
+            dbias += d.sum(0)
+        if red_param is not None:
+            if dgamma is not None:
+                dgamma += red_param[C:]
+            if dbeta is not None:
+                dbeta += red_param[:C]
+
+    # ---- layer norm -------------------------------------------------------------------------
+    def ln_fwd(self, y, gamma, beta, eps, z, mean_rstd):
+        C = y.shape[1]
+        z.copy_(F.layer_norm(y.contiguous(), (C,), gamma, beta, eps))
+        if mean_rstd is not None:
+            mean = y.mean(1)
+            var = y.var(1, unbiased=False)
+            mean_rstd[:, 0] = mean
+            mean_rstd[:, 1] = 1.0 / torch.sqrt(var + eps)
+
+    def ln_bwd(self, dz, y, mean_rstd, gamma, act_slope, dpre, dgamma, dbeta, dbias):
+        xh = (y - mean_rstd[:, 0:1]) * mean_rstd[:, 1:2]
+        g = dz * gamma
+        d = mean_rstd[:, 1:2] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+        if act_slope >= 0:
+            d = d * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, act_slope))
+        dpre.copy_(d)
+        if dgamma is not None:
+            dgamma += (dz * xh).sum(0)
+        if dbeta is not None:
+            dbeta += dz.sum(0)
+        if dbias is not None:
+            dbias += d.sum(0)
+
+    # ---- ConvLSTM cell: Keras gate order i,f,c,o; hard_sigmoid = clip(.2x+.5,0,1) ------------
+    @staticmethod
+    def _hs(x):
+        return torch.clamp(0.2 * x + 0.5, 0, 1)
+
+    @staticmethod
+    def _hs_grad(x):
+        v = 0.2 * x + 0.5
+        return torch.where((v >= 0) & (v <= 1), torch.full_like(x, 0.2), torch.zeros_like(x))
+
+    def lstm_fwd(self, gates, c_prev, c, h, F_):
+        gi, gf = self._hs(gates[:, :F_]), self._hs(gates[:, F_:2 * F_])
+        gc, go = torch.tanh(gates[:, 2 * F_:3 * F_]), self._hs(gates[:, 3 * F_:4 * F_])
+        cn = gi * gc
+        if c_prev is not None:
+            cn = cn + gf * c_prev[:, :F_]
+        c[:, :F_] = cn
+        h[:, :F_] = go * torch.tanh(cn)
+
+    def lstm_bwd(self, gates, c_prev, c, dh, dc_in, dgates, dc_prev, F_):
+        xi, xf, xc, xo = (gates[:, k * F_:(k + 1) * F_] for k in range(4))
+        gi, gf, gc, go = self._hs(xi), self._hs(xf), torch.tanh(xc), self._hs(xo)
+        cp = c_prev[:, :F_] if c_prev is not None else torch.zeros_like(gi)
+        tc = torch.tanh(c[:, :F_])
+        dhv = dh[:, :F_]
+        dc = dhv * go * (1 - tc * tc)
+        if dc_in is not None:
+            dc = dc + dc_in[:, :F_]
+        dgates[:, :F_] = dc * gc * self._hs_grad(xi)
+        dgates[:, F_:2 * F_] = dc * cp * self._hs_grad(xf)
+        dgates[:, 2 * F_:3 * F_] = dc * gi * (1 - gc * gc)
+        dgates[:, 3 * F_:4 * F_] = dhv * tc * self._hs_grad(xo)
+        if dc_prev is not None:
+            dc_prev[:, :F_] = dc * gf
+
+    # ---- resampling / head ------------------------------------------------------------------
+    def upsample2x_fwd(self, x, y):
+        out = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+        y.copy_(out.permute(0, 2, 3, 1))
+
+    def upsample2x_bwd(self, dy, dx, accumulate=False):
+        xin = torch.zeros(dx.shape, dtype=dy.dtype).permute(0, 3, 1, 2).requires_grad_(True)
+        out = F.interpolate(xin, scale_factor=2, mode="bilinear", align_corners=False)
+        (gx,) = torch.autograd.grad(out, xin, dy.permute(0, 3, 1, 2))
+        gx = gx.permute(0, 2, 3, 1)
+        if accumulate:
+            dx += gx
+        else:
+            dx.copy_(gx)
+
+    def dense_gap_fwd(self, x, w, b, score, B, T):
+        s = (x @ w + b[0]).reshape(T, B)  # rows are time-major
+        score.copy_(s.mean(0))
+
+    def dense_gap_bwd(self, x, w, dscore, dx, dw, db, B, T):
+        drow = (dscore.reshape(1, B) / T).expand(T, B).reshape(-1)
+        if dx is not None:
+            dx.copy_(drow[:, None] * w[None, :])
+        if dw is not None:
+            dw += x.t() @ drow
+        if db is not None:
+            db += dscore.sum()
+
+    # ---- elementwise / reductions -----------------------------------------------------------
+    def copy_channels(self, src, dst, accumulate=False):
+        if accumulate:
+            dst += src
+        else:
+            dst.copy_(src)
+
+    def colsum(self, x, out, accumulate=True):
+        if accumulate:
+            out += x.sum(0)
+        else:
+            out.copy_(x.sum(0))
+
+    def lerp_batch(self, a, b, eps, out, pixels_per_img, B):
+        P = a.shape[0]
+        bi = (torch.arange(P) // pixels_per_img) % B
+        e = eps[bi][:, None]
+        out.copy_(e * a + (1 - e) * b)
+
+    def sumsq_batch_ch(self, x, pixels_per_img, T, B, out):
+        Cc = x.shape[1]
+        out.copy_((x * x).reshape(T, B, pixels_per_img, Cc).sum((0, 2)))
+
+    def segment_meansq(self, flat, offsets, out):
+        for i in range(out.numel()):
+            seg = flat[int(offsets[i]):int(offsets[i + 1])]
+            out[i] = (seg * seg).mean()
+
+    def philox_normal(self, out, seed, offset, std, add=None):
+        P, Cc = out.shape
+        z = torch.from_numpy(philox_normal_np(P * Cc, seed, offset)).to(self.dtype).reshape(P, Cc)
+        out.copy_(std * z if add is None else add + std * z)
+
+    def philox_uniform(self, out, seed, offset):
+        out.copy_(torch.from_numpy(philox_uniform_np(out.numel(), seed, offset)).to(self.dtype).reshape(out.shape))
+
+    def adam_tf(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
+        gg = g * grad_scale
+        m += (1 - beta1) * (gg - m)
+        v += (1 - beta2) * (gg * gg - v)
+        p -= lr_t * m / (torch.sqrt(v) + eps)

@@ -1,0 +1,308 @@
+"""Operator parity on the GPU: every entry point of libwdgan.so (through the C ABI / HipOps) against
+the float64 CPU oracle (oracle/torch_backend.py) on identical seeded inputs.
+
+Tolerance: the HIP path computes in exact fp32 (v_mfma_f32_16x16x4_f32 is an fp32 fma chain), so the
+only difference to the fp64 oracle is fp32 rounding: max|err| <= 2e-5 * max|ref| (K up to 12,544),
+far inside the 1e-4 relative target of BASELINE.json.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def both(hip_ops, t64):
+    """float64 CPU tensor -> (cpu64, gpu32) pair."""
+    return t64, t64.float().to(hip_ops.device)
+
+
+CONV_CASES = [
+    # name, n, H, W, cin, cout, k, s, p
+    ("g5_3x3", 2, 16, 16, 128, 64, 3, 1, 1),
+    ("g0_8x8s2_cin23", 2, 32, 32, 23, 128, 8, 2, 3),
+    ("g2_4x4s2", 2, 16, 16, 128, 128, 4, 2, 1),
+    ("d_7x7s3", 3, 20, 20, 32, 64, 7, 3, 1),
+    ("d_7x7s3_odd", 2, 27, 27, 64, 128, 7, 3, 1),
+    ("d_3x3s2_valid", 4, 3, 3, 256, 512, 3, 2, 0),
+    ("lstm_2to8", 2, 24, 24, 2, 8, 3, 1, 1),
+    ("lstm_5to64", 2, 24, 24, 5, 64, 3, 1, 1),
+    ("out_16to2", 2, 24, 24, 16, 2, 3, 1, 1),
+    ("convT2x2_as_conv", 2, 16, 16, 32, 192, 2, 2, 0),
+    ("convT5x5_as_conv", 2, 16, 16, 16, 160, 5, 1, 2),
+    ("multi_tile", 4, 64, 64, 128, 128, 3, 1, 1),
+    ("splitk_7x7_small_m", 8, 8, 8, 256, 512, 7, 3, 1),
+    ("gates_128to512", 2, 16, 16, 128, 512, 3, 1, 1),
+]
+
+
+def _mk(case, seed=0):
+    name, n, H, W, cin, cout, k, s, p = case
+    g = torch.Generator().manual_seed(seed)
+    Ho = (H + 2 * p - k) // s + 1
+    Wo = (W + 2 * p - k) // s + 1
+    cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    x = torch.zeros(n, H, W, cin_p, dtype=torch.float64)
+    x[..., :cin] = torch.randn(n, H, W, cin, generator=g, dtype=torch.float64)
+    dy = torch.zeros(n, Ho, Wo, cout_p, dtype=torch.float64)
+    dy[..., :cout] = torch.randn(n, Ho, Wo, cout, generator=g, dtype=torch.float64)
+    w = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) * 0.05
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    return dict(n=n, H=H, W=W, Ho=Ho, Wo=Wo, cin=cin, cout=cout, cin_p=cin_p, cout_p=cout_p, k=k, s=s, p=p,
+                x=x, dy=dy, w=w, b=b)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, hip_ops, ref_ops):
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    d = _mk(case)
+    g, rg = ConvGeom(d["k"], d["k"], d["s"], d["p"]), RG(d["k"], d["k"], d["s"], d["p"])
+    dev = hip_ops.device
+    w_g = d["w"].float().to(dev).contiguous()
+    pk_g, pk_r = hip_ops.pack_weights(w_g), ref_ops.pack_weights(d["w"])
+    x_g, dy_g, b_g = d["x"].float().to(dev), d["dy"].float().to(dev), d["b"].float().to(dev)
+
+    # forward: bias + LeakyReLU, then accumulate on top of a non-zero output
+    y_r = torch.zeros(d["n"], d["Ho"], d["Wo"], d["cout_p"], dtype=torch.float64)
+    y_g = torch.zeros_like(y_r, dtype=torch.float32, device=dev)
+    ref_ops.conv_fwd(d["x"], pk_r, d["b"], y_r, rg, act=True)
+    hip_ops.conv_fwd(x_g, pk_g, b_g, y_g, g, act=True)
+    assert rel_err(y_g, y_r) < TOL, "fwd"
+    if d["cout_p"] != d["cout"]:
+        assert float(y_g[..., d["cout"]:].abs().max()) == 0.0, "pad channels must stay zero"
+    ref_ops.conv_fwd(d["x"], pk_r, None, y_r, rg, act=False, accumulate=True)
+    hip_ops.conv_fwd(x_g, pk_g, None, y_g, g, act=False, accumulate=True)
+    assert rel_err(y_g, y_r) < TOL, "fwd accumulate"
+
+    # data gradient (also the Conv2DTranspose forward when bias/act are given)
+    dx_r = torch.zeros(d["n"], d["H"], d["W"], d["cin_p"], dtype=torch.float64)
+    dx_g = torch.zeros_like(dx_r, dtype=torch.float32, device=dev)
+    ref_ops.conv_dgrad(d["dy"], pk_r, dx_r, rg)
+    hip_ops.conv_dgrad(dy_g, pk_g, dx_g, g)
+    assert rel_err(dx_g, dx_r) < TOL, "dgrad"
+    bi_r = torch.linspace(-1, 1, d["cin"], dtype=torch.float64)
+    ref_ops.conv_dgrad(d["dy"], pk_r, dx_r, rg, bias=bi_r, act=True, accumulate=True)
+    hip_ops.conv_dgrad(dy_g, pk_g, dx_g, g, bias=bi_r.float().to(dev), act=True, accumulate=True)
+    assert rel_err(dx_g, dx_r) < TOL, "dgrad bias/act/accumulate"
+
+    # weight gradient, overwrite then accumulate
+    dw_r = torch.zeros_like(d["w"])
+    dw_g = torch.full_like(w_g, 7.0)
+    ref_ops.conv_wgrad(d["x"], d["dy"], pk_r, dw_r, rg, accumulate=False)
+    hip_ops.conv_wgrad(x_g, dy_g, pk_g, dw_g, g, accumulate=False)
+    assert rel_err(dw_g, dw_r) < TOL, "wgrad"
+    ref_ops.conv_wgrad(d["x"], d["dy"], pk_r, dw_r, rg, accumulate=True)
+    hip_ops.conv_wgrad(x_g, dy_g, pk_g, dw_g, g, accumulate=True)
+    assert rel_err(dw_g, dw_r) < TOL, "wgrad accumulate"
+
+
+def test_conv_on_concat_and_time_views(hip_ops, ref_ops):
+    """Zero-copy channel concat (ld > C, channel offset) and time-sliced image stride."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    g, rg = ConvGeom(3, 3, 1, 1), RG(3, 3, 1, 1)
+    gen = torch.Generator().manual_seed(5)
+    dev = hip_ops.device
+    buf = torch.randn(2, 3, 12, 12, 192, generator=gen, dtype=torch.float64)  # [B,T,H,W,C]
+    w = torch.randn(3, 3, 128, 32, generator=gen, dtype=torch.float64) * 0.05
+    buf_g = buf.float().to(dev)
+    x_r, x_g = buf[:, 1, :, :, 64:192], buf_g[:, 1, :, :, 64:192]
+    out = torch.zeros(2, 12, 12, 64, dtype=torch.float64)
+    out_g = out.float().to(dev)
+    pk_r, pk_g = ref_ops.pack_weights(w), hip_ops.pack_weights(w.float().to(dev).contiguous())
+    ref_ops.conv_fwd(x_r, pk_r, None, out[..., 32:64], rg)
+    hip_ops.conv_fwd(x_g, pk_g, None, out_g[..., 32:64], g)
+    assert rel_err(out_g, out) < TOL
+    assert float(out_g[..., :32].abs().max()) == 0.0
+    # dgrad accumulating into the strided concat view
+    ref_ops.conv_dgrad(out[..., 32:64], pk_r, x_r, rg, accumulate=True)
+    hip_ops.conv_dgrad(out_g[..., 32:64], pk_g, x_g, g, accumulate=True)
+    assert rel_err(buf_g, buf) < TOL
+
+
+def test_sn_power_iter(hip_ops, ref_ops):
+    gen = torch.Generator().manual_seed(1)
+    for rows, cols in [(8 * 8 * 23, 128), (7 * 7 * 256, 512), (18, 16), (2 * 2 * 32, 192)]:
+        w = torch.randn(rows, cols, generator=gen, dtype=torch.float64) * 0.05
+        u = torch.randn(cols, generator=gen, dtype=torch.float64) * 0.02
+        w_g, u_g = w.float().to(hip_ops.device), u.float().to(hip_ops.device)
+        ref_ops.sn_power_iter(w, u)
+        hip_ops.sn_power_iter(w_g, u_g)
+        assert rel_err(w_g, w) < TOL and rel_err(u_g, u) < TOL, (rows, cols)
+
+
+@pytest.mark.parametrize("C,P", [(128, 5000), (64, 777), (32, 4096), (16, 70000)])
+def test_batchnorm(C, P, hip_ops, ref_ops):
+    gen = torch.Generator().manual_seed(2)
+    dev = hip_ops.device
+    y = torch.randn(P, C, generator=gen, dtype=torch.float64) * 1.5 + 0.3
+    dz = torch.randn(P, C, generator=gen, dtype=torch.float64)
+    gamma = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=gen, dtype=torch.float64)
+    res = {}
+    for name, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev))):
+        yy, dzz, ga, be = cv(y), cv(dz), cv(gamma), cv(beta)
+        stats = ops.zeros(2 * C, dtype=torch.float64)
+        mm, mv = cv(torch.zeros(C, dtype=torch.float64)), cv(torch.ones(C, dtype=torch.float64))
+        ss, saved = ops.empty(2 * C), ops.empty(2 * C)
+        ops.bn_stats(yy, stats)
+        ops.bn_finalize_train(stats, P, ga, be, mm, mv, 0.99, 1e-3, ss, saved)
+        z = ops.empty(P, C)
+        ops.bn_apply(yy, ss, z)
+        red = ops.zeros(2 * C, dtype=torch.float64)
+        ops.bn_bwd_reduce(dzz, yy, saved, red)
+        dpre = ops.empty(P, C)
+        dg, db, dbias = cv(torch.zeros(C, dtype=torch.float64)), cv(torch.zeros(C, dtype=torch.float64)), cv(torch.zeros(C, dtype=torch.float64))
+        ops.bn_bwd_apply(dzz, yy, saved, ga, red, red, P, 0.2, dpre, dg, db, dbias)
+        ss2 = ops.empty(2 * C)
+        ops.bn_finalize_infer(ga, be, mm, mv, 1e-3, ss2)
+        res[name] = dict(z=z, mm=mm, mv=mv, dpre=dpre, dg=dg, db=db, dbias=dbias, ss2=ss2)
+    # independent check of the oracle itself against torch's batch_norm
+    zz = torch.nn.functional.batch_norm(y.t()[None], None, None, gamma, beta, True, 0.0, 1e-3)[0].t()
+    assert rel_err(res["ref"]["z"], zz) < 1e-12
+    for k in res["ref"]:
+        assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+
+
+@pytest.mark.parametrize("C,P", [(16, 5000), (32, 1234), (64, 999), (128, 500), (256, 130), (512, 77)])
+def test_layernorm(C, P, hip_ops, ref_ops):
+    gen = torch.Generator().manual_seed(3)
+    dev = hip_ops.device
+    y = torch.randn(P, C, generator=gen, dtype=torch.float64) * 2 + 0.5
+    dz = torch.randn(P, C, generator=gen, dtype=torch.float64)
+    gamma = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=gen, dtype=torch.float64)
+    res = {}
+    for name, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev))):
+        yy, dzz, ga, be = cv(y), cv(dz), cv(gamma), cv(beta)
+        z, mr, dpre = ops.empty(P, C), ops.empty(P, 2), ops.empty(P, C)
+        ops.ln_fwd(yy, ga, be, 1e-3, z, mr)
+        dg, db, dbias = (cv(torch.zeros(C, dtype=torch.float64)) for _ in range(3))
+        ops.ln_bwd(dzz, yy, mr, ga, 0.2, dpre, dg, db, dbias)
+        res[name] = dict(z=z, dpre=dpre, dg=dg, db=db, dbias=dbias)
+    for k in res["ref"]:
+        assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+
+
+@pytest.mark.parametrize("F_,P", [(128, 3000), (2, 5000), (16, 4097)])
+def test_lstm_cell(F_, P, hip_ops, ref_ops):
+    gen = torch.Generator().manual_seed(4)
+    dev = hip_ops.device
+    Fp = (F_ + 3) // 4 * 4
+    gates = torch.randn(P, 4 * F_, generator=gen, dtype=torch.float64) * 2.5
+    cprev = torch.randn(P, F_, generator=gen, dtype=torch.float64)
+    dh = torch.randn(P, Fp, generator=gen, dtype=torch.float64)
+    dcin = torch.randn(P, F_, generator=gen, dtype=torch.float64)
+    for use_prev in (True, False):
+        res = {}
+        for name, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev))):
+            g_, cp, dh_, dci = cv(gates), (cv(cprev) if use_prev else None), cv(dh), (cv(dcin) if use_prev else None)
+            c, h = ops.empty(P, F_), ops.zeros(P, Fp)
+            ops.lstm_fwd(g_, cp, c, h, F_)
+            dg = ops.empty(P, 4 * F_)
+            dcp = ops.empty(P, F_) if use_prev else None
+            ops.lstm_bwd(g_, cp, c, dh_, dci, dg, dcp, F_)
+            res[name] = dict(c=c, h=h, dg=dg)
+            if use_prev:
+                res[name]["dcp"] = dcp
+        for k in res["ref"]:
+            assert rel_err(res["hip"][k], res["ref"][k]) < TOL, (k, use_prev)
+
+
+def test_upsample_dense_misc(hip_ops, ref_ops):
+    gen = torch.Generator().manual_seed(6)
+    dev = hip_ops.device
+    cv = lambda t: t.float().to(dev)
+    # bilinear x2 forward + adjoint
+    x = torch.randn(2, 7, 9, 160, generator=gen, dtype=torch.float64)
+    dy = torch.randn(2, 14, 18, 160, generator=gen, dtype=torch.float64)
+    y_r, y_g = torch.zeros(2, 14, 18, 160, dtype=torch.float64), hip_ops.empty(2, 14, 18, 160)
+    ref_ops.upsample2x_fwd(x, y_r)
+    hip_ops.upsample2x_fwd(cv(x), y_g)
+    assert rel_err(y_g, y_r) < TOL
+    dx_r, dx_g = torch.ones_like(x), cv(torch.ones_like(x))
+    ref_ops.upsample2x_bwd(dy, dx_r, accumulate=True)
+    hip_ops.upsample2x_bwd(cv(dy), dx_g, accumulate=True)
+    assert rel_err(dx_g, dx_r) < TOL
+    # dense + GAP (time-major rows)
+    B, T, K = 5, 3, 2048
+    xr = torch.randn(T * B, K, generator=gen, dtype=torch.float64)
+    w = torch.randn(K, generator=gen, dtype=torch.float64) * 0.05
+    b = torch.randn(1, generator=gen, dtype=torch.float64)
+    ds = torch.randn(B, generator=gen, dtype=torch.float64)
+    s_r, s_g = torch.zeros(B, dtype=torch.float64), hip_ops.empty(B)
+    ref_ops.dense_gap_fwd(xr, w, b, s_r, B, T)
+    hip_ops.dense_gap_fwd(cv(xr), cv(w), cv(b), s_g, B, T)
+    assert rel_err(s_g, s_r) < TOL
+    dxr, dwr, dbr = torch.zeros_like(xr), torch.ones_like(w), torch.ones(1, dtype=torch.float64)
+    dxg, dwg, dbg = hip_ops.empty(T * B, K), cv(torch.ones_like(w)), cv(torch.ones(1, dtype=torch.float64))
+    ref_ops.dense_gap_bwd(xr, w, ds, dxr, dwr, dbr, B, T)
+    hip_ops.dense_gap_bwd(cv(xr), cv(w), cv(ds), dxg, dwg, dbg, B, T)
+    assert rel_err(dxg, dxr) < TOL and rel_err(dwg, dwr) < TOL and rel_err(dbg, dbr) < TOL
+    # channel pack with image permutation, colsum, lerp, sumsq, segment mean-square, adam
+    src = torch.randn(4, 6, 6, 3, generator=gen, dtype=torch.float64)
+    dst_r, dst_g = torch.zeros(4, 6, 6, 8, dtype=torch.float64), hip_ops.zeros(4, 6, 6, 8)
+    ref_ops.copy_channels(src, dst_r[..., 0:3])
+    hip_ops.copy_channels(cv(src), dst_g[..., 0:3])
+    ref_ops.copy_channels(src[..., :2], dst_r[..., 3:5], accumulate=True)
+    hip_ops.copy_channels(cv(src)[..., :2], dst_g[..., 3:5], accumulate=True)
+    assert rel_err(dst_g, dst_r) < 1e-7
+    bt = torch.randn(2, 3, 5, 5, 4, generator=gen, dtype=torch.float64)  # [B,T,...] -> time-major
+    tm_r, tm_g = torch.zeros(3, 2, 5, 5, 4, dtype=torch.float64), hip_ops.zeros(3, 2, 5, 5, 4)
+    for t in range(3):
+        ref_ops.copy_channels(bt[:, t], tm_r[t])
+        hip_ops.copy_channels(cv(bt)[:, t], tm_g[t])
+    assert rel_err(tm_g, bt.transpose(0, 1)) < 1e-7
+    xx = torch.randn(3000, 512, generator=gen, dtype=torch.float64)
+    o_r, o_g = torch.ones(512, dtype=torch.float64), cv(torch.ones(512, dtype=torch.float64))
+    ref_ops.colsum(xx, o_r, accumulate=True)
+    hip_ops.colsum(cv(xx), o_g, accumulate=True)
+    assert rel_err(o_g, o_r) < TOL
+    Tt, Bb, ppi = 2, 3, 50
+    a, bb = torch.randn(Tt * Bb * ppi, 4, generator=gen, dtype=torch.float64), torch.randn(Tt * Bb * ppi, 4, generator=gen, dtype=torch.float64)
+    eps = torch.rand(Bb, generator=gen, dtype=torch.float64)
+    l_r, l_g = torch.zeros_like(a), hip_ops.empty(*a.shape)
+    ref_ops.lerp_batch(a, bb, eps, l_r, ppi, Bb)
+    hip_ops.lerp_batch(cv(a), cv(bb), cv(eps), l_g, ppi, Bb)
+    assert rel_err(l_g, l_r) < 1e-6
+    q_r, q_g = torch.zeros(Bb, 4, dtype=torch.float64), hip_ops.empty(Bb, 4)
+    ref_ops.sumsq_batch_ch(a, ppi, Tt, Bb, q_r)
+    hip_ops.sumsq_batch_ch(cv(a), ppi, Tt, Bb, q_g)
+    assert rel_err(q_g, q_r) < TOL
+    flat = torch.randn(10000, generator=gen, dtype=torch.float64)
+    off = torch.tensor([0, 10, 5000, 10000], dtype=torch.int64)
+    m_r, m_g = torch.zeros(3, dtype=torch.float64), hip_ops.empty(3)
+    ref_ops.segment_meansq(flat, off, m_r)
+    hip_ops.segment_meansq(cv(flat), off.to(dev), m_g)
+    assert rel_err(m_g, m_r) < TOL
+    p, gr = torch.randn(5000, generator=gen, dtype=torch.float64), torch.randn(5000, generator=gen, dtype=torch.float64) * 0.01
+    m, v = torch.zeros(5000, dtype=torch.float64), torch.zeros(5000, dtype=torch.float64)
+    pg, mg, vg, gg = cv(p), cv(m), cv(v), cv(gr)
+    for step in (1, 2, 3):
+        lr_t = 1e-4 * np.sqrt(1 - 0.9 ** step) / (1 - 0.5 ** step)
+        ref_ops.adam_tf(p, gr, m, v, lr_t, 0.5, 0.9, 0.1, 0.5)
+        hip_ops.adam_tf(pg, gg, mg, vg, lr_t, 0.5, 0.9, 0.1, 0.5)
+    assert rel_err(pg, p) < 1e-6 and rel_err(mg, m) < 1e-5 and rel_err(vg, v) < 1e-5
+
+
+def test_philox_noise(hip_ops, ref_ops):
+    """Bitstream parity with the numpy Philox4x32-10 restatement; logf/cosf ulps only."""
+    dev = hip_ops.device
+    out_r, out_g = torch.zeros(1001, 20, dtype=torch.float64), hip_ops.zeros(1001, 24)
+    ref_ops.philox_normal(out_r, 1234567, 77, 0.1)
+    hip_ops.philox_normal(out_g[:, :20], 1234567, 77, 0.1)
+    assert float((out_g[:, :20].double().cpu() - out_r).abs().max()) < 1e-6
+    assert float(out_g[:, 20:].abs().max()) == 0.0
+    assert abs(float(out_g[:, :20].std()) - 0.1) < 2e-3
+    u_r, u_g = torch.zeros(37, dtype=torch.float64), hip_ops.empty(37)
+    ref_ops.philox_uniform(u_r, 99, 5)
+    hip_ops.philox_uniform(u_g, 99, 5)
+    assert float((u_g.double().cpu() - u_r).abs().max()) == 0.0

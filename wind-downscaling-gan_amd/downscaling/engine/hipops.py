@@ -1,0 +1,279 @@
+"""HIP operator backend: thin typed wrappers over libwdgan.so for torch (ROCm) tensors.
+
+PyTorch is used for device memory, streams and tensor views only; every arithmetic op below is a
+hand-written gfx950 kernel reached through the C ABI (include/wdgan.h).  All activation tensors are
+channels-last fp32 views with unit channel stride; 4-D views are (n_img, H, W, C), 2-D views (P, C).
+"""
+import ctypes as C
+import torch
+
+from . import native
+from .common import ConvGeom  # noqa: F401  (re-exported)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _v2(t):
+    """(ptr, ld) of a 2-D [P, C] view with unit channel stride."""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    return t.data_ptr(), ld
+
+
+def _v4(t):
+    """(ptr, ld, img_stride) of a 4-D [N, H, W, C] view: dense over (H, W) with pixel stride ld."""
+    assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1), (t.shape, t.stride())
+    n, h, w, c = t.shape
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else max(c, t.stride(2)))
+    if h > 1:
+        assert t.stride(1) == w * ld, (t.shape, t.stride())
+    isx = t.stride(0) if n > 1 else h * w * ld
+    return t.data_ptr(), ld, isx
+
+
+class PackedWeights:
+    """Master HWIO weights (a view into the flat parameter buffer) + the two kernel layouts."""
+
+    def __init__(self, ops, w):
+        kh, kw, cin, cout = w.shape
+        self.ops, self.w = ops, w
+        self.taps, self.cin, self.cout = kh * kw, cin, cout
+        cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+        self.wF = torch.empty(cout * self.taps * cin_p, dtype=torch.float32, device=w.device)
+        self.wD = w if cout % 4 == 0 else torch.empty(self.taps * cin * cout_p, dtype=torch.float32, device=w.device)
+        self.refresh()
+
+    def refresh(self):
+        lib = self.ops.lib
+        native.check(lib.wdg_weight_pack(self.w.data_ptr(), self.wF.data_ptr(),
+                                         0 if self.wD is self.w else self.wD.data_ptr(),
+                                         self.taps, self.cin, self.cout, self.ops.stream), "weight_pack")
+
+
+class HipOps:
+    name = "hip"
+    dtype = torch.float32
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise native.NativeError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                     "there is no CPU execution path in this package")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self.lib = native.load()
+        self._plans = {}
+        self._ws = None
+        self._sn_scratch = None
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def from_host(self, arr):
+        return torch.as_tensor(arr, dtype=torch.float32).to(self.device)
+
+    def pack_weights(self, w):
+        return PackedWeights(self, w)
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _plan(self, x, y, cin, cout, g: ConvGeom):
+        px, ldx, isx = _v4(x)
+        py, ldy, isy = _v4(y)
+        n, H, W, _ = x.shape
+        _, Ho, Wo, _ = y.shape
+        key = (n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad)
+        plan = self._plans.get(key)
+        if plan is None:
+            geom = native.ConvGeom(n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad, g.pad)
+            handle = C.c_void_p()
+            native.check(self.lib.wdg_conv_plan_create(C.byref(handle), C.byref(geom)), f"plan_create{key}")
+            plan = (handle, int(self.lib.wdg_conv_ws_bytes(handle)))
+            self._plans[key] = plan
+        return plan
+
+    # ---- convolution family -----------------------------------------------------------------
+    def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2):
+        """y = act(conv(x, W) + bias) (+ y);  x:(N,H,W,>=Cin) y:(N,Ho,Wo,>=Cout)."""
+        plan, wsb = self._plan(x, y, pk.cin, pk.cout, g)
+        ws = self._workspace(wsb)
+        native.check(self.lib.wdg_conv_fwd(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(),
+                                           int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
+                                           self.stream), "conv_fwd")
+
+    def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2):
+        """dx = act(conv_transpose(dy, W) + bias) (+ dx);  the geometry is that of the forward conv."""
+        plan, wsb = self._plan(dx, dy, pk.cin, pk.cout, g)
+        ws = self._workspace(wsb)
+        native.check(self.lib.wdg_conv_dgrad(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(),
+                                             int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
+                                             self.stream), "conv_dgrad")
+
+    def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True):
+        """dw[kh,kw,Cin,Cout] (+)= x (*) dy."""
+        plan, wsb = self._plan(x, dy, pk.cin, pk.cout, g)
+        ws = self._workspace(wsb)
+        assert dw.is_contiguous()
+        native.check(self.lib.wdg_conv_wgrad(plan, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),
+                                             ws.data_ptr(), ws.numel(), self.stream), "conv_wgrad")
+
+    def sn_power_iter(self, w2d, u):
+        rows, cols = w2d.shape
+        assert w2d.is_contiguous() and u.numel() == cols
+        need = int(self.lib.wdg_sn_scratch_floats(rows, cols))
+        if self._sn_scratch is None or self._sn_scratch.numel() < need:
+            self._sn_scratch = self.empty(max(need, 1 << 16))
+        native.check(self.lib.wdg_sn_power_iter(w2d.data_ptr(), u.data_ptr(), rows, cols,
+                                                self._sn_scratch.data_ptr(), self.stream), "sn_power_iter")
+
+    # ---- batch norm -------------------------------------------------------------------------
+    def bn_stats(self, x, stats):
+        px, ld = _v2(x)
+        native.check(self.lib.wdg_bn_stats(px, x.shape[0], x.shape[1], ld, stats.data_ptr(), self.stream), "bn_stats")
+
+    def bn_finalize_train(self, stats, count, gamma, beta, mmean, mvar, momentum, eps, ss, saved):
+        native.check(self.lib.wdg_bn_finalize_train(stats.data_ptr(), float(count), gamma.data_ptr(), beta.data_ptr(),
+                                                    mmean.data_ptr(), mvar.data_ptr(), momentum, eps, ss.data_ptr(),
+                                                    saved.data_ptr(), gamma.numel(), self.stream), "bn_finalize_train")
+
+    def bn_finalize_infer(self, gamma, beta, mmean, mvar, eps, ss):
+        native.check(self.lib.wdg_bn_finalize_infer(gamma.data_ptr(), beta.data_ptr(), mmean.data_ptr(),
+                                                    mvar.data_ptr(), eps, ss.data_ptr(), gamma.numel(),
+                                                    self.stream), "bn_finalize_infer")
+
+    def bn_apply(self, x, ss, z):
+        px, ldx = _v2(x)
+        pz, ldz = _v2(z)
+        native.check(self.lib.wdg_bn_apply(px, ldx, ss.data_ptr(), pz, ldz, x.shape[0], x.shape[1], self.stream), "bn_apply")
+
+    def bn_bwd_reduce(self, dz, y, saved, red):
+        pdz, lddz = _v2(dz)
+        py, ldy = _v2(y)
+        native.check(self.lib.wdg_bn_bwd_reduce(pdz, lddz, py, ldy, saved.data_ptr(), dz.shape[0], dz.shape[1],
+                                                red.data_ptr(), self.stream), "bn_bwd_reduce")
+
+    def bn_bwd_apply(self, dz, y, saved, gamma, red_mean, red_param, count, act_slope, dpre, dgamma, dbeta, dbias):
+        pdz, lddz = _v2(dz)
+        py, ldy = _v2(y)
+        pd, ldd = _v2(dpre)
+        native.check(self.lib.wdg_bn_bwd_apply(pdz, lddz, py, ldy, saved.data_ptr(), gamma.data_ptr(),
+                                               red_mean.data_ptr(), _ptr(red_param), float(count), act_slope,
+                                               pd, ldd, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), dz.shape[0],
+                                               dz.shape[1], self.stream), "bn_bwd_apply")
+
+    # ---- layer norm -------------------------------------------------------------------------
+    def ln_fwd(self, y, gamma, beta, eps, z, mean_rstd):
+        py, ldy = _v2(y)
+        pz, ldz = _v2(z)
+        native.check(self.lib.wdg_ln_fwd(py, ldy, gamma.data_ptr(), beta.data_ptr(), eps, pz, ldz, _ptr(mean_rstd),
+                                         y.shape[0], y.shape[1], self.stream), "ln_fwd")
+
+    def ln_bwd(self, dz, y, mean_rstd, gamma, act_slope, dpre, dgamma, dbeta, dbias):
+        pdz, lddz = _v2(dz)
+        py, ldy = _v2(y)
+        pd, ldd = _v2(dpre)
+        native.check(self.lib.wdg_ln_bwd(pdz, lddz, py, ldy, mean_rstd.data_ptr(), gamma.data_ptr(), act_slope, pd,
+                                         ldd, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), dz.shape[0], dz.shape[1],
+                                         self.stream), "ln_bwd")
+
+    # ---- ConvLSTM cell ----------------------------------------------------------------------
+    def lstm_fwd(self, gates, c_prev, c, h, F):
+        pg, ldg = _v2(gates)
+        pcp, ldcp = _v2(c_prev) if c_prev is not None else (0, 0)
+        pc, ldc = _v2(c)
+        ph, ldh = _v2(h)
+        native.check(self.lib.wdg_lstm_fwd(pg, ldg, pcp, ldcp, pc, ldc, ph, ldh, gates.shape[0], F, self.stream), "lstm_fwd")
+
+    def lstm_bwd(self, gates, c_prev, c, dh, dc_in, dgates, dc_prev, F):
+        pg, ldg = _v2(gates)
+        pcp, ldcp = _v2(c_prev) if c_prev is not None else (0, 0)
+        pc, ldc = _v2(c)
+        pdh, lddh = _v2(dh)
+        pdci, lddci = _v2(dc_in) if dc_in is not None else (0, 0)
+        pdg, lddg = _v2(dgates)
+        pdcp, lddcp = _v2(dc_prev) if dc_prev is not None else (0, 0)
+        native.check(self.lib.wdg_lstm_bwd(pg, ldg, pcp, ldcp, pc, ldc, pdh, lddh, pdci, lddci, pdg, lddg, pdcp,
+                                           lddcp, gates.shape[0], F, self.stream), "lstm_bwd")
+
+    # ---- resampling / head ------------------------------------------------------------------
+    def upsample2x_fwd(self, x, y):
+        px, ldx, isx = _v4(x)
+        py, ldy, isy = _v4(y)
+        n, H, W, Cc = x.shape
+        native.check(self.lib.wdg_upsample2x_fwd(px, ldx, isx, py, ldy, isy, n, H, W, Cc, self.stream), "upsample_fwd")
+
+    def upsample2x_bwd(self, dy, dx, accumulate=False):
+        pdy, lddy, isdy = _v4(dy)
+        pdx, lddx, isdx = _v4(dx)
+        n, H, W, Cc = dx.shape
+        native.check(self.lib.wdg_upsample2x_bwd(pdy, lddy, isdy, pdx, lddx, isdx, n, H, W, Cc, int(accumulate),
+                                                 self.stream), "upsample_bwd")
+
+    def dense_gap_fwd(self, x, w, b, score, B, T):
+        assert x.is_contiguous()
+        native.check(self.lib.wdg_dense_gap_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), score.data_ptr(), B, T,
+                                                x.shape[1], self.stream), "dense_gap_fwd")
+
+    def dense_gap_bwd(self, x, w, dscore, dx, dw, db, B, T):
+        native.check(self.lib.wdg_dense_gap_bwd(x.data_ptr(), w.data_ptr(), dscore.data_ptr(), _ptr(dx), _ptr(dw),
+                                                _ptr(db), B, T, x.shape[1], self.stream), "dense_gap_bwd")
+
+    # ---- elementwise / reductions -----------------------------------------------------------
+    def copy_channels(self, src, dst, accumulate=False):
+        """dst[..., :C] (+)= src[..., :C] for 4-D views (N,H,W,C) (any channel alignment)."""
+        n, H, W, Cc = src.shape
+        assert dst.shape == src.shape
+
+        def strides(t):
+            ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else max(Cc, t.stride(2)))
+            if H > 1:
+                assert t.stride(1) == W * ld
+            return ld, (t.stride(0) if n > 1 else H * W * ld)
+        lds, iss = strides(src)
+        ldd, isd = strides(dst)
+        native.check(self.lib.wdg_copy_channels(src.data_ptr(), lds, iss, dst.data_ptr(), ldd, isd, n, H * W, Cc,
+                                                int(accumulate), self.stream), "copy_channels")
+
+    def colsum(self, x, out, accumulate=True):
+        px, ld = _v2(x)
+        native.check(self.lib.wdg_colsum(px, ld, x.shape[0], x.shape[1], out.data_ptr(), int(accumulate), self.stream), "colsum")
+
+    def lerp_batch(self, a, b, eps, out, pixels_per_img, B):
+        pa, lda = _v2(a)
+        pb, ldb = _v2(b)
+        po, ldo = _v2(out)
+        native.check(self.lib.wdg_lerp_batch(pa, lda, pb, ldb, eps.data_ptr(), po, ldo, a.shape[0], pixels_per_img, B,
+                                             a.shape[1], self.stream), "lerp_batch")
+
+    def sumsq_batch_ch(self, x, pixels_per_img, T, B, out):
+        px, ld = _v2(x)
+        native.check(self.lib.wdg_sumsq_batch_ch(px, ld, pixels_per_img, T, B, x.shape[1], out.data_ptr(), self.stream), "sumsq_batch_ch")
+
+    def segment_meansq(self, flat, offsets, out):
+        native.check(self.lib.wdg_segment_meansq(flat.data_ptr(), offsets.data_ptr(), out.numel(), out.data_ptr(),
+                                                 self.stream), "segment_meansq")
+
+    def philox_normal(self, out, seed, offset, std, add=None):
+        po, ldo = _v2(out)
+        pa, lda = _v2(add) if add is not None else (0, 0)
+        native.check(self.lib.wdg_philox_normal(po, ldo, pa, lda, out.shape[0], out.shape[1], seed & (2**64 - 1),
+                                                offset, std, self.stream), "philox_normal")
+
+    def philox_uniform(self, out, seed, offset):
+        native.check(self.lib.wdg_philox_uniform(out.data_ptr(), out.numel(), seed & (2**64 - 1), offset, self.stream), "philox_uniform")
+
+    def adam_tf(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
+        native.check(self.lib.wdg_adam_tf(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_t,
+                                          beta1, beta2, eps, grad_scale, self.stream), "adam_tf")

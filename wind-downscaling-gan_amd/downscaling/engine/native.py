@@ -1,0 +1,96 @@
+"""ctypes binding of libwdgan.so (the C ABI declared in include/wdgan.h).
+
+The library is the product path: if it is missing or cannot be loaded this module raises — there
+is no CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "libwdgan.so"
+
+c_fp = C.c_void_p  # device pointers travel as integers
+i32, i64, u64, f32, f64, szt = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [
+        ("n_img", i32), ("H", i32), ("W", i32), ("Cin", i32), ("ldx", i32), ("img_stride_x", i64),
+        ("Ho", i32), ("Wo", i32), ("Cout", i32), ("ldy", i32), ("img_stride_y", i64),
+        ("kh", i32), ("kw", i32), ("stride", i32), ("pad_h", i32), ("pad_w", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol of include/wdgan.h
+SIGNATURES = {
+    "wdg_last_error": (C.c_char_p, []),
+    "wdg_version": (C.c_char_p, []),
+    "wdg_device_cus": (i32, []),
+    "wdg_conv_plan_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom)]),
+    "wdg_conv_plan_destroy": (i32, [C.c_void_p]),
+    "wdg_conv_ws_bytes": (szt, [C.c_void_p]),
+    "wdg_conv_fwd": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp, szt, c_fp]),
+    "wdg_conv_dgrad": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp, szt, c_fp]),
+    "wdg_conv_wgrad": (i32, [C.c_void_p, c_fp, c_fp, c_fp, i32, c_fp, szt, c_fp]),
+    "wdg_weight_pack": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wdg_sn_scratch_floats": (szt, [i32, i32]),
+    "wdg_sn_power_iter": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp]),
+    "wdg_bn_stats": (i32, [c_fp, i64, i32, i32, c_fp, c_fp]),
+    "wdg_bn_finalize_train": (i32, [c_fp, f64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, c_fp, i32, c_fp]),
+    "wdg_bn_finalize_infer": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),
+    "wdg_bn_apply": (i32, [c_fp, i32, c_fp, c_fp, i32, i64, i32, c_fp]),
+    "wdg_bn_bwd_reduce": (i32, [c_fp, i32, c_fp, i32, c_fp, i64, i32, c_fp, c_fp]),
+    "wdg_bn_bwd_apply": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, c_fp, f64, f32, c_fp, i32,
+                                c_fp, c_fp, c_fp, i64, i32, c_fp]),
+    "wdg_ln_fwd": (i32, [c_fp, i32, c_fp, c_fp, f32, c_fp, i32, c_fp, i64, i32, c_fp]),
+    "wdg_ln_bwd": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, f32, c_fp, i32, c_fp, c_fp, c_fp, i64, i32, c_fp]),
+    "wdg_lstm_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, i64, i32, c_fp]),
+    "wdg_lstm_bwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32,
+                            i64, i32, c_fp]),
+    "wdg_upsample2x_fwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
+    "wdg_upsample2x_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
+    "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wdg_dense_gap_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wdg_copy_channels": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i64, i32, i32, c_fp]),
+    "wdg_colsum": (i32, [c_fp, i32, i64, i32, c_fp, i32, c_fp]),
+    "wdg_lerp_batch": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, i64, i64, i32, i32, c_fp]),
+    "wdg_sumsq_batch_ch": (i32, [c_fp, i32, i64, i32, i32, i32, c_fp, c_fp]),
+    "wdg_segment_meansq": (i32, [c_fp, c_fp, i32, c_fp, c_fp]),
+    "wdg_philox_normal": (i32, [c_fp, i32, c_fp, i32, i64, i32, u64, u64, f32, c_fp]),
+    "wdg_philox_uniform": (i32, [c_fp, i64, u64, u64, c_fp]),
+    "wdg_adam_tf": (i32, [c_fp, c_fp, c_fp, c_fp, i64, f32, f32, f32, f32, f32, c_fp]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libwdgan.so once; raise loudly when it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise NativeError(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C wind-downscaling-gan_amd/csrc`. The HIP library is required; there is no CPU path.")
+    lib = C.CDLL(os.fspath(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing = broken build
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().wdg_last_error().decode(errors="replace")
+        raise NativeError(f"libwdgan {what} failed (status {rc}): {msg}")
