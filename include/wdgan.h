@@ -208,7 +208,7 @@ int wdg_lerp_batch(const float* a, int lda, const float* b_, int ldb, const floa
 /* out[b][c] = sum over t and the pixels of batch element b of x^2          ganbase.py:36 */
 int wdg_sumsq_batch_ch(const float* x, int ldx, int64_t pixels_per_img, int T, int B, int C,
                        float* out, wdg_stream stream);
-/* out[i] = mean(x[off[i]:off[i+1]]^2)     (g_gradient_param / d_gradient_param, ganbase.py:80-81) */
+/* out[i] = mean(x[off[2i]:off[2i+1]]^2)   (g_gradient_param / d_gradient_param, ganbase.py:80-81) */
 int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out,
                        wdg_stream stream);
 

@@ -231,13 +231,13 @@ class TorchOps:
         d = mean_rstd[:, 1:2] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
         if act_slope >= 0:
             d = d * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, act_slope))
-        dpre.copy_(d)
-        if dgamma is not None:
+        if dgamma is not None:     # before the copy: dpre may alias dz
             dgamma += (dz * xh).sum(0)
         if dbeta is not None:
             dbeta += dz.sum(0)
         if dbias is not None:
             dbias += d.sum(0)
+        dpre.copy_(d)
 
     # ---- ConvLSTM cell: Keras gate order i,f,c,o; hard_sigmoid = clip(.2x+.5,0,1) ------------
     @staticmethod
@@ -327,7 +327,7 @@ class TorchOps:
 
     def segment_meansq(self, flat, offsets, out):
         for i in range(out.numel()):
-            seg = flat[int(offsets[i]):int(offsets[i + 1])]
+            seg = flat[int(offsets[2 * i]):int(offsets[2 * i + 1])]
             out[i] = (seg * seg).mean()
 
     def philox_normal(self, out, seed, offset, std, add=None):

@@ -1,0 +1,140 @@
+"""Host-logic parity on CPU: the layer engine (explicit forward/backward programs, zero-copy concat
+views, time-major layout, fused norm/activation backward, SN/BN state handling, train-step
+sequencing) driven by the float64 oracle operator backend must reproduce the independent
+autograd restatement of the reference (oracle/torch_model.py) to float64 round-off.
+
+The GPU parity tests (tests/test_model_gpu.py) run the same engine on the HIP backend."""
+import numpy as np
+import pytest
+import torch
+
+from downscaling.engine.networks import DiscriminatorNet, GeneratorNet, discriminator_plan
+from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
+from oracle import torch_model as TM
+from oracle.torch_backend import TorchOps
+from tests.helpers import Draws, grads64, randomize, rel_err, weights64
+
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return TorchOps()
+
+
+def _inputs(B, T, S, cin, nz, ch, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    low = torch.randn(B, T, S, S, cin, generator=g, dtype=torch.float64)
+    noise = torch.randn(B, T, S, S, nz, generator=g, dtype=torch.float64) * 0.1
+    high = torch.randn(B, T, S, S, ch, generator=g, dtype=torch.float64)
+    return low, noise, high
+
+
+@pytest.mark.parametrize("S,T,training", [(12, 2, True), (12, 2, False), (20, 1, True), (16, 3, True)])
+def test_generator_forward_backward(ops, S, T, training):
+    B, cin, nz, ch, F = 2, 3, 2, 2, 32
+    net = GeneratorNet(ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
+    w = randomize(net, 11)
+    low, noise, _ = _inputs(B, T, S, cin, nz, ch)
+    net.set_image(low)
+    net.set_noise(noise)
+    out_tm = net.forward(B, training)
+    out = torch.zeros(B, T, S, S, ch, dtype=torch.float64)
+    net.from_time_major(out_tm, out)
+
+    keys = TM.trainable_keys(w)
+    for k in keys:
+        w[k].requires_grad_(True)
+    TM.apply_sn(w, TM.generator_sn_keys(), training)
+    st = {}
+    ref = TM.generator_forward(w, low, noise, training, st)
+    assert rel_err(out, ref) < TOL
+    assert float(out_tm[..., ch:].abs().max()) == 0.0
+    got = weights64(net)
+    for k in TM.generator_sn_keys():          # SN mutated w and u in place (training only)
+        assert rel_err(got[k + "/w"], w[k + "/w"]) < TOL and rel_err(got[k + "/sn_u"], w[k + "/sn_u"]) < TOL
+    for k, v in st.items():                   # BN moving statistics
+        assert rel_err(got[k], v) < TOL
+    if not training:
+        return
+    gout = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    gref = TM._grads((ref * gout).sum(), w, keys)
+    dout = ops.zeros(T * B, S, S, 4)
+    net.to_time_major(gout, dout)
+    net.params.zero_grad()
+    net.backward(B, dout)
+    g = grads64(net)
+    for k in keys:
+        assert rel_err(g[k], gref[k]) < 1e-8, k
+
+
+@pytest.mark.parametrize("S,T", [(12, 2), (20, 1), (32, 2), (24, 1)])
+def test_discriminator_forward_backward(ops, S, T):
+    B, cl, ch, Fd = 2, 3, 2, 8
+    net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=Fd, seed=4)
+    w = randomize(net, 12)
+    low, _, high = _inputs(B, T, S, cl, 1, ch, seed=1)
+    keys = TM.trainable_keys(w)
+    for k in keys:
+        w[k].requires_grad_(True)
+    net.set_low(low)
+    high_tm = ops.zeros(T * B, S, S, 4)
+    net.to_time_major(high, high_tm)
+    net.set_high_tm(high_tm, B)
+    score = net.forward(B, training=True).clone()
+
+    TM.apply_sn(w, TM.discriminator_sn_keys(S), True)
+    hreq = high.clone().requires_grad_(True)
+    ref = TM.discriminator_forward(w, low, hreq)
+    assert rel_err(score, ref.reshape(-1)) < TOL
+    dscore = torch.randn(B, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    loss = (ref.reshape(-1) * dscore).sum()
+    gref = TM._grads(loss, w, keys + [])
+    (ghigh,) = torch.autograd.grad((TM.discriminator_forward(w, low, hreq).reshape(-1) * dscore).sum(), hreq)
+
+    net.params.zero_grad()
+    dhigh_tm = net.backward(B, dscore.clone(), need_wgrad=True)
+    g = grads64(net)
+    for k in keys:
+        assert rel_err(g[k], gref[k]) < 1e-8, k
+    dhigh = torch.zeros_like(high)
+    net.from_time_major(dhigh_tm, dhigh)
+    assert rel_err(dhigh, ghigh) < 1e-8
+    # input-gradient-only pass leaves the parameter gradients untouched
+    net.params.zero_grad()
+    net.forward(B, training=False)
+    d2 = net.backward(B, dscore.clone(), need_wgrad=False).clone()
+    assert float(net.params.grads.abs().max()) == 0.0
+    assert rel_err(d2, dhigh_tm) < TOL
+
+
+def test_discriminator_plan_matches_reference_sizes():
+    """loop structure at the shipped / benchmark sizes."""
+    assert [(b[0], b[5], b[4]) for b in discriminator_plan(256, 32)[0]] == [(7, 84, 64), (7, 27, 128), (7, 8, 256), (7, 2, 512)]
+    assert [(b[0], b[5], b[4]) for b in discriminator_plan(128, 32)[0]] == [(7, 42, 64), (7, 13, 128), (7, 3, 256), (3, 1, 512)]
+    assert [(b[0], b[5], b[4]) for b in discriminator_plan(96, 32)[0]] == [(7, 31, 64), (7, 9, 128), (7, 2, 256)]
+    assert discriminator_plan(256, 32)[1:] == (2, 512) and discriminator_plan(96, 32)[1:] == (2, 256)
+
+
+@pytest.mark.parametrize("S,T", [(12, 2), (20, 1)])
+def test_train_step_matches_oracle(ops, S, T):
+    """Two consecutive GAN.train_step calls: weights, optimizer effect, SN/BN state and every
+    reported scalar against the autograd restatement consuming the identical Philox stream."""
+    B, cin, nz, ch = 2, 3, 2, 2
+    gen = GeneratorNet(ops, S, cin, nz, ch, T, feature_channels=32, seed=5)
+    disc = DiscriminatorNet(ops, S, S, cin, ch, T, feature_channels=8, seed=6)
+    gw, dw = randomize(gen, 21), randomize(disc, 22)
+    eng = GanEngine(gen, disc, PhiloxSource(ops, seed=99), noise_std=0.1, n_critic=3)
+    g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
+    og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
+    draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
+    for step in range(2):
+        low, _, high = _inputs(B, T, S, cin, nz, ch, seed=30 + step)
+        res = eng.train_step(low, high, g_opt, d_opt)
+        ref = TM.train_step(gw, dw, low, high, draws, og, od)
+        for k in ("g_loss", "g_disc_loss", "d_loss", "d_gradient_pen", "g_gradient_param", "d_gradient_param", "_d_loss_train"):
+            assert rel_err(res[k], ref[k]) < 1e-7, (step, k)
+        for net, w in ((gen, gw), (disc, dw)):
+            got = weights64(net)
+            for k in w:
+                assert rel_err(got[k], w[k]) < 1e-7, (step, k)

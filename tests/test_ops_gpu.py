@@ -278,7 +278,7 @@ def test_upsample_dense_misc(hip_ops, ref_ops):
     hip_ops.sumsq_batch_ch(cv(a), ppi, Tt, Bb, q_g)
     assert rel_err(q_g, q_r) < TOL
     flat = torch.randn(10000, generator=gen, dtype=torch.float64)
-    off = torch.tensor([0, 10, 5000, 10000], dtype=torch.int64)
+    off = torch.tensor([0, 10, 12, 5000, 5000, 10000], dtype=torch.int64)  # {begin, end} pairs
     m_r, m_g = torch.zeros(3, dtype=torch.float64), hip_ops.empty(3)
     ref_ops.segment_meansq(flat, off, m_r)
     hip_ops.segment_meansq(cv(flat), off.to(dev), m_g)

@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) wdg_segment_meansq_kernel(const float* __
                                                                  const int64_t* __restrict__ off, float* out) {
     __shared__ double red[4];
     const int s = blockIdx.x;
-    const int64_t b = off[s], e = off[s + 1];
+    const int64_t b = off[2 * s], e = off[2 * s + 1];  // {begin, end} pairs
     double acc = 0.0;
     for (int64_t i = b + threadIdx.x; i < e; i += 256) acc += (double)x[i] * (double)x[i];
     acc = wdg_wave_sum_d(acc);

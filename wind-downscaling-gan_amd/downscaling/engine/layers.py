@@ -1,0 +1,223 @@
+"""Layer objects with explicit forward / backward, written against the operator interface
+(`HipOps` on the GPU; tests inject the float64 CPU oracle backend to check this host logic).
+
+There is no autograd graph: the generator and discriminator are fixed graphs
+(/root/reference/src/downscaling/gan/models.py:9-142), so each layer stores exactly what its own
+backward needs and the networks call the backward passes in reverse order.  Layer order of
+operations follows the reference: conv -> bias -> LeakyReLU(0.2) -> norm; the LeakyReLU derivative
+is taken from the sign of the stored activation and fused into the norm backward.
+"""
+from . import params as P
+from .common import ConvGeom, round4, v2
+
+LRELU = 0.2
+BN_EPS = 1e-3      # keras.layers.BatchNormalization default
+BN_MOMENTUM = 0.99
+LN_EPS = 1e-3      # keras.layers.LayerNormalization default
+
+
+class Conv:
+    """Conv2D or Conv2DTranspose (+ optional tfa SpectralNormalization wrapper).
+
+    For `transposed=True` (cin, cout) are those of the convolution the layer is the adjoint of, so
+    the TF kernel (kh, kw, out, in) is stored unchanged as HWIO with I = layer outputs, O = layer
+    inputs; forward runs the data-gradient kernel, input-gradient runs the forward kernel.
+    """
+
+    def __init__(self, net, name, k, cin, cout, stride, pad, *, transposed=False, sn=False, act=True, prefix="layer"):
+        self.net, self.ops, self.name = net, net.ops, name
+        self.g = ConvGeom(k, k, stride, pad)
+        self.cin, self.cout, self.transposed, self.sn, self.act = cin, cout, transposed, sn, act
+        store = net.params
+        # TF checkpoint keys (weights-55.ckpt/*.index): TimeDistributed -> "layer", SN wrapper -> "w"/"sn_u"
+        wname = f"{name}/{prefix}/w" if sn else f"{name}/{prefix}/kernel"
+        bname = f"{name}/{prefix}/layer/bias" if sn else f"{name}/{prefix}/bias"
+        self.w = store.add(wname, (k, k, cin, cout), P.conv_glorot)
+        self.b = store.add(bname, (cin if transposed else cout,), P.zeros_init)
+        self.u = store.add(f"{name}/{prefix}/sn_u", (1, cout), P.sn_u_init, trainable=False) if sn else None
+        self.pk = None
+        self._packed_version = -1
+
+    def build(self):
+        self.pk = self.ops.pack_weights(self.w.value)
+        self._packed_version = self.net.params.version
+
+    def prepare(self, training):
+        """SN power iteration (training only, in place on w and u) and refresh of the packed copies."""
+        if self.sn and training:
+            self.ops.sn_power_iter(self.w.value.view(-1, self.cout), self.u.value.view(-1))
+            self.pk.refresh()
+            self._packed_version = self.net.params.version
+        elif self._packed_version != self.net.params.version:
+            self.pk.refresh()
+            self._packed_version = self.net.params.version
+
+    def forward(self, x, y):
+        if self.transposed:
+            self.ops.conv_dgrad(x, self.pk, y, self.g, bias=self.b.value, act=self.act, slope=LRELU)
+        else:
+            self.ops.conv_fwd(x, self.pk, self.b.value, y, self.g, act=self.act, slope=LRELU)
+
+    def backward_weights(self, x, dpre):
+        if self.transposed:
+            self.ops.conv_wgrad(dpre, x, self.pk, self.w.grad, self.g, accumulate=True)
+        else:
+            self.ops.conv_wgrad(x, dpre, self.pk, self.w.grad, self.g, accumulate=True)
+
+    def backward_input(self, dpre, dx, accumulate=False):
+        if self.transposed:
+            self.ops.conv_fwd(dpre, self.pk, None, dx, self.g, act=False, accumulate=accumulate)
+        else:
+            self.ops.conv_dgrad(dpre, self.pk, dx, self.g, accumulate=accumulate)
+
+
+class BatchNorm:
+    def __init__(self, net, name, C):
+        self.net, self.ops, self.C = net, net.ops, C
+        st = net.params
+        self.gamma = st.add(f"{name}/gamma", (C,), P.ones_init)
+        self.beta = st.add(f"{name}/beta", (C,), P.zeros_init)
+        self.mmean = st.add(f"{name}/moving_mean", (C,), P.zeros_init, trainable=False)
+        self.mvar = st.add(f"{name}/moving_variance", (C,), P.ones_init, trainable=False)
+
+    def build(self):
+        import torch
+        o, C = self.ops, self.C
+        self.stats = o.zeros(2 * C, dtype=torch.float64)
+        self.red = o.zeros(2 * C, dtype=torch.float64)
+        self.red_local = o.zeros(2 * C, dtype=torch.float64)
+        self.ss = o.empty(2 * C)
+        self.saved = o.empty(2 * C)
+        self.count = 1.0
+
+    def forward(self, y, z, training):
+        o = self.ops
+        if training:
+            self.stats.zero_()
+            o.bn_stats(y, self.stats)
+            count = float(y.shape[0])
+            sync = self.net.sync
+            if sync is not None:  # SyncBN: the batch statistics couple the *global* batch
+                sync.all_reduce_sum(self.stats)
+                count *= sync.world_size
+            self.count = count
+            o.bn_finalize_train(self.stats, count, self.gamma.value, self.beta.value, self.mmean.value,
+                                self.mvar.value, BN_MOMENTUM, BN_EPS, self.ss, self.saved)
+        else:
+            o.bn_finalize_infer(self.gamma.value, self.beta.value, self.mmean.value, self.mvar.value, BN_EPS, self.ss)
+        o.bn_apply(y, self.ss, z)
+
+    def backward(self, dz, y, dpre, dbias, act_slope=LRELU):
+        """dpre = BN-backward(dz) * lrelu'(y); accumulates dgamma, dbeta and (fused) the conv bias grad."""
+        o = self.ops
+        self.red.zero_()
+        o.bn_bwd_reduce(dz, y, self.saved, self.red)
+        red_param = self.red
+        sync = self.net.sync
+        if sync is not None:
+            self.red_local.copy_(self.red)
+            red_param = self.red_local
+            sync.all_reduce_sum(self.red)
+        o.bn_bwd_apply(dz, y, self.saved, self.gamma.value, self.red, red_param, self.count, act_slope, dpre,
+                       self.gamma.grad, self.beta.grad, dbias)
+
+
+class LayerNorm:
+    def __init__(self, net, name, C):
+        self.net, self.ops, self.C = net, net.ops, C
+        st = net.params
+        self.gamma = st.add(f"{name}/gamma", (C,), P.ones_init)
+        self.beta = st.add(f"{name}/beta", (C,), P.zeros_init)
+        self.mean_rstd = None
+
+    def forward(self, y, z, keep_stats=True):
+        if self.mean_rstd is None or self.mean_rstd.shape[0] != y.shape[0]:
+            self.mean_rstd = self.ops.empty(y.shape[0], 2)
+        self.ops.ln_fwd(y, self.gamma.value, self.beta.value, LN_EPS, z, self.mean_rstd)
+
+    def backward(self, dz, y, dpre, dbias, need_param_grads, act_slope=LRELU):
+        if need_param_grads:
+            self.ops.ln_bwd(dz, y, self.mean_rstd, self.gamma.value, act_slope, dpre, self.gamma.grad,
+                            self.beta.grad, dbias)
+        else:
+            self.ops.ln_bwd(dz, y, self.mean_rstd, self.gamma.value, act_slope, dpre, None, None, None)
+
+
+class ConvLSTM:
+    """keras.layers.ConvLSTM2D(F, 3x3, 'same', return_sequences=True) on time-major activations.
+
+    gates = conv(x_t, kernel) + bias + conv(h_{t-1}, recurrent_kernel); order i,f,c,o; recurrent
+    activation hard_sigmoid, activation tanh; h_0 = c_0 = 0, so the recurrent convolution and the
+    forget path are skipped at t = 0.  The input convolution runs for all T timesteps in one launch.
+    """
+
+    def __init__(self, net, name, cin, F):
+        self.net, self.ops, self.cin, self.F = net, net.ops, cin, F
+        st = net.params
+        self.wx = st.add(f"{name}/cell/kernel", (3, 3, cin, 4 * F), P.conv_glorot)
+        self.wh = st.add(f"{name}/cell/recurrent_kernel", (3, 3, F, 4 * F), P.orthogonal)
+        self.b = st.add(f"{name}/cell/bias", (4 * F,), P.lstm_bias(F))
+        self.g = ConvGeom(3, 3, 1, 1)
+        self._packed_version = -1
+
+    def build(self):
+        self.pkx = self.ops.pack_weights(self.wx.value)
+        self.pkh = self.ops.pack_weights(self.wh.value)
+        self._packed_version = self.net.params.version
+        self._shape = None
+
+    def prepare(self, training):
+        if self._packed_version != self.net.params.version:
+            self.pkx.refresh()
+            self.pkh.refresh()
+            self._packed_version = self.net.params.version
+
+    def _buffers(self, N, H, W):
+        if self._shape != (N, H, W):
+            o, F = self.ops, self.F
+            self.gates = o.empty(N, H, W, 4 * F)
+            self.c = o.empty(N, H, W, F)
+            self.dgates = None
+            self._shape = (N, H, W)
+
+    def forward(self, x, h, B, T):
+        """x: [T*B,H,W,>=cin] view; h: [T*B,H,W,round4(F)] output buffer (pad channels stay zero)."""
+        o, F = self.ops, self.F
+        N, H, W, _ = h.shape
+        self._buffers(N, H, W)
+        o.conv_fwd(x, self.pkx, self.b.value, self.gates, self.g, act=False)
+        for t in range(T):
+            sl = slice(t * B, (t + 1) * B)
+            if t > 0:
+                pv = slice((t - 1) * B, t * B)
+                o.conv_fwd(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
+                o.lstm_fwd(v2(self.gates[sl]), v2(self.c[pv]), v2(self.c[sl]), v2(h[sl]), F)
+            else:
+                o.lstm_fwd(v2(self.gates[sl]), None, v2(self.c[sl]), v2(h[sl]), F)
+
+    def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False):
+        """dh: total gradient w.r.t. every h_t (modified in place by the BPTT recursion);
+        dx: view receiving the input gradient (None to skip)."""
+        o, F = self.ops, self.F
+        N, H, W, _ = h.shape
+        if self.dgates is None:
+            self.dgates = o.empty(N, H, W, 4 * F)
+            self.dc = [o.empty(B, H, W, F), o.empty(B, H, W, F)]
+        dc_in = None
+        for t in range(T - 1, -1, -1):
+            sl = slice(t * B, (t + 1) * B)
+            pv = slice((t - 1) * B, t * B)
+            dc_out = self.dc[t & 1] if t > 0 else None
+            o.lstm_bwd(v2(self.gates[sl]), v2(self.c[pv]) if t > 0 else None, v2(self.c[sl]), v2(dh[sl]),
+                       v2(dc_in) if dc_in is not None else None, v2(self.dgates[sl]),
+                       v2(dc_out) if dc_out is not None else None, F)
+            if t > 0:
+                o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
+            dc_in = dc_out
+        if need_wgrad:
+            o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True)
+            if T > 1:
+                o.conv_wgrad(h[:(T - 1) * B], self.dgates[B:], self.pkh, self.wh.grad, self.g, accumulate=True)
+            o.colsum(v2(self.dgates), self.b.grad, accumulate=True)
+        if dx is not None:
+            o.conv_dgrad(self.dgates, self.pkx, dx, self.g, accumulate=accumulate_dx)

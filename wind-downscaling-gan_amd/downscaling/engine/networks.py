@@ -1,0 +1,369 @@
+"""Generator and discriminator graphs of the reference, as explicit forward/backward programs.
+
+Follows /root/reference/src/downscaling/gan/models.py line by line (citations inline).  Internal
+activations are TIME-MAJOR channels-last: image index n = t*B + b, shape [T*B, H, W, C]; channel
+concatenations are zero-copy views into wider buffers; channel counts that are not multiples of 4
+are zero-padded (input 23 -> 24, wind 2 -> 4, low+high 5 -> 8).
+"""
+import numpy as np
+
+from .common import round4, v2
+from .layers import BatchNorm, Conv, ConvLSTM, LayerNorm
+from .params import ParamStore, glorot_uniform, zeros_init
+
+
+class _Net:
+    def __init__(self, ops, sync=None):
+        self.ops = ops
+        self.sync = sync
+        self.params = ParamStore(ops)
+        self._layers = []
+        self._bufs = {}
+
+    def _add(self, layer):
+        self._layers.append(layer)
+        return layer
+
+    def _finalize(self, seed):
+        self.params.finalize(np.random.default_rng(seed))
+        for l in self._layers:
+            if hasattr(l, "build"):
+                l.build()
+
+    def _prepare(self, training):
+        for l in self._layers:
+            if hasattr(l, "prepare"):
+                l.prepare(training)
+
+    # ---- [B,T,...] <-> time-major ---------------------------------------------------------------
+    def to_time_major(self, src, dst):
+        """src [B,T,H,W,C] (API layout) -> dst[..., :C] of a [T*B,H,W,C'] buffer."""
+        B, T = src.shape[0], src.shape[1]
+        C = src.shape[-1]
+        for t in range(T):
+            self.ops.copy_channels(src[:, t], dst[t * B:(t + 1) * B][..., :C])
+
+    def from_time_major(self, src, dst):
+        """src [T*B,H,W,>=C] -> dst [B,T,H,W,C]."""
+        B, T = dst.shape[0], dst.shape[1]
+        C = dst.shape[-1]
+        for t in range(T):
+            self.ops.copy_channels(src[t * B:(t + 1) * B][..., :C], dst[:, t])
+
+
+class GeneratorNet(_Net):
+    """make_generator, gan/models.py:9-73."""
+
+    def __init__(self, ops, image_size, in_channels, noise_channels, out_channels, n_timesteps,
+                 feature_channels=128, seed=0, sync=None):
+        super().__init__(ops, sync)
+        assert image_size % 4 == 0                      # models.py:19
+        assert feature_channels % 8 == 0                # models.py:20
+        S, F = image_size, feature_channels
+        cin = in_channels + noise_channels              # models.py:21
+        IF = cin * 8 if cin * 8 <= F else F             # models.py:31
+        if F / 8 < out_channels:
+            # models.py:66-68: that branch skips the upsampling and fails its own shape assertion
+            raise AssertionError("feature_channels / 8 must be >= out_channels (reference else-branch is dead)")
+        if F % 32 != 0 or IF % 4 != 0:
+            raise NotImplementedError("this build needs feature_channels % 32 == 0 (16-byte aligned channel slices)")
+        self.S, self.F, self.IF, self.T = S, F, IF, n_timesteps
+        self.cin, self.in_channels, self.noise_channels, self.out_channels = cin, in_channels, noise_channels, out_channels
+        L = "layer_with_weights-"
+        self.c0 = self._add(Conv(self, L + "0", 8, cin, IF, 2, 3, sn=True))           # :32-33
+        self.bn1 = self._add(BatchNorm(self, L + "1", IF))                            # :34
+        self.c2 = self._add(Conv(self, L + "2", 4, IF, F, 2, 1, sn=True))             # :38-39
+        self.bn3 = self._add(BatchNorm(self, L + "3", F))                             # :40
+        self.lstm = self._add(ConvLSTM(self, L + "4", F, F))                          # :45
+        self.c5 = self._add(Conv(self, L + "5", 3, F, F // 2, 1, 1, sn=True))         # :49
+        self.bn6 = self._add(BatchNorm(self, L + "6", F // 2))                        # :50
+        self.c7 = self._add(Conv(self, L + "7", 2, F // 4, F // 2 + F, 2, 0, transposed=True, sn=True))  # :54-55
+        self.bn8 = self._add(BatchNorm(self, L + "8", F // 4))                        # :56
+        self.c9 = self._add(Conv(self, L + "9", 5, F // 8, F // 4 + IF, 1, 2, transposed=True))          # :60-64
+        self.bn10 = self._add(BatchNorm(self, L + "10", F // 8))                      # :69
+        self.c11 = self._add(Conv(self, L + "11", 3, F // 8, out_channels, 1, 1, act=False))            # :70-71
+        self._finalize(seed)
+
+    def buffers(self, B):
+        b = self._bufs.get(B)
+        if b is not None:
+            return b
+        o, S, F, IF, T = self.ops, self.S, self.F, self.IF, self.T
+        N, S2, S4 = T * B, self.S // 2, self.S // 4
+        b = dict(
+            x0=o.zeros(N, S, S, round4(self.cin)),
+            y0=o.empty(N, S2, S2, IF),
+            cat2=o.empty(N, S2, S2, F // 4 + IF),      # [c7 path | res_2]
+            y2=o.empty(N, S4, S4, F),
+            cat4=o.empty(N, S4, S4, F // 2 + F),       # [c5 path | res_4]
+            h=o.zeros(N, S4, S4, F),
+            y5=o.empty(N, S4, S4, F // 2),
+            y7=o.empty(N, S2, S2, F // 4),
+            up=o.empty(N, S, S, F // 4 + IF),
+            y9=o.empty(N, S, S, F // 8),
+            z9=o.empty(N, S, S, F // 8),
+            out=o.zeros(N, S, S, round4(self.out_channels)),
+        )
+        self._bufs = {B: b}      # one resident batch size at a time
+        self._grad_bufs = None
+        return b
+
+    def grad_buffers(self, B):
+        if self._grad_bufs is None:
+            o, S, F, IF, T = self.ops, self.S, self.F, self.IF, self.T
+            N, S2, S4 = T * B, S // 2, S // 4
+            self._grad_bufs = dict(
+                dz9=o.empty(N, S, S, F // 8),
+                dup=o.empty(N, S, S, F // 4 + IF),
+                dcat2=o.empty(N, S2, S2, F // 4 + IF),
+                dcat4=o.empty(N, S4, S4, F // 2 + F),
+                dh=o.zeros(N, S4, S4, F),
+            )
+        return self._grad_bufs
+
+    # ---- inputs ------------------------------------------------------------------------------------
+    def set_image(self, image):
+        """image [B,T,S,S,in] -> channels [0:in] of the concatenated input buffer (models.py:28)."""
+        b = self.buffers(image.shape[0])
+        self.to_time_major(image, b["x0"])
+
+    def set_noise(self, noise):
+        b = self.buffers(noise.shape[0])
+        B, T = noise.shape[0], noise.shape[1]
+        for t in range(T):
+            self.ops.copy_channels(noise[:, t], b["x0"][t * B:(t + 1) * B][..., self.in_channels:self.cin])
+
+    def noise_view(self, B):
+        """[T*B*S*S, noise_channels] view of the input buffer: noise can be generated in place."""
+        return v2(self.buffers(B)["x0"][..., self.in_channels:self.cin])
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, B, training):
+        """Runs on the resident input buffer; returns the [T*B,S,S,round4(out)] time-major output."""
+        b = self.buffers(B)
+        F, IF, T = self.F, self.IF, self.T
+        self._prepare(training)
+        res2 = b["cat2"][..., F // 4:]
+        res4 = b["cat4"][..., F // 2:]
+        self.c0.forward(b["x0"], b["y0"])
+        self.bn1.forward(v2(b["y0"]), v2(res2), training)
+        self.c2.forward(res2, b["y2"])
+        self.bn3.forward(v2(b["y2"]), v2(res4), training)
+        self.lstm.forward(res4, b["h"], B, T)
+        self.c5.forward(b["h"], b["y5"])
+        self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), training)
+        self.c7.forward(b["cat4"], b["y7"])
+        self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), training)
+        self.ops.upsample2x_fwd(b["cat2"], b["up"])                                   # models.py:62
+        self.c9.forward(b["up"], b["y9"])
+        self.bn10.forward(v2(b["y9"]), v2(b["z9"]), training)
+        self.c11.forward(b["z9"], b["out"])
+        return b["out"]
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def backward(self, B, dout):
+        """dout: gradient w.r.t. the time-major output [T*B,S,S,round4(out)] (pad channels zero).
+        Accumulates into params.grads (generator inputs need no gradient)."""
+        b, g = self.buffers(B), self.grad_buffers(B)
+        o, F, IF, T = self.ops, self.F, self.IF, self.T
+        res2, res4 = b["cat2"][..., F // 4:], b["cat4"][..., F // 2:]
+        # c11 (linear)
+        o.colsum(v2(dout[..., :self.out_channels]), self.c11.b.grad, accumulate=True)
+        self.c11.backward_weights(b["z9"], dout)
+        self.c11.backward_input(dout, g["dz9"])
+        # bn10 + LeakyReLU of c9
+        self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad)
+        self.c9.backward_weights(b["up"], g["dz9"])
+        self.c9.backward_input(g["dz9"], g["dup"])
+        o.upsample2x_bwd(g["dup"], g["dcat2"])
+        # bn8 + c7
+        d7 = g["dcat2"][..., :F // 4]
+        self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad)
+        self.c7.backward_weights(b["cat4"], d7)
+        self.c7.backward_input(d7, g["dcat4"])
+        # bn6 + c5
+        d5 = g["dcat4"][..., :F // 2]
+        self.bn6.backward(v2(d5), v2(b["y5"]), v2(d5), self.c5.b.grad)
+        self.c5.backward_weights(b["h"], d5)
+        self.c5.backward_input(d5, g["dh"])
+        # ConvLSTM; its input gradient adds to the skip gradient already in dcat4[..., F/2:]
+        dres4 = g["dcat4"][..., F // 2:]
+        self.lstm.backward(res4, b["h"], g["dh"], dres4, B, T, need_wgrad=True, accumulate_dx=True)
+        # bn3 + c2
+        self.bn3.backward(v2(dres4), v2(b["y2"]), v2(dres4), self.c2.b.grad)
+        self.c2.backward_weights(res2, dres4)
+        dres2 = g["dcat2"][..., F // 4:]
+        self.c2.backward_input(dres4, dres2, accumulate=True)
+        # bn1 + c0
+        self.bn1.backward(v2(dres2), v2(b["y0"]), v2(dres2), self.c0.b.grad)
+        self.c0.backward_weights(b["x0"], dres2)
+
+
+def discriminator_plan(size, channels):
+    """The three `while` loops of make_discriminator (models.py:111-136) as a list of conv blocks
+    (k, stride, pad, cin, cout, out_size).  `i > 1` (models.py:127) cannot happen."""
+    blocks = []
+    while size >= 16:                                   # models.py:111
+        nxt = (size + 2 - 7) // 3 + 1
+        blocks.append((7, 3, 1, channels, channels * 2, nxt))
+        size, channels = nxt, channels * 2
+    i = 0
+    while size >= 4:                                    # models.py:120
+        nxt = (size + 2 - 7) // 3 + 1
+        if nxt <= 0:
+            raise ValueError(f"discriminator: a {size}x{size} map cannot take another 7x7 stride-3 conv")
+        blocks.append((7, 3, 1, channels, channels * 2, nxt))
+        size, channels = nxt, channels * 2
+        i += 1
+    if i > 1:
+        raise NotImplementedError("shortcut_convolution branch (models.py:127-130) is unreachable in the reference")
+    while size > 2:                                     # models.py:132
+        nxt = (size - 3) // 2 + 1
+        if nxt <= 0:
+            raise ValueError("discriminator: map too small for the 3x3 stride-2 conv")
+        blocks.append((3, 2, 0, channels, channels * 2, nxt))
+        size, channels = nxt, channels * 2
+    return blocks, size, channels
+
+
+class DiscriminatorNet(_Net):
+    """make_discriminator, gan/models.py:76-142."""
+
+    def __init__(self, ops, low_res_size, high_res_size, low_res_channels, high_res_channels, n_timesteps,
+                 feature_channels=16, seed=1, sync=None):
+        super().__init__(ops, sync)
+        if low_res_size != high_res_size:               # models.py:89-91
+            raise NotImplementedError("The discriminator assumes that the low res and high res images have the "
+                                      "same size.Perhaps you should upsample your low res image first?")
+        if feature_channels % 4 != 0:
+            raise NotImplementedError("this build needs discriminator feature_channels % 4 == 0")
+        S, Fd, T = high_res_size, feature_channels, n_timesteps
+        self.S, self.Fd, self.T = S, Fd, T
+        self.cl, self.ch = low_res_channels, high_res_channels
+        L = "layer_with_weights-"
+        # checkpoint numbering of weights-55.ckpt/discriminator.index (breadth-first layer order)
+        self.lstm_a = self._add(ConvLSTM(self, L + "0", self.ch, self.ch))                    # :93
+        self.lstm_b = self._add(ConvLSTM(self, L + "1", self.cl + self.ch, Fd))               # :101
+        self.conv_a = self._add(Conv(self, L + "2", 3, self.ch, Fd, 1, 1, sn=True))           # :94-96
+        self.conv_b = self._add(Conv(self, L + "3", 3, Fd, Fd, 1, 1, sn=True))                # :102-104
+        self.ln_a = self._add(LayerNorm(self, L + "4", Fd))                                   # :97
+        self.ln_b = self._add(LayerNorm(self, L + "5", Fd))                                   # :105
+        plan, self.final_size, self.final_ch = discriminator_plan(S, 2 * Fd)
+        self.blocks = []
+        idx = 6
+        for (k, s, p, ci, co, osz) in plan:
+            conv = self._add(Conv(self, L + str(idx), k, ci, co, s, p, sn=True))              # :113-114,122-123,134
+            ln = self._add(LayerNorm(self, L + str(idx + 1), co))                             # :116,125,136
+            self.blocks.append((conv, ln, osz, co))
+            idx += 2
+        K = self.final_size * self.final_size * self.final_ch
+        self.K = K
+        self.dense_w = self.params.add(L + f"{idx}/layer/kernel", (K, 1), glorot_uniform(K, 1))   # :138
+        self.dense_b = self.params.add(L + f"{idx}/layer/bias", (1,), zeros_init)
+        self._finalize(seed)
+
+    def buffers(self, B):
+        b = self._bufs.get(B)
+        if b is not None:
+            return b
+        o, S, Fd, T = self.ops, self.S, self.Fd, self.T
+        N = T * B
+        chp = round4(self.ch)
+        b = dict(
+            hi=o.zeros(N, S, S, chp),                          # high-res input, padded
+            mix=o.zeros(N, S, S, round4(self.cl + self.ch)),   # concat(low, high), models.py:100
+            ha=o.zeros(N, S, S, chp),
+            ya=o.empty(N, S, S, Fd),
+            hb=o.zeros(N, S, S, Fd),
+            yb=o.empty(N, S, S, Fd),
+            cat=o.empty(N, S, S, 2 * Fd),                      # concat(hr, mix), models.py:108
+            ys=[], zs=[],
+            score=o.empty(B),
+            # gradients
+            dcat=o.empty(N, S, S, 2 * Fd),
+            dha=o.zeros(N, S, S, chp),
+            dhb=o.zeros(N, S, S, Fd),
+            dhi=o.zeros(N, S, S, chp),
+            dmix=o.zeros(N, S, S, round4(self.cl + self.ch)),
+            dhigh=o.zeros(N, S, S, chp),
+            dzs=[],
+        )
+        for (conv, ln, osz, co) in self.blocks:
+            b["ys"].append(o.empty(N, osz, osz, co))
+            b["zs"].append(o.empty(N, osz, osz, co))
+            b["dzs"].append(o.empty(N, osz, osz, co))
+        self._bufs = {B: b}
+        return b
+
+    def set_low(self, low):
+        """low [B,T,S,S,cl] -> channels [0:cl] of the mix buffer (constant over a train step)."""
+        b = self.buffers(low.shape[0])
+        self.to_time_major(low, b["mix"])
+
+    def set_high_tm(self, high_tm, B):
+        """high_tm: time-major [T*B,S,S,>=ch] view (e.g. the generator's output buffer)."""
+        b = self.buffers(B)
+        self.ops.copy_channels(high_tm[..., :self.ch], b["hi"][..., :self.ch])
+        self.ops.copy_channels(high_tm[..., :self.ch], b["mix"][..., self.cl:self.cl + self.ch])
+
+    def forward(self, B, training):
+        """Scores [B] for the resident (low, high) buffers."""
+        b = self.buffers(B)
+        o, Fd, T = self.ops, self.Fd, self.T
+        self._prepare(training)
+        self.lstm_a.forward(b["hi"], b["ha"], B, T)
+        self.conv_a.forward(b["ha"], b["ya"])
+        self.ln_a.forward(v2(b["ya"]), v2(b["cat"][..., :Fd]))
+        self.lstm_b.forward(b["mix"], b["hb"], B, T)
+        self.conv_b.forward(b["hb"], b["yb"])
+        self.ln_b.forward(v2(b["yb"]), v2(b["cat"][..., Fd:]))
+        x = b["cat"]
+        for i, (conv, ln, osz, co) in enumerate(self.blocks):
+            conv.forward(x, b["ys"][i])
+            ln.forward(v2(b["ys"][i]), v2(b["zs"][i]))
+            x = b["zs"][i]
+        self._last = x
+        o.dense_gap_fwd(x.view(T * B, self.K), self.dense_w.value.view(-1), self.dense_b.value, b["score"], B, T)
+        return b["score"]
+
+    def backward(self, B, dscore, need_wgrad):
+        """dscore [B].  Returns the time-major gradient w.r.t. the high-res input [T*B,S,S,round4(ch)].
+        need_wgrad=False is the input-gradient-only pass (gradient penalty and generator step,
+        ganbase.py:35,60)."""
+        b = self.buffers(B)
+        o, Fd, T = self.ops, self.Fd, self.T
+        x = self._last
+        N = T * B
+        if self.blocks:
+            dx = b["dzs"][-1]
+        else:
+            dx = b["dcat"]
+        o.dense_gap_bwd(x.view(N, self.K), self.dense_w.value.view(-1), dscore, dx.view(N, self.K),
+                        self.dense_w.grad.view(-1) if need_wgrad else None,
+                        self.dense_b.grad if need_wgrad else None, B, T)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            conv, ln, osz, co = self.blocks[i]
+            dz = b["dzs"][i]
+            ln.backward(v2(dz), v2(b["ys"][i]), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
+            xin = b["zs"][i - 1] if i > 0 else b["cat"]
+            if need_wgrad:
+                conv.backward_weights(xin, dz)
+            conv.backward_input(dz, b["dzs"][i - 1] if i > 0 else b["dcat"])
+        # branch A (high-res only)
+        da = b["dcat"][..., :Fd]
+        self.ln_a.backward(v2(da), v2(b["ya"]), v2(da), self.conv_a.b.grad if need_wgrad else None, need_wgrad)
+        if need_wgrad:
+            self.conv_a.backward_weights(b["ha"], da)
+        self.conv_a.backward_input(da, b["dha"])
+        self.lstm_a.backward(b["hi"], b["ha"], b["dha"], b["dhi"], B, T, need_wgrad)
+        # branch B (low + high)
+        db_ = b["dcat"][..., Fd:]
+        self.ln_b.backward(v2(db_), v2(b["yb"]), v2(db_), self.conv_b.b.grad if need_wgrad else None, need_wgrad)
+        if need_wgrad:
+            self.conv_b.backward_weights(b["hb"], db_)
+        self.conv_b.backward_input(db_, b["dhb"])
+        self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"], B, T, need_wgrad)
+        # d(high) = d(hi) + d(mix)[cl:cl+ch]
+        o.copy_channels(b["dhi"][..., :self.ch], b["dhigh"][..., :self.ch])
+        o.copy_channels(b["dmix"][..., self.cl:self.cl + self.ch], b["dhigh"][..., :self.ch], accumulate=True)
+        return b["dhigh"]

@@ -1,0 +1,151 @@
+"""Flat parameter storage.
+
+All trainable variables of a network live in ONE flat fp32 buffer (and their gradients / Adam slots
+in parallel flat buffers): the optimizer is a single fused kernel launch and the data-parallel
+gradient exchange is a single RCCL all-reduce over `grads`.  Variable order mirrors Keras'
+`model.trainable_weights` order of the reference graphs (gan/models.py:9-142), and every variable
+keeps its TF name/shape (`layer_with_weights-N/...` keys decoded from weights-55.ckpt).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+class Var:
+    __slots__ = ("name", "shape", "trainable", "init", "offset", "size", "value", "grad")
+
+    def __init__(self, name, shape, trainable, init):
+        self.name, self.shape, self.trainable, self.init = name, tuple(shape), trainable, init
+        self.size = int(np.prod(shape))
+        self.offset = -1
+        self.value = None
+        self.grad = None
+
+
+class ParamStore:
+    def __init__(self, ops):
+        self.ops = ops
+        self.vars = []
+        self.version = 0  # bumped whenever values change outside SN (optimizer step, load, set)
+        self.flat = self.grads = self.state = None
+
+    def add(self, name, shape, init, trainable=True):
+        v = Var(name, shape, trainable, init)
+        self.vars.append(v)
+        return v
+
+    def finalize(self, rng):
+        """Allocate the flat buffers and initialise every variable (Keras default initialisers)."""
+        train = [v for v in self.vars if v.trainable]
+        other = [v for v in self.vars if not v.trainable]
+        # 4-element alignment keeps every weight view 16-byte aligned for the b128 loads
+        off = 0
+        for v in train:
+            v.offset = off
+            off += (v.size + 3) // 4 * 4
+        self.n_train = off
+        host = np.zeros(off, dtype=np.float64)
+        for v in train:
+            host[v.offset:v.offset + v.size] = v.init(v.shape, rng).reshape(-1)
+        self.flat = self.ops.from_host(host)
+        self.grads = self.ops.zeros(off)
+        off2 = 0
+        for v in other:
+            v.offset = off2
+            off2 += (v.size + 3) // 4 * 4
+        host2 = np.zeros(max(off2, 4), dtype=np.float64)
+        for v in other:
+            host2[v.offset:v.offset + v.size] = v.init(v.shape, rng).reshape(-1)
+        self.state = self.ops.from_host(host2)
+        for v in train:
+            v.value = self.flat[v.offset:v.offset + v.size].view(v.shape)
+            v.grad = self.grads[v.offset:v.offset + v.size].view(v.shape)
+        for v in other:
+            v.value = self.state[v.offset:v.offset + v.size].view(v.shape)
+        self.trainable = train
+        self.non_trainable = other
+        # segment table for the g/d_gradient_param metric (mean over variables of mean(g^2))
+        pairs = []
+        for v in train:
+            pairs += [v.offset, v.offset + v.size]
+        self.seg_pairs = torch.tensor(pairs, dtype=torch.int64).to(self.flat.device)
+        self.seg_out = self.ops.empty(len(train))
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def num_trainable(self):
+        return sum(v.size for v in self.trainable)
+
+    def by_name(self, name):
+        for v in self.vars:
+            if v.name == name:
+                return v
+        raise KeyError(name)
+
+    # ---- host <-> device ------------------------------------------------------------------------
+    def get_weights(self):
+        """{name: numpy array} of every variable (trainable and not), TF shapes."""
+        return {v.name: v.value.detach().double().cpu().numpy().astype(np.float32) for v in self.vars}
+
+    def set_weights(self, mapping, strict=True):
+        for v in self.vars:
+            if v.name in mapping:
+                arr = np.asarray(mapping[v.name])
+                if tuple(arr.shape) != v.shape:
+                    raise ValueError(f"{v.name}: shape {arr.shape} != {v.shape}")
+                v.value.copy_(self.ops.from_host(arr).view(v.shape))
+            elif strict:
+                raise KeyError(f"missing variable {v.name}")
+        self.version += 1
+
+
+# ---- Keras default initialisers -------------------------------------------------------------------
+def glorot_uniform(fan_in, fan_out):
+    def init(shape, rng):
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape)
+    return init
+
+
+def conv_glorot(shape, rng):
+    kh, kw, cin, cout = shape
+    lim = math.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+    return rng.uniform(-lim, lim, size=shape)
+
+
+def orthogonal(shape, rng):
+    rows = int(np.prod(shape[:-1]))
+    cols = shape[-1]
+    a = rng.standard_normal((max(rows, cols), min(rows, cols)))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    if rows < cols:
+        q = q.T
+    return q.reshape(shape)
+
+
+def zeros_init(shape, rng):
+    return np.zeros(shape)
+
+
+def ones_init(shape, rng):
+    return np.ones(shape)
+
+
+def lstm_bias(F):
+    def init(shape, rng):  # Keras unit_forget_bias: gate order i,f,c,o
+        b = np.zeros(shape)
+        b[F:2 * F] = 1.0
+        return b
+    return init
+
+
+def sn_u_init(shape, rng):  # tf.initializers.TruncatedNormal(stddev=0.02)
+    x = rng.standard_normal(shape) * 0.02
+    bad = np.abs(x) > 0.04
+    while bad.any():
+        x[bad] = rng.standard_normal(int(bad.sum())) * 0.02
+        bad = np.abs(x) > 0.04
+    return x

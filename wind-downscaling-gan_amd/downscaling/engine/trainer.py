@@ -1,0 +1,212 @@
+"""GAN train / test step of the reference (/root/reference/src/downscaling/gan/ganbase.py:21-113) on
+the layer engine, plus the TF-form Adam optimizer (gan/train.py:34-35,57-58), the Philox noise
+source behind FlexibleNoiseGenerator (data/data_generator.py:319-335) and the data-parallel glue.
+"""
+import math
+import os
+
+import torch
+
+from .common import round4, v2
+
+
+class AdamTF:
+    """tf.keras.optimizers.Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)."""
+
+    def __init__(self, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, learning_rate=None):
+        self.lr = float(learning_rate if learning_rate is not None else lr)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self.iterations = 0
+        self.m = self.v = None
+
+    def apply_gradients(self, store, grad_scale=1.0):
+        ops = store.ops
+        if self.m is None:
+            self.m = ops.zeros(store.flat.numel())
+            self.v = ops.zeros(store.flat.numel())
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        ops.adam_tf(store.flat, store.grads, self.m, self.v, lr_t, self.beta_1, self.beta_2, self.epsilon, grad_scale)
+        store.version += 1
+
+
+class PhiloxSource:
+    """Counter-based normal/uniform source: (seed, running counter offset).  Every draw advances the
+    offset by the number of Philox blocks it consumed, so a sequence of draws is reproducible."""
+
+    def __init__(self, ops, seed=None, rank=0):
+        self.ops = ops
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
+        self.seed = (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & (2 ** 64 - 1)
+        self.offset = 0
+
+    def normal_into(self, view2d, std, add=None):
+        self.ops.philox_normal(view2d, self.seed, self.offset, float(std), add)
+        self.offset += (view2d.shape[0] * view2d.shape[1] + 3) // 4
+
+    def uniform_into(self, vec):
+        self.ops.philox_uniform(vec, self.seed, self.offset)
+        self.offset += (vec.numel() + 3) // 4
+
+
+class DistSync:
+    """One process per GPU; RCCL (backend "nccl") all-reduce over xGMI.  The path has exactly two
+    exchange points: the flat gradient buffers (once per optimizer step) and the BatchNorm batch
+    statistics (SyncBN, so a global batch of 8x32 normalises like the single-device reference)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class GanEngine:
+    GAMMA = 100.0  # ganbase.py:22
+
+    def __init__(self, gen, disc, noise_source, noise_std, n_critic=3, sync=None, sync_bn=True):
+        self.gen, self.disc, self.noise, self.noise_std = gen, disc, noise_source, float(noise_std)
+        self.n_critic = n_critic
+        self.sync = sync
+        self.ops = gen.ops
+        if sync is not None and sync_bn:
+            gen.sync = sync
+        self._tmp = {}
+
+    def _buf(self, key, *shape):
+        t = self._tmp.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self.ops.zeros(*shape)
+            self._tmp[key] = t
+        return t
+
+    def _reduce_and_step(self, net, opt):
+        scale = 1.0
+        if self.sync is not None and self.sync.world_size > 1:
+            self.sync.all_reduce_sum(net.params.grads)
+            scale = 1.0 / self.sync.world_size
+        opt.apply_gradients(net.params, grad_scale=scale)
+        return scale
+
+    def _grad_param_metric(self, net, scale):
+        st = net.params
+        self.ops.segment_meansq(st.grads, st.seg_pairs, st.seg_out)
+        return st.seg_out.mean() * (scale * scale)
+
+    def train_step(self, low, high, g_opt, d_opt, sample_weight=None, reconstruction_loss=None):
+        """One GAN.train_step (ganbase.py:21-94).  low [B,T,S,S,cl], high [B,T,S,S,ch] device tensors."""
+        gen, disc, ops, noise = self.gen, self.disc, self.ops, self.noise
+        B, T = low.shape[0], low.shape[1]
+        S, ch = gen.S, disc.ch
+        chp = round4(ch)
+        N, ppi = T * B, S * S
+        sw_mean = 1.0 if sample_weight is None else float(torch.as_tensor(sample_weight).double().mean())
+        gen.set_image(low)
+        disc.set_low(low)
+        real = self._buf("real", N, S, S, chp)
+        gen.to_time_major(high, real)
+        comb, noisy = self._buf("comb", N, S, S, chp), self._buf("noisy", N, S, S, chp)
+        eps, gsq = self._buf("eps", B), self._buf("gsq", B, chp)
+        ones = self._buf("ones", B)
+        ones.fill_(1.0)
+        dscore = self._buf("dscore", B)
+
+        for _ in range(self.n_critic):                                            # ganbase.py:26
+            noise.normal_into(gen.noise_view(B), self.noise_std)                   # :28
+            fake = gen.forward(B, training=True)                                  # :29
+            noise.uniform_into(eps)                                               # :30
+            ops.lerp_batch(v2(real), v2(fake), eps, v2(comb), ppi, B)             # :31
+            disc.set_high_tm(comb, B)
+            disc.forward(B, training=True)                                        # :32-34
+            dcomb = disc.backward(B, ones, need_wgrad=False)                      # :35
+            ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                         # :36
+            gnorm = torch.sqrt(gsq[:, :ch])
+            gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()               # :37  (a constant w.r.t. D's weights)
+            disc.params.zero_grad()
+            noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(real[..., :ch]))   # :40
+            disc.set_high_tm(noisy, B)
+            real_mean = disc.forward(B, training=True).mean()                     # :41
+            dscore.fill_(-sw_mean / B)
+            disc.backward(B, dscore, need_wgrad=True)
+            noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(fake[..., :ch]))   # :42
+            disc.set_high_tm(noisy, B)
+            fake_mean = disc.forward(B, training=True).mean()                     # :43
+            dscore.fill_(sw_mean / B)
+            disc.backward(B, dscore, need_wgrad=True)
+            disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45, train.py:11-12
+            dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
+        d_gradient_param = self._grad_param_metric(disc, dscale)
+
+        gen.params.zero_grad()                                                    # generator step, :50-61
+        noise.normal_into(gen.noise_view(B), self.noise_std)
+        fake = gen.forward(B, training=True)
+        disc.set_high_tm(fake, B)
+        gen_disc_loss = -disc.forward(B, training=True).mean()                    # :54
+        dscore.fill_(-1.0 / B)
+        dfake = disc.backward(B, dscore, need_wgrad=False)
+        gen_loss, reco_loss = gen_disc_loss, None
+        if reconstruction_loss is not None:                                       # :57-59
+            reco_loss, dreco = self._reco_grad(reconstruction_loss, low, fake, B, T)
+            gen_loss = gen_loss + reco_loss
+            ops.copy_channels(dreco, dfake[..., :ch], accumulate=True)
+        gen.backward(B, dfake)
+        gscale = self._reduce_and_step(gen, g_opt)
+        g_gradient_param = self._grad_param_metric(gen, gscale)
+
+        disc.set_high_tm(real, B)                                                 # metrics recompute, :63-68
+        real_mean = disc.forward(B, training=False).mean()
+        noise.normal_into(gen.noise_view(B), self.noise_std)
+        fake = gen.forward(B, training=False)
+        disc.set_high_tm(fake, B)
+        fake_scores = disc.forward(B, training=False)
+        fake_mean = fake_scores.mean()
+        self.last_fake_tm = fake
+        return {
+            "g_loss": -fake_mean,
+            "g_disc_loss": gen_disc_loss,
+            "g_reco_loss": reco_loss,
+            "d_loss": (fake_mean - real_mean) * sw_mean,
+            "d_gradient_pen": gnorm.mean(),
+            "g_gradient_param": g_gradient_param,
+            "d_gradient_param": d_gradient_param,
+            "_d_loss_train": disc_loss,
+            "_d_real": real_mean,
+            "_d_fake": fake_mean,
+        }
+
+    def _reco_grad(self, reconstruction_loss, low, fake_tm, B, T):
+        """User-supplied reconstruction loss (train.py:19-26) evaluated with torch autograd on a leaf
+        copy of the generator output; returns (loss, d loss / d fake as a time-major view)."""
+        gen = self.gen
+        ch = self.disc.ch
+        fake_api = torch.empty(B, T, gen.S, gen.S, ch, dtype=fake_tm.dtype, device=fake_tm.device)
+        gen.from_time_major(fake_tm, fake_api)
+        leaf = fake_api.detach().requires_grad_(True)
+        loss = reconstruction_loss(low[..., :2], leaf)
+        (gapi,) = torch.autograd.grad(loss, leaf)
+        gtm = self._buf("dreco", T * B, gen.S, gen.S, ch)
+        gen.to_time_major(gapi, gtm)
+        return loss.detach(), gtm
+
+    def test_step(self, low, high):
+        """GAN.test_step (ganbase.py:96-113): discriminator loss on real vs generated, inference mode."""
+        gen, disc = self.gen, self.disc
+        B, T = low.shape[0], low.shape[1]
+        S, chp = gen.S, round4(disc.ch)
+        gen.set_image(low)
+        disc.set_low(low)
+        real = self._buf("real", T * B, S, S, chp)
+        gen.to_time_major(high, real)
+        self.noise.normal_into(gen.noise_view(B), self.noise_std)
+        disc.set_high_tm(real, B)
+        real_mean = disc.forward(B, training=False).mean()
+        fake = gen.forward(B, training=False)
+        disc.set_high_tm(fake, B)
+        fake_mean = disc.forward(B, training=False).mean()
+        return {"loss": fake_mean - real_mean}
