@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: full GAN train step (G + D + Adam, n_critic = 3, metrics recompute included —
+exactly GAN.train_step of the reference, ganbase.py:21-94) on synthetic 2-channel 32x32 -> 256x256
+fp32 wind tiles, batch 32 per GPU, T = 1 (BASELINE.json configs[1]; weak scaling over GPUs).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every launch of the
+conv kernels on their launch stream inside the timed region; `cpu_baseline` times the CPU restatement
+(oracle/torch_model.py, torch-CPU fp32 on all host cores) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "wind-downscaling-gan_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+S, T, CIN, NZ, CH = 256, 1, 3, 20, 2
+
+
+def synthetic_batch(B, seed, device):
+    """configs[1]: 32x32 N(0,1) winds regridded x8 (nearest) + N(0,1) DEM at 256x256; N(0,1) high-res winds."""
+    rng = np.random.default_rng(seed)
+    wind = rng.standard_normal((B, T, 32, 32, 2)).astype(np.float32)
+    wind = np.repeat(np.repeat(wind, 8, axis=2), 8, axis=3)
+    dem = rng.standard_normal((B, T, S, S, 1)).astype(np.float32)
+    low = np.concatenate([wind, dem], -1)
+    high = rng.standard_normal((B, T, S, S, CH)).astype(np.float32)
+    return torch.from_numpy(low).to(device), torch.from_numpy(high).to(device)
+
+
+class ConvTimer:
+    """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, ops):
+        from downscaling.engine import hipops
+        timer = self
+
+        def tile(ncols):
+            return (256, 16, 4, 1) if ncols <= 16 else (256, 32, 4, 1) if ncols <= 32 else (128, 64, 2, 2) if ncols <= 64 else (128, 128, 2, 2)
+
+        def flops(x, y, pk, g):
+            n, Ho, Wo = y.shape[0], y.shape[1], y.shape[2]
+            return 2.0 * n * Ho * Wo * pk.cout * g.kh * g.kw * pk.cin
+
+        orig_fwd, orig_dgrad, orig_wgrad = ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad
+
+        def timed(name, fl, fn, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            timer.records.append((name, fl, e0, e1))
+
+        def conv_fwd(x, pk, bias, y, g, **k):
+            timed("wdg_igemm_kernel<%d,%d,%d,%d>" % tile(pk.cout), flops(x, y, pk, g), orig_fwd, x, pk, bias, y, g, **k)
+
+        def conv_dgrad(dy, pk, dx, g, **k):
+            timed("wdg_igemm_kernel<%d,%d,%d,%d>" % tile(pk.cin), flops(dx, dy, pk, g), orig_dgrad, dy, pk, dx, g, **k)
+
+        def conv_wgrad(x, dy, pk, dw, g, **k):
+            bn = 16 if pk.cout <= 16 else 32 if pk.cout <= 32 else 64 if pk.cout <= 64 else 128
+            timed("wdg_wgrad_kernel<%d>" % bn, flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g, **k)
+
+        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
+
+    def summary(self):
+        agg = {}
+        for name, fl, e0, e1 in self.records:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        return agg
+
+
+def cpu_baseline(batch=1):
+    """The CPU restatement of the same train step (torch-CPU fp32, all host cores) on a bounded sample."""
+    from oracle import torch_model as TM
+    from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
+    from oracle.torch_backend import TorchOps
+    from tests.helpers import Draws
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ops = TorchOps(torch.float32)
+    gen = GeneratorNet(ops, S, CIN, NZ, CH, T, seed=1)     # only used to initialise weights with the TF names/shapes
+    disc = DiscriminatorNet(ops, S, S, CIN, CH, T, seed=2)
+    gw = {v.name: v.value.clone() for v in gen.params.vars}
+    dw = {v.name: v.value.clone() for v in disc.params.vars}
+    del gen, disc
+    rng = np.random.default_rng(0)
+    low = torch.from_numpy(rng.standard_normal((batch, T, S, S, CIN)).astype(np.float32))
+    high = torch.from_numpy(rng.standard_normal((batch, T, S, S, CH)).astype(np.float32))
+
+    class D32(Draws):
+        def _normal(self, C):
+            return super()._normal(C).float()
+
+        def eps(self):
+            return super().eps().float()
+    draws = D32(7, batch, T, S, NZ, CH, 0.1)
+    t0 = time.perf_counter()
+    TM.train_step(gw, dw, low, high, draws, TM.AdamTF(1e-4), TM.AdamTF(4e-4))
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 full GAN train step (n_critic=3), batch {batch}, {S}x{S}, T={T}, torch-CPU fp32 restatement "
+                      f"(oracle/torch_model.py; TensorFlow is not installable here), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true", help="per-replica BatchNorm statistics instead of SyncBN")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    from downscaling.engine import runtime
+    from downscaling.gan import train
+    from downscaling.gan.ganbase import GAN
+    from downscaling.gan.models import make_discriminator, make_generator
+
+    ops = runtime.get_ops()
+    dev = ops.device
+    B = args.batch
+    generator = make_generator(S, CIN, NZ, CH, T)
+    discriminator = make_discriminator(S, S, CIN, CH, T)
+    gan = GAN(generator, discriminator, FlexibleNoiseGenerator((B, T, S, S, NZ), std=0.1, random_seed=1234, rank=rank),
+              n_critic=3, distributed=world > 1, sync_bn=not args.no_sync_bn)
+    gan.compile(generator_optimizer=train.generator_optimizer(), discriminator_optimizer=train.discriminator_optimizer(),
+                discriminator_loss=train.discriminator_loss)
+    low, high = synthetic_batch(B, 10 + rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gan.train_step((low, high))
+    timer = ConvTimer()
+    timer.wrap(ops)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = gan.train_step((low, high))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        # algorithmic FLOPs of one reference step per sample: 7*Gf + 28*Df (SURVEY §8 d), T = 1
+        gf, df = 22.385e9, 2.994e9
+        step_flops = (7 * gf + 28 * df) * B
+        agg = timer.summary()
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        conv_time = sum(a[1] for a in agg.values())
+        conv_flops = sum(a[0] for a in agg.values())
+        out = {
+            "metric": "GAN train-step samples/s, 32x32->256x256 wind tiles",
+            "value": world * B * args.steps / dt,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "GAN.train_step (G fwd x5, D fwd x12, 7 backward passes, Adam on both, n_critic=3, "
+                                   "metrics recompute) on G(256,3,20,2,T=1)+D(256,256,3,2,T=1), configs[1]",
+                       "per_gpu_batch": B, "global_batch": world * B, "image_size": S, "n_timesteps": T,
+                       "parallelism": f"dp{world}" + ("" if args.no_sync_bn or world == 1 else "+syncbn")},
+            "step_tflops_algorithmic": step_flops * 1e-12,
+            "step_frac_of_mfma_f32_peak": step_flops / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            "roofline": {"bound": "mfma", "kernel": dom[0],
+                         "achieved": dom[1][0] / dom[1][1] * 1e-12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom[1][0] / dom[1][1] * 1e-12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches": dom[1][2], "avg_launch_ms": 1e3 * dom[1][1] / dom[1][2],
+                         "all_conv_kernels": {k: {"tflops": v[0] / v[1] * 1e-12, "ms_per_step": 1e3 * v[1] / args.steps,
+                                                   "launches_per_step": v[2] / args.steps} for k, v in agg.items()},
+                         "conv_share_of_step": conv_time / dt, "all_conv_tflops": conv_flops / conv_time * 1e-12},
+            "losses": {k: float(v) for k, v in logs.items() if v is not None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""Generates the golden fixtures of tests/golden/ from the reference tree (run in the build container
+only: /root/reference does not exist on the GPU box).
+
+  tile_plan.json        the integer tile planner of predict(), AST-extracted from
+                        /root/reference/src/downscaling/api.py:99-116 and executed as written
+                        (np.math shimmed for numpy 2) — TensorFlow/xarray are not needed for it.
+  generator_index.json  variable names / shapes decoded from
+                        /root/reference/src/downscaling/weights-55.ckpt/generator.index
+  discriminator_index.json  same for the discriminator (shortcut variant, SURVEY §8 a2 note 2)
+"""
+import ast
+import json
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REF = Path("/root/reference/src/downscaling")
+sys.path.insert(0, str(HERE.parent.parent / "wind-downscaling-gan_amd"))
+
+
+def reference_planner():
+    src = (REF / "api.py").read_text()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "predict")
+    # statements from `ntimeseq = ...` to `slices_start_y = ...` (api.py:99-116)
+    names = [getattr(s.targets[0], "id", None) if isinstance(s, ast.Assign) else None for s in fn.body]
+    first = next(i for i, s in enumerate(fn.body) if isinstance(s, ast.Assign) and getattr(s.targets[0], "id", "") == "ntimeseq")
+    last = max(i for i, s in enumerate(fn.body) if isinstance(s, ast.Assign) and
+               any(getattr(t, "id", "") == "slices_start_y" for t in s.targets))
+    body = fn.body[first:last + 1]
+    mod = ast.Module(body=body, type_ignores=[])
+    code = compile(mod, "api.py[99:116]", "exec")
+
+    class _NP:
+        math = math
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+    def plan(pixels_lat, pixels_lon, time_window, overlap_factor):
+        env = dict(np=_NP(), SEQUENCE_LENGTH=24, IMG_SIZE=96, pixels_lat=pixels_lat, pixels_lon=pixels_lon,
+                   time_window=time_window, overlap_factor=overlap_factor)
+        exec(code, env)
+        return {k: (int(env[k]) if not isinstance(env[k], list) else [int(v) for v in env[k]])
+                for k in ("ntimeseq", "ncols", "nrows", "xdist", "ydist", "leftovers_x", "leftovers_y",
+                          "slices_start_x", "slices_start_y")}
+    return plan
+
+
+def main():
+    plan = reference_planner()
+    cases = []
+    for (la, lo, tw, of) in [(1200, 1200, 24, 0.05), (1200, 1200, 24, 0.01), (128, 128, 24, 0.05), (260, 300, 48, 0.05),
+                             (300, 500, 72, 0.3), (2000, 1500, 25, 0.1), (400, 400, 24, 1.0), (192, 192, 24, 0.0)]:
+        cases.append(dict(pixels_lat=la, pixels_lon=lo, time_window=tw, overlap_factor=of, expected=plan(la, lo, tw, of)))
+    (HERE / "tile_plan.json").write_text(json.dumps(cases, indent=1))
+    from downscaling.engine.tf_bundle import read_index
+    for name in ("generator", "discriminator"):
+        ents = read_index(REF / "weights-55.ckpt" / f"{name}.index")
+        suffix = "/.ATTRIBUTES/VARIABLE_VALUE"
+        var = {k[:-len(suffix)]: list(shape) for (k, dt, shape, shard, off, size) in ents
+               if k.endswith(suffix) and k.startswith("layer_with_weights") and ".OPTIMIZER_SLOT" not in k}
+        nbytes = sum(size for (k, dt, shape, shard, off, size) in ents
+                     if k.endswith(suffix) and k.startswith("layer_with_weights") and ".OPTIMIZER_SLOT" not in k)
+        (HERE / f"{name}_index.json").write_text(json.dumps(dict(variables=var, variable_bytes=nbytes), indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""API surface of the `downscaling` package (reference names / signatures / error behaviour) exercised on
+CPU by injecting the oracle operator backend; the C-ABI library must load and export every declared symbol."""
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from downscaling.engine import native, runtime
+from oracle.torch_backend import TorchOps
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture()
+def cpu_backend():
+    runtime.set_ops(TorchOps(torch.float64))
+    yield
+    runtime.set_ops(None)
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "wdgan.h").read_text()
+    declared = set(re.findall(r"\b(wdg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"wdg_stream"}
+    lib = native.load()
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wdg_version().decode() == "wdgan 0.1 gfx950"
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from downscaling.engine.hipops import HipOps
+    with pytest.raises(native.NativeError):
+        HipOps()
+    runtime.set_ops(None)
+    from downscaling.gan.models import make_generator
+    with pytest.raises(native.NativeError):
+        make_generator(16, 3, 2, 2, 1, feature_channels=32)
+
+
+def test_reference_signatures_and_errors(cpu_backend):
+    import inspect
+    from downscaling.gan import models, ganbase, train
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    assert list(inspect.signature(models.make_generator).parameters) == [
+        "image_size", "in_channels", "noise_channels", "out_channels", "n_timesteps", "batch_size", "feature_channels"]
+    assert list(inspect.signature(models.make_discriminator).parameters) == [
+        "low_res_size", "high_res_size", "low_res_channels", "high_res_channels", "n_timesteps", "batch_size", "feature_channels"]
+    assert inspect.signature(models.make_generator).parameters["feature_channels"].default == 128
+    assert inspect.signature(models.make_discriminator).parameters["feature_channels"].default == 16
+    assert list(inspect.signature(ganbase.GAN.__init__).parameters)[:6] == [
+        "self", "generator", "discriminator", "noise_generator", "n_critic", "reconstruction_loss"]
+    assert list(inspect.signature(FlexibleNoiseGenerator.__init__).parameters)[:4] == ["self", "noise_shape", "std", "random_seed"]
+    with pytest.raises(AssertionError):
+        models.make_generator(18, 3, 2, 2, 1, feature_channels=32)      # image_size % 4 (models.py:19)
+    with pytest.raises(AssertionError):
+        models.make_generator(16, 3, 2, 2, 1, feature_channels=36)      # feature_channels % 8 (models.py:20)
+    with pytest.raises(NotImplementedError):
+        models.make_discriminator(16, 32, 3, 2, 1)                      # models.py:89-91
+    o = train.generator_optimizer(), train.discriminator_optimizer()
+    assert (o[0].lr, o[0].beta_1, o[0].beta_2, o[0].epsilon) == (1e-4, 0.5, 0.9, 0.1)
+    assert (o[1].lr, o[1].beta_1, o[1].beta_2, o[1].epsilon) == (4e-4, 0.5, 0.9, 0.1)
+    r, f = torch.tensor([1.0, 3.0]), torch.tensor([0.0, 1.0])
+    assert float(train.discriminator_loss(r, f)) == -1.5
+
+
+def test_checkpoint_variable_names_match_shipped_index(cpu_backend):
+    """SURVEY §8 c(iii): every generator variable name/shape of weights-55.ckpt/generator.index
+    (decoded once with engine/tf_bundle.read_index; committed as a fixture) is produced by the build."""
+    import json
+    from downscaling.gan.models import make_generator
+    fixture = json.loads((ROOT / "tests" / "golden" / "generator_index.json").read_text())
+    gen = make_generator(96, 3, 20, 2, 1)   # T does not change the variables
+    mine = {v.name: list(v.shape) for v in gen.net.params.vars}
+    assert mine == {k: v for k, v in fixture["variables"].items()}
+    # 7,182,688 B in SURVEY §8 a1 = these variables + 24 B of optimizer scalars (iter, lr, decay, momentum, rho)
+    assert sum(int(np.prod(s)) for s in mine.values()) * 4 == fixture["variable_bytes"] == 7182688 - 24
+    assert gen.net.params.num_trainable() == 1794418
+
+
+def test_gan_api_train_save_load_predict(cpu_backend, tmp_path):
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    from downscaling.gan import train
+    from downscaling.gan.ganbase import GAN
+    from downscaling.gan.metrics import discriminator_score_fake, discriminator_score_real, WindSpeedWeightedRMSE
+    from downscaling.gan.models import make_discriminator, make_generator
+    B, T, S = 2, 2, 12
+    g = make_generator(S, 3, 2, 2, T, feature_channels=32)
+    d = make_discriminator(S, S, 3, 2, T, feature_channels=8)
+    assert g.name == "generator" and d.name == "discriminator"
+    gan = GAN(g, d, FlexibleNoiseGenerator((B, T, S, S, 2), std=0.1, random_seed=3), n_critic=2)
+    with pytest.raises(RuntimeError):
+        gan.train_step((torch.zeros(B, T, S, S, 3), torch.zeros(B, T, S, S, 2)))   # not compiled
+    gan.compile(generator_optimizer=train.generator_optimizer(), discriminator_optimizer=train.discriminator_optimizer(),
+                discriminator_loss=train.discriminator_loss, generator_metrics=[WindSpeedWeightedRMSE()],
+                metrics=[discriminator_score_fake(), discriminator_score_real()])
+    rng = np.random.default_rng(0)
+    low, high = rng.standard_normal((B, T, S, S, 3)), rng.standard_normal((B, T, S, S, 2))
+    logs = gan.train_step((low, high))
+    assert {"g_loss", "g_disc_loss", "g_reco_loss", "d_loss", "d_gradient_pen", "g_gradient_param", "d_gradient_param",
+            "d_fake", "d_real", "g_ws_weighted_rmse"} <= set(logs)
+    assert logs["g_reco_loss"] is None and np.isfinite(float(logs["d_loss"]))
+    t = gan.test_step((low, high))
+    assert np.isfinite(float(t["loss"]))
+    noise = gan.noise_generator(bs=B)
+    assert tuple(noise.shape) == (B, T, S, S, 2) and abs(float(noise.std()) - 0.1) < 0.02
+    assert tuple(gan.noise_generator(bs=3, channels=5, std=2.0).shape) == (3, T, S, S, 5)
+    p1 = g.predict([low, noise.numpy()])
+    assert p1.shape == (B, T, S, S, 2) and p1.dtype in (np.float32, np.float64)
+    assert tuple(d([low, high]).shape) == (B, 1)
+    gan.save_weights(str(tmp_path / "ckpt"))
+    g2 = make_generator(S, 3, 2, 2, T, feature_channels=32)
+    d2 = make_discriminator(S, S, 3, 2, T, feature_channels=8)
+    gan2 = GAN(g2, d2, FlexibleNoiseGenerator((B, T, S, S, 2), std=0.1, random_seed=3))
+    gan2.load_weights(str(tmp_path / "ckpt"))
+    np.testing.assert_allclose(g2.predict([low, noise.numpy()]), p1, rtol=1e-6, atol=1e-7)
+    # reconstruction-loss slot (ganbase.py:57-59) with the wind-speed-weighted RMSE as content loss
+    from downscaling.gan.metrics import wind_speed_weighted_rmse
+    gan3 = GAN(g, d, gan.noise_generator, n_critic=1, reconstruction_loss=lambda lo, hi: wind_speed_weighted_rmse(lo, hi).mean())
+    gan3.compile(train.generator_optimizer(), train.discriminator_optimizer(), discriminator_loss=train.discriminator_loss)
+    logs3 = gan3.train_step((low, high))
+    assert logs3["g_reco_loss"] is not None and float(logs3["g_reco_loss"]) > 0
+
+
+def test_tile_plan_golden():
+    """Golden vectors captured from the reference's own planner (api.py:99-116, AST-extracted and run
+    with numpy; SURVEY §8 c) — committed in tests/golden/tile_plan.json with the generating script."""
+    import json
+    from downscaling.api import tile_plan
+    for case in json.loads((ROOT / "tests" / "golden" / "tile_plan.json").read_text()):
+        got = tile_plan(case["pixels_lat"], case["pixels_lon"], case["time_window"], case["overlap_factor"])
+        for k, v in case["expected"].items():
+            assert got[k] == v, (case, k, got[k])
+    with pytest.raises(RuntimeError):
+        tile_plan(300, 90, 24, 0.05)

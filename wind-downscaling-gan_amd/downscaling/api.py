@@ -1,0 +1,199 @@
+"""Inference driver with the reference names and defaults
+(/root/reference/src/downscaling/api.py:21-160): constants, get_network, the tiled `predict`
+(tile plan, per-tile latitude flip, normalisation, groups of 16, 2-px crop, mean blend) and the
+xarray-facing `downscale` wrappers.  The array core (`tile_plan`, `predict_array`) is plain numpy so it
+runs where xarray / netCDF4 / rasterio are absent; the generator calls run on the HIP kernels."""
+import math
+import os
+from pathlib import Path
+
+import numpy as np
+
+from downscaling.data.data_generator import FlexibleNoiseGenerator
+from downscaling.gan import train, metrics
+from downscaling.gan.ganbase import GAN
+from downscaling.gan.models import make_generator, make_discriminator
+
+WEIGHTS_PATH = (Path(__file__) / '../weights-55.ckpt').resolve()
+SEQUENCE_LENGTH = 24
+IMG_SIZE = 96
+BATCH_SIZE = 8
+NOISE_CHANNELS = 20
+NOISE_STD = 0.1
+NB_INPUTS = 3
+NB_OUTPUTS = 2
+
+__all__ = ['WEIGHTS_PATH', 'SEQUENCE_LENGTH', 'IMG_SIZE', 'BATCH_SIZE', 'NOISE_CHANNELS', 'NOISE_STD', 'NB_INPUTS',
+           'NB_OUTPUTS', 'process_topo', 'process_era5', 'build_high_res_template_from_era5', 'get_network',
+           'predict', 'downscale', 'tile_plan', 'predict_array', 'GAN', 'make_generator', 'make_discriminator',
+           'FlexibleNoiseGenerator']
+
+
+def _xr():
+    try:
+        import xarray as xr
+        return xr
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("the xarray-facing wrappers need xarray (+ netCDF4 / rasterio); "
+                          "use predict_array() on numpy fields instead") from e
+
+
+def process_topo(raster_topo, high_res_template):
+    xr = _xr()
+    lon_coord, lat_coord = [c for c in high_res_template.coords if c.startswith('lon')][0], [c for c in high_res_template.coords if c.startswith('lat')][0]
+    dem = raster_topo.isel(band=0, drop=True)
+    inputs_topo = xr.DataArray(dem, coords=dem.coords, name='elevation').to_dataset().sel(
+        x=high_res_template.get(lon_coord), y=high_res_template.get(lat_coord), method='nearest').drop(['x', 'y'])
+    return inputs_topo
+
+
+def process_era5(ds_era5, high_res_template):
+    lon_coord, lat_coord = [c for c in high_res_template.coords if c.startswith('lon')][0], [c for c in high_res_template.coords if c.startswith('lat')][0]
+    inputs_surface = ds_era5[['u10', 'v10']].sel(longitude=high_res_template.get(lon_coord), latitude=high_res_template.get(lat_coord), method='nearest').drop(['longitude', 'latitude'])
+    return inputs_surface
+
+
+def build_high_res_template_from_era5(ds_era5, range_lon=None, range_lat=None):
+    upsampling_lat = 26
+    upsampling_lon = 18
+    if not range_lon:
+        range_lon = (float(ds_era5.longitude.min()), float(ds_era5.longitude.max()))
+    else:
+        ds_era5 = ds_era5.sel(longitude=slice(range_lon[0], range_lon[1]))
+    if not range_lat:
+        range_lat = (float(ds_era5.latitude.min()), float(ds_era5.latitude.max()))
+    else:
+        ds_era5 = ds_era5.sel(latitude=slice(range_lat[1], range_lat[0]))
+    nb_lon = ds_era5.dims['longitude']
+    nb_lat = ds_era5.dims['latitude']
+    new_longitudes = np.linspace(range_lon[0], range_lon[1], upsampling_lon * nb_lon)
+    new_latitudes = np.linspace(range_lat[0], range_lat[1], upsampling_lat * nb_lat)
+    high_res_template = ds_era5.coords.to_dataset().assign_coords({'lon_1': new_longitudes, 'lat_1': new_latitudes}).drop(['longitude', 'latitude'])
+    return high_res_template
+
+
+def get_network(weights_path=WEIGHTS_PATH, allow_random_init=None, random_seed=None):
+    """Builds G(96,3,20,2,T=24) / D and the compiled GAN exactly as api.py:65-86 and loads the checkpoint.
+    The shipped weights-55.ckpt blobs are absent from the reference tree (.MISSING_LARGE_BLOBS); unless
+    `allow_random_init` (or DOWNSCALING_ALLOW_RANDOM_INIT=1) is set a missing checkpoint raises, as the
+    reference's load_weights would."""
+    print('Loading network...')
+    generator = make_generator(image_size=IMG_SIZE, in_channels=NB_INPUTS,
+                               noise_channels=NOISE_CHANNELS, out_channels=NB_OUTPUTS,
+                               n_timesteps=SEQUENCE_LENGTH)
+    discriminator = make_discriminator(low_res_size=IMG_SIZE, high_res_size=IMG_SIZE,
+                                       low_res_channels=NB_INPUTS,
+                                       high_res_channels=NB_OUTPUTS, n_timesteps=SEQUENCE_LENGTH)
+    noise_shape = (BATCH_SIZE, SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NOISE_CHANNELS)
+    gan = GAN(generator, discriminator, noise_generator=FlexibleNoiseGenerator(noise_shape, std=NOISE_STD, random_seed=random_seed))
+    gan.compile(generator_optimizer=train.generator_optimizer(),
+                generator_metrics=[metrics.WindSpeedWeightedRMSE()],
+                discriminator_optimizer=train.discriminator_optimizer(),
+                discriminator_loss=train.discriminator_loss,
+                metrics=[metrics.discriminator_score_fake(), metrics.discriminator_score_real()])
+    if allow_random_init is None:
+        allow_random_init = os.environ.get('DOWNSCALING_ALLOW_RANDOM_INIT', '0') == '1'
+    try:
+        # only the generator is needed for inference; the shipped discriminator checkpoint was trained
+        # with the (unreachable) shortcut variant and does not match the published graph
+        generator.load_weights(Path(weights_path) / 'generator')
+    except FileNotFoundError:
+        if not allow_random_init:
+            raise
+        print(f'WARNING: no checkpoint at {weights_path}; using randomly initialised weights')
+    return gan
+
+
+def tile_plan(pixels_lat, pixels_lon, time_window, overlap_factor=0.05):
+    """The integer tile planner of predict (api.py:98-116), quirks included (the row check tests the
+    column variables, api.py:105)."""
+    ntimeseq = time_window // SEQUENCE_LENGTH
+    # ceil and not floor, we want to cover the whole map
+    min_cols, max_cols = math.ceil(pixels_lon / IMG_SIZE), pixels_lon - IMG_SIZE
+    if max_cols < min_cols:
+        raise RuntimeError(f'Lon dimension too small: got {pixels_lon} pixels, need at least {IMG_SIZE}')
+    min_rows, max_rows = math.ceil(pixels_lat / IMG_SIZE), pixels_lat - IMG_SIZE
+    if max_cols < min_cols:
+        raise RuntimeError(f'Lat dimension too small: got {pixels_lat} pixels, need at least {IMG_SIZE}')
+    assert 0 <= overlap_factor <= 1, 'overlap_factor must be in [0,1] range'
+    ncols = math.floor(min_cols + overlap_factor ** 2 * (max_cols - min_cols))
+    nrows = math.floor(min_rows + overlap_factor ** 2 * (max_rows - min_rows))
+    ydist, xdist = (pixels_lat - IMG_SIZE) // (nrows - 1), (pixels_lon - IMG_SIZE) // (ncols - 1)
+    leftovers_y, leftovers_x = pixels_lat - ((nrows - 1) * ydist + IMG_SIZE), pixels_lon - ((ncols - 1) * xdist + IMG_SIZE)
+    x_vec_leftovers, y_vec_leftovers = np.concatenate(
+        [[0], np.ones(leftovers_x), np.zeros(ncols - leftovers_x - 1)]).cumsum(), np.concatenate(
+        [[0], np.ones(leftovers_y), np.zeros(nrows - leftovers_y - 1)]).cumsum()
+    slices_start_x = [int(i * xdist + x) for (i, x) in zip(range(ncols), x_vec_leftovers)]
+    slices_start_y = [int(j * ydist + y) for (j, y) in zip(range(nrows), y_vec_leftovers)]
+    return dict(ntimeseq=ntimeseq, ncols=ncols, nrows=nrows, xdist=xdist, ydist=ydist, leftovers_x=leftovers_x,
+                leftovers_y=leftovers_y, slices_start_x=slices_start_x, slices_start_y=slices_start_y)
+
+
+def _tile_lat_index(sy):
+    """Row indices of one tile: latitude flipped; the sy == 0 tile covers rows 1..96 (api.py:119)."""
+    if sy != 0:
+        return np.arange(sy + IMG_SIZE - 1, sy - 1, -1)
+    return np.arange(IMG_SIZE, 0, -1)
+
+
+def predict_array(fields, overlap_factor=0.05, network=None, return_count=False):
+    """Array core of predict (api.py:96-151).  fields: (time, lat, lon, 3) float array with channels
+    [u10, v10, elevation in metres].  Returns (ntimeseq*24, lat, lon, 2) with NaN where no tile
+    contributes (the reference's dataframe simply has no such rows)."""
+    fields = np.asarray(fields, dtype=np.float32).copy()
+    fields[..., 2] = fields[..., 2] / 1e3                                         # api.py:96
+    time_window, pixels_lat, pixels_lon = fields.shape[:3]
+    plan = tile_plan(pixels_lat, pixels_lon, time_window, overlap_factor)
+    network = network or get_network()
+    keys = [(sx, sy, k) for sx in plan['slices_start_x'] for sy in plan['slices_start_y'] for k in range(plan['ntimeseq'])]
+    print(f'Applying model to {len(keys)} patches')
+    lat_ok = pixels_lat > IMG_SIZE or all(sy != 0 for sy in plan['slices_start_y'])
+    if not lat_ok:
+        raise RuntimeError('the sy == 0 tile needs lat row 96 (reference slice(IMG_SIZE, 0, -1)): lat dimension too small')
+    tensors = np.stack([fields[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH][:, _tile_lat_index(sy)][:, :, sx:sx + IMG_SIZE]
+                        for (sx, sy, k) in keys], axis=0)                         # (N, T, H, W, C)
+    tensors = (tensors - np.nanmean(tensors, axis=(0, 1, 2), keepdims=True)) / np.nanstd(tensors, axis=(0, 1, 2), keepdims=True)
+    gen = network.generator
+    preds = []
+    group_size = BATCH_SIZE * 2
+    num_groups = math.ceil(tensors.shape[0] / group_size)
+    for t in range(num_groups):
+        tensor = tensors[t * group_size:(t + 1) * group_size, ...]
+        noise = network.noise_generator(bs=tensor.shape[0], channels=NOISE_CHANNELS)
+        preds.append(gen.predict([tensor, noise]))
+        print(f'Predicted {(t + 1) / num_groups:.0%}')
+    predictions = np.concatenate(preds, axis=0)
+    nt = plan['ntimeseq'] * SEQUENCE_LENGTH
+    acc = np.zeros((nt, pixels_lat, pixels_lon, NB_OUTPUTS), dtype=np.float64)
+    cnt = np.zeros((nt, pixels_lat, pixels_lon), dtype=np.int32)
+    for i, (sx, sy, k) in enumerate(keys):
+        rows = _tile_lat_index(sy)[2:-2]                                          # api.py:148
+        ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
+        acc[ts, rows[:, None], np.arange(sx + 2, sx + IMG_SIZE - 2)[None, :]] += predictions[i][:, 2:-2, 2:-2]
+        cnt[ts, rows[:, None], np.arange(sx + 2, sx + IMG_SIZE - 2)[None, :]] += 1
+    with np.errstate(invalid='ignore', divide='ignore'):
+        out = (acc / cnt[..., None]).astype(np.float32)                           # api.py:149-150 (uniform mean)
+    return (out, cnt) if return_count else out
+
+
+def predict(inputs_era5, inputs_topo, high_res_template, overlap_factor=0.05):
+    xr = _xr()
+    lat_coord_hr, lon_coord_hr = [c for c in high_res_template.dims if c.startswith('lat') or c.startswith('y')][0], [c for c in high_res_template.dims if c.startswith('lon') or c.startswith('x')][0]
+    time_var_topo = inputs_topo.expand_dims({'time': inputs_era5.time})
+    inputs = xr.merge([inputs_era5, time_var_topo])
+    inputs = inputs.drop(c for c in inputs.coords if c not in ['time'] + [lat_coord_hr, lon_coord_hr])
+    fields = np.stack([inputs[v].transpose('time', lat_coord_hr, lon_coord_hr).to_numpy() for v in ('u10', 'v10', 'elevation')], axis=-1)
+    out, cnt = predict_array(fields, overlap_factor=overlap_factor, return_count=True)
+    nt = out.shape[0]
+    keep_lat, keep_lon = cnt[0].any(axis=1), cnt[0].any(axis=0)
+    coords = {'time': inputs.time[:nt], lat_coord_hr: inputs[lat_coord_hr][keep_lat], lon_coord_hr: inputs[lon_coord_hr][keep_lon]}
+    out = out[:, keep_lat][:, :, keep_lon]
+    return xr.Dataset({v: (('time', lat_coord_hr, lon_coord_hr), out[..., i]) for i, v in enumerate(['u10', 'v10'])}, coords=coords)
+
+
+def downscale(era5, raster_topo, range_lon=None, range_lat=None, overlap_factor=0.05):
+    high_res_template = build_high_res_template_from_era5(era5, range_lon=range_lon, range_lat=range_lat)
+    inputs_era5 = process_era5(era5, high_res_template)
+    inputs_topo = process_topo(raster_topo, high_res_template)
+    prediction = predict(inputs_era5, inputs_topo, high_res_template, overlap_factor=overlap_factor)
+    return prediction

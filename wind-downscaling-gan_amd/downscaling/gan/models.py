@@ -1,0 +1,184 @@
+"""`make_generator` / `make_discriminator` with the reference signatures
+(/root/reference/src/downscaling/gan/models.py:9-17,76-84) returning Keras-like model objects whose
+arithmetic runs on the hand-written HIP kernels (engine.networks on engine.hipops).
+
+Tensors are channels-last (B, T, H, W, C) fp32, as in the reference.  Inputs may be torch tensors
+(any device) or numpy arrays; outputs are torch tensors on the GPU (`predict` returns numpy).
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from downscaling.engine import runtime
+from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
+from downscaling.engine.common import round4
+
+
+def _to_dev(x, ops):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=ops.device, dtype=ops.dtype)
+    return torch.as_tensor(np.asarray(x)).to(device=ops.device, dtype=ops.dtype)
+
+
+class _Metrics:
+    def __init__(self, metrics=None):
+        self.metrics = list(metrics or [])
+
+    def update_state(self, y_true, y_pred, sample_weight=None):
+        for m in self.metrics:
+            m.update_state(y_true, y_pred, sample_weight)
+
+
+class _Model:
+    """The slice of keras.Model the reference uses: call / predict / trainable_weights / compile /
+    save_weights / load_weights / optimizer / compiled_loss / compiled_metrics / metrics."""
+
+    name = "model"
+
+    def __init__(self, net):
+        self.net = net
+        self.ops = net.ops
+        self.optimizer = None
+        self.loss = None
+        self.compiled_metrics = _Metrics()
+        self._compiled = False
+
+    # -- keras.Model surface -------------------------------------------------------------------------
+    def compile(self, optimizer=None, loss=None, metrics=None, **kwargs):
+        self.optimizer, self.loss = optimizer, loss
+        self.compiled_metrics = _Metrics(metrics)
+        self._compiled = True
+
+    def compiled_loss(self, y_true, y_pred, sample_weight=None, regularization_losses=None):
+        if self.loss is None:
+            raise RuntimeError("compile() with a loss first")
+        value = self.loss(y_true, y_pred)
+        if sample_weight is not None:
+            value = value * torch.as_tensor(sample_weight, dtype=value.dtype, device=value.device).mean()
+        for r in regularization_losses or []:
+            value = value + r
+        return value
+
+    def _assert_compile_was_called(self):
+        if not self._compiled:
+            raise RuntimeError("You must compile your model before training/testing.")
+        return True
+
+    @property
+    def metrics(self):
+        return self.compiled_metrics.metrics
+
+    @property
+    def trainable_weights(self):
+        return [v.value for v in self.net.params.trainable]
+
+    @property
+    def non_trainable_weights(self):
+        return [v.value for v in self.net.params.non_trainable]
+
+    @property
+    def weights(self):
+        return [v.value for v in self.net.params.vars]
+
+    def count_params(self):
+        return sum(v.size for v in self.net.params.vars)
+
+    def get_weights_dict(self):
+        return self.net.params.get_weights()
+
+    def set_weights_dict(self, mapping, strict=True):
+        self.net.params.set_weights(mapping, strict=strict)
+
+    def save_weights(self, filepath, *args, **kwargs):
+        """Writes `<filepath>.npz` keyed by the TF checkpoint variable names (layer_with_weights-N/...)."""
+        filepath = os.fspath(filepath)
+        Path(filepath).parent.mkdir(parents=True, exist_ok=True)
+        np.savez(filepath + ".npz", **{k.replace("/", "|"): v for k, v in self.get_weights_dict().items()})
+
+    def load_weights(self, filepath, *args, **kwargs):
+        filepath = os.fspath(filepath)
+        if os.path.exists(filepath + ".npz"):
+            with np.load(filepath + ".npz") as z:
+                self.set_weights_dict({k.replace("|", "/"): z[k] for k in z.files})
+            return
+        if os.path.exists(filepath + ".index"):
+            from downscaling.engine.tf_bundle import read_bundle
+            self.set_weights_dict(read_bundle(filepath), strict=False)
+            return
+        raise FileNotFoundError(f"no checkpoint at {filepath}(.npz|.index)")
+
+
+class Generator(_Model):
+    name = "generator"
+
+    def __call__(self, inputs, training=False, mask=None):
+        image, noise = inputs
+        ops, net = self.ops, self.net
+        image, noise = _to_dev(image, ops), _to_dev(noise, ops)
+        B, T = image.shape[0], image.shape[1]
+        assert tuple(image.shape[1:]) == (net.T, net.S, net.S, net.in_channels), image.shape
+        assert tuple(noise.shape) == (B, net.T, net.S, net.S, net.noise_channels), noise.shape
+        net.set_image(image)
+        net.set_noise(noise)
+        out_tm = net.forward(B, bool(training))
+        out = torch.empty(B, T, net.S, net.S, net.out_channels, dtype=ops.dtype, device=ops.device)
+        net.from_time_major(out_tm, out)
+        return out
+
+    call = __call__
+
+    def predict(self, inputs, batch_size=32, **kwargs):
+        image, noise = inputs
+        n = len(image)
+        outs = []
+        for i in range(0, n, batch_size):
+            outs.append(self([image[i:i + batch_size], noise[i:i + batch_size]], training=False).cpu().numpy())
+        return np.concatenate(outs, axis=0)
+
+
+class Discriminator(_Model):
+    name = "discriminator"
+
+    def __call__(self, inputs, training=False, mask=None):
+        low, high = inputs
+        ops, net = self.ops, self.net
+        low, high = _to_dev(low, ops), _to_dev(high, ops)
+        B, T = low.shape[0], low.shape[1]
+        net.set_low(low)
+        high_tm = ops.zeros(T * B, net.S, net.S, round4(net.ch))
+        net.to_time_major(high, high_tm)
+        net.set_high_tm(high_tm, B)
+        return net.forward(B, bool(training)).clone().view(B, 1)
+
+    call = __call__
+
+
+def make_generator(
+        image_size: int,
+        in_channels: int,
+        noise_channels: int,
+        out_channels: int,
+        n_timesteps: int,
+        batch_size: int = None,
+        feature_channels=128
+):
+    return Generator(GeneratorNet(runtime.get_ops(), image_size, in_channels, noise_channels, out_channels,
+                                  n_timesteps, feature_channels=feature_channels))
+
+
+def make_discriminator(
+        low_res_size: int,
+        high_res_size: int,
+        low_res_channels: int,
+        high_res_channels: int,
+        n_timesteps: int,
+        batch_size: int = None,
+        feature_channels: int = 16
+):
+    if low_res_size != high_res_size:
+        raise NotImplementedError("The discriminator assumes that the low res and high res images have the same size."
+                                  "Perhaps you should upsample your low res image first?")
+    return Discriminator(DiscriminatorNet(runtime.get_ops(), low_res_size, high_res_size, low_res_channels,
+                                          high_res_channels, n_timesteps, feature_channels=feature_channels))
