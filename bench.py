@@ -51,9 +51,6 @@ class ConvTimer:
         from downscaling.engine import hipops
         timer = self
 
-        def tile(ncols):
-            return (256, 16, 4, 1) if ncols <= 16 else (256, 32, 4, 1) if ncols <= 32 else (128, 64, 2, 2) if ncols <= 64 else (128, 128, 2, 2)
-
         def flops(x, y, pk, g):
             n, Ho, Wo = y.shape[0], y.shape[1], y.shape[2]
             return 2.0 * n * Ho * Wo * pk.cout * g.kh * g.kw * pk.cin
@@ -68,14 +65,13 @@ class ConvTimer:
             timer.records.append((name, fl, e0, e1))
 
         def conv_fwd(x, pk, bias, y, g, **k):
-            timed("wdg_igemm_kernel<%d,%d,%d,%d>" % tile(pk.cout), flops(x, y, pk, g), orig_fwd, x, pk, bias, y, g, **k)
+            timed(ops.conv_kernel_label("fwd", x, y, pk, g), flops(x, y, pk, g), orig_fwd, x, pk, bias, y, g, **k)
 
         def conv_dgrad(dy, pk, dx, g, **k):
-            timed("wdg_igemm_kernel<%d,%d,%d,%d>" % tile(pk.cin), flops(dx, dy, pk, g), orig_dgrad, dy, pk, dx, g, **k)
+            timed(ops.conv_kernel_label("dgrad", dx, dy, pk, g), flops(dx, dy, pk, g), orig_dgrad, dy, pk, dx, g, **k)
 
         def conv_wgrad(x, dy, pk, dw, g, **k):
-            bn = 16 if pk.cout <= 16 else 32 if pk.cout <= 32 else 64 if pk.cout <= 64 else 128
-            timed("wdg_wgrad_kernel<%d>" % bn, flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g, **k)
+            timed(ops.conv_kernel_label("wgrad", x, dy, pk, g), flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g, **k)
 
         ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
 
@@ -95,7 +91,9 @@ def cpu_baseline(batch=1):
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
     from oracle.torch_backend import TorchOps
     from tests.helpers import Draws
-    cores = os.cpu_count() or 1
+    # torch-CPU conv kernels stop scaling (and oversubscribe badly) far below the 256 hardware threads of the
+    # GPU node for a batch-1 sample: use at most 32 threads and report that number as `cores`.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     ops = TorchOps(torch.float32)
     gen = GeneratorNet(ops, S, CIN, NZ, CH, T, seed=1)     # only used to initialise weights with the TF names/shapes

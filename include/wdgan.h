@@ -74,6 +74,9 @@ int wdg_conv_plan_create(wdg_conv_plan** plan, const wdg_conv_geom* geom);
 int wdg_conv_plan_destroy(wdg_conv_plan* plan);
 /* Bytes of split-K scratch the plan may use (max over fwd/dgrad/wgrad). */
 size_t wdg_conv_ws_bytes(const wdg_conv_plan* plan);
+/* Launch configuration chosen for the plan (for profiling labels):
+ * info[0..7] = {fwd BM, fwd BN, fwd split, dgrad BM, dgrad BN, dgrad split, wgrad BN, wgrad split}. */
+int wdg_conv_plan_info(const wdg_conv_plan* plan, int32_t* info);
 
 /* y = act(conv(x, wF) + bias) [+ y if accumulate].
  *   wF: forward-packed weights [Cout][kh*kw][roundup4(Cin)] (see wdg_weight_pack).
@@ -89,6 +92,13 @@ int wdg_conv_fwd(const wdg_conv_plan* plan, const float* x, const float* wF, con
 int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, const float* bias,
                    float* dx, int act, float slope, int accumulate,
                    void* ws, size_t ws_bytes, wdg_stream stream);
+
+/* Fused UpSampling2D(2,'bilinear') + Conv2DTranspose forward: y = act(convT(upsample2x(x_low), wD) + bias).
+ * `plan` is the transposed conv's plan on the UPSAMPLED grid (conv-output side 2H x 2W, stride 1, k <= 5,
+ * Cin <= 64); x_low is the H x W tensor with pixel stride ld_low.  The upsampled tensor is never
+ * written to memory.                                                                    models.py:62-64 */
+int wdg_upconv_fwd(const wdg_conv_plan* plan, const float* x_low, int ld_low, int64_t img_stride_low,
+                   const float* wD, const float* bias, float* y, int act, float slope, wdg_stream stream);
 
 /* dw[kh][kw][Cin][Cout] (+)= sum_pixels x (*) dy  — HWIO, the master layout.   ganbase.py:46,60 */
 int wdg_conv_wgrad(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw,

@@ -145,6 +145,11 @@ class TorchOps:
             out = out + dx[..., :pk.cin]
         dx[..., :pk.cin] = out
 
+    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
+        up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
+        self.upsample2x_fwd(x_low, up)
+        self.conv_dgrad(up, pk, y, g, bias=bias, act=act, slope=slope)
+
     def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True):
         xin = x[..., :pk.cin].permute(0, 3, 1, 2).contiguous()
         gout = dy[..., :pk.cout].permute(0, 3, 1, 2).contiguous()

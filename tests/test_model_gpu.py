@@ -59,7 +59,7 @@ def test_generator(hip_ops, S, T, F, nz, training):
         assert rel_err(g[k], gref[k]) < TOL, k
 
 
-@pytest.mark.parametrize("S,T,Fd", [(32, 2, 16), (12, 2, 8), (48, 1, 16), (96, 1, 16)])
+@pytest.mark.parametrize("S,T,Fd", [(32, 2, 16), (12, 2, 8), (40, 1, 16), (96, 1, 16)])
 def test_discriminator(hip_ops, S, T, Fd):
     from downscaling.engine.networks import DiscriminatorNet
     B, cl, ch = 2, 3, 2

@@ -40,6 +40,14 @@ CONV_CASES = [
     ("multi_tile", 4, 64, 64, 128, 128, 3, 1, 1),
     ("splitk_7x7_small_m", 8, 8, 8, 256, 512, 7, 3, 1),
     ("gates_128to512", 2, 16, 16, 128, 512, 3, 1, 1),
+    # >= 65536 output pixels, stride 1, few channels: these take the halo-tile kernel (conv_halo.hip)
+    ("halo_lstm_2to8", 5, 120, 136, 2, 8, 3, 1, 1),
+    ("halo_lstm_5to64", 4, 128, 128, 5, 64, 3, 1, 1),
+    ("halo_16to16", 5, 120, 136, 16, 16, 3, 1, 1),
+    ("halo_out_16to2", 4, 128, 128, 16, 2, 3, 1, 1),
+    ("halo_convT5x5_as_conv", 4, 128, 130, 16, 160, 5, 1, 2),
+    ("halo_3x3_128to64", 4, 128, 128, 128, 64, 3, 1, 1),
+    ("n160_tile32", 2, 24, 24, 16, 160, 5, 1, 2),
 ]
 
 
@@ -126,6 +134,24 @@ def test_conv_on_concat_and_time_views(hip_ops, ref_ops):
     ref_ops.conv_dgrad(out[..., 32:64], pk_r, x_r, rg, accumulate=True)
     hip_ops.conv_dgrad(out_g[..., 32:64], pk_g, x_g, g, accumulate=True)
     assert rel_err(buf_g, buf) < TOL
+
+
+def test_fused_upsample_conv_transpose(hip_ops, ref_ops):
+    """UpSampling2D(bilinear) + Conv2DTranspose(5x5,'same') + bias + LeakyReLU in one kernel (models.py:62-64),
+    input taken from a channel-concat view, odd tile boundaries."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    g, rg = ConvGeom(5, 5, 1, 2), RG(5, 5, 1, 2)
+    gen = torch.Generator().manual_seed(9)
+    dev = hip_ops.device
+    x = torch.randn(3, 60, 68, 160, generator=gen, dtype=torch.float64)
+    w = torch.randn(5, 5, 16, 160, generator=gen, dtype=torch.float64) * 0.05
+    b = torch.randn(16, generator=gen, dtype=torch.float64)
+    y_r = torch.zeros(3, 120, 136, 16, dtype=torch.float64)
+    y_g = hip_ops.zeros(3, 120, 136, 16)
+    ref_ops.upconv_fwd(x, ref_ops.pack_weights(w), b, y_r, rg, act=True)
+    hip_ops.upconv_fwd(x.float().to(dev), hip_ops.pack_weights(w.float().to(dev).contiguous()), b.float().to(dev), y_g, g, act=True)
+    assert rel_err(y_g, y_r) < TOL
 
 
 def test_sn_power_iter(hip_ops, ref_ops):

@@ -1,0 +1,269 @@
+// conv_halo.hip — halo-tile convolution for stride-1 layers with few output channels (<= 64).
+//
+// The implicit-GEMM kernel re-fetches the shifted input window from L2 for every tap; for layers whose
+// output-channel count is small (N <= 64: the 5x5 transposed conv after the bilinear upsample,
+// models.py:60-64; the 16->2 output conv, :70; the discriminator's full-resolution 2/5/16-channel
+// ConvLSTM / conv layers, :93-104, and all their data gradients) that traffic, not the MFMA, is the
+// bound.  Here a block owns an 8x32 output tile, stages the (8+kh-1)x(32+kw-1) input halo of 16 channels
+// ONCE into LDS and reuses it for all kh*kw taps, so every input element is read from L2/HBM once
+// (plus the halo overlap) instead of kh*kw times.  Optionally the staged input is the bilinear x2
+// upsampling of a low-resolution tensor computed on the fly (UpSampling2D + Conv2DTranspose fused:
+// the 160-channel upsampled tensor, 1.3 GB at batch 32, is never materialised).
+//
+// MFMA mapping as in conv_igemm.hip: rows = 16 consecutive output pixels of one image row,
+// cols = output channels, k = 4 channels per lane group; LDS halo layout [kg][pixel] float4 with the
+// pixel count padded to a multiple of 16, which makes every ds_read_b128 fragment read conflict-free
+// for any tap displacement.
+#include "conv_plan.h"
+#include <algorithm>
+
+constexpr int HALO_TH = 8, HALO_TW = 32;
+
+struct WdgHalo {
+    const float* A;
+    const float* B;
+    float* Out;
+    const float* bias;
+    const int4* taps;  // {dh, dw, b_off0, 0}
+    long long imgStrideA, imgStrideO;
+    int n_img, H, W, ldA;   // A tensor as stored (low-res dims in upsample mode)
+    int Hc, Wc;             // conv-input dims (= 2H, 2W in upsample mode, else H, W)
+    int Ho, Wo, ldO;
+    int ntaps, C4;          // taps, channel groups of 4
+    int Ncols, ldB;
+    int dh_min, dw_min, halo_h, halo_w, npix;  // npix = halo_h*halo_w rounded up to 16
+    int act, accumulate, upsample;
+    float slope;
+    int tiles_h, tiles_w;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
+    f32x4* lds_a = smem;                 // [4][npix]
+    f32x4* lds_w = smem + 4 * p.npix;    // [ntaps][4][NT*16]
+    constexpr int NW = NT * 16;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_w;
+    bid /= p.tiles_w;
+    const int ty = bid % p.tiles_h;
+    const int img = bid / p.tiles_h;
+    const int oy0 = ty * HALO_TH, ox0 = tx * HALO_TW;
+    const int hy0 = oy0 + p.dh_min, hx0 = ox0 + p.dw_min;
+    const int npr = p.halo_h * p.halo_w;
+    const float* Aimg = p.A + (long long)img * p.imgStrideA;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = (p.C4 + 3) >> 2;
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const int kgs = min(4, p.C4 - 4 * ck);
+        __syncthreads();  // previous chunk's fragment reads are done
+        // ---- stage the input halo: lanes run over pixels (conflict-free ds_write_b128)
+        for (int idx = t; idx < 4 * npr; idx += 256) {
+            const int kg = idx / npr;
+            const int pix = idx - kg * npr;
+            const int hy = pix / p.halo_w;
+            const int hx = pix - hy * p.halo_w;
+            const int gy = hy0 + hy, gx = hx0 + hx;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kg < kgs && (unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc) {
+                const int c = (4 * ck + kg) * 4;
+                if (!p.upsample) {
+                    v = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + c);
+                } else {
+                    // bilinear x2, half-pixel centres, edge clamp (same arithmetic as wdg_up2_fwd_kernel)
+                    const int jh = gy >> 1, jw = gx >> 1;
+                    const int h0 = (gy & 1) ? jh : max(jh - 1, 0), h1 = (gy & 1) ? min(jh + 1, p.H - 1) : jh;
+                    const int w0 = (gx & 1) ? jw : max(jw - 1, 0), w1 = (gx & 1) ? min(jw + 1, p.W - 1) : jw;
+                    const float fh = (gy & 1) ? 0.25f : 0.75f, fw = (gx & 1) ? 0.25f : 0.75f;
+                    const float* xb = Aimg + c;
+                    const f32x4 a00 = *reinterpret_cast<const f32x4*>(xb + ((long long)h0 * p.W + w0) * p.ldA);
+                    const f32x4 a01 = *reinterpret_cast<const f32x4*>(xb + ((long long)h0 * p.W + w1) * p.ldA);
+                    const f32x4 a10 = *reinterpret_cast<const f32x4*>(xb + ((long long)h1 * p.W + w0) * p.ldA);
+                    const f32x4 a11 = *reinterpret_cast<const f32x4*>(xb + ((long long)h1 * p.W + w1) * p.ldA);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float top = a00[j] + (a01[j] - a00[j]) * fw;
+                        const float bot = a10[j] + (a11[j] - a10[j]) * fw;
+                        v[j] = top + (bot - top) * fh;
+                    }
+                }
+            }
+            lds_a[kg * p.npix + pix] = v;
+        }
+        // ---- stage this chunk's weights: [tap][kg][n]
+        for (int idx = t; idx < p.ntaps * 4 * NW; idx += 256) {
+            const int n = idx % NW;
+            const int r = idx / NW;
+            const int kg = r & 3;
+            const int tap = r >> 2;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kg < kgs && n < p.Ncols)
+                v = *reinterpret_cast<const f32x4*>(p.B + (long long)n * p.ldB + p.taps[tap].z + (4 * ck + kg) * 4);
+            lds_w[idx] = v;
+        }
+        __syncthreads();
+        // ---- all taps from LDS
+        for (int tap = 0; tap < p.ntaps; ++tap) {
+            const int4 e = p.taps[tap];
+            const int rowoff = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
+            f32x4 af[4], bf[NT];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int row = 2 * wave + (a >> 1), col = (a & 1) * 16 + li;
+                af[a] = lds_a[lg * p.npix + row * p.halo_w + col + rowoff];
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bf[b] = lds_w[(tap * 4 + lg) * NW + b * 16 + li];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: accumulator reg r of lane (li, lg) is pixel column 4*lg + r, channel li
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int oy = oy0 + 2 * wave + (a >> 1);
+        if (oy >= p.Ho) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ox = ox0 + (a & 1) * 16 + lg * 4 + r;
+            if (ox >= p.Wo) continue;
+            float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = b * 16 + li;
+                if (n < p.Ncols) {
+                    float v = acc[a][b][r];
+                    if (p.bias) v += p.bias[n];
+                    if (p.act) v = wdg_lrelu(v, p.slope);
+                    if (p.accumulate) v += dst[n];
+                    dst[n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols <= 64 ? 4 : 0; }
+
+static size_t halo_lds_bytes(int kh, int kw, int nt) {
+    const int npix = wdg_round_up((HALO_TH + kh - 1) * (HALO_TW + kw - 1), 16);
+    return (size_t)(4 * npix + kh * kw * 4 * nt * 16) * sizeof(f32x4);
+}
+
+int wdg_halo_plan_init(wdg_conv_plan* pl) {
+    const wdg_conv_geom& g = pl->g;
+    pl->halo_fwd_nt = pl->halo_dgrad_nt = 0;
+    if (g.stride != 1 || g.kh > 5 || g.kw > 5) return WDG_OK;
+    // only worth it where the im2col-free gather is traffic-bound: few output channels, large maps
+    const long long pixels = (long long)g.n_img * g.Ho * g.Wo;
+    if (pixels < 65536) return WDG_OK;
+    int nf = halo_nt(g.Cout), nd = halo_nt(g.Cin);
+    if (nf && halo_lds_bytes(g.kh, g.kw, nf) > 64 * 1024) nf = 0;
+    if (nd && halo_lds_bytes(g.kh, g.kw, nd) > 64 * 1024) nd = 0;
+    std::vector<int4> tf, td;
+    for (int th = 0; th < g.kh; ++th)
+        for (int tw = 0; tw < g.kw; ++tw) {
+            const int tap = th * g.kw + tw;
+            tf.push_back((int4){th - g.pad_h, tw - g.pad_w, tap * pl->Cin_p, 0});
+            td.push_back((int4){g.pad_h - th, g.pad_w - tw, tap * g.Cin * pl->Cout_p, 0});
+        }
+    if (nf) {
+        WDG_HIP(hipMalloc((void**)&pl->d_taps_fwd, tf.size() * sizeof(int4)));
+        WDG_HIP(hipMemcpy(pl->d_taps_fwd, tf.data(), tf.size() * sizeof(int4), hipMemcpyHostToDevice));
+        pl->halo_fwd_nt = nf;
+    }
+    if (nd) {
+        WDG_HIP(hipMalloc((void**)&pl->d_taps_dgrad, td.size() * sizeof(int4)));
+        WDG_HIP(hipMemcpy(pl->d_taps_dgrad, td.data(), td.size() * sizeof(int4), hipMemcpyHostToDevice));
+        pl->halo_dgrad_nt = nd;
+    }
+    return WDG_OK;
+}
+
+void wdg_halo_plan_free(wdg_conv_plan* pl) {
+    if (pl->d_taps_fwd) (void)hipFree(pl->d_taps_fwd);
+    if (pl->d_taps_dgrad) (void)hipFree(pl->d_taps_dgrad);
+}
+
+int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
+                    const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
+                    hipStream_t st) {
+    const wdg_conv_geom& g = pl->g;
+    WdgHalo p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = Bw; p.Out = Out; p.bias = bias;
+    p.n_img = g.n_img; p.ldA = ldA; p.imgStrideA = imgStrideA;
+    p.ntaps = pl->taps;
+    p.act = act; p.slope = slope; p.accumulate = accumulate; p.upsample = upsample;
+    int nt;
+    if (!dgrad) {
+        p.taps = pl->d_taps_fwd;
+        p.Hc = g.H; p.Wc = g.W;
+        p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy; p.imgStrideO = g.img_stride_y;
+        p.C4 = pl->Cin_p / 4; p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p;
+        p.dh_min = -g.pad_h; p.dw_min = -g.pad_w;
+        nt = pl->halo_fwd_nt;
+    } else {
+        p.taps = pl->d_taps_dgrad;
+        p.Hc = g.Ho; p.Wc = g.Wo;
+        p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx; p.imgStrideO = g.img_stride_x;
+        p.C4 = pl->Cout_p / 4; p.Ncols = g.Cin; p.ldB = pl->Cout_p;
+        p.dh_min = g.pad_h - (g.kh - 1); p.dw_min = g.pad_w - (g.kw - 1);
+        nt = pl->halo_dgrad_nt;
+    }
+    if (upsample) {
+        if ((p.Hc & 1) || (p.Wc & 1)) {
+            wdg_set_error("halo: upsample mode needs even conv-input dims");
+            return WDG_ERR_ARG;
+        }
+        p.H = p.Hc / 2; p.W = p.Wc / 2;
+    } else {
+        p.H = p.Hc; p.W = p.Wc;
+    }
+    if (!nt) {
+        wdg_set_error("halo: plan is not eligible for the halo-tile kernel");
+        return WDG_ERR_ARG;
+    }
+    p.halo_h = HALO_TH + g.kh - 1; p.halo_w = HALO_TW + g.kw - 1;
+    p.npix = wdg_round_up(p.halo_h * p.halo_w, 16);
+    p.tiles_h = (p.Ho + HALO_TH - 1) / HALO_TH;
+    p.tiles_w = (p.Wo + HALO_TW - 1) / HALO_TW;
+    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt);
+    dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
+    if (nt == 1)
+        hipLaunchKernelGGL(wdg_conv_halo_kernel<1>, grid, block, lds, st, p);
+    else if (nt == 2)
+        hipLaunchKernelGGL(wdg_conv_halo_kernel<2>, grid, block, lds, st, p);
+    else
+        hipLaunchKernelGGL(wdg_conv_halo_kernel<4>, grid, block, lds, st, p);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// Fused UpSampling2D(2,'bilinear') + Conv2DTranspose forward (models.py:62-64): the plan describes the
+// transposed conv on the UPSAMPLED grid (its conv-output side is 2H x 2W); `x_low` is the H x W tensor.
+extern "C" int wdg_upconv_fwd(const wdg_conv_plan* pl, const float* x_low, int ld_low, int64_t img_stride_low,
+                              const float* wD, const float* bias, float* y, int act, float slope,
+                              wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x_low && wD && y, "null argument");
+    WDG_CHECK_ARG(((uintptr_t)x_low & 15) == 0 && ld_low % 4 == 0, "x_low must be 16-byte aligned, ld % 4 == 0");
+    WDG_CHECK_ARG(pl->halo_dgrad_nt != 0, "plan not eligible (needs stride 1, k <= 5, Cin <= 64)");
+    return wdg_halo_launch(pl, true, x_low, ld_low, img_stride_low, 1, wD, bias, y, act, slope, 0,
+                           (hipStream_t)stream);
+}

@@ -19,17 +19,8 @@
 //     XOR (guide: cdna_hip_programming.md section 2 / T2).
 // MFMA operand map (16x16x4 f32): lane l supplies A[row l&15][k l>>4], B[k l>>4][col l&15];
 // accumulator reg r of lane l is C[row (l>>4)*4 + r][col l&15].
-#include "common.h"
-#include <vector>
+#include "conv_plan.h"
 #include <algorithm>
-
-struct WdgPhase {
-    int Pa, Pb;            // output sub-grid of this phase (rows, cols per image)
-    int a_off_h, a_off_w;  // A coord = pa * a_mul + a_off + tap displacement
-    int o_off_h, o_off_w;  // Out coord = pa * o_mul + o_off
-    int K4;                // k4 groups (padded to a multiple of 8 with invalid entries)
-    int tab_off;           // first table entry of this phase
-};
 
 struct WdgIgemm {
     const float* A;
@@ -443,23 +434,6 @@ __global__ void __launch_bounds__(256) wdg_weight_pack_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // Host side: plans
 // ------------------------------------------------------------------------------------------
-struct wdg_conv_plan {
-    wdg_conv_geom g;
-    int Cin_p, Cout_p, taps;
-    int cus;
-    // forward
-    int4* d_tab_fwd = nullptr;
-    int2* d_wrow = nullptr;
-    int K4_fwd = 0;  // padded to 8
-    // dgrad
-    int4* d_tab_dgrad = nullptr;
-    std::vector<WdgPhase> ph_dgrad;
-    int K4_dgrad_max = 0;
-    size_t ws_bytes = 0;
-    // launch configs (chosen at creation)
-    int fwd_split = 1, dgrad_split = 1, wgrad_split = 1;
-};
-
 static int g_cus = 0;
 extern "C" int wdg_device_cus(void) {
     if (g_cus == 0) {
@@ -474,18 +448,17 @@ extern "C" int wdg_device_cus(void) {
 struct TileCfg {
     int BM, BN;
 };
+// largest tile whose padded column count stays within 13 % of the best achievable padding
 static TileCfg pick_tile(int ncols) {
-    if (ncols <= 16) return {256, 16};
-    if (ncols <= 32) return {256, 32};
-    if (ncols <= 64) return {128, 64};
-    return {128, 128};
+    static const TileCfg cand[4] = {{128, 128}, {128, 64}, {256, 32}, {256, 16}};
+    int best = 1 << 30;
+    for (auto& c : cand) best = std::min(best, wdg_round_up(ncols, c.BN));
+    for (auto& c : cand)
+        if (wdg_round_up(ncols, c.BN) * 100 <= best * 113) return c;
+    return cand[3];
 }
-static int pick_wgrad_bn(int ncols) {
-    if (ncols <= 16) return 16;
-    if (ncols <= 32) return 32;
-    if (ncols <= 64) return 64;
-    return 128;
-}
+static int pick_wgrad_bn(int ncols) { return pick_tile(ncols).BN; }
+static int wgrad_blocks_per_cu(int bn) { return bn >= 128 ? 3 : bn >= 64 ? 4 : 6; }
 
 // choose a split-K factor so that roughly >= 2 blocks per CU exist, keeping >= 16 k4 groups per split
 static int pick_split(long long tiles, int K4, int cus) {
@@ -600,10 +573,12 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         const long long P = (long long)g->n_img * g->Ho * g->Wo;
         const int bn = pick_wgrad_bn(g->Cout);
         long long tiles = (long long)((pl->K4_fwd * 4 + 127) / 128) * ((g->Cout + bn - 1) / bn);
-        long long want = tiles >= 2LL * pl->cus ? 1 : (2LL * pl->cus + tiles - 1) / tiles;
-        long long maxs = std::max<long long>(1, P / 256);  // >= 256 pixels per split
+        // enough resident blocks to hide the (single-stage) global-load latency of the pixel reduction
+        const long long target = (long long)pl->cus * wgrad_blocks_per_cu(bn);
+        long long want = tiles >= target ? 1 : (target + tiles - 1) / tiles;
+        long long maxs = std::max<long long>(1, P / 512);  // >= 512 pixels (16 steps) per split
         want = std::min(want, maxs);
-        want = std::min<long long>(want, 256);
+        want = std::min<long long>(want, 2048);
         pl->wgrad_split = (int)std::max<long long>(1, want);
         if (pl->wgrad_split > 1)
             pl->ws_bytes = std::max(pl->ws_bytes, (size_t)pl->wgrad_split * pl->K4_fwd * 4 * g->Cout * 4);
@@ -618,6 +593,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     if ((rc = upload(tf.data(), tf.size() * sizeof(int4), (void**)&pl->d_tab_fwd)) != WDG_OK) { delete pl; return rc; }
     if ((rc = upload(wr.data(), wr.size() * sizeof(int2), (void**)&pl->d_wrow)) != WDG_OK) { delete pl; return rc; }
     if ((rc = upload(td.data(), td.size() * sizeof(int4), (void**)&pl->d_tab_dgrad)) != WDG_OK) { delete pl; return rc; }
+    if ((rc = wdg_halo_plan_init(pl)) != WDG_OK) { delete pl; return rc; }
     *out = pl;
     return WDG_OK;
 }
@@ -627,11 +603,24 @@ extern "C" int wdg_conv_plan_destroy(wdg_conv_plan* pl) {
     if (pl->d_tab_fwd) (void)hipFree(pl->d_tab_fwd);
     if (pl->d_wrow) (void)hipFree(pl->d_wrow);
     if (pl->d_tab_dgrad) (void)hipFree(pl->d_tab_dgrad);
+    wdg_halo_plan_free(pl);
     delete pl;
     return WDG_OK;
 }
 
 extern "C" size_t wdg_conv_ws_bytes(const wdg_conv_plan* pl) { return pl ? pl->ws_bytes : 0; }
+
+// info[0..7] = {fwd BM, fwd BN, fwd split, dgrad BM, dgrad BN, dgrad split, wgrad BN, wgrad split}
+extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
+    WDG_CHECK_ARG(pl && info, "null argument");
+    TileCfg f = pick_tile(pl->g.Cout), d = pick_tile(pl->g.Cin);
+    info[0] = f.BM; info[1] = f.BN; info[2] = pl->fwd_split;
+    info[3] = d.BM; info[4] = d.BN; info[5] = pl->dgrad_split;
+    info[6] = pick_wgrad_bn(pl->g.Cout); info[7] = pl->wgrad_split;
+    if (pl->halo_fwd_nt) { info[0] = 0; info[1] = 16 * pl->halo_fwd_nt; info[2] = 1; }     // BM = 0 marks the halo kernel
+    if (pl->halo_dgrad_nt) { info[3] = 0; info[4] = 16 * pl->halo_dgrad_nt; info[5] = 1; }
+    return WDG_OK;
+}
 
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
                         hipStream_t st) {
@@ -682,6 +671,9 @@ extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float
     WDG_CHECK_ARG(pl && x && wF && y, "null argument");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0, "x / wF must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
+    if (pl->halo_fwd_nt)
+        return wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, accumulate,
+                               (hipStream_t)stream);
     WdgIgemm p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
@@ -705,6 +697,9 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
     WDG_CHECK_ARG(pl && dy && wD && dx, "null argument");
     WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0, "dy / wD must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
+    if (pl->halo_dgrad_nt)
+        return wdg_halo_launch(pl, true, dy, g.ldy, g.img_stride_y, 0, wD, bias, dx, act, slope, accumulate,
+                               (hipStream_t)stream);
     WdgIgemm p;
     memset(&p, 0, sizeof(p));
     p.A = dy; p.B = wD; p.Out = dx; p.bias = bias; p.ktab = pl->d_tab_dgrad;

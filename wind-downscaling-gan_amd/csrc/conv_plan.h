@@ -1,0 +1,41 @@
+// conv_plan.h — host-side convolution plan shared by the implicit-GEMM and halo-tile kernels.
+#pragma once
+#include "common.h"
+#include <vector>
+
+struct WdgPhase {
+    int Pa, Pb;            // output sub-grid of this phase (rows, cols per image)
+    int a_off_h, a_off_w;  // A coord = pa * a_mul + a_off + tap displacement
+    int o_off_h, o_off_w;  // Out coord = pa * o_mul + o_off
+    int K4;                // k4 groups (padded to a multiple of 8 with invalid entries)
+    int tab_off;           // first table entry of this phase
+};
+
+struct wdg_conv_plan {
+    wdg_conv_geom g;
+    int Cin_p, Cout_p, taps;
+    int cus;
+    // forward
+    int4* d_tab_fwd = nullptr;
+    int2* d_wrow = nullptr;
+    int K4_fwd = 0;  // padded to 8
+    // dgrad
+    int4* d_tab_dgrad = nullptr;
+    std::vector<WdgPhase> ph_dgrad;
+    int K4_dgrad_max = 0;
+    size_t ws_bytes = 0;
+    // launch configs (chosen at creation)
+    int fwd_split = 1, dgrad_split = 1, wgrad_split = 1;
+    // halo-tile kernel (stride 1, few output channels): per-tap tables {dh, dw, b_off0, 0}
+    int4* d_taps_fwd = nullptr;
+    int4* d_taps_dgrad = nullptr;
+    int halo_fwd_nt = 0, halo_dgrad_nt = 0;   // 0 = not eligible; else 16-column tiles per block (1, 2, 4)
+};
+
+
+// conv_halo.hip
+int wdg_halo_plan_init(wdg_conv_plan* pl);
+void wdg_halo_plan_free(wdg_conv_plan* pl);
+int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
+                    const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
+                    hipStream_t st);

@@ -358,22 +358,30 @@ extern "C" int wdg_sumsq_batch_ch(const float* x, int ldx, int64_t pixels_per_im
 }
 
 // ---- mean of squares per parameter segment (gan/ganbase.py:80-81) -------------------------------
+// grid (chunks, nseg): every block adds its share of sum(x^2)/n to out[seg] (fp32 atomics: a reported
+// metric only, never fed back into the weights).
 __global__ void __launch_bounds__(256) wdg_segment_meansq_kernel(const float* __restrict__ x,
                                                                  const int64_t* __restrict__ off, float* out) {
     __shared__ double red[4];
-    const int s = blockIdx.x;
+    const int s = blockIdx.y;
     const int64_t b = off[2 * s], e = off[2 * s + 1];  // {begin, end} pairs
     double acc = 0.0;
-    for (int64_t i = b + threadIdx.x; i < e; i += 256) acc += (double)x[i] * (double)x[i];
+    for (int64_t i = b + (int64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += (int64_t)gridDim.x * 256)
+        acc += (double)x[i] * (double)x[i];
     acc = wdg_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[s] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)(e > b ? e - b : 1));
+    if (threadIdx.x == 0) {
+        const double t = red[0] + red[1] + red[2] + red[3];
+        if (t != 0.0) atomicAdd(&out[s], (float)(t / (double)(e > b ? e - b : 1)));
+    }
 }
 
 extern "C" int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out, wdg_stream stream) {
     WDG_CHECK_ARG(x && off && out && nseg > 0, "bad argument");
-    hipLaunchKernelGGL(wdg_segment_meansq_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, x, off, out);
+    hipStream_t st = (hipStream_t)stream;
+    WDG_HIP(hipMemsetAsync(out, 0, (size_t)nseg * sizeof(float), st));
+    hipLaunchKernelGGL(wdg_segment_meansq_kernel, dim3(64, nseg), dim3(256), 0, st, x, off, out);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -94,20 +94,38 @@ class HipOps:
         py, ldy, isy = _v4(y)
         n, H, W, _ = x.shape
         _, Ho, Wo, _ = y.shape
+        return self._plan_dims(n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g)
+
+    def _plan_dims(self, n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g):
         key = (n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad)
         plan = self._plans.get(key)
         if plan is None:
             geom = native.ConvGeom(n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad, g.pad)
             handle = C.c_void_p()
             native.check(self.lib.wdg_conv_plan_create(C.byref(handle), C.byref(geom)), f"plan_create{key}")
-            plan = (handle, int(self.lib.wdg_conv_ws_bytes(handle)))
+            info = (C.c_int32 * 8)()
+            native.check(self.lib.wdg_conv_plan_info(handle, info), "plan_info")
+            plan = (handle, int(self.lib.wdg_conv_ws_bytes(handle)), tuple(info))
             self._plans[key] = plan
         return plan
+
+    @staticmethod
+    def _label(bm, bn):
+        return "wdg_conv_halo_kernel<%d>" % (bn // 16) if bm == 0 else "wdg_igemm_kernel<%d,%d>" % (bm, bn)
+
+    def conv_kernel_label(self, which, x, y, pk, g):
+        """Name of the kernel template a conv call launches (profiling labels; which: fwd|dgrad|wgrad)."""
+        info = self._plan(x, y, pk.cin, pk.cout, g)[2]
+        if which == "fwd":
+            return self._label(info[0], info[1])
+        if which == "dgrad":
+            return self._label(info[3], info[4])
+        return "wdg_wgrad_kernel<%d>" % info[6]
 
     # ---- convolution family -----------------------------------------------------------------
     def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2):
         """y = act(conv(x, W) + bias) (+ y);  x:(N,H,W,>=Cin) y:(N,Ho,Wo,>=Cout)."""
-        plan, wsb = self._plan(x, y, pk.cin, pk.cout, g)
+        plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         native.check(self.lib.wdg_conv_fwd(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(),
                                            int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
@@ -115,15 +133,26 @@ class HipOps:
 
     def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2):
         """dx = act(conv_transpose(dy, W) + bias) (+ dx);  the geometry is that of the forward conv."""
-        plan, wsb = self._plan(dx, dy, pk.cin, pk.cout, g)
+        plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         native.check(self.lib.wdg_conv_dgrad(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(),
                                              int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                              self.stream), "conv_dgrad")
 
+    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
+        """y = act(convT(bilinear_x2(x_low), W) + bias) without materialising the upsampled tensor.
+        pk/g describe the transposed conv as the conv it is the adjoint of (cin = y channels)."""
+        px, ldl, isl = _v4(x_low)
+        py, ldy, isy = _v4(y)
+        n, H, W, _ = y.shape
+        cp = (pk.cout + 3) // 4 * 4
+        plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
+        native.check(self.lib.wdg_upconv_fwd(plan, px, ldl, isl, pk.wD.data_ptr(), _ptr(bias), py, int(act), slope,
+                                             self.stream), "upconv_fwd")
+
     def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True):
         """dw[kh,kw,Cin,Cout] (+)= x (*) dy."""
-        plan, wsb = self._plan(x, dy, pk.cin, pk.cout, g)
+        plan, wsb, _ = self._plan(x, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         assert dw.is_contiguous()
         native.check(self.lib.wdg_conv_wgrad(plan, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),

@@ -99,7 +99,6 @@ class GeneratorNet(_Net):
             h=o.zeros(N, S4, S4, F),
             y5=o.empty(N, S4, S4, F // 2),
             y7=o.empty(N, S2, S2, F // 4),
-            up=o.empty(N, S, S, F // 4 + IF),
             y9=o.empty(N, S, S, F // 8),
             z9=o.empty(N, S, S, F // 8),
             out=o.zeros(N, S, S, round4(self.out_channels)),
@@ -107,6 +106,13 @@ class GeneratorNet(_Net):
         self._bufs = {B: b}      # one resident batch size at a time
         self._grad_bufs = None
         return b
+
+    def _up(self, B):
+        """The materialised upsampled tensor (only the back-propagated forward needs it)."""
+        b = self.buffers(B)
+        if "up" not in b:
+            b["up"] = self.ops.empty(self.T * B, self.S, self.S, self.F // 4 + self.IF)
+        return b["up"]
 
     def grad_buffers(self, B):
         if self._grad_bufs is None:
@@ -138,8 +144,13 @@ class GeneratorNet(_Net):
         return v2(self.buffers(B)["x0"][..., self.in_channels:self.cin])
 
     # ---- forward -----------------------------------------------------------------------------------
-    def forward(self, B, training):
-        """Runs on the resident input buffer; returns the [T*B,S,S,round4(out)] time-major output."""
+    def forward(self, B, training, need_backward=None):
+        """Runs on the resident input buffer; returns the [T*B,S,S,round4(out)] time-major output.
+        Only a forward that will be back-propagated (the generator step, ganbase.py:50-61) materialises
+        the bilinear-upsampled tensor (it is the weight-gradient operand); every other forward fuses the
+        upsampling into the transposed conv's input staging."""
+        if need_backward is None:
+            need_backward = training
         b = self.buffers(B)
         F, IF, T = self.F, self.IF, self.T
         self._prepare(training)
@@ -154,8 +165,11 @@ class GeneratorNet(_Net):
         self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), training)
         self.c7.forward(b["cat4"], b["y7"])
         self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), training)
-        self.ops.upsample2x_fwd(b["cat2"], b["up"])                                   # models.py:62
-        self.c9.forward(b["up"], b["y9"])
+        if need_backward:
+            self.ops.upsample2x_fwd(b["cat2"], self._up(B))                           # models.py:62
+            self.c9.forward(self._up(B), b["y9"])
+        else:
+            self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)   # :62-64 fused
         self.bn10.forward(v2(b["y9"]), v2(b["z9"]), training)
         self.c11.forward(b["z9"], b["out"])
         return b["out"]
@@ -173,7 +187,7 @@ class GeneratorNet(_Net):
         self.c11.backward_input(dout, g["dz9"])
         # bn10 + LeakyReLU of c9
         self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad)
-        self.c9.backward_weights(b["up"], g["dz9"])
+        self.c9.backward_weights(self._up(B), g["dz9"])
         self.c9.backward_input(g["dz9"], g["dup"])
         o.upsample2x_bwd(g["dup"], g["dcat2"])
         # bn8 + c7

@@ -119,7 +119,7 @@ class GanEngine:
 
         for _ in range(self.n_critic):                                            # ganbase.py:26
             noise.normal_into(gen.noise_view(B), self.noise_std)                   # :28
-            fake = gen.forward(B, training=True)                                  # :29
+            fake = gen.forward(B, training=True, need_backward=False)             # :29 (outside any tape)
             noise.uniform_into(eps)                                               # :30
             ops.lerp_batch(v2(real), v2(fake), eps, v2(comb), ppi, B)             # :31
             disc.set_high_tm(comb, B)
@@ -145,7 +145,7 @@ class GanEngine:
 
         gen.params.zero_grad()                                                    # generator step, :50-61
         noise.normal_into(gen.noise_view(B), self.noise_std)
-        fake = gen.forward(B, training=True)
+        fake = gen.forward(B, training=True, need_backward=True)
         disc.set_high_tm(fake, B)
         gen_disc_loss = -disc.forward(B, training=True).mean()                    # :54
         dscore.fill_(-1.0 / B)

@@ -52,7 +52,7 @@ def wind_speed_weighted_rmse(real_output, fake_output):
     epsilon = 4  # See Jerome Dujardin thesis
     t = 0.425  # See Jerome Dujardin thesis
     beta = (epsilon + realized_wind_speed) / (epsilon + estimated_wind_speed)
-    tau = torch.where(estimated_wind_speed >= realized_wind_speed, t, 1 - t)
+    tau = torch.where(estimated_wind_speed >= realized_wind_speed, torch.full_like(u, t), torch.full_like(u, 1 - t))
     result = tau * ((u_hat - beta * u) ** 2 + (v_hat - beta * v) ** 2)
     result = torch.where(torch.isnan(result), torch.zeros_like(result), result)
     return torch.sqrt(torch.mean(result, dim=(1, 2, 3)))
