@@ -75,7 +75,8 @@ int wdg_conv_plan_destroy(wdg_conv_plan* plan);
 /* Bytes of split-K scratch the plan may use (max over fwd/dgrad/wgrad). */
 size_t wdg_conv_ws_bytes(const wdg_conv_plan* plan);
 /* Launch configuration chosen for the plan (for profiling labels):
- * info[0..7] = {fwd BM, fwd BN, fwd split, dgrad BM, dgrad BN, dgrad split, wgrad BN, wgrad split}. */
+ * info[0..7] = {fwd BM, fwd BN, fwd split, dgrad BM, dgrad BN, dgrad split, wgrad BN, wgrad split};
+ * BM == 0 / wgrad BN == 0 mark the halo-tile kernels (conv_halo.hip, wgrad_halo.hip). */
 int wdg_conv_plan_info(const wdg_conv_plan* plan, int32_t* info);
 
 /* y = act(conv(x, wF) + bias) [+ y if accumulate].

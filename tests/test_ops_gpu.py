@@ -47,6 +47,8 @@ CONV_CASES = [
     ("halo_out_16to2", 4, 128, 128, 16, 2, 3, 1, 1),
     ("halo_convT5x5_as_conv", 4, 128, 130, 16, 160, 5, 1, 2),
     ("halo_3x3_128to64", 4, 128, 128, 128, 64, 3, 1, 1),
+    ("halo_5x5_8to16", 4, 128, 128, 8, 16, 5, 1, 2),
+    ("halo_3x3_12to24", 4, 128, 132, 12, 24, 3, 1, 1),
     ("n160_tile32", 2, 24, 24, 16, 160, 5, 1, 2),
 ]
 

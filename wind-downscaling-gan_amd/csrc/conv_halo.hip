@@ -63,18 +63,19 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
         for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nchunk = (p.C4 + 3) >> 2;
+    const bool flat = p.C4 < 4;   // fewer than 16 channels: pack (tap, channel-group) pairs densely into the MFMA k
     for (int ck = 0; ck < nchunk; ++ck) {
         const int kgs = min(4, p.C4 - 4 * ck);
         __syncthreads();  // previous chunk's fragment reads are done
         // ---- stage the input halo: lanes run over pixels (conflict-free ds_write_b128)
-        for (int idx = t; idx < 4 * npr; idx += 256) {
+        for (int idx = t; idx < kgs * npr; idx += 256) {
             const int kg = idx / npr;
             const int pix = idx - kg * npr;
             const int hy = pix / p.halo_w;
             const int hx = pix - hy * p.halo_w;
             const int gy = hy0 + hy, gx = hx0 + hx;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kg < kgs && (unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc) {
+            if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc) {
                 const int c = (4 * ck + kg) * 4;
                 if (!p.upsample) {
                     v = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + c);
@@ -99,37 +100,68 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
             }
             lds_a[kg * p.npix + pix] = v;
         }
-        // ---- stage this chunk's weights: [tap][kg][n]
-        for (int idx = t; idx < p.ntaps * 4 * NW; idx += 256) {
+        // ---- stage this chunk's weights: [tap][kg][n] (kg < kgs only)
+        for (int idx = t; idx < p.ntaps * kgs * NW; idx += 256) {
             const int n = idx % NW;
             const int r = idx / NW;
-            const int kg = r & 3;
-            const int tap = r >> 2;
+            const int kg = r % kgs;
+            const int tap = r / kgs;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kg < kgs && n < p.Ncols)
+            if (n < p.Ncols)
                 v = *reinterpret_cast<const f32x4*>(p.B + (long long)n * p.ldB + p.taps[tap].z + (4 * ck + kg) * 4);
             lds_w[idx] = v;
         }
         __syncthreads();
-        // ---- all taps from LDS
-        for (int tap = 0; tap < p.ntaps; ++tap) {
-            const int4 e = p.taps[tap];
-            const int rowoff = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
-            f32x4 af[4], bf[NT];
+        if (!flat) {
+            // ---- all taps from LDS; lane group lg takes channel group lg of the chunk
+            const bool kvalid = lg < kgs;
+            for (int tap = 0; tap < p.ntaps; ++tap) {
+                const int4 e = p.taps[tap];
+                const int rowoff = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
+                f32x4 af[4], bf[NT];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int row = 2 * wave + (a >> 1), col = (a & 1) * 16 + li;
-                af[a] = lds_a[lg * p.npix + row * p.halo_w + col + rowoff];
+                for (int a = 0; a < 4; ++a) {
+                    const int row = 2 * wave + (a >> 1), col = (a & 1) * 16 + li;
+                    af[a] = kvalid ? lds_a[lg * p.npix + row * p.halo_w + col + rowoff] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    bf[b] = kvalid ? lds_w[(tap * kgs + lg) * NW + b * 16 + li] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
             }
+        } else {
+            // ---- flattened (tap, channel-group) entries, 4 per MFMA k-group: lane group lg takes entry 4q+lg
+            const int nent = p.ntaps * kgs;
+            for (int q = 0; q < nent; q += 4) {
+                const int ent = q + lg;
+                const bool kvalid = ent < nent;
+                const int tap = kvalid ? ent / kgs : 0;
+                const int kg = ent - tap * kgs;
+                const int4 e = p.taps[tap];
+                const int rowoff = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
+                f32x4 af[4], bf[NT];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bf[b] = lds_w[(tap * 4 + lg) * NW + b * 16 + li];
+                for (int a = 0; a < 4; ++a) {
+                    const int row = 2 * wave + (a >> 1), col = (a & 1) * 16 + li;
+                    af[a] = kvalid ? lds_a[kg * p.npix + row * p.halo_w + col + rowoff] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int b = 0; b < NT; ++b)
+                    bf[b] = kvalid ? lds_w[ent * NW + b * 16 + li] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+            }
         }
     }
 
@@ -169,10 +201,12 @@ static size_t halo_lds_bytes(int kh, int kw, int nt) {
 int wdg_halo_plan_init(wdg_conv_plan* pl) {
     const wdg_conv_geom& g = pl->g;
     pl->halo_fwd_nt = pl->halo_dgrad_nt = 0;
+    pl->halo_auto = 0;
     if (g.stride != 1 || g.kh > 5 || g.kw > 5) return WDG_OK;
-    // only worth it where the im2col-free gather is traffic-bound: few output channels, large maps
+    // the conv entry points switch to the halo kernel only where the im2col-free gather is
+    // traffic-bound (few output channels, large maps); wdg_upconv_fwd uses it at any size
     const long long pixels = (long long)g.n_img * g.Ho * g.Wo;
-    if (pixels < 65536) return WDG_OK;
+    pl->halo_auto = pixels >= 65536;
     int nf = halo_nt(g.Cout), nd = halo_nt(g.Cin);
     if (nf && halo_lds_bytes(g.kh, g.kw, nf) > 64 * 1024) nf = 0;
     if (nd && halo_lds_bytes(g.kh, g.kw, nd) > 64 * 1024) nd = 0;

@@ -392,19 +392,32 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
 }
 
 __global__ void __launch_bounds__(256) wdg_wgrad_reduce_kernel(const WdgWgrad p) {
+    // block = 16 consecutive outputs x 16 split lanes; fixed summation order -> reproducible
+    __shared__ float red[256];
     const long long total = (long long)p.K4 * 4 * p.Cout;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * 256) {
-        const int R = (int)(idx / p.Cout);
-        const int n = (int)(idx - (long long)R * p.Cout);
-        const int2 wr = p.wrow[R >> 2];
-        const int r = R & 3;
-        if (r >= wr.y) continue;
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    for (long long base = (long long)blockIdx.x * 16; base < total; base += (long long)gridDim.x * 16) {
+        const long long idx = base + el;
         float v = 0.f;
-        for (int s = 0; s < p.splitk; ++s) v += p.partial[((long long)s * p.K4 * 4 + R) * p.Cout + n];
-        float* dst = p.dW + wr.x + (long long)r * p.Cout + n;
-        if (p.accumulate) v += *dst;
-        *dst = v;
+        if (idx < total)
+            for (int s = sl; s < p.splitk; s += 16) v += p.partial[(long long)s * p.K4 * 4 * p.Cout + idx];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (sl == 0 && idx < total) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k * 16 + el];
+            const int R = (int)(idx / p.Cout);
+            const int n = (int)(idx - (long long)R * p.Cout);
+            const int2 wr = p.wrow[R >> 2];
+            const int r = R & 3;
+            if (r < wr.y) {
+                float* dst = p.dW + wr.x + (long long)r * p.Cout + n;
+                if (p.accumulate) t += *dst;
+                *dst = t;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -594,6 +607,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     if ((rc = upload(wr.data(), wr.size() * sizeof(int2), (void**)&pl->d_wrow)) != WDG_OK) { delete pl; return rc; }
     if ((rc = upload(td.data(), td.size() * sizeof(int4), (void**)&pl->d_tab_dgrad)) != WDG_OK) { delete pl; return rc; }
     if ((rc = wdg_halo_plan_init(pl)) != WDG_OK) { delete pl; return rc; }
+    pl->ws_bytes = std::max(pl->ws_bytes, wdg_wgrad_halo_ws_bytes(pl));
     *out = pl;
     return WDG_OK;
 }
@@ -617,8 +631,9 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
     info[0] = f.BM; info[1] = f.BN; info[2] = pl->fwd_split;
     info[3] = d.BM; info[4] = d.BN; info[5] = pl->dgrad_split;
     info[6] = pick_wgrad_bn(pl->g.Cout); info[7] = pl->wgrad_split;
-    if (pl->halo_fwd_nt) { info[0] = 0; info[1] = 16 * pl->halo_fwd_nt; info[2] = 1; }     // BM = 0 marks the halo kernel
-    if (pl->halo_dgrad_nt) { info[3] = 0; info[4] = 16 * pl->halo_dgrad_nt; info[5] = 1; }
+    if (wdg_wgrad_halo_eligible(pl)) { info[6] = 0; info[7] = 1; }   // BN = 0 marks the halo weight-gradient kernel
+    if (pl->halo_auto && pl->halo_fwd_nt) { info[0] = 0; info[1] = 16 * pl->halo_fwd_nt; info[2] = 1; }     // BM = 0 marks the halo kernel
+    if (pl->halo_auto && pl->halo_dgrad_nt) { info[3] = 0; info[4] = 16 * pl->halo_dgrad_nt; info[5] = 1; }
     return WDG_OK;
 }
 
@@ -671,7 +686,7 @@ extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float
     WDG_CHECK_ARG(pl && x && wF && y, "null argument");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0, "x / wF must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
-    if (pl->halo_fwd_nt)
+    if (pl->halo_auto && pl->halo_fwd_nt)
         return wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, accumulate,
                                (hipStream_t)stream);
     WdgIgemm p;
@@ -697,7 +712,7 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
     WDG_CHECK_ARG(pl && dy && wD && dx, "null argument");
     WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0, "dy / wD must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
-    if (pl->halo_dgrad_nt)
+    if (pl->halo_auto && pl->halo_dgrad_nt)
         return wdg_halo_launch(pl, true, dy, g.ldy, g.img_stride_y, 0, wD, bias, dx, act, slope, accumulate,
                                (hipStream_t)stream);
     WdgIgemm p;
@@ -725,6 +740,7 @@ extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const flo
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "x / dy must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
     hipStream_t st = (hipStream_t)stream;
+    if (wdg_wgrad_halo_eligible(pl)) return wdg_wgrad_halo_launch(pl, x, dy, dw, accumulate, ws, ws_bytes, st);
     WdgWgrad p;
     memset(&p, 0, sizeof(p));
     p.X = x; p.DY = dy; p.dW = dw; p.ktab = pl->d_tab_fwd; p.wrow = pl->d_wrow;
@@ -764,7 +780,7 @@ extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const flo
     WDG_LAUNCH_CHECK();
     if (split > 1) {
         long long total = (long long)p.K4 * 4 * p.Cout;
-        int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        int blocks = (int)std::min<long long>((total + 15) / 16, 8192);
         hipLaunchKernelGGL(wdg_wgrad_reduce_kernel, dim3(blocks), block, 0, st, p);
         WDG_LAUNCH_CHECK();
     }

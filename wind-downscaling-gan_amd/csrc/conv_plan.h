@@ -30,6 +30,7 @@ struct wdg_conv_plan {
     int4* d_taps_fwd = nullptr;
     int4* d_taps_dgrad = nullptr;
     int halo_fwd_nt = 0, halo_dgrad_nt = 0;   // 0 = not eligible; else 16-column tiles per block (1, 2, 4)
+    int halo_auto = 0;                        // conv_fwd / conv_dgrad dispatch to the halo kernel by themselves
 };
 
 
@@ -39,3 +40,9 @@ void wdg_halo_plan_free(wdg_conv_plan* pl);
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
                     hipStream_t st);
+
+// wgrad_halo.hip
+int wdg_wgrad_halo_eligible(const wdg_conv_plan* pl);
+size_t wdg_wgrad_halo_ws_bytes(const wdg_conv_plan* pl);
+int wdg_wgrad_halo_launch(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw, int accumulate,
+                          void* ws, size_t ws_bytes, hipStream_t st);

@@ -33,9 +33,48 @@ __global__ void __launch_bounds__(256) wdg_lstm_fwd_kernel(const float* __restri
     }
 }
 
+// float4 variant (F % 4 == 0, every stride % 4 == 0): one thread = 4 features of one pixel
+__global__ void __launch_bounds__(256) wdg_lstm_fwd4_kernel(const float* __restrict__ gates, int ldg,
+                                                            const float* __restrict__ c_prev, int ldcp, float* c,
+                                                            int ldc, float* h, int ldh, int64_t P, int F) {
+    const int f4n = F / 4;
+    const int64_t total = P * f4n;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / f4n;
+        const int f = 4 * (int)(idx - p * f4n);
+        const float* g = gates + p * ldg + f;
+        const f32x4 xi = *reinterpret_cast<const f32x4*>(g);
+        const f32x4 xc = *reinterpret_cast<const f32x4*>(g + 2 * F);
+        const f32x4 xo = *reinterpret_cast<const f32x4*>(g + 3 * F);
+        f32x4 xf = (f32x4){0.f, 0.f, 0.f, 0.f}, cp = xf;
+        if (c_prev) {
+            xf = *reinterpret_cast<const f32x4*>(g + F);
+            cp = *reinterpret_cast<const f32x4*>(c_prev + p * ldcp + f);
+        }
+        f32x4 cn, hn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = wdg_hsig(xi[j]) * tanhf(xc[j]);
+            if (c_prev) v += wdg_hsig(xf[j]) * cp[j];
+            cn[j] = v;
+            hn[j] = wdg_hsig(xo[j]) * tanhf(v);
+        }
+        *reinterpret_cast<f32x4*>(c + p * ldc + f) = cn;
+        *reinterpret_cast<f32x4*>(h + p * ldh + f) = hn;
+    }
+}
+
+static inline bool wdg_al4(const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && ld % 4 == 0); }
+
 extern "C" int wdg_lstm_fwd(const float* gates, int ldg, const float* c_prev, int ldcp, float* c, int ldc,
                             float* h, int ldh, int64_t P, int F, wdg_stream stream) {
     WDG_CHECK_ARG(gates && c && h && F > 0, "bad argument");
+    if (F % 4 == 0 && wdg_al4(gates, ldg) && wdg_al4(c_prev, ldcp) && wdg_al4(c, ldc) && wdg_al4(h, ldh)) {
+        hipLaunchKernelGGL(wdg_lstm_fwd4_kernel, dim3(ew_blocks(P * (F / 4))), dim3(256), 0, (hipStream_t)stream,
+                           gates, ldg, c_prev, ldcp, c, ldc, h, ldh, P, F);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
     hipLaunchKernelGGL(wdg_lstm_fwd_kernel, dim3(ew_blocks(P * F)), dim3(256), 0, (hipStream_t)stream, gates,
                        ldg, c_prev, ldcp, c, ldc, h, ldh, P, F);
     WDG_LAUNCH_CHECK();
@@ -70,10 +109,58 @@ __global__ void __launch_bounds__(256) wdg_lstm_bwd_kernel(const float* __restri
     }
 }
 
+__global__ void __launch_bounds__(256) wdg_lstm_bwd4_kernel(const float* __restrict__ gates, int ldg,
+                                                            const float* __restrict__ c_prev, int ldcp,
+                                                            const float* __restrict__ c, int ldc,
+                                                            const float* __restrict__ dh, int lddh,
+                                                            const float* __restrict__ dc_in, int lddci,
+                                                            float* dgates, int lddg, float* dc_prev, int lddcp,
+                                                            int64_t P, int F) {
+    const int f4n = F / 4;
+    const int64_t total = P * f4n;
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / f4n;
+        const int f = 4 * (int)(idx - p * f4n);
+        const float* g = gates + p * ldg + f;
+        const f32x4 xi = *reinterpret_cast<const f32x4*>(g), xf = *reinterpret_cast<const f32x4*>(g + F);
+        const f32x4 xc = *reinterpret_cast<const f32x4*>(g + 2 * F), xo = *reinterpret_cast<const f32x4*>(g + 3 * F);
+        const f32x4 cp = c_prev ? *reinterpret_cast<const f32x4*>(c_prev + p * ldcp + f) : z4;
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(c + p * ldc + f);
+        const f32x4 dhv = *reinterpret_cast<const f32x4*>(dh + p * lddh + f);
+        const f32x4 dci = dc_in ? *reinterpret_cast<const f32x4*>(dc_in + p * lddci + f) : z4;
+        f32x4 di, df, dcg, dout, dcp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = wdg_hsig(xi[j]), gf = wdg_hsig(xf[j]), gc = tanhf(xc[j]), go = wdg_hsig(xo[j]);
+            const float tc = tanhf(cc[j]);
+            const float dc = dhv[j] * go * (1.f - tc * tc) + dci[j];
+            di[j] = dc * gc * wdg_hsig_grad(xi[j]);
+            df[j] = dc * cp[j] * wdg_hsig_grad(xf[j]);
+            dcg[j] = dc * gi * (1.f - gc * gc);
+            dout[j] = dhv[j] * tc * wdg_hsig_grad(xo[j]);
+            dcp[j] = dc * gf;
+        }
+        float* dg = dgates + p * lddg + f;
+        *reinterpret_cast<f32x4*>(dg) = di;
+        *reinterpret_cast<f32x4*>(dg + F) = df;
+        *reinterpret_cast<f32x4*>(dg + 2 * F) = dcg;
+        *reinterpret_cast<f32x4*>(dg + 3 * F) = dout;
+        if (dc_prev) *reinterpret_cast<f32x4*>(dc_prev + p * lddcp + f) = dcp;
+    }
+}
+
 extern "C" int wdg_lstm_bwd(const float* gates, int ldg, const float* c_prev, int ldcp, const float* c, int ldc,
                             const float* dh, int lddh, const float* dc_in, int lddci, float* dgates, int lddg,
                             float* dc_prev, int lddcp, int64_t P, int F, wdg_stream stream) {
     WDG_CHECK_ARG(gates && c && dh && dgates && F > 0, "bad argument");
+    if (F % 4 == 0 && wdg_al4(gates, ldg) && wdg_al4(c_prev, ldcp) && wdg_al4(c, ldc) && wdg_al4(dh, lddh) &&
+        wdg_al4(dc_in, lddci) && wdg_al4(dgates, lddg) && wdg_al4(dc_prev, lddcp)) {
+        hipLaunchKernelGGL(wdg_lstm_bwd4_kernel, dim3(ew_blocks(P * (F / 4))), dim3(256), 0, (hipStream_t)stream,
+                           gates, ldg, c_prev, ldcp, c, ldc, dh, lddh, dc_in, lddci, dgates, lddg, dc_prev, lddcp, P, F);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
     hipLaunchKernelGGL(wdg_lstm_bwd_kernel, dim3(ew_blocks(P * F)), dim3(256), 0, (hipStream_t)stream, gates,
                        ldg, c_prev, ldcp, c, ldc, dh, lddh, dc_in, lddci, dgates, lddg, dc_prev, lddcp, P, F);
     WDG_LAUNCH_CHECK();

@@ -120,7 +120,7 @@ class HipOps:
             return self._label(info[0], info[1])
         if which == "dgrad":
             return self._label(info[3], info[4])
-        return "wdg_wgrad_kernel<%d>" % info[6]
+        return "wdg_wgrad_halo_kernel" if info[6] == 0 else "wdg_wgrad_kernel<%d>" % info[6]
 
     # ---- convolution family -----------------------------------------------------------------
     def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2):
