@@ -41,7 +41,7 @@ struct WdgIgemm {
     WdgPhase ph[9];
 };
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int PIPE>
 __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;
@@ -50,8 +50,9 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(MT >= 1 && NT >= 1, "tile");
 
-    __shared__ f32x4 ldsA[8 * BM];
-    __shared__ f32x4 ldsB[8 * BN];
+    // one LDS array (dynamic): [stage][A tile | B tile]; PIPE >= 1 uses two stages
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds_all[];
+    constexpr int STAGE = 8 * (BM + BN);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -133,9 +134,7 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
         }
     };
 
-    if (nk > 0) load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage registers -> LDS
+    auto store_tile = [&](f32x4* ldsA, f32x4* ldsB) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int row = lrow + 32 * i;
@@ -146,27 +145,73 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
             const int row = lrow + 32 * i;
             if (row < BN) ldsB[kg * BN + (row ^ kg)] = rb[i];
         }
-        __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);  // in flight under the MFMAs below
+    };
+    auto read_frags = [&](const f32x4* ldsA, const f32x4* ldsB, int h, f32x4 (&af)[MT], f32x4 (&bf)[NT]) {
+        const int kgr = 4 * h + (lane >> 4);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kgr = 4 * h + (lane >> 4);
-            f32x4 af[MT], bf[NT];
+        for (int a = 0; a < MT; ++a) af[a] = ldsA[kgr * BM + ((wm * (BM / WGM) + a * 16 + (lane & 15)) ^ kgr)];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bf[b] = ldsB[kgr * BN + ((wn * (BN / WGN) + b * 16 + (lane & 15)) ^ kgr)];
+    };
+    auto mfma_block = [&](const f32x4 (&af)[MT], const f32x4 (&bf)[NT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int a = 0; a < MT; ++a)
-                af[a] = ldsA[kgr * BM + ((wm * (BM / WGM) + a * 16 + (lane & 15)) ^ kgr)];
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
-                bf[b] = ldsB[kgr * BN + ((wn * (BN / WGN) + b * 16 + (lane & 15)) ^ kgr)];
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+    };
+
+    if (PIPE == 0) {
+        f32x4* ldsA = lds_all;
+        f32x4* ldsB = lds_all + 8 * BM;
+        if (nk > 0) load_tile(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            store_tile(ldsA, ldsB);
+            __syncthreads();
+            if (kt + 1 < nk) load_tile(kt + 1);  // in flight under the MFMAs below
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-#pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                f32x4 af[MT], bf[NT];
+                read_frags(ldsA, ldsB, h, af, bf);
+                mfma_block(af, bf);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        // double-buffered LDS: the next tile is written into the other stage right after this wave's own
+        // MFMAs, one barrier per K-step
+        if (nk > 0) {
+            load_tile(0);
+            store_tile(lds_all, lds_all + 8 * BM);
+            __syncthreads();
+            if (nk > 1) load_tile(1);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const f32x4* ldsA = lds_all + (kt & 1) * STAGE;
+            const f32x4* ldsB = ldsA + 8 * BM;
+            if (PIPE == 1) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 af[MT], bf[NT];
+                    read_frags(ldsA, ldsB, h, af, bf);
+                    mfma_block(af, bf);
+                }
+            } else {
+                f32x4 af0[MT], bf0[NT], af1[MT], bf1[NT];
+                read_frags(ldsA, ldsB, 0, af0, bf0);
+                read_frags(ldsA, ldsB, 1, af1, bf1);   // second half's fragments land under the first half's MFMAs
+                mfma_block(af0, bf0);
+                mfma_block(af1, bf1);
+            }
+            if (kt + 1 < nk) {
+                f32x4* nA = lds_all + ((kt + 1) & 1) * STAGE;
+                store_tile(nA, nA + 8 * BM);
+            }
+            __syncthreads();
+            if (kt + 2 < nk) load_tile(kt + 2);
+        }
     }
 
     // ---- epilogue
@@ -637,6 +682,35 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
     return WDG_OK;
 }
 
+// tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
+// 2 = 1 + fragment prefetch
+static int g_igemm_pipe = 1;
+
+extern "C" int wdg_set_tuning(const char* key, int value) {
+    if (key && !strcmp(key, "igemm_pipe")) {
+        if (value < 0 || value > 2) return WDG_ERR_ARG;
+        g_igemm_pipe = value;
+        return WDG_OK;
+    }
+    wdg_set_error("wdg_set_tuning: unknown key");
+    return WDG_ERR_ARG;
+}
+
+template <int BM, int BN, int WGM, int WGN, int PIPE>
+static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
+    constexpr size_t lds = (size_t)(PIPE == 0 ? 1 : 2) * 8 * (BM + BN) * sizeof(f32x4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 48 * 1024)
+            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE>), grid, block, lds, st, p);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
                         hipStream_t st) {
     TileCfg tc = pick_tile(p.Ncols);
@@ -662,14 +736,20 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         p.partial = nullptr;
     }
     dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
-    if (tc.BM == 128 && tc.BN == 128)
-        hipLaunchKernelGGL((wdg_igemm_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
-    else if (tc.BM == 128 && tc.BN == 64)
-        hipLaunchKernelGGL((wdg_igemm_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
-    else if (tc.BM == 256 && tc.BN == 32)
-        hipLaunchKernelGGL((wdg_igemm_kernel<256, 32, 4, 1>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((wdg_igemm_kernel<256, 16, 4, 1>), grid, block, 0, st, p);
+    const int pipe = g_igemm_pipe;
+    int rc = WDG_OK;
+#define WDG_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                              \
+    if (tc.BM == BM_ && tc.BN == BN_) {                                                                 \
+        if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);                  \
+        else if (pipe == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 1>(grid, block, st, p);             \
+        else rc = launch_variant<BM_, BN_, WM_, WN_, 2>(grid, block, st, p);                            \
+    }
+    WDG_IGEMM_CASE(128, 128, 2, 2)
+    WDG_IGEMM_CASE(128, 64, 2, 2)
+    WDG_IGEMM_CASE(256, 32, 4, 1)
+    WDG_IGEMM_CASE(256, 16, 4, 1)
+#undef WDG_IGEMM_CASE
+    if (rc != WDG_OK) return rc;
     WDG_LAUNCH_CHECK();
     if (split > 1) {
         long long total = (long long)p.Mmax * p.Ncols;
