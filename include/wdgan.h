@@ -42,7 +42,7 @@ const char* wdg_last_error(void);
 /* Library version / target string, e.g. "wdgan 0.1 gfx950". */
 const char* wdg_version(void);
 /* Performance knobs for A/B measurements (results are identical for every setting):
- *   "igemm_pipe": 0 single LDS stage + two barriers per K-step, 1 double-buffered LDS + one barrier (default),
+ *   "igemm_pipe": 0 single LDS stage + two barriers per K-step (default), 1 double-buffered LDS + one barrier,
  *                 2 = 1 + fragment prefetch. */
 int wdg_set_tuning(const char* key, int value);
 /* Number of compute units of the current device (used by the host-side split-K heuristic). */

@@ -30,6 +30,21 @@ SHAPES = [
     ("G9 convT5x5 wgrad (16,160)", (B, 256, 256, 16, 16), 160, 5, 1, 2, "wgrad"),
     ("G9 convT5x5 dx (16->160 fwd)", (B, 256, 256, 16, 16), 160, 5, 1, 2, "fwd"),
     ("D 7x7s3 32->64 wgrad", (B, 256, 256, 32, 32), 64, 7, 3, 1, "wgrad"),
+    # HBM-bound full-resolution layers with few channels (halo-tile kernels)
+    ("D lstm_a 2->8 fwd", (B, 256, 256, 2, 4), 8, 3, 1, 1, "fwd"),
+    ("D conv_a 2->16 fwd", (B, 256, 256, 2, 4), 16, 3, 1, 1, "fwd"),
+    ("D conv_b 16->16 fwd", (B, 256, 256, 16, 16), 16, 3, 1, 1, "fwd"),
+    ("D lstm_b 5->64 fwd", (B, 256, 256, 5, 8), 64, 3, 1, 1, "fwd"),
+    ("G11 16->2 fwd", (B, 256, 256, 16, 16), 2, 3, 1, 1, "fwd"),
+    ("D lstm_a 2->8 dgrad", (B, 256, 256, 2, 4), 8, 3, 1, 1, "dgrad"),
+    ("D conv_a 2->16 dgrad", (B, 256, 256, 2, 4), 16, 3, 1, 1, "dgrad"),
+    ("D conv_b 16->16 dgrad", (B, 256, 256, 16, 16), 16, 3, 1, 1, "dgrad"),
+    ("D lstm_b 5->64 dgrad", (B, 256, 256, 5, 8), 64, 3, 1, 1, "dgrad"),
+    ("G11 16->2 dgrad", (B, 256, 256, 16, 16), 2, 3, 1, 1, "dgrad"),
+    ("D conv_a 2->16 wgrad", (B, 256, 256, 2, 4), 16, 3, 1, 1, "wgrad"),
+    ("D conv_b 16->16 wgrad", (B, 256, 256, 16, 16), 16, 3, 1, 1, "wgrad"),
+    ("D lstm_b 5->64 wgrad", (B, 256, 256, 5, 8), 64, 3, 1, 1, "wgrad"),
+    ("G9 fused up+convT5x5 fwd", None, 0, 0, 0, 0, "upconv"),
 ]
 
 
@@ -38,7 +53,17 @@ def main():
     ops = HipOps("cuda:0")
     lib = ops.lib
     cases = []
-    for name, (n, H, W, cin, ld), cout, k, s, p, which in SHAPES:
+    for name, shp, cout, k, s, p, which in SHAPES:
+        if which == "upconv":
+            xl = torch.randn(B, 128, 128, 160, device=ops.device)
+            w = (torch.randn(5, 5, 16, 160, device=ops.device) * 0.05).contiguous()
+            pk = ops.pack_weights(w)
+            yo = torch.empty(B, 256, 256, 16, device=ops.device)
+            g = ConvGeom(5, 5, 1, 2)
+            cases.append((name, lambda xl=xl, pk=pk, yo=yo, g=g: ops.upconv_fwd(xl, pk, None, yo, g, act=True),
+                          2.0 * B * 65536 * 16 * 25 * 160, "wdg_conv_halo_kernel<1>+up", (xl.numel() + yo.numel()) * 4))
+            continue
+        n, H, W, cin, ld = shp
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         xb = torch.randn(n, H, W, ld, device=ops.device)
         x = xb[..., :(cin + 3) // 4 * 4]
@@ -57,13 +82,14 @@ def main():
         else:
             fn = lambda x=x, pk=pk, y=y, g=g, dw=dw: ops.conv_wgrad(x, y, pk, dw, g, accumulate=False)
         label = ops.conv_kernel_label(which, x, y, pk, g)
-        cases.append((name, fn, flops, label))
+        nbytes = 4.0 * (n * H * W * ((cin + 3) // 4 * 4) + n * Ho * Wo * ((cout + 3) // 4 * 4))
+        cases.append((name, fn, flops, label, nbytes))
     pipes = (0, 1, 2)
     times = {(c[0], pp): [] for c in cases for pp in pipes}
     for r in range(reps + 1):
         for pp in pipes:
             lib.wdg_set_tuning(b"igemm_pipe", pp)
-            for name, fn, flops, label in cases:
+            for name, fn, flops, label, nbytes in cases:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 fn()
@@ -72,12 +98,13 @@ def main():
                 if r > 0:
                     times[(name, pp)].append(e0.elapsed_time(e1))
     print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"pipe{pp}: ms (TF/s)     " for pp in pipes))
-    for name, fn, flops, label in cases:
+    for name, fn, flops, label, nbytes in cases:
         row = f"{name:32s} {label:28s} "
         for pp in pipes:
             t = sorted(times[(name, pp)])[len(times[(name, pp)]) // 2]
             row += f"{t:7.3f} ({flops / t * 1e-9:6.1f})   "
-        print(row)
+        t0 = sorted(times[(name, 0)])[len(times[(name, 0)]) // 2]
+        print(row + f" in+out {nbytes / t0 * 1e-9:6.2f} TB/s")
 
 
 if __name__ == "__main__":

@@ -684,7 +684,7 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
-static int g_igemm_pipe = 1;
+static int g_igemm_pipe = 0;   // measured: the single-stage form is 2-10 % faster (profiles/r01e_perf_conv.log)
 
 extern "C" int wdg_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "igemm_pipe")) {

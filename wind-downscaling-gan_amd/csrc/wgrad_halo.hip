@@ -25,6 +25,7 @@ struct WdgWgradHalo {
     int kh, kw, pad_h, pad_w;
     int halo_w, tiles_h, tiles_w, ntiles;
     int nparts, accumulate;
+    int nchunks;   // column chunks of NT*16 output channels (blockIdx.y)
 };
 
 template <int TAPS, int NT>
@@ -38,6 +39,8 @@ __global__ void __launch_bounds__(256) wdg_wgrad_halo_kernel(const WdgWgradHalo 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
+    const int co0 = blockIdx.y * NT * 16;                       // first output channel of this chunk
+    const int c4lim = min(NT * 4, p.Cout4 - blockIdx.y * NT * 4);   // staged channel groups of dy
 
     f32x4 acc[TAPS][NT];
 #pragma unroll
@@ -71,14 +74,14 @@ __global__ void __launch_bounds__(256) wdg_wgrad_halo_kernel(const WdgWgradHalo 
         }
         // ---- stage dy tile
         const float* Yimg = p.DY + (long long)img * p.imgStrideY;
-        for (int idx = t; idx < 128 * p.Cout4; idx += 256) {
-            const int c4 = idx % p.Cout4;
-            const int pix = idx / p.Cout4;
+        for (int idx = t; idx < 128 * c4lim; idx += 256) {
+            const int c4 = idx % c4lim;
+            const int pix = idx / c4lim;
             const int py = pix >> 5, px = pix & 31;
             const int gy = oy0 + py, gx = ox0 + px;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (gy < p.Ho && gx < p.Wo)
-                v = *reinterpret_cast<const f32x4*>(Yimg + ((long long)gy * p.Wo + gx) * p.ldy + 4 * c4);
+                v = *reinterpret_cast<const f32x4*>(Yimg + ((long long)gy * p.Wo + gx) * p.ldy + co0 + 4 * c4);
             *reinterpret_cast<f32x4*>(&dyt[pix * RSY + 4 * c4]) = v;
         }
         __syncthreads();
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) wdg_wgrad_halo_kernel(const WdgWgradHalo 
         }
     }
     // ---- per-wave partial: [part][tap][ci = 4*lg + r][co = b*16 + li]
-    float* dst = p.partial + ((long long)(blockIdx.x * 4 + wave) * TAPS) * 16 * (NT * 16);
+    float* dst = p.partial + (((long long)blockIdx.y * p.nparts + blockIdx.x * 4 + wave) * TAPS) * 16 * (NT * 16);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
@@ -115,18 +118,19 @@ __global__ void __launch_bounds__(256) wdg_wgrad_halo_reduce_kernel(const WdgWgr
     __shared__ float red[256];
     const long long per = (long long)taps * 16 * nw;
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const float* part = p.partial + (long long)blockIdx.y * p.nparts * per;
     for (long long base = (long long)blockIdx.x * 16; base < per; base += (long long)gridDim.x * 16) {
         const long long idx = base + el;
         float v = 0.f;
         if (idx < per)
-            for (int s = sl; s < p.nparts; s += 16) v += p.partial[(long long)s * per + idx];
+            for (int s = sl; s < p.nparts; s += 16) v += part[(long long)s * per + idx];
         red[threadIdx.x] = v;
         __syncthreads();
         if (sl == 0 && idx < per) {
             float tsum = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) tsum += red[k * 16 + el];
-            const int co = (int)(idx % nw);
+            const int co = (int)(idx % nw) + blockIdx.y * nw;
             const int ci = (int)((idx / nw) % 16);
             const int tap = (int)(idx / ((long long)nw * 16));
             if (ci < p.Cin && co < p.Cout) {
@@ -139,25 +143,26 @@ __global__ void __launch_bounds__(256) wdg_wgrad_halo_reduce_kernel(const WdgWgr
     }
 }
 
-static int wh_nt(int cout) { return cout <= 16 ? 1 : cout <= 32 ? 2 : cout <= 64 ? 4 : 0; }
 static const int WH_BLOCKS = 512;
 
-// 0 if the plan cannot use this kernel, else the number of 16-column tiles
+// 0 if the plan cannot use this kernel, else the number of 16-column tiles per block (column chunks of
+// NT*16 output channels run as blockIdx.y, so wide dy tensors such as the 160-channel upsampled input of
+// the 5x5 transposed conv are covered with the x halo re-read once per chunk)
 int wdg_wgrad_halo_eligible(const wdg_conv_plan* pl) {
     const wdg_conv_geom& g = pl->g;
     if (g.stride != 1 || g.Cin > 16) return 0;
-    const int nt = wh_nt(g.Cout);
-    if (!nt) return 0;
-    const int taps = g.kh * g.kw;
-    if (!((taps == 9 && g.kh == 3) || (taps == 25 && g.kh == 5 && nt == 1))) return 0;
     if ((long long)g.n_img * g.Ho * g.Wo < 65536) return 0;
-    return nt;
+    const int taps = g.kh * g.kw;
+    if (taps == 9 && g.kh == 3) return g.Cout <= 16 ? 1 : g.Cout <= 32 ? 2 : 4;
+    if (taps == 25 && g.kh == 5) return g.Cout <= 16 ? 1 : 2;
+    return 0;
 }
+static int wh_chunks(const wdg_conv_plan* pl, int nt) { return (pl->Cout_p + nt * 16 - 1) / (nt * 16); }
 
 size_t wdg_wgrad_halo_ws_bytes(const wdg_conv_plan* pl) {
     const int nt = wdg_wgrad_halo_eligible(pl);
     if (!nt) return 0;
-    return (size_t)WH_BLOCKS * 4 * pl->taps * 16 * nt * 16 * sizeof(float);
+    return (size_t)wh_chunks(pl, nt) * WH_BLOCKS * 4 * pl->taps * 16 * nt * 16 * sizeof(float);
 }
 
 int wdg_wgrad_halo_launch(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw, int accumulate,
@@ -179,7 +184,8 @@ int wdg_wgrad_halo_launch(const wdg_conv_plan* pl, const float* x, const float* 
     const int nblocks = std::min(WH_BLOCKS, p.ntiles);
     p.nparts = nblocks * 4;
     p.accumulate = accumulate;
-    const size_t need = (size_t)p.nparts * pl->taps * 16 * nt * 16 * sizeof(float);
+    p.nchunks = wh_chunks(pl, nt);
+    const size_t need = (size_t)p.nchunks * p.nparts * pl->taps * 16 * nt * 16 * sizeof(float);
     if (!ws || ws_bytes < need) {
         wdg_set_error("wgrad_halo: workspace too small (%zu < %zu)", ws_bytes, need);
         return WDG_ERR_WORKSPACE;
@@ -187,19 +193,21 @@ int wdg_wgrad_halo_launch(const wdg_conv_plan* pl, const float* x, const float* 
     p.partial = (float*)ws;
     const int rsy = nt * 16 + ((nt * 16) % 32 == 0 ? 16 : 0);
     const size_t lds = ((size_t)(WH_TH + g.kh - 1) * p.halo_w * 16 + 128 * rsy) * sizeof(float);
-    dim3 grid(nblocks), block(256);
+    dim3 grid(nblocks, p.nchunks), block(256);
     if (pl->taps == 9 && nt == 1)
         hipLaunchKernelGGL((wdg_wgrad_halo_kernel<9, 1>), grid, block, lds, st, p);
     else if (pl->taps == 9 && nt == 2)
         hipLaunchKernelGGL((wdg_wgrad_halo_kernel<9, 2>), grid, block, lds, st, p);
     else if (pl->taps == 9 && nt == 4)
         hipLaunchKernelGGL((wdg_wgrad_halo_kernel<9, 4>), grid, block, lds, st, p);
-    else
+    else if (nt == 1)
         hipLaunchKernelGGL((wdg_wgrad_halo_kernel<25, 1>), grid, block, lds, st, p);
+    else
+        hipLaunchKernelGGL((wdg_wgrad_halo_kernel<25, 2>), grid, block, lds, st, p);
     WDG_LAUNCH_CHECK();
     const long long per = (long long)pl->taps * 16 * nt * 16;
     const int rblocks = (int)std::min<long long>((per + 15) / 16, 4096);
-    hipLaunchKernelGGL(wdg_wgrad_halo_reduce_kernel, dim3(rblocks), block, 0, st, p, pl->taps, nt * 16);
+    hipLaunchKernelGGL(wdg_wgrad_halo_reduce_kernel, dim3(rblocks, p.nchunks), block, 0, st, p, pl->taps, nt * 16);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
