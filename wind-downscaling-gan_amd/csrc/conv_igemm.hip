@@ -38,8 +38,17 @@ struct WdgIgemm {
     float slope;
     int splitk, k4_per_split;
     int Mmax, nphase;
+    int xcd_swizzle;   // remap blockIdx.x so that each XCD (blocks b, b+8, ...) walks a contiguous range of tiles
     WdgPhase ph[9];
 };
+
+// Bijective XCD-aware remap (cdna_hip_programming.md T1): hardware deals consecutive workgroups round-robin
+// over the 8 XCDs; give XCD x the contiguous tile range [x*q + min(x,r), ...) so that neighbouring output
+// tiles, which share input rows (kh > stride) and the same filter panel, hit the same 4 MiB L2.
+__device__ __forceinline__ int wdg_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
 
 template <int BM, int BN, int WGM, int WGN, int PIPE>
 __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
@@ -63,8 +72,9 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
 
     const WdgPhase ph = p.ph[blockIdx.z];
     const int tiles_m = (p.Mmax + BM - 1) / BM;
-    const int tm = blockIdx.x % tiles_m;
-    const int tn = blockIdx.x / tiles_m;
+    const int bid = p.xcd_swizzle ? wdg_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tm = bid % tiles_m;
+    const int tn = bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int PaPb = ph.Pa * ph.Pb;
     const int Mph = p.n_img * PaPb;
@@ -684,12 +694,17 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
+static int g_xcd_swizzle = 1;
 static int g_igemm_pipe = 0;   // measured: the single-stage form is 2-10 % faster (profiles/r01e_perf_conv.log)
 
 extern "C" int wdg_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "igemm_pipe")) {
         if (value < 0 || value > 2) return WDG_ERR_ARG;
         g_igemm_pipe = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "xcd_swizzle")) {
+        g_xcd_swizzle = value != 0;
         return WDG_OK;
     }
     wdg_set_error("wdg_set_tuning: unknown key");
@@ -736,6 +751,7 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         p.partial = nullptr;
     }
     dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
+    p.xcd_swizzle = g_xcd_swizzle && grid.x >= 16;
     const int pipe = g_igemm_pipe;
     int rc = WDG_OK;
 #define WDG_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                              \

@@ -17,9 +17,11 @@ from downscaling.engine.common import round4
 
 
 def _to_dev(x, ops):
+    """Dense row-major (B,T,H,W,C) tensor of the backend dtype on the backend device (numpy arrays coming
+    out of fancy indexing / np.stack are often not C-contiguous)."""
     if isinstance(x, torch.Tensor):
-        return x.to(device=ops.device, dtype=ops.dtype)
-    return torch.as_tensor(np.asarray(x)).to(device=ops.device, dtype=ops.dtype)
+        return x.to(device=ops.device, dtype=ops.dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x)).to(device=ops.device, dtype=ops.dtype).contiguous()
 
 
 class _Metrics:
