@@ -216,6 +216,15 @@ def main():
                          "conv_share_of_step": conv_time / dt, "all_conv_tflops": conv_flops / conv_time * 1e-12},
             "losses": {k: float(v) for k, v in logs.items() if v is not None},
         }
+        # HBM traffic of the dominant kernel comes from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes
+        # (counters cannot be read inside this process); the committed summary is attached when it names the
+        # same kernel.
+        tj = ROOT / "profiles" / "pmc_traffic.json"
+        if tj.exists():
+            t = json.loads(tj.read_text())
+            if t.get("kernel") == dom[0]:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
