@@ -120,6 +120,48 @@ def cpu_baseline(batch=1):
                       f"(oracle/torch_model.py; TensorFlow is not installable here), {dt:.1f} s"}
 
 
+def bench_generator_forward(args, generator, gan, low, world, rank, dev):
+    """Generator-only forward at `--batch` tiles per GPU (inference mode, fresh Philox noise each step)."""
+    import torch.distributed as dist
+    net, B = generator.net, low.shape[0]
+    net.set_image(low)
+
+    def step():
+        gan.noise_generator.prng.normal_into(net.noise_view(B), 0.1)
+        return net.forward(B, training=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        gf = 22.385e9  # SURVEY §8 d: algorithmic generator-forward FLOPs per sample at S=256, T=1
+        tf = gf * B * args.steps / dt * 1e-12
+        print(json.dumps({
+            "metric": "generator forward samples/s, 32x32->256x256 wind tiles", "value": world * B * args.steps / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"make_generator(256,3,20,2,T=1) forward, inference mode, batch {B}/GPU", "per_gpu_batch": B},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "note": "whole generator forward (all kernels), algorithmic FLOPs 22.385 GFLOP/sample"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +169,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["train", "gen_fwd"], default="train",
+                    help="train: the headline GAN train step (default); gen_fwd: generator-only forward (inference "
+                         "mode) at --batch tiles, the 'generator conv stack at batch 64' figure of BASELINE.json")
     ap.add_argument("--no-sync-bn", action="store_true", help="per-replica BatchNorm statistics instead of SyncBN")
     args = ap.parse_args()
 
@@ -158,6 +203,8 @@ def main():
     gan.compile(generator_optimizer=train.generator_optimizer(), discriminator_optimizer=train.discriminator_optimizer(),
                 discriminator_loss=train.discriminator_loss)
     low, high = synthetic_batch(B, 10 + rank, dev)
+    if args.workload == "gen_fwd":
+        return bench_generator_forward(args, generator, gan, low, world, rank, dev)
 
     def barrier():
         torch.cuda.synchronize()
