@@ -185,6 +185,22 @@ int wdg_lstm_bwd(const float* gates, int ldg, const float* c_prev, int ldcp, con
                  float* dgates, int lddg, float* dc_prev, int lddcp, int64_t P, int F,
                  wdg_stream stream);
 
+/* Single-timestep ConvLSTM2D with few channels, fused (models.py:93,101 at n_timesteps = 1, where
+ * h_0 = c_0 = 0 removes the recurrent conv and the forget path):  h = hs(o)*tanh(hs(i)*tanh(c~)) with
+ * (i,f,c~,o) = conv3x3_same(x, wx) + bias.  wx is the master HWIO kernel [3][3][cin][4F].
+ * Supported (cin, F): see wdg_convlstm1_supported (the discriminator's (2,2) and (5,16)).
+ * The backward recomputes the gates from x instead of storing them; it writes the dense dgates tensor
+ * [n_img*H*W][4F] (forget-gate slots zero) only when `dgates` is non-NULL (the weight gradient then is
+ * wdg_conv_wgrad(x, dgates) and the bias gradient wdg_colsum(dgates)), and dx only when non-NULL. */
+int wdg_convlstm1_supported(int cin, int F);
+int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                      float* h, int ldh, int64_t img_stride_h, int n_img, int H, int W, int cin, int F,
+                      wdg_stream stream);
+int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                      const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
+                      int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                      wdg_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * UpSampling2D(2, 'bilinear'): half-pixel centres, edge clamp.                     models.py:62
  * ------------------------------------------------------------------------------------------ */

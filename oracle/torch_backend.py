@@ -279,6 +279,32 @@ class TorchOps:
         if dc_prev is not None:
             dc_prev[:, :F_] = dc * gf
 
+    def convlstm1_supported(self, cin, F_):
+        return (cin, F_) in ((2, 2), (5, 16))
+
+    def convlstm1_fwd(self, x, wx, bias, h, cin, F_):
+        gates = torch.zeros(*x.shape[:3], 4 * F_, dtype=x.dtype)
+        self.conv_fwd(x, PackedWeights(self, wx), bias, gates, ConvGeom(3, 3, 1, 1))
+        c = torch.zeros(*x.shape[:3], F_, dtype=x.dtype)
+        hh = torch.zeros(*x.shape[:3], F_, dtype=x.dtype)
+        self.lstm_fwd(gates.view(-1, 4 * F_), None, c.view(-1, F_), hh.view(-1, F_), F_)
+        h[..., :F_] = hh
+
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False):
+        pk = PackedWeights(self, wx)
+        gates = torch.zeros(*x.shape[:3], 4 * F_, dtype=x.dtype)
+        self.conv_fwd(x, pk, bias, gates, ConvGeom(3, 3, 1, 1))
+        c = torch.zeros(*x.shape[:3], F_, dtype=x.dtype)
+        hh = torch.zeros(*x.shape[:3], F_, dtype=x.dtype)
+        self.lstm_fwd(gates.view(-1, 4 * F_), None, c.view(-1, F_), hh.view(-1, F_), F_)
+        dg = torch.zeros_like(gates)
+        self.lstm_bwd(gates.view(-1, 4 * F_), None, c.view(-1, F_), dh[..., :F_].reshape(-1, F_), None,
+                      dg.view(-1, 4 * F_), None, F_)
+        if dgates is not None:
+            dgates.copy_(dg)
+        if dx is not None:
+            self.conv_dgrad(dg, pk, dx, ConvGeom(3, 3, 1, 1), accumulate=accumulate_dx)
+
     # ---- resampling / head ------------------------------------------------------------------
     def upsample2x_fwd(self, x, y):
         out = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)

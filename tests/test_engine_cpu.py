@@ -68,9 +68,10 @@ def test_generator_forward_backward(ops, S, T, training):
         assert rel_err(g[k], gref[k]) < 1e-8, k
 
 
-@pytest.mark.parametrize("S,T", [(12, 2), (20, 1), (32, 2), (24, 1)])
-def test_discriminator_forward_backward(ops, S, T):
-    B, cl, ch, Fd = 2, 3, 2, 8
+@pytest.mark.parametrize("S,T,Fd", [(12, 2, 8), (20, 1, 8), (32, 2, 8), (24, 1, 8), (20, 1, 16)])
+def test_discriminator_forward_backward(ops, S, T, Fd):
+    """(.., T=1, Fd=16) takes the fused single-timestep ConvLSTM ops (convlstm1_*), the others the general path."""
+    B, cl, ch = 2, 3, 2
     net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=Fd, seed=4)
     w = randomize(net, 12)
     low, _, high = _inputs(B, T, S, cl, 1, ch, seed=1)

@@ -156,6 +156,37 @@ def test_fused_upsample_conv_transpose(hip_ops, ref_ops):
     assert rel_err(y_g, y_r) < TOL
 
 
+@pytest.mark.parametrize("cin,F_,n,H,W", [(2, 2, 3, 37, 45), (5, 16, 2, 33, 70), (5, 16, 1, 4, 32)])
+def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
+    """convlstm1.hip: x -> h and (x, dh) -> (dgates, dx) with gate recomputation, against
+    conv_fwd + lstm_fwd / lstm_bwd + conv_dgrad of the oracle backend; strided concat-style views."""
+    gen = torch.Generator().manual_seed(13)
+    dev = hip_ops.device
+    cp, Fp = (cin + 3) // 4 * 4, (F_ + 3) // 4 * 4
+    xb = torch.zeros(n, H, W, cp + 4, dtype=torch.float64)
+    xb[..., :cin] = torch.randn(n, H, W, cin, generator=gen, dtype=torch.float64)
+    wx = torch.randn(3, 3, cin, 4 * F_, generator=gen, dtype=torch.float64) * 0.4
+    bias = torch.randn(4 * F_, generator=gen, dtype=torch.float64) * 0.3
+    dh = torch.zeros(n, H, W, Fp, dtype=torch.float64)
+    dh[..., :F_] = torch.randn(n, H, W, F_, generator=gen, dtype=torch.float64)
+    res = {}
+    for name, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev))):
+        xx, ww, bb, dd = cv(xb), cv(wx).contiguous(), cv(bias), cv(dh)
+        xv = xx[..., :cp]
+        h = ops.zeros(n, H, W, Fp)
+        ops.convlstm1_fwd(xv, ww, bb, h, cin, F_)
+        dg = ops.empty(n, H, W, 4 * F_)
+        dx = cv(torch.ones(n, H, W, cp, dtype=torch.float64))
+        ops.convlstm1_bwd(xv, ww, bb, dd, dg, dx, cin, F_, accumulate_dx=True)
+        dx2 = ops.zeros(n, H, W, cp)
+        ops.convlstm1_bwd(xv, ww, bb, dd, None, dx2, cin, F_, accumulate_dx=False)
+        res[name] = dict(h=h, dg=dg, dx=dx, dx2=dx2)
+    for k in res["ref"]:
+        assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+    if Fp > F_:
+        assert float(res["hip"]["h"][..., F_:].abs().max()) == 0.0
+
+
 def test_sn_power_iter(hip_ops, ref_ops):
     gen = torch.Generator().manual_seed(1)
     for rows, cols in [(8 * 8 * 23, 128), (7 * 7 * 256, 512), (18, 16), (2 * 2 * 32, 192)]:

@@ -1,0 +1,279 @@
+// convlstm1.hip — single-timestep ConvLSTM2D for few channels, fused and gate-recomputing.
+//
+// The discriminator starts with two ConvLSTM2D layers at FULL resolution on 2 and 5 input channels
+// (/root/reference/src/downscaling/gan/models.py:93,101).  With n_timesteps = 1 the recurrence vanishes
+// (h_0 = c_0 = 0): h = hs(o) * tanh(hs(i) * tanh(c~)), the forget gate and the recurrent kernel play no role.
+// Unfused, the layer writes the gate pre-activations (64 channels for 16 features), re-reads them for the
+// cell, stores them for the backward pass, and the backward pass writes and re-reads dgates: ~1.5 KB of HBM
+// traffic per pixel for a layer whose input is 32 bytes per pixel.  Here
+//   * forward:  x -> h in one kernel (plain fp32 FMAs with wave-uniform weights; for fp32 the vector unit has
+//               the same peak as the MFMA unit and needs no padding of K = 9*Cin = 18 / 45 to the MFMA shape);
+//   * backward: recomputes the gates from x, forms dgates, and produces dx from an LDS tile of dgates
+//               (+ optionally the dense dgates tensor that the weight-gradient kernel consumes).
+// Numerics are those of wdg_conv_fwd + wdg_lstm_fwd / wdg_lstm_bwd (same fp32 operations, different
+// summation order).
+#include "common.h"
+#include <algorithm>
+
+constexpr int CL_TH = 4, CL_TW = 32;   // backward tile: 128 centre pixels, 2 threads (feature halves) per pixel
+
+__device__ __forceinline__ float cl_hsig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); }
+__device__ __forceinline__ float cl_hsig_grad(float x) {
+    const float v = 0.2f * x + 0.5f;
+    return (v >= 0.f && v <= 1.f) ? 0.2f : 0.f;
+}
+
+struct WdgCl1 {
+    const float* X;      // [n_img,H,W,ldx], CIN logical channels
+    const float* Wx;     // HWIO [3][3][CIN][4F]
+    const float* bias;   // [4F]
+    const float* dH;     // [.., lddh] (backward)
+    float* Hout;         // forward output [.., ldh]
+    float* dG;           // optional dense dgates [P][4F] (forget-gate slots zero)
+    float* dX;           // optional input gradient [.., lddx]
+    long long imgStrideX, imgStrideH, imgStrideDH, imgStrideDX;
+    int n_img, H, W, ldx, ldh, lddh, lddx;
+    int accumulate_dx;
+    int tiles_h, tiles_w;
+};
+
+// gate pre-activations (i, c~, o) of FH features starting at f0 for one pixel, x read through `load`
+template <int CIN, int F, int FH, typename LoadX>
+__device__ __forceinline__ void cl_gates(const WdgCl1& p, int f0, LoadX load, float (&gi)[FH], float (&gc)[FH], float (&go)[FH]) {
+    constexpr int C4 = (CIN + 3) / 4;
+#pragma unroll
+    for (int f = 0; f < FH; ++f) {
+        gi[f] = p.bias[f0 + f];
+        gc[f] = p.bias[2 * F + f0 + f];
+        go[f] = p.bias[3 * F + f0 + f];
+    }
+#pragma unroll 1   // keep the tap loop rolled: full unrolling hoists every weight and spills
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const f32x4 xv = load(tap / 3, tap % 3, c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * c4 + j;
+                if (c < CIN) {
+                    const float* w = p.Wx + (tap * CIN + c) * 4 * F + f0;   // wave-uniform address -> scalar loads
+#pragma unroll
+                    for (int f = 0; f < FH; ++f) {
+                        gi[f] = fmaf(xv[j], w[f], gi[f]);
+                        gc[f] = fmaf(xv[j], w[2 * F + f], gc[f]);
+                        go[f] = fmaf(xv[j], w[3 * F + f], go[f]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- forward: 128 pixels per block, thread = (pixel, feature half) -------------------------------------
+template <int CIN, int F>
+__global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p) {
+    constexpr int FH = F >= 2 ? F / 2 : 1;
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);   // waves 0,1 -> half 0; waves 2,3 -> half 1
+    const int f0 = half * FH;
+    const long long P = (long long)p.n_img * p.H * p.W;
+    const long long pix = (long long)blockIdx.x * 128 + (threadIdx.x & 127);
+    if (pix >= P || (F < 2 && half)) return;
+    const int img = (int)(pix / ((long long)p.H * p.W));
+    const int rem = (int)(pix - (long long)img * p.H * p.W);
+    const int oy = rem / p.W, ox = rem - oy * p.W;
+    const float* Ximg = p.X + (long long)img * p.imgStrideX;
+    auto load = [&](int th, int tw, int c4) -> f32x4 {
+        const int gy = oy + th - 1, gx = ox + tw - 1;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+            return *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4);
+        return (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    float gi[FH], gc[FH], go[FH];
+    cl_gates<CIN, F, FH>(p, f0, load, gi, gc, go);
+    float* hp = p.Hout + (long long)img * p.imgStrideH + ((long long)oy * p.W + ox) * p.ldh + f0;
+#pragma unroll
+    for (int f = 0; f < FH; ++f) hp[f] = cl_hsig(go[f]) * tanhf(cl_hsig(gi[f]) * tanhf(gc[f]));
+}
+
+// ---- backward: 4x32 centre tile; dgates recomputed on the 6x34 halo into LDS, dx gathered from it --------
+template <int CIN, int F>
+__global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p) {
+    constexpr int FH = F >= 2 ? F / 2 : 1;
+    constexpr int C4 = (CIN + 3) / 4;
+    constexpr int XH = CL_TH + 4, XW = CL_TW + 4;    // x halo (two 3x3 stages)
+    constexpr int GH = CL_TH + 2, GW = CL_TW + 2;    // dgates halo
+    constexpr int G3 = 3 * F;                        // compact dgates: [i | c~ | o]
+    __shared__ __attribute__((aligned(16))) f32x4 xs[XH * XW * C4];
+    __shared__ __attribute__((aligned(16))) float dgs[GH * GW * G3];
+    __shared__ float dxp[128 * CIN];
+
+    const int t = threadIdx.x;
+    const int half = __builtin_amdgcn_readfirstlane(t >> 7);
+    const int f0 = half * FH;
+    const bool half_on = !(F < 2 && half);
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_w;
+    b /= p.tiles_w;
+    const int ty = b % p.tiles_h;
+    const int img = b / p.tiles_h;
+    const int oy0 = ty * CL_TH, ox0 = tx * CL_TW;
+    const float* Ximg = p.X + (long long)img * p.imgStrideX;
+    const float* DHimg = p.dH + (long long)img * p.imgStrideDH;
+
+    // 1. x halo -> LDS (zero outside the image = the conv's zero padding)
+    for (int idx = t; idx < XH * XW * C4; idx += 256) {
+        const int c4 = idx % C4;
+        const int pix = idx / C4;
+        const int hy = pix / XW, hx = pix - hy * XW;
+        const int gy = oy0 - 2 + hy, gx = ox0 - 2 + hx;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+            v = *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4);
+        xs[idx] = v;
+    }
+    __syncthreads();
+    // 2. dgates on the (GH x GW) halo: work item = (halo pixel, half); halves are wave-uniform
+    for (int base = 0; base < GH * GW; base += 128) {
+        const int hp_ = base + (t & 127);
+        if (hp_ < GH * GW && half_on) {
+            const int hy = hp_ / GW, hx = hp_ - hy * GW;
+            const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            float dgi[FH], dgc[FH], dgo[FH];
+#pragma unroll
+            for (int f = 0; f < FH; ++f) dgi[f] = dgc[f] = dgo[f] = 0.f;
+            if (inside) {
+                auto load = [&](int th, int tw, int c4) -> f32x4 { return xs[((hy + th) * XW + hx + tw) * C4 + c4]; };
+                float gi[FH], gc[FH], go[FH];
+                cl_gates<CIN, F, FH>(p, f0, load, gi, gc, go);
+                const float* dhp = DHimg + ((long long)gy * p.W + gx) * p.lddh + f0;
+#pragma unroll
+                for (int f = 0; f < FH; ++f) {
+                    const float si = cl_hsig(gi[f]), tc_ = tanhf(gc[f]), so = cl_hsig(go[f]);
+                    const float c = si * tc_;
+                    const float th = tanhf(c);
+                    const float dh = dhp[f];
+                    const float dc = dh * so * (1.f - th * th);
+                    dgi[f] = dc * tc_ * cl_hsig_grad(gi[f]);
+                    dgc[f] = dc * si * (1.f - tc_ * tc_);
+                    dgo[f] = dh * th * cl_hsig_grad(go[f]);
+                }
+                // dense dgates for the weight-gradient kernel: centre pixels only, gate order i,f,c,o (f = 0)
+                if (p.dG && hy >= 1 && hy <= CL_TH && hx >= 1 && hx <= CL_TW) {
+                    float* dg = p.dG + (((long long)img * p.H + gy) * p.W + gx) * 4 * F + f0;
+#pragma unroll
+                    for (int f = 0; f < FH; ++f) {
+                        dg[f] = dgi[f];
+                        dg[F + f] = 0.f;
+                        dg[2 * F + f] = dgc[f];
+                        dg[3 * F + f] = dgo[f];
+                    }
+                }
+            }
+            float* d = &dgs[hp_ * G3 + f0];
+#pragma unroll
+            for (int f = 0; f < FH; ++f) {
+                d[f] = dgi[f];
+                d[F + f] = dgc[f];
+                d[2 * F + f] = dgo[f];
+            }
+        }
+    }
+    __syncthreads();
+    if (!p.dX) return;
+    // 3. dx[c] = sum_tap sum_g dgates[pixel + (1 - th, 1 - tw)][g] * Wx[tap][c][g]; each half sums its own gates
+    const int cp = t & 127;
+    const int py = cp >> 5, px = cp & 31;
+    float dx[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) dx[c] = 0.f;
+    if (half_on) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int th = tap / 3, tw = tap % 3;
+            const float* dgp = &dgs[((py + 2 - th) * GW + px + 2 - tw) * G3 + f0];
+            float v[3][FH];
+#pragma unroll
+            for (int f = 0; f < FH; ++f) {
+                v[0][f] = dgp[f];
+                v[1][f] = dgp[F + f];
+                v[2][f] = dgp[2 * F + f];
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float* w = p.Wx + (tap * CIN + c) * 4 * F + f0;
+#pragma unroll
+                for (int f = 0; f < FH; ++f) {
+                    dx[c] = fmaf(v[0][f], w[f], dx[c]);
+                    dx[c] = fmaf(v[1][f], w[2 * F + f], dx[c]);
+                    dx[c] = fmaf(v[2][f], w[3 * F + f], dx[c]);
+                }
+            }
+        }
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dxp[cp * CIN + c] = dx[c];
+    }
+    __syncthreads();
+    if (half == 0) {
+        const int gy = oy0 + py, gx = ox0 + px;
+        if (gy < p.H && gx < p.W) {
+            float* dst = p.dX + (long long)img * p.imgStrideDX + ((long long)gy * p.W + gx) * p.lddx;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                float v = dx[c] + (F >= 2 ? dxp[cp * CIN + c] : 0.f);
+                if (p.accumulate_dx) v += dst[c];
+                dst[c] = v;
+            }
+        }
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------------------
+extern "C" int wdg_convlstm1_supported(int cin, int F) { return (cin == 2 && F == 2) || (cin == 5 && F == 16); }
+
+extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                                 float* h, int ldh, int64_t img_stride_h, int n_img, int H, int W, int cin, int F,
+                                 wdg_stream stream) {
+    WDG_CHECK_ARG(x && wx && bias && h, "null argument");
+    WDG_CHECK_ARG(wdg_convlstm1_supported(cin, F), "unsupported (cin, F)");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x alignment / ld");
+    WdgCl1 p;
+    memset(&p, 0, sizeof(p));
+    p.X = x; p.Wx = wx; p.bias = bias; p.Hout = h;
+    p.imgStrideX = img_stride_x; p.imgStrideH = img_stride_h;
+    p.n_img = n_img; p.H = H; p.W = W; p.ldx = ldx; p.ldh = ldh;
+    const long long P = (long long)n_img * H * W;
+    dim3 grid((unsigned)((P + 127) / 128)), block(256);
+    if (cin == 2)
+        hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+extern "C" int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                                 const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
+                                 int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                                 wdg_stream stream) {
+    WDG_CHECK_ARG(x && wx && bias && dh, "null argument");
+    WDG_CHECK_ARG(wdg_convlstm1_supported(cin, F), "unsupported (cin, F)");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x alignment / ld");
+    WdgCl1 p;
+    memset(&p, 0, sizeof(p));
+    p.X = x; p.Wx = wx; p.bias = bias; p.dH = dh; p.dG = dgates; p.dX = dx;
+    p.imgStrideX = img_stride_x; p.imgStrideDH = img_stride_dh; p.imgStrideDX = img_stride_dx;
+    p.n_img = n_img; p.H = H; p.W = W; p.ldx = ldx; p.lddh = lddh; p.lddx = lddx;
+    p.accumulate_dx = accumulate_dx;
+    p.tiles_h = (H + CL_TH - 1) / CL_TH;
+    p.tiles_w = (W + CL_TW - 1) / CL_TW;
+    dim3 grid((unsigned)((long long)n_img * p.tiles_h * p.tiles_w)), block(256);
+    if (cin == 2)
+        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}

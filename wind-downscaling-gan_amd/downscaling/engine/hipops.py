@@ -236,6 +236,29 @@ class HipOps:
         native.check(self.lib.wdg_lstm_bwd(pg, ldg, pcp, ldcp, pc, ldc, pdh, lddh, pdci, lddci, pdg, lddg, pdcp,
                                            lddcp, gates.shape[0], F, self.stream), "lstm_bwd")
 
+    def convlstm1_supported(self, cin, F):
+        return bool(self.lib.wdg_convlstm1_supported(cin, F))
+
+    def convlstm1_fwd(self, x, wx, bias, h, cin, F):
+        """Fused single-timestep ConvLSTM: x [N,H,W,>=cin] -> h[..., :F] (gates are not stored)."""
+        px, ldx, isx = _v4(x)
+        ph, ldh, ish = _v4(h)
+        n, H, W, _ = x.shape
+        native.check(self.lib.wdg_convlstm1_fwd(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), ph, ldh, ish, n, H, W,
+                                                cin, F, self.stream), "convlstm1_fwd")
+
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False):
+        """dgates [N,H,W,4F] (dense, optional) and dx[..., :cin] (optional) from x and dh, recomputing the gates."""
+        px, ldx, isx = _v4(x)
+        pdh, lddh, isdh = _v4(dh)
+        n, H, W, _ = x.shape
+        pdx, lddx, isdx = _v4(dx) if dx is not None else (0, 0, 0)
+        if dgates is not None:
+            assert dgates.is_contiguous() and dgates.shape[-1] == 4 * F
+        native.check(self.lib.wdg_convlstm1_bwd(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), pdh, lddh, isdh,
+                                                _ptr(dgates), pdx, lddx, isdx, int(accumulate_dx), n, H, W, cin, F,
+                                                self.stream), "convlstm1_bwd")
+
     # ---- resampling / head ------------------------------------------------------------------
     def upsample2x_fwd(self, x, y):
         px, ldx, isx = _v4(x)

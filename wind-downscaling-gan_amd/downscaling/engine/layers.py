@@ -178,12 +178,20 @@ class ConvLSTM:
             self.gates = o.empty(N, H, W, 4 * F)
             self.c = o.empty(N, H, W, F)
             self.dgates = None
+            self.dgates1 = None
             self._shape = (N, H, W)
+
+    def _fused1(self, T):
+        """Single timestep + few channels: the fused, gate-recomputing kernels (convlstm1.hip)."""
+        return T == 1 and self.ops.convlstm1_supported(self.cin, self.F)
 
     def forward(self, x, h, B, T):
         """x: [T*B,H,W,>=cin] view; h: [T*B,H,W,round4(F)] output buffer (pad channels stay zero)."""
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
+        if self._fused1(T):
+            o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
+            return
         self._buffers(N, H, W)
         o.conv_fwd(x, self.pkx, self.b.value, self.gates, self.g, act=False)
         for t in range(T):
@@ -200,6 +208,15 @@ class ConvLSTM:
         dx: view receiving the input gradient (None to skip)."""
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
+        if self._fused1(T):
+            if need_wgrad and getattr(self, "dgates1", None) is None:
+                self.dgates1 = o.empty(N, H, W, 4 * F)
+            dg = self.dgates1 if need_wgrad else None
+            o.convlstm1_bwd(x, self.wx.value, self.b.value, dh, dg, dx, self.cin, F, accumulate_dx=accumulate_dx)
+            if need_wgrad:
+                o.conv_wgrad(x, dg, self.pkx, self.wx.grad, self.g, accumulate=True)
+                o.colsum(v2(dg), self.b.grad, accumulate=True)
+            return
         if self.dgates is None:
             self.dgates = o.empty(N, H, W, 4 * F)
             self.dc = [o.empty(B, H, W, F), o.empty(B, H, W, F)]
