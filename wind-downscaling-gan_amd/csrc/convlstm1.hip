@@ -38,14 +38,17 @@ struct WdgCl1 {
 };
 
 // gate pre-activations (i, c~, o) of FH features starting at f0 for one pixel, x read through `load`
+// Wx / bias are separate `const __restrict__` kernel arguments: only then does hipcc treat the (wave-uniform)
+// weight reads as invariant and emit scalar loads (s_load_dwordx8) feeding v_fma SGPR operands.
 template <int CIN, int F, int FH, typename LoadX>
-__device__ __forceinline__ void cl_gates(const WdgCl1& p, int f0, LoadX load, float (&gi)[FH], float (&gc)[FH], float (&go)[FH]) {
+__device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const float* __restrict__ bias, int f0,
+                                         LoadX load, float (&gi)[FH], float (&gc)[FH], float (&go)[FH]) {
     constexpr int C4 = (CIN + 3) / 4;
 #pragma unroll
     for (int f = 0; f < FH; ++f) {
-        gi[f] = p.bias[f0 + f];
-        gc[f] = p.bias[2 * F + f0 + f];
-        go[f] = p.bias[3 * F + f0 + f];
+        gi[f] = bias[f0 + f];
+        gc[f] = bias[2 * F + f0 + f];
+        go[f] = bias[3 * F + f0 + f];
     }
 #pragma unroll 1   // keep the tap loop rolled: full unrolling hoists every weight and spills
     for (int tap = 0; tap < 9; ++tap) {
@@ -56,7 +59,7 @@ __device__ __forceinline__ void cl_gates(const WdgCl1& p, int f0, LoadX load, fl
             for (int j = 0; j < 4; ++j) {
                 const int c = 4 * c4 + j;
                 if (c < CIN) {
-                    const float* w = p.Wx + (tap * CIN + c) * 4 * F + f0;   // wave-uniform address -> scalar loads
+                    const float* w = Wx + (tap * CIN + c) * 4 * F + f0;   // wave-uniform address -> scalar loads
 #pragma unroll
                     for (int f = 0; f < FH; ++f) {
                         gi[f] = fmaf(xv[j], w[f], gi[f]);
@@ -71,7 +74,8 @@ __device__ __forceinline__ void cl_gates(const WdgCl1& p, int f0, LoadX load, fl
 
 // ---- forward: 128 pixels per block, thread = (pixel, feature half) -------------------------------------
 template <int CIN, int F>
-__global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p) {
+__global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, const float* __restrict__ Wx,
+                                                                const float* __restrict__ bias) {
     constexpr int FH = F >= 2 ? F / 2 : 1;
     const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);   // waves 0,1 -> half 0; waves 2,3 -> half 1
     const int f0 = half * FH;
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p) 
         return (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     float gi[FH], gc[FH], go[FH];
-    cl_gates<CIN, F, FH>(p, f0, load, gi, gc, go);
+    cl_gates<CIN, F, FH>(Wx, bias, f0, load, gi, gc, go);
     float* hp = p.Hout + (long long)img * p.imgStrideH + ((long long)oy * p.W + ox) * p.ldh + f0;
 #pragma unroll
     for (int f = 0; f < FH; ++f) hp[f] = cl_hsig(go[f]) * tanhf(cl_hsig(gi[f]) * tanhf(gc[f]));
@@ -97,7 +101,8 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p) 
 
 // ---- backward: 4x32 centre tile; dgates recomputed on the 6x34 halo into LDS, dx gathered from it --------
 template <int CIN, int F>
-__global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p) {
+__global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, const float* __restrict__ Wx,
+                                                                const float* __restrict__ bias) {
     constexpr int FH = F >= 2 ? F / 2 : 1;
     constexpr int C4 = (CIN + 3) / 4;
     constexpr int XH = CL_TH + 4, XW = CL_TW + 4;    // x halo (two 3x3 stages)
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p) 
             if (inside) {
                 auto load = [&](int th, int tw, int c4) -> f32x4 { return xs[((hy + th) * XW + hx + tw) * C4 + c4]; };
                 float gi[FH], gc[FH], go[FH];
-                cl_gates<CIN, F, FH>(p, f0, load, gi, gc, go);
+                cl_gates<CIN, F, FH>(Wx, bias, f0, load, gi, gc, go);
                 const float* dhp = DHimg + ((long long)gy * p.W + gx) * p.lddh + f0;
 #pragma unroll
                 for (int f = 0; f < FH; ++f) {
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p) 
             }
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
-                const float* w = p.Wx + (tap * CIN + c) * 4 * F + f0;
+                const float* w = Wx + (tap * CIN + c) * 4 * F + f0;
 #pragma unroll
                 for (int f = 0; f < FH; ++f) {
                     dx[c] = fmaf(v[0][f], w[f], dx[c]);
@@ -247,9 +252,9 @@ extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, 
     const long long P = (long long)n_img * H * W;
     dim3 grid((unsigned)((P + 127) / 128)), block(256);
     if (cin == 2)
-        hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
     else
-        hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
@@ -271,9 +276,9 @@ extern "C" int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, 
     p.tiles_w = (W + CL_TW - 1) / CL_TW;
     dim3 grid((unsigned)((long long)n_img * p.tiles_h * p.tiles_w)), block(256);
     if (cin == 2)
-        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
     else
-        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
