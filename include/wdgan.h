@@ -44,6 +44,8 @@ const char* wdg_version(void);
 /* Performance knobs for A/B measurements (results are identical for every setting):
  *   "igemm_pipe": 0 single LDS stage + two barriers per K-step (default), 1 double-buffered LDS + one barrier,
  *                 2 = 1 + fragment prefetch;
+ *   "halo_weights_global": 1 (default) halo-tile kernel reads weight fragments from global memory, 0 stages
+ *                 them in LDS;
  *   "xcd_swizzle": 1 (default) XCD-aware workgroup -> tile remap in the implicit-GEMM kernel, 0 off. */
 int wdg_set_tuning(const char* key, int value);
 /* Number of compute units of the current device (used by the host-side split-K heuristic). */

@@ -37,8 +37,11 @@ struct WdgHalo {
     int tiles_h, tiles_w;
 };
 
-template <int NT>
-__global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
+// WG = 1: the weight fragments are read straight from global memory (they are a few hundred KB, L1/L2
+// resident, and each lane needs exactly one float4 per tap and column tile), which frees the LDS weight
+// stage (25.6 of 52 KB for the 5x5 layer) and lets more blocks share a CU.
+template <int NT, int WG>
+__global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, const float* __restrict__ Bw) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     f32x4* lds_a = smem;                 // [4][npix]
     f32x4* lds_w = smem + 4 * p.npix;    // [ntaps][4][NT*16]
@@ -101,6 +104,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
             lds_a[kg * p.npix + pix] = v;
         }
         // ---- stage this chunk's weights: [tap][kg][n] (kg < kgs only)
+        if (!WG)
         for (int idx = t; idx < p.ntaps * kgs * NW; idx += 256) {
             const int n = idx % NW;
             const int r = idx / NW;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
             const int tap = r / kgs;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (n < p.Ncols)
-                v = *reinterpret_cast<const f32x4*>(p.B + (long long)n * p.ldB + p.taps[tap].z + (4 * ck + kg) * 4);
+                v = *reinterpret_cast<const f32x4*>(Bw + (long long)n * p.ldB + p.taps[tap].z + (4 * ck + kg) * 4);
             lds_w[idx] = v;
         }
         __syncthreads();
@@ -125,8 +129,15 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
                     af[a] = kvalid ? lds_a[lg * p.npix + row * p.halo_w + col + rowoff] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    bf[b] = kvalid ? lds_w[(tap * kgs + lg) * NW + b * 16 + li] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < NT; ++b) {
+                    const int n = b * 16 + li;
+                    if (WG)
+                        bf[b] = (kvalid && n < p.Ncols)
+                                    ? *reinterpret_cast<const f32x4*>(Bw + (long long)n * p.ldB + e.z + (4 * ck + lg) * 4)
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    else
+                        bf[b] = kvalid ? lds_w[(tap * kgs + lg) * NW + n] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -152,8 +163,15 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
                     af[a] = kvalid ? lds_a[kg * p.npix + row * p.halo_w + col + rowoff] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    bf[b] = kvalid ? lds_w[ent * NW + b * 16 + li] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < NT; ++b) {
+                    const int n = b * 16 + li;
+                    if (WG)
+                        bf[b] = (kvalid && n < p.Ncols)
+                                    ? *reinterpret_cast<const f32x4*>(Bw + (long long)n * p.ldB + e.z + (4 * ck + kg) * 4)
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    else
+                        bf[b] = kvalid ? lds_w[ent * NW + n] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -193,9 +211,12 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p) {
 // ---- host side -------------------------------------------------------------------------------------
 static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols <= 64 ? 4 : 0; }
 
-static size_t halo_lds_bytes(int kh, int kw, int nt) {
+static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
+void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
+
+static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0) {
     const int npix = wdg_round_up((HALO_TH + kh - 1) * (HALO_TW + kw - 1), 16);
-    return (size_t)(4 * npix + kh * kw * 4 * nt * 16) * sizeof(f32x4);
+    return (size_t)(4 * npix + (wg ? 0 : kh * kw * 4 * nt * 16)) * sizeof(f32x4);
 }
 
 int wdg_halo_plan_init(wdg_conv_plan* pl) {
@@ -278,14 +299,18 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     p.npix = wdg_round_up(p.halo_h * p.halo_w, 16);
     p.tiles_h = (p.Ho + HALO_TH - 1) / HALO_TH;
     p.tiles_w = (p.Wo + HALO_TW - 1) / HALO_TW;
-    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt);
+    const int wg = g_halo_wg;
+    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
-    if (nt == 1)
-        hipLaunchKernelGGL(wdg_conv_halo_kernel<1>, grid, block, lds, st, p);
-    else if (nt == 2)
-        hipLaunchKernelGGL(wdg_conv_halo_kernel<2>, grid, block, lds, st, p);
-    else
-        hipLaunchKernelGGL(wdg_conv_halo_kernel<4>, grid, block, lds, st, p);
+#define WDG_HALO_CASE(NT_)                                                                             \
+    if (nt == NT_) {                                                                                   \
+        if (wg) hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 1>), grid, block, lds, st, p, Bw);       \
+        else hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 0>), grid, block, lds, st, p, Bw);          \
+    }
+    WDG_HALO_CASE(1)
+    WDG_HALO_CASE(2)
+    WDG_HALO_CASE(4)
+#undef WDG_HALO_CASE
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -703,6 +703,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_igemm_pipe = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "halo_weights_global")) {
+        wdg_halo_set_wg(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "xcd_swizzle")) {
         g_xcd_swizzle = value != 0;
         return WDG_OK;
