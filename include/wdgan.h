@@ -203,6 +203,21 @@ int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float
                       int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
                       wdg_stream stream);
 
+/* Thin 3x3 'same' conv + bias + LeakyReLU + LayerNormalization fused (models.py:94-97,102-105).
+ * forward : y = lrelu(conv(x, w) + bias) (kept for the backward), z = LN(y)*gamma + beta, mean_rstd [P][2].
+ * backward: dpre = LN'(dz)*lrelu'(y) (dense [P][cout], must not alias dz), dx = conv^T(dpre) (optional),
+ *           dgamma/dbeta/dbias += (all three or none).  w_hwio is the master kernel [3][3][cin][cout].
+ * Supported (cin, cout): wdg_convln_supported ((2,16), (16,16)). */
+int wdg_convln_supported(int cin, int cout);
+int wdg_convln_fwd(const float* x, int ldx, int64_t isx, const float* w_hwio, const float* bias,
+                   const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
+                   int64_t isy, float* z, int ldz, int64_t isz, float* mean_rstd, int n_img, int H, int W,
+                   int cin, int cout, wdg_stream stream);
+int wdg_convln_bwd(const float* dz, int lddz, int64_t isdz, const float* y, int ldy, int64_t isy,
+                   const float* mean_rstd, const float* w_hwio, const float* gamma, float slope,
+                   float* dpre, float* dx, int lddx, int64_t isdx, float* dgamma, float* dbeta,
+                   float* dbias, int n_img, int H, int W, int cin, int cout, wdg_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * UpSampling2D(2, 'bilinear'): half-pixel centres, edge clamp.                     models.py:62
  * ------------------------------------------------------------------------------------------ */

@@ -305,6 +305,22 @@ class TorchOps:
         if dx is not None:
             self.conv_dgrad(dg, pk, dx, ConvGeom(3, 3, 1, 1), accumulate=accumulate_dx)
 
+    def convln_supported(self, cin, cout):
+        return cout == 16 and cin in (2, 16)
+
+    def convln_fwd(self, x, w, bias, gamma, beta, eps, slope, y, z, mean_rstd):
+        self.conv_fwd(x, PackedWeights(self, w), bias, y, ConvGeom(3, 3, 1, 1), act=True, slope=slope)
+        C = w.shape[3]
+        zz = torch.zeros(y.shape, dtype=y.dtype)
+        self.ln_fwd(y.reshape(-1, C), gamma, beta, eps, zz.view(-1, C), mean_rstd)
+        z.copy_(zz)
+
+    def convln_bwd(self, dz, y, mean_rstd, w, gamma, slope, dpre, dx, dgamma, dbeta, dbias):
+        C = w.shape[3]
+        self.ln_bwd(dz.reshape(-1, C), y.reshape(-1, C), mean_rstd, gamma, slope, dpre.view(-1, C), dgamma, dbeta, dbias)
+        if dx is not None:
+            self.conv_dgrad(dpre, PackedWeights(self, w), dx, ConvGeom(3, 3, 1, 1))
+
     # ---- resampling / head ------------------------------------------------------------------
     def upsample2x_fwd(self, x, y):
         out = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)

@@ -187,6 +187,37 @@ def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
         assert float(res["hip"]["h"][..., F_:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,n,H,W", [(2, 3, 37, 45), (16, 2, 33, 70), (16, 1, 8, 32)])
+def test_fused_conv_layernorm(cin, n, H, W, hip_ops, ref_ops):
+    """convln.hip: conv3x3 + bias + LeakyReLU + LayerNorm forward, and its backward (LN', LeakyReLU', dx,
+    dgamma/dbeta/dbias) against conv_fwd + ln_fwd / ln_bwd + conv_dgrad of the oracle backend; z and dz are
+    channel slices of a wider concat buffer."""
+    gen = torch.Generator().manual_seed(17)
+    dev = hip_ops.device
+    cp = (cin + 3) // 4 * 4
+    x = torch.zeros(n, H, W, cp, dtype=torch.float64)
+    x[..., :cin] = torch.randn(n, H, W, cin, generator=gen, dtype=torch.float64)
+    w = torch.randn(3, 3, cin, 16, generator=gen, dtype=torch.float64) * 0.3
+    bias = torch.randn(16, generator=gen, dtype=torch.float64) * 0.3
+    gamma = torch.rand(16, generator=gen, dtype=torch.float64) + 0.5
+    beta = torch.randn(16, generator=gen, dtype=torch.float64)
+    dcat = torch.randn(n, H, W, 32, generator=gen, dtype=torch.float64)
+    res = {}
+    for name, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev))):
+        xx, ww, bb, ga, be, dc = cv(x), cv(w).contiguous(), cv(bias), cv(gamma), cv(beta), cv(dcat)
+        y, cat, mr = ops.empty(n, H, W, 16), ops.zeros(n, H, W, 32), ops.empty(n * H * W, 2)
+        ops.convln_fwd(xx, ww, bb, ga, be, 1e-3, 0.2, y, cat[..., 16:], mr)
+        dpre, dx = ops.empty(n, H, W, 16), ops.zeros(n, H, W, cp)
+        dg, db, dbias = (cv(torch.ones(16, dtype=torch.float64)) for _ in range(3))
+        ops.convln_bwd(dc[..., 16:], y, mr, ww, ga, 0.2, dpre, dx, dg, db, dbias)
+        dx2 = ops.zeros(n, H, W, cp)
+        dpre2 = ops.empty(n, H, W, 16)
+        ops.convln_bwd(dc[..., 16:], y, mr, ww, ga, 0.2, dpre2, dx2, None, None, None)
+        res[name] = dict(y=y, cat=cat, mr=mr, dpre=dpre, dx=dx, dg=dg, db=db, dbias=dbias, dx2=dx2, dpre2=dpre2)
+    for k in res["ref"]:
+        assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+
+
 def test_sn_power_iter(hip_ops, ref_ops):
     gen = torch.Generator().manual_seed(1)
     for rows, cols in [(8 * 8 * 23, 128), (7 * 7 * 256, 512), (18, 16), (2 * 2 * 32, 192)]:

@@ -1,0 +1,276 @@
+// convln.hip — thin 3x3 'same' conv + bias + LeakyReLU + LayerNormalization, fused, for the discriminator's
+// full-resolution branches (/root/reference/src/downscaling/gan/models.py:94-97 and :102-105: SN-Conv2D
+// (2->16 / 16->16) with LeakyReLU(0.2) followed by LayerNormalization over the 16 channels).
+//
+// These layers are HBM/latency bound (K = 18 / 144, N = 16).  One thread owns one pixel and all 16 output
+// channels, so the LayerNorm statistics are thread-local; weights are wave-uniform scalar loads; there is no
+// MFMA padding.
+//   forward : x -> y = lrelu(conv(x) + b) (kept for the backward), z = LN(y)*gamma + beta, (mean, rstd)
+//   backward: dz, y, (mean, rstd) -> dpre = LN'(dz) * lrelu'(y) on an 8x32 tile + 1-pixel halo (recomputed),
+//             dx = conv^T(dpre) from the LDS tile, dpre written once for the weight-gradient kernel,
+//             dgamma / dbeta / dbias accumulated (block reduction + fp32 atomics, as wdg_ln_bwd does).
+// Same fp32 operations as wdg_conv_fwd + wdg_ln_fwd / wdg_ln_bwd + wdg_conv_dgrad, different summation order.
+#include "common.h"
+#include <algorithm>
+
+constexpr int CN_TH = 8, CN_TW = 32;
+constexpr int CN_CO = 16;
+
+struct WdgConvLn {
+    const float* X;   // [n,H,W,ldx]
+    float* Y;         // [n,H,W,ldy]  (forward out / backward in)
+    float* Z;         // forward out view (ldz)
+    float* MR;        // [P][2] mean, rstd
+    const float* dZ;  // backward in (lddz)
+    float* dPre;      // backward out, dense [P][16]
+    float* dX;        // backward out view (lddx), optional
+    float* dgamma;    // accumulate, optional
+    float* dbeta;
+    float* dbias;
+    long long isx, isy, isz, isdz, isdx;
+    int n_img, H, W, ldx, ldy, ldz, lddz, lddx;
+    float eps, slope;
+    int tiles_h, tiles_w;
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256) wdg_convln_fwd_kernel(const WdgConvLn p, const float* __restrict__ Wt,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta) {
+    constexpr int C4 = (CIN + 3) / 4;
+    const long long P = (long long)p.n_img * p.H * p.W;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= P) return;
+    const int img = (int)(pix / ((long long)p.H * p.W));
+    const int rem = (int)(pix - (long long)img * p.H * p.W);
+    const int oy = rem / p.W, ox = rem - oy * p.W;
+    const float* Ximg = p.X + (long long)img * p.isx;
+    float acc[CN_CO];
+#pragma unroll
+    for (int o = 0; o < CN_CO; ++o) acc[o] = bias[o];
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int gy = oy + tap / 3 - 1, gx = ox + tap % 3 - 1;
+        if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
+        const float* xp = Ximg + ((long long)gy * p.W + gx) * p.ldx;
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * c4 + j;
+                if (c < CIN) {
+                    const float* w = Wt + (tap * CIN + c) * CN_CO;   // HWIO, wave-uniform -> scalar loads
+#pragma unroll
+                    for (int o = 0; o < CN_CO; ++o) acc[o] = fmaf(xv[j], w[o], acc[o]);
+                }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < CN_CO; ++o) {
+        acc[o] = acc[o] > 0.f ? acc[o] : acc[o] * p.slope;
+        s += acc[o];
+    }
+    const float mean = s * (1.f / CN_CO);
+    float q = 0.f;
+#pragma unroll
+    for (int o = 0; o < CN_CO; ++o) {
+        const float d = acc[o] - mean;
+        q += d * d;
+    }
+    const float rstd = 1.f / sqrtf(q * (1.f / CN_CO) + p.eps);
+    float* yp = p.Y + (long long)img * p.isy + ((long long)oy * p.W + ox) * p.ldy;
+    float* zp = p.Z + (long long)img * p.isz + ((long long)oy * p.W + ox) * p.ldz;
+#pragma unroll
+    for (int o4 = 0; o4 < CN_CO / 4; ++o4) {
+        f32x4 yv, zv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = 4 * o4 + j;
+            yv[j] = acc[o];
+            zv[j] = (acc[o] - mean) * rstd * gamma[o] + beta[o];
+        }
+        *reinterpret_cast<f32x4*>(yp + 4 * o4) = yv;
+        *reinterpret_cast<f32x4*>(zp + 4 * o4) = zv;
+    }
+    p.MR[2 * pix] = mean;
+    p.MR[2 * pix + 1] = rstd;
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(256) wdg_convln_bwd_kernel(const WdgConvLn p, const float* __restrict__ Wt,
+                                                             const float* __restrict__ gamma) {
+    constexpr int GH = CN_TH + 2, GW = CN_TW + 2;
+    __shared__ __attribute__((aligned(16))) float dps[GH * GW * CN_CO];   // dpre on the halo
+    __shared__ float red[3 * CN_CO * 4];                                  // per-wave partials of dgamma/dbeta/dbias
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_w;
+    b /= p.tiles_w;
+    const int ty = b % p.tiles_h;
+    const int img = b / p.tiles_h;
+    const int oy0 = ty * CN_TH, ox0 = tx * CN_TW;
+    const float* dZimg = p.dZ + (long long)img * p.isdz;
+    const float* Yimg = p.Y + (long long)img * p.isy;
+
+    float ag[CN_CO], ab[CN_CO], abias[CN_CO];
+#pragma unroll
+    for (int o = 0; o < CN_CO; ++o) ag[o] = ab[o] = abias[o] = 0.f;
+
+    // 1. dpre on the halo (LN backward + LeakyReLU'), zero outside the image
+    for (int hp = t; hp < GH * GW; hp += 256) {
+        const int hy = hp / GW, hx = hp - hy * GW;
+        const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+        float d[CN_CO];
+#pragma unroll
+        for (int o = 0; o < CN_CO; ++o) d[o] = 0.f;
+        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+            const long long pl = ((long long)img * p.H + gy) * p.W + gx;
+            const float mean = p.MR[2 * pl], rstd = p.MR[2 * pl + 1];
+            const float* dzp = dZimg + ((long long)gy * p.W + gx) * p.lddz;
+            const float* yp = Yimg + ((long long)gy * p.W + gx) * p.ldy;
+            float g[CN_CO], xh[CN_CO], yv[CN_CO];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int o4 = 0; o4 < CN_CO / 4; ++o4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(dzp + 4 * o4);
+                const f32x4 y4 = *reinterpret_cast<const f32x4*>(yp + 4 * o4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = 4 * o4 + j;
+                    yv[o] = y4[j];
+                    xh[o] = (y4[j] - mean) * rstd;
+                    g[o] = a[j];
+                    const float gg = a[j] * gamma[o];
+                    s1 += gg;
+                    s2 += gg * xh[o];
+                }
+            }
+            s1 *= (1.f / CN_CO);
+            s2 *= (1.f / CN_CO);
+            const bool centre = hy >= 1 && hy <= CN_TH && hx >= 1 && hx <= CN_TW;
+#pragma unroll
+            for (int o = 0; o < CN_CO; ++o) {
+                float v = rstd * (g[o] * gamma[o] - s1 - xh[o] * s2);
+                v *= (yv[o] > 0.f ? 1.f : p.slope);
+                d[o] = v;
+                if (centre) {                       // parameter gradients: every pixel counted once
+                    ag[o] += g[o] * xh[o];
+                    ab[o] += g[o];
+                    abias[o] += v;
+                }
+            }
+            if (centre) {
+                float* dp = p.dPre + pl * CN_CO;
+#pragma unroll
+                for (int o4 = 0; o4 < CN_CO / 4; ++o4)
+                    *reinterpret_cast<f32x4*>(dp + 4 * o4) = (f32x4){d[4 * o4], d[4 * o4 + 1], d[4 * o4 + 2], d[4 * o4 + 3]};
+            }
+        }
+#pragma unroll
+        for (int o4 = 0; o4 < CN_CO / 4; ++o4)
+            *reinterpret_cast<f32x4*>(&dps[hp * CN_CO + 4 * o4]) = (f32x4){d[4 * o4], d[4 * o4 + 1], d[4 * o4 + 2], d[4 * o4 + 3]};
+    }
+    // 2. parameter-gradient partials: wave reduction, then 4 waves through LDS, one atomic per value
+    if (p.dgamma) {
+#pragma unroll
+        for (int o = 0; o < CN_CO; ++o) {
+            const float a0 = wdg_wave_sum(ag[o]), a1 = wdg_wave_sum(ab[o]), a2 = wdg_wave_sum(abias[o]);
+            if (lane == 0) {
+                red[(0 * CN_CO + o) * 4 + wave] = a0;
+                red[(1 * CN_CO + o) * 4 + wave] = a1;
+                red[(2 * CN_CO + o) * 4 + wave] = a2;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.dgamma && t < 3 * CN_CO) {
+        const float v = (red[t * 4] + red[t * 4 + 1]) + (red[t * 4 + 2] + red[t * 4 + 3]);
+        float* dst = t < CN_CO ? p.dgamma + t : t < 2 * CN_CO ? p.dbeta + (t - CN_CO) : p.dbias + (t - 2 * CN_CO);
+        atomicAdd(dst, v);
+    }
+    if (!p.dX) return;
+    // 3. dx[c] = sum_tap sum_o dpre[pixel + (1 - th, 1 - tw)][o] * W[tap][c][o]
+    const int py = t >> 5, px = t & 31;
+    float dx[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) dx[c] = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int th = tap / 3, tw = tap % 3;
+        const float* dp = &dps[((py + 2 - th) * GW + px + 2 - tw) * CN_CO];
+        float v[CN_CO];
+#pragma unroll
+        for (int o4 = 0; o4 < CN_CO / 4; ++o4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(dp + 4 * o4);
+            v[4 * o4] = a[0]; v[4 * o4 + 1] = a[1]; v[4 * o4 + 2] = a[2]; v[4 * o4 + 3] = a[3];
+        }
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            const float* w = Wt + (tap * CIN + c) * CN_CO;
+#pragma unroll
+            for (int o = 0; o < CN_CO; ++o) dx[c] = fmaf(v[o], w[o], dx[c]);
+        }
+    }
+    const int gy = oy0 + py, gx = ox0 + px;
+    if (gy < p.H && gx < p.W) {
+        float* dst = p.dX + (long long)img * p.isdx + ((long long)gy * p.W + gx) * p.lddx;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dst[c] = dx[c];
+    }
+}
+
+extern "C" int wdg_convln_supported(int cin, int cout) { return cout == 16 && (cin == 2 || cin == 16); }
+
+extern "C" int wdg_convln_fwd(const float* x, int ldx, int64_t isx, const float* w_hwio, const float* bias,
+                              const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
+                              int64_t isy, float* z, int ldz, int64_t isz, float* mean_rstd, int n_img, int H, int W,
+                              int cin, int cout, wdg_stream stream) {
+    WDG_CHECK_ARG(x && w_hwio && bias && gamma && beta && y && z && mean_rstd, "null argument");
+    WDG_CHECK_ARG(wdg_convln_supported(cin, cout), "unsupported (cin, cout)");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ((uintptr_t)y & 15) == 0 && ldy % 4 == 0 &&
+                      ((uintptr_t)z & 15) == 0 && ldz % 4 == 0, "alignment");
+    WdgConvLn p;
+    memset(&p, 0, sizeof(p));
+    p.X = x; p.Y = y; p.Z = z; p.MR = mean_rstd;
+    p.isx = isx; p.isy = isy; p.isz = isz;
+    p.n_img = n_img; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldy; p.ldz = ldz;
+    p.eps = eps; p.slope = slope;
+    const long long P = (long long)n_img * H * W;
+    dim3 grid((unsigned)((P + 255) / 256)), block(256);
+    if (cin == 2)
+        hipLaunchKernelGGL(wdg_convln_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, p, w_hwio, bias, gamma, beta);
+    else
+        hipLaunchKernelGGL(wdg_convln_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, p, w_hwio, bias, gamma, beta);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+extern "C" int wdg_convln_bwd(const float* dz, int lddz, int64_t isdz, const float* y, int ldy, int64_t isy,
+                              const float* mean_rstd, const float* w_hwio, const float* gamma, float slope,
+                              float* dpre, float* dx, int lddx, int64_t isdx, float* dgamma, float* dbeta,
+                              float* dbias, int n_img, int H, int W, int cin, int cout, wdg_stream stream) {
+    WDG_CHECK_ARG(dz && y && mean_rstd && w_hwio && gamma && dpre, "null argument");
+    WDG_CHECK_ARG(wdg_convln_supported(cin, cout), "unsupported (cin, cout)");
+    WDG_CHECK_ARG((dgamma && dbeta && dbias) || (!dgamma && !dbeta && !dbias), "parameter gradients: all or none");
+    WDG_CHECK_ARG(((uintptr_t)dz & 15) == 0 && lddz % 4 == 0 && ((uintptr_t)y & 15) == 0 && ldy % 4 == 0, "alignment");
+    WdgConvLn p;
+    memset(&p, 0, sizeof(p));
+    p.dZ = dz; p.Y = const_cast<float*>(y); p.MR = const_cast<float*>(mean_rstd); p.dPre = dpre; p.dX = dx;
+    p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias;
+    p.isdz = isdz; p.isy = isy; p.isdx = isdx;
+    p.n_img = n_img; p.H = H; p.W = W; p.lddz = lddz; p.ldy = ldy; p.lddx = lddx;
+    p.slope = slope;
+    p.tiles_h = (H + CN_TH - 1) / CN_TH;
+    p.tiles_w = (W + CN_TW - 1) / CN_TW;
+    dim3 grid((unsigned)((long long)n_img * p.tiles_h * p.tiles_w)), block(256);
+    if (cin == 2)
+        hipLaunchKernelGGL(wdg_convln_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, p, w_hwio, gamma);
+    else
+        hipLaunchKernelGGL(wdg_convln_bwd_kernel<16>, grid, block, 0, (hipStream_t)stream, p, w_hwio, gamma);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}

@@ -259,6 +259,29 @@ class HipOps:
                                                 _ptr(dgates), pdx, lddx, isdx, int(accumulate_dx), n, H, W, cin, F,
                                                 self.stream), "convlstm1_bwd")
 
+    def convln_supported(self, cin, cout):
+        return bool(self.lib.wdg_convln_supported(cin, cout))
+
+    def convln_fwd(self, x, w, bias, gamma, beta, eps, slope, y, z, mean_rstd):
+        """y = lrelu(conv3x3(x, w) + bias), z = LN(y); w: master HWIO [3,3,cin,cout]."""
+        px, ldx, isx = _v4(x)
+        py, ldy, isy = _v4(y)
+        pz, ldz, isz = _v4(z)
+        n, H, W, _ = y.shape
+        native.check(self.lib.wdg_convln_fwd(px, ldx, isx, w.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                             beta.data_ptr(), eps, slope, py, ldy, isy, pz, ldz, isz,
+                                             mean_rstd.data_ptr(), n, H, W, w.shape[2], w.shape[3], self.stream), "convln_fwd")
+
+    def convln_bwd(self, dz, y, mean_rstd, w, gamma, slope, dpre, dx, dgamma, dbeta, dbias):
+        pdz, lddz, isdz = _v4(dz)
+        py, ldy, isy = _v4(y)
+        pdx, lddx, isdx = _v4(dx) if dx is not None else (0, 0, 0)
+        n, H, W, _ = y.shape
+        assert dpre.is_contiguous()
+        native.check(self.lib.wdg_convln_bwd(pdz, lddz, isdz, py, ldy, isy, mean_rstd.data_ptr(), w.data_ptr(),
+                                             gamma.data_ptr(), slope, dpre.data_ptr(), pdx, lddx, isdx, _ptr(dgamma),
+                                             _ptr(dbeta), _ptr(dbias), n, H, W, w.shape[2], w.shape[3], self.stream), "convln_bwd")
+
     # ---- resampling / head ------------------------------------------------------------------
     def upsample2x_fwd(self, x, y):
         px, ldx, isx = _v4(x)

@@ -130,9 +130,12 @@ class LayerNorm:
         self.beta = st.add(f"{name}/beta", (C,), P.zeros_init)
         self.mean_rstd = None
 
+    def ensure_stats(self, P):
+        if self.mean_rstd is None or self.mean_rstd.shape[0] != P:
+            self.mean_rstd = self.ops.empty(P, 2)
+
     def forward(self, y, z, keep_stats=True):
-        if self.mean_rstd is None or self.mean_rstd.shape[0] != y.shape[0]:
-            self.mean_rstd = self.ops.empty(y.shape[0], 2)
+        self.ensure_stats(y.shape[0])
         self.ops.ln_fwd(y, self.gamma.value, self.beta.value, LN_EPS, z, self.mean_rstd)
 
     def backward(self, dz, y, dpre, dbias, need_param_grads, act_slope=LRELU):

@@ -54,6 +54,11 @@ SIGNATURES = {
     "wdg_convlstm1_fwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_bwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp, i32, i64, i32,
                                  i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convln_supported": (i32, [i32, i32]),
+    "wdg_convln_fwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, i64, c_fp, i32, i64,
+                              c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convln_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, c_fp, c_fp, c_fp, f32, c_fp, c_fp, i32, i64,
+                              c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upsample2x_fwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "wdg_upsample2x_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

@@ -8,7 +8,7 @@ are zero-padded (input 23 -> 24, wind 2 -> 4, low+high 5 -> 8).
 import numpy as np
 
 from .common import round4, v2
-from .layers import BatchNorm, Conv, ConvLSTM, LayerNorm
+from .layers import LN_EPS, LRELU, BatchNorm, Conv, ConvLSTM, LayerNorm
 from .params import ParamStore, glorot_uniform, zeros_init
 
 
@@ -295,6 +295,7 @@ class DiscriminatorNet(_Net):
             score=o.empty(B),
             # gradients
             dcat=o.empty(N, S, S, 2 * Fd),
+            dpre=o.empty(N, S, S, Fd),                         # dense pre-activation gradient of one branch
             dha=o.zeros(N, S, S, chp),
             dhb=o.zeros(N, S, S, Fd),
             dhi=o.zeros(N, S, S, chp),
@@ -326,11 +327,9 @@ class DiscriminatorNet(_Net):
         o, Fd, T = self.ops, self.Fd, self.T
         self._prepare(training)
         self.lstm_a.forward(b["hi"], b["ha"], B, T)
-        self.conv_a.forward(b["ha"], b["ya"])
-        self.ln_a.forward(v2(b["ya"]), v2(b["cat"][..., :Fd]))
+        self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
         self.lstm_b.forward(b["mix"], b["hb"], B, T)
-        self.conv_b.forward(b["hb"], b["yb"])
-        self.ln_b.forward(v2(b["yb"]), v2(b["cat"][..., Fd:]))
+        self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
         x = b["cat"]
         for i, (conv, ln, osz, co) in enumerate(self.blocks):
             conv.forward(x, b["ys"][i])
@@ -339,6 +338,32 @@ class DiscriminatorNet(_Net):
         self._last = x
         o.dense_gap_fwd(x.view(T * B, self.K), self.dense_w.value.view(-1), self.dense_b.value, b["score"], B, T)
         return b["score"]
+
+    def _fused_conv_ln(self, conv):
+        return self.ops.convln_supported(conv.cin, conv.cout)
+
+    def _conv_ln_fwd(self, conv, ln, x, y, z):
+        """SN-Conv2D 3x3 + LeakyReLU + LayerNormalization of one branch (models.py:94-97 / 102-105)."""
+        if self._fused_conv_ln(conv):
+            ln.ensure_stats(y.shape[0] * y.shape[1] * y.shape[2])
+            self.ops.convln_fwd(x, conv.w.value, conv.b.value, ln.gamma.value, ln.beta.value, LN_EPS, LRELU, y, z,
+                                ln.mean_rstd)
+        else:
+            conv.forward(x, y)
+            ln.forward(v2(y), v2(z))
+
+    def _conv_ln_bwd(self, conv, ln, dz, y, x, dpre_dense, dx, need_wgrad):
+        if self._fused_conv_ln(conv):
+            self.ops.convln_bwd(dz, y, ln.mean_rstd, conv.w.value, ln.gamma.value, LRELU, dpre_dense, dx,
+                                ln.gamma.grad if need_wgrad else None, ln.beta.grad if need_wgrad else None,
+                                conv.b.grad if need_wgrad else None)
+            if need_wgrad:
+                conv.backward_weights(x, dpre_dense)
+        else:
+            ln.backward(v2(dz), v2(y), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
+            if need_wgrad:
+                conv.backward_weights(x, dz)
+            conv.backward_input(dz, dx)
 
     def backward(self, B, dscore, need_wgrad):
         """dscore [B].  Returns the time-major gradient w.r.t. the high-res input [T*B,S,S,round4(ch)].
@@ -364,18 +389,10 @@ class DiscriminatorNet(_Net):
                 conv.backward_weights(xin, dz)
             conv.backward_input(dz, b["dzs"][i - 1] if i > 0 else b["dcat"])
         # branch A (high-res only)
-        da = b["dcat"][..., :Fd]
-        self.ln_a.backward(v2(da), v2(b["ya"]), v2(da), self.conv_a.b.grad if need_wgrad else None, need_wgrad)
-        if need_wgrad:
-            self.conv_a.backward_weights(b["ha"], da)
-        self.conv_a.backward_input(da, b["dha"])
+        self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
         self.lstm_a.backward(b["hi"], b["ha"], b["dha"], b["dhi"], B, T, need_wgrad)
         # branch B (low + high)
-        db_ = b["dcat"][..., Fd:]
-        self.ln_b.backward(v2(db_), v2(b["yb"]), v2(db_), self.conv_b.b.grad if need_wgrad else None, need_wgrad)
-        if need_wgrad:
-            self.conv_b.backward_weights(b["hb"], db_)
-        self.conv_b.backward_input(db_, b["dhb"])
+        self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dpre"], b["dhb"], need_wgrad)
         self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"], B, T, need_wgrad)
         # d(high) = d(hi) + d(mix)[cl:cl+ch]
         o.copy_channels(b["dhi"][..., :self.ch], b["dhigh"][..., :self.ch])
