@@ -207,7 +207,7 @@ int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float
  * forward : y = lrelu(conv(x, w) + bias) (kept for the backward), z = LN(y)*gamma + beta, mean_rstd [P][2].
  * backward: dpre = LN'(dz)*lrelu'(y) (dense [P][cout], must not alias dz), dx = conv^T(dpre) (optional),
  *           dgamma/dbeta/dbias += (all three or none).  w_hwio is the master kernel [3][3][cin][cout].
- * Supported (cin, cout): wdg_convln_supported ((2,16), (16,16)). */
+ * Supported (cin, cout): wdg_convln_supported ((2,16): the high-res-only branch). */
 int wdg_convln_supported(int cin, int cout);
 int wdg_convln_fwd(const float* x, int ldx, int64_t isx, const float* w_hwio, const float* bias,
                    const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,

@@ -187,7 +187,7 @@ def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
         assert float(res["hip"]["h"][..., F_:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cin,n,H,W", [(2, 3, 37, 45), (16, 2, 33, 70), (16, 1, 8, 32)])
+@pytest.mark.parametrize("cin,n,H,W", [(2, 3, 37, 45), (2, 2, 33, 70), (2, 1, 8, 32)])
 def test_fused_conv_layernorm(cin, n, H, W, hip_ops, ref_ops):
     """convln.hip: conv3x3 + bias + LeakyReLU + LayerNorm forward, and its backward (LN', LeakyReLU', dx,
     dgamma/dbeta/dbias) against conv_fwd + ln_fwd / ln_bwd + conv_dgrad of the oracle backend; z and dz are
