@@ -49,25 +49,29 @@ __global__ void __launch_bounds__(256) wdg_convln_fwd_kernel(const WdgConvLn p, 
     float acc[CN_CO];
 #pragma unroll
     for (int o = 0; o < CN_CO; ++o) acc[o] = bias[o];
-#pragma unroll 1
+    f32x4 xv[9][C4];   // every tap's input first: one exposed load latency instead of nine
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int gy = oy + tap / 3 - 1, gx = ox + tap % 3 - 1;
-        if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
-        const float* xp = Ximg + ((long long)gy * p.W + gx) * p.ldx;
+        const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
 #pragma unroll
-        for (int c4 = 0; c4 < C4; ++c4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * c4);
+        for (int c4 = 0; c4 < C4; ++c4)
+            xv[tap][c4] = ok ? *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4)
+                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = 4 * c4 + j;
                 if (c < CIN) {
                     const float* w = Wt + (tap * CIN + c) * CN_CO;   // HWIO, wave-uniform -> scalar loads
 #pragma unroll
-                    for (int o = 0; o < CN_CO; ++o) acc[o] = fmaf(xv[j], w[o], acc[o]);
+                    for (int o = 0; o < CN_CO; ++o) acc[o] = fmaf(xv[tap][c4][j], w[o], acc[o]);
                 }
             }
-        }
-    }
     float s = 0.f;
 #pragma unroll
     for (int o = 0; o < CN_CO; ++o) {

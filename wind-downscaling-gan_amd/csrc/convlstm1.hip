@@ -40,7 +40,7 @@ struct WdgCl1 {
 // gate pre-activations (i, c~, o) of FH features starting at f0 for one pixel, x read through `load`
 // Wx / bias are separate `const __restrict__` kernel arguments: only then does hipcc treat the (wave-uniform)
 // weight reads as invariant and emit scalar loads (s_load_dwordx8) feeding v_fma SGPR operands.
-template <int CIN, int F, int FH, typename LoadX>
+template <int CIN, int F, int FH, bool PRELOAD, typename LoadX>
 __device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const float* __restrict__ bias, int f0,
                                          LoadX load, float (&gi)[FH], float (&gc)[FH], float (&go)[FH]) {
     constexpr int C4 = (CIN + 3) / 4;
@@ -50,7 +50,33 @@ __device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const flo
         gc[f] = bias[2 * F + f0 + f];
         go[f] = bias[3 * F + f0 + f];
     }
-#pragma unroll 1   // keep the tap loop rolled: full unrolling hoists every weight and spills
+    if (PRELOAD) {
+        // x comes from global memory: issue every tap's load first (one latency instead of 9 exposed ones)
+        f32x4 xv[9][C4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) xv[tap][c4] = load(tap / 3, tap % 3, c4);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * c4 + j;
+                    if (c < CIN) {
+                        const float* w = Wx + (tap * CIN + c) * 4 * F + f0;
+#pragma unroll
+                        for (int f = 0; f < FH; ++f) {
+                            gi[f] = fmaf(xv[tap][c4][j], w[f], gi[f]);
+                            gc[f] = fmaf(xv[tap][c4][j], w[2 * F + f], gc[f]);
+                            go[f] = fmaf(xv[tap][c4][j], w[3 * F + f], go[f]);
+                        }
+                    }
+                }
+        return;
+    }
+#pragma unroll 1   // x from LDS: keep the tap loop rolled (full unrolling hoists every weight and spills)
     for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
         for (int c4 = 0; c4 < C4; ++c4) {
@@ -93,7 +119,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
         return (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     float gi[FH], gc[FH], go[FH];
-    cl_gates<CIN, F, FH>(Wx, bias, f0, load, gi, gc, go);
+    cl_gates<CIN, F, FH, true>(Wx, bias, f0, load, gi, gc, go);
     float* hp = p.Hout + (long long)img * p.imgStrideH + ((long long)oy * p.W + ox) * p.ldh + f0;
 #pragma unroll
     for (int f = 0; f < FH; ++f) hp[f] = cl_hsig(go[f]) * tanhf(cl_hsig(gi[f]) * tanhf(gc[f]));
@@ -150,7 +176,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
             if (inside) {
                 auto load = [&](int th, int tw, int c4) -> f32x4 { return xs[((hy + th) * XW + hx + tw) * C4 + c4]; };
                 float gi[FH], gc[FH], go[FH];
-                cl_gates<CIN, F, FH>(Wx, bias, f0, load, gi, gc, go);
+                cl_gates<CIN, F, FH, false>(Wx, bias, f0, load, gi, gc, go);
                 const float* dhp = DHimg + ((long long)gy * p.W + gx) * p.lddh + f0;
 #pragma unroll
                 for (int f = 0; f < FH; ++f) {
