@@ -51,14 +51,20 @@ __device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const flo
         go[f] = bias[3 * F + f0 + f];
     }
     if (PRELOAD) {
-        // x comes from global memory: issue every tap's load first (one latency instead of 9 exposed ones)
-        f32x4 xv[9][C4];
+        // x comes from global memory: rolled tap loop (full unrolling blows the SGPR budget: measured 5x slower)
+        // with the next tap's loads issued before the current tap's FMA chain
+        f32x4 nxt[C4];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+        for (int c4 = 0; c4 < C4; ++c4) nxt[c4] = load(0, 0, c4);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            f32x4 cur[C4];
 #pragma unroll
-            for (int c4 = 0; c4 < C4; ++c4) xv[tap][c4] = load(tap / 3, tap % 3, c4);
+            for (int c4 = 0; c4 < C4; ++c4) cur[c4] = nxt[c4];
+            if (tap < 8) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
+                for (int c4 = 0; c4 < C4; ++c4) nxt[c4] = load((tap + 1) / 3, (tap + 1) % 3, c4);
+            }
 #pragma unroll
             for (int c4 = 0; c4 < C4; ++c4)
 #pragma unroll
@@ -68,12 +74,13 @@ __device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const flo
                         const float* w = Wx + (tap * CIN + c) * 4 * F + f0;
 #pragma unroll
                         for (int f = 0; f < FH; ++f) {
-                            gi[f] = fmaf(xv[tap][c4][j], w[f], gi[f]);
-                            gc[f] = fmaf(xv[tap][c4][j], w[2 * F + f], gc[f]);
-                            go[f] = fmaf(xv[tap][c4][j], w[3 * F + f], go[f]);
+                            gi[f] = fmaf(cur[c4][j], w[f], gi[f]);
+                            gc[f] = fmaf(cur[c4][j], w[2 * F + f], gc[f]);
+                            go[f] = fmaf(cur[c4][j], w[3 * F + f], go[f]);
                         }
                     }
                 }
+        }
         return;
     }
 #pragma unroll 1   // x from LDS: keep the tap loop rolled (full unrolling hoists every weight and spills)
