@@ -87,7 +87,11 @@ def get_network(weights_path=WEIGHTS_PATH, allow_random_init=None, random_seed=N
     noise_shape = (BATCH_SIZE, SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NOISE_CHANNELS)
     gan = GAN(generator, discriminator, noise_generator=FlexibleNoiseGenerator(noise_shape, std=NOISE_STD, random_seed=random_seed))
     gan.compile(generator_optimizer=train.generator_optimizer(),
-                generator_metrics=[metrics.WindSpeedWeightedRMSE()],
+                generator_metrics=[metrics.AngularCosineDistance(),
+                                   metrics.LogSpectralDistance(),
+                                   metrics.WeightedRMSEForExtremes(),
+                                   metrics.WindSpeedWeightedRMSE(),
+                                   metrics.SpatialKS()],
                 discriminator_optimizer=train.discriminator_optimizer(),
                 discriminator_loss=train.discriminator_loss,
                 metrics=[metrics.discriminator_score_fake(), metrics.discriminator_score_real()])
