@@ -108,6 +108,19 @@ int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, 
 int wdg_upconv_fwd(const wdg_conv_plan* plan, const float* x_low, int ld_low, int64_t img_stride_low,
                    const float* wD, const float* bias, float* y, int act, float slope, wdg_stream stream);
 
+/* ---- inference precision (BASELINE configs[3]: bf16 tiled inference) --------------------------------
+ * bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 activations in memory (rounded to bf16
+ * while being staged).  w*16 are bf16 copies (wdg_convert_bf16) of the packed fp32 layouts wF / wD.
+ * `affine` (optional, [2*C]: scale | shift) is applied after the activation: the inference-mode
+ * BatchNormalization that follows every generator conv (models.py:34,40,50,56) fused into the epilogue.
+ * Needs roundup4(Cin) % 8 == 0 (forward) / roundup4(Cout) % 8 == 0 (transposed).  The reference is fp32 only;
+ * the tolerance of this path is defined by the build (tests/test_bf16_gpu.py). */
+int wdg_convert_bf16(const float* src, void* dst_bf16, int64_t n, wdg_stream stream);
+int wdg_conv_fwd_bf16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,
+                      const float* affine, float* y, int act, float slope, int accumulate, wdg_stream stream);
+int wdg_conv_dgrad_bf16(const wdg_conv_plan* plan, const float* dy, const void* wD16, const float* bias,
+                        const float* affine, float* dx, int act, float slope, int accumulate, wdg_stream stream);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum_pixels x (*) dy  — HWIO, the master layout.   ganbase.py:46,60 */
 int wdg_conv_wgrad(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw,
                    int accumulate, void* ws, size_t ws_bytes, wdg_stream stream);

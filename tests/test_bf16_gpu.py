@@ -1,0 +1,78 @@
+"""Inference precision (bf16 operands, fp32 accumulation) — BASELINE configs[3].  The reference is fp32-only, so
+the tolerance is defined here: the bf16 kernels must equal an emulation that rounds the operands to bf16 and
+accumulates exactly (rel 1e-4), and the bf16 generator forward must stay within 3e-2 (relative to the output
+scale) of the fp32 oracle."""
+import pytest
+import torch
+
+from oracle import torch_model as TM
+from tests.helpers import randomize, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("g0_8x8s2_cin23", 2, 32, 32, 23, 128, 8, 2, 3),
+    ("g2_4x4s2", 2, 16, 16, 128, 128, 4, 2, 1),
+    ("gates_128to512", 2, 16, 16, 128, 512, 3, 1, 1),
+    ("c5_128to64", 2, 16, 16, 128, 64, 3, 1, 1),
+    ("convT2x2_as_conv", 2, 16, 16, 32, 192, 2, 2, 0),
+    ("odd_sizes", 3, 21, 19, 40, 72, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_bf16_conv_kernels(case, hip_ops, ref_ops):
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    name, n, H, W, cin, cout, k, s, p = case
+    gen = torch.Generator().manual_seed(3)
+    dev = hip_ops.device
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    x = torch.zeros(n, H, W, cin_p, dtype=torch.float64)
+    x[..., :cin] = torch.randn(n, H, W, cin, generator=gen, dtype=torch.float64)
+    dy = torch.zeros(n, Ho, Wo, cout_p, dtype=torch.float64)
+    dy[..., :cout] = torch.randn(n, Ho, Wo, cout, generator=gen, dtype=torch.float64)
+    w = torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) * 0.05
+    b = torch.randn(cout, generator=gen, dtype=torch.float64)
+    aff = torch.cat([torch.rand(cout, generator=gen, dtype=torch.float64) + 0.5, torch.randn(cout, generator=gen, dtype=torch.float64)])
+    g, rg = ConvGeom(k, k, s, p), RG(k, k, s, p)
+    pk_g, pk_r = hip_ops.pack_weights(w.float().to(dev).contiguous()), ref_ops.pack_weights(w)
+    if cin_p % 8 == 0:
+        y_r, y_g = torch.zeros(n, Ho, Wo, cout_p, dtype=torch.float64), hip_ops.zeros(n, Ho, Wo, cout_p)
+        ref_ops.conv_fwd_bf16(x.float().double(), pk_r, b, y_r, rg, act=True, affine=aff)
+        hip_ops.conv_fwd_bf16(x.float().to(dev), pk_g, b.float().to(dev), y_g, g, act=True, affine=aff.float().to(dev))
+        assert rel_err(y_g, y_r) < 1e-4, "fwd"
+        ref_ops.conv_fwd_bf16(x.float().double(), pk_r, None, y_r, rg, accumulate=True)
+        hip_ops.conv_fwd_bf16(x.float().to(dev), pk_g, None, y_g, g, accumulate=True)
+        assert rel_err(y_g, y_r) < 1e-4, "fwd accumulate"
+    if cout_p % 8 == 0:
+        bi = torch.linspace(-1, 1, cin, dtype=torch.float64)
+        dx_r, dx_g = torch.zeros(n, H, W, cin_p, dtype=torch.float64), hip_ops.zeros(n, H, W, cin_p)
+        ref_ops.conv_dgrad_bf16(dy.float().double(), pk_r, dx_r, rg, bias=bi, act=True)
+        hip_ops.conv_dgrad_bf16(dy.float().to(dev), pk_g, dx_g, g, bias=bi.float().to(dev), act=True)
+        assert rel_err(dx_g, dx_r) < 1e-4, "transposed"
+
+
+@pytest.mark.parametrize("S,T,F", [(32, 2, 128), (48, 1, 64)])
+def test_bf16_generator_forward(hip_ops, S, T, F):
+    from downscaling.engine.networks import GeneratorNet
+    B, cin, nz, ch = 2, 3, 20, 2
+    dev = hip_ops.device
+    net = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
+    w = randomize(net, 11)
+    g = torch.Generator().manual_seed(0)
+    low = torch.randn(B, T, S, S, cin, generator=g, dtype=torch.float64)
+    noise = torch.randn(B, T, S, S, nz, generator=g, dtype=torch.float64) * 0.1
+    net.set_image(low.float().to(dev))
+    net.set_noise(noise.float().to(dev))
+    out16 = torch.zeros(B, T, S, S, ch, device=dev)
+    net.from_time_major(net.forward(B, False, precision="bf16"), out16)
+    out32 = torch.zeros(B, T, S, S, ch, device=dev)
+    net.from_time_major(net.forward(B, False, precision="fp32"), out32)
+    ref = TM.generator_forward(w, low, noise, False)
+    assert rel_err(out32, ref) < 1e-4
+    err = rel_err(out16, ref)
+    assert 1e-6 < err < 3e-2, err          # really a different precision, and within the stated tolerance
+    with pytest.raises(ValueError):
+        net.forward(B, True, precision="bf16")

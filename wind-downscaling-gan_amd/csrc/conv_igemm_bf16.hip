@@ -1,0 +1,266 @@
+// conv_igemm_bf16.hip — inference-precision variant of the implicit-GEMM convolution:
+// bf16 operands on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate), fp32 accumulation, fp32 activations in
+// HBM.  Used for the generator forward of the tiled-inference configuration (BASELINE.json configs[3]); the
+// reference itself is fp32-only (gan/models.py), so the tolerance of this path is defined by the build
+// (tests: <= 2e-2 relative to the fp32 path).
+//
+// Same GEMM view, same per-plan index tables and phases as conv_igemm.hip.  Differences:
+//   * activations are read as fp32 (two float4 = 8 channels per slot) and rounded to bf16
+//     (v_cvt_pk_bf16_f32, round-to-nearest-even) while being staged; weights are pre-converted bf16 copies of
+//     the packed fp32 layouts (wdg_convert_bf16), so one 16-byte load is one LDS slot;
+//   * a K-step is 64 (8 slots of 8 channels); a lane's ds_read_b128 is a whole MFMA operand (k = 8 per lane);
+//   * the kernel is L2-bandwidth bound, not MFMA bound, so the epilogue can also apply the inference-mode
+//     BatchNorm (per-channel scale/shift after the LeakyReLU) instead of a separate pass.
+#include "conv_plan.h"
+#include <algorithm>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct WdgIgemmBf16 {
+    const float* A;
+    const __bf16* B;
+    float* Out;
+    const float* bias;
+    const float* affine;   // optional [2*Ncols]: scale | shift applied after the activation
+    const int4* ktab;
+    long long imgStrideA, imgStrideO;
+    int n_img, H, W, ldA;
+    int Ho, Wo, ldO;
+    int Ncols, ldB;
+    int a_mul, o_mul;
+    int act, accumulate;
+    float slope;
+    int Mmax, nphase;
+    WdgPhase ph[9];
+};
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(256) wdg_igemm_bf16_kernel(const WdgIgemmBf16 p) {
+    constexpr int MT = BM / WGM / 16;
+    constexpr int NT = BN / WGN / 16;
+    constexpr int A_SLOTS = BM / 32;                // slots (8 channels of one row) per thread per K-step
+    constexpr int B_SLOTS = (BN + 31) / 32;
+    static_assert(WGM * WGN == 4, "4 waves");
+    __shared__ bf16x8 ldsA[8 * BM];
+    __shared__ bf16x8 ldsB[8 * BN];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int kg = t & 7, lrow = t >> 3;
+
+    const WdgPhase ph = p.ph[blockIdx.z];
+    const int tiles_m = (p.Mmax + BM - 1) / BM;
+    const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int PaPb = ph.Pa * ph.Pb;
+    const int Mph = p.n_img * PaPb;
+    if (m0 >= Mph) return;
+    const int nk = (ph.K4 + 15) >> 4;               // K-steps of 16 table entries (64 channels-taps)
+
+    long long a_base[A_SLOTS];
+    int a_ih0[A_SLOTS], a_iw0[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < Mph) {
+            const int img = m / PaPb;
+            const int rem = m - img * PaPb;
+            const int pa = rem / ph.Pb, pb = rem - pa * ph.Pb;
+            a_ih0[i] = pa * p.a_mul + ph.a_off_h;
+            a_iw0[i] = pb * p.a_mul + ph.a_off_w;
+            a_base[i] = (long long)img * p.imgStrideA + ((long long)a_ih0[i] * p.W + a_iw0[i]) * p.ldA;
+        } else {
+            a_ih0[i] = a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
+        }
+    }
+    long long b_base[B_SLOTS];
+    bool b_ok[B_SLOTS];
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) {
+        const int nl = lrow + 32 * i;
+        b_ok[i] = (nl < BN) && (n0 + nl < p.Ncols);
+        b_base[i] = (long long)(n0 + nl) * p.ldB;
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[A_SLOTS][2];
+    bf16x8 rb[B_SLOTS];
+    const int4* tab = p.ktab + ph.tab_off;
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto load_tile = [&](int kt) {
+        const int k4 = kt * 16 + 2 * kg;            // this thread's pair of table entries
+        int4 e0 = (int4){0, -(1 << 28), -(1 << 28), -1}, e1 = e0;
+        if (k4 < ph.K4) e0 = tab[k4];
+        if (k4 + 1 < ph.K4) e1 = tab[k4 + 1];
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const int ih = a_ih0[i] + e0.y, iw = a_iw0[i] + e0.z;
+            const bool ok0 = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (e0.w >= 0);
+            const int ih1 = a_ih0[i] + e1.y, iw1 = a_iw0[i] + e1.z;
+            const bool ok1 = ((unsigned)ih1 < (unsigned)p.H) && ((unsigned)iw1 < (unsigned)p.W) && (e1.w >= 0);
+            ra[i][0] = ok0 ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + e0.x) : z4;
+            ra[i][1] = ok1 ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + e1.x) : z4;
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            // the weight rows are K-contiguous and zero-padded, and e1 directly follows e0 (Cin_p % 8 == 0)
+            if (b_ok[i] && e0.w >= 0) v = *reinterpret_cast<const bf16x8*>(p.B + b_base[i] + e0.w);
+            rb[i] = v;
+        }
+    };
+
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = (__bf16)ra[i][0][j];
+                v[4 + j] = (__bf16)ra[i][1][j];
+            }
+            const int row = lrow + 32 * i;
+            ldsA[kg * BM + (row ^ kg)] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int row = lrow + 32 * i;
+            if (row < BN) ldsB[kg * BN + (row ^ kg)] = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kgr = 4 * h + (lane >> 4);
+            bf16x8 af[MT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) af[a] = ldsA[kgr * BM + ((wm * (BM / WGM) + a * 16 + (lane & 15)) ^ kgr)];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bf[b] = ldsB[kgr * BN + ((wn * (BN / WGN) + b * 16 + (lane & 15)) ^ kgr)];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int col = lane & 15;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * (BM / WGM) + a * 16 + (lane >> 4) * 4 + r;
+            if (m >= Mph) continue;
+            const int img = m / PaPb;
+            const int rem = m - img * PaPb;
+            const int pa = rem / ph.Pb, pb = rem - pa * ph.Pb;
+            const int oh = pa * p.o_mul + ph.o_off_h, ow = pb * p.o_mul + ph.o_off_w;
+            float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + col;
+                if (n < p.Ncols) {
+                    float v = acc[a][b][r];
+                    if (p.bias) v += p.bias[n];
+                    if (p.act) v = wdg_lrelu(v, p.slope);
+                    if (p.affine) v = v * p.affine[n] + p.affine[p.Ncols + n];
+                    if (p.accumulate) v += dst[n];
+                    dst[n] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wdg_convert_bf16_kernel(const float* __restrict__ src, __bf16* dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = (__bf16)src[i];
+}
+
+extern "C" int wdg_convert_bf16(const float* src, void* dst_bf16, int64_t n, wdg_stream stream) {
+    WDG_CHECK_ARG(src && dst_bf16 && n >= 0, "bad argument");
+    if (n == 0) return WDG_OK;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192));
+    hipLaunchKernelGGL(wdg_convert_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst_bf16, n);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+static int launch_bf16(WdgIgemmBf16& p, int nphase, hipStream_t st) {
+    if (p.Mmax <= 0) return WDG_OK;
+    p.nphase = nphase;
+    const bool wide = p.Ncols > 64;
+    const int BM = 128, BN = wide ? 128 : 64;
+    const int tiles_m = (p.Mmax + BM - 1) / BM, tiles_n = (p.Ncols + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, nphase), block(256);
+    if (wide)
+        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    else
+        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// y = affine(act(conv(x, wF16) + bias)); wF16 = bf16 copy of the forward-packed weights [Cout][taps][Cin_p]
+extern "C" int wdg_conv_fwd_bf16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
+                                 const float* affine, float* y, int act, float slope, int accumulate,
+                                 wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && wF16 && y, "null argument");
+    WDG_CHECK_ARG(pl->Cin_p % 8 == 0, "bf16 path needs the padded input channel count to be a multiple of 8");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF16 & 15) == 0, "alignment");
+    const wdg_conv_geom& g = pl->g;
+    WdgIgemmBf16 p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.B = (const __bf16*)wF16; p.Out = y; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_fwd;
+    p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
+    p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
+    p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
+    p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p;
+    p.a_mul = g.stride; p.o_mul = 1;
+    p.act = act; p.slope = slope; p.accumulate = accumulate;
+    p.Mmax = g.n_img * g.Ho * g.Wo;
+    WdgPhase ph;
+    ph.Pa = g.Ho; ph.Pb = g.Wo; ph.a_off_h = -g.pad_h; ph.a_off_w = -g.pad_w;
+    ph.o_off_h = 0; ph.o_off_w = 0; ph.K4 = pl->K4_fwd; ph.tab_off = 0;
+    p.ph[0] = ph;
+    return launch_bf16(p, 1, (hipStream_t)stream);
+}
+
+// dx = affine(act(conv_transpose(dy, wD16) + bias)) — the Conv2DTranspose forward in bf16.
+extern "C" int wdg_conv_dgrad_bf16(const wdg_conv_plan* pl, const float* dy, const void* wD16, const float* bias,
+                                   const float* affine, float* dx, int act, float slope, int accumulate,
+                                   wdg_stream stream) {
+    WDG_CHECK_ARG(pl && dy && wD16 && dx, "null argument");
+    WDG_CHECK_ARG(pl->Cout_p % 8 == 0, "bf16 path needs the padded channel count of dy to be a multiple of 8");
+    WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD16 & 15) == 0, "alignment");
+    const wdg_conv_geom& g = pl->g;
+    WdgIgemmBf16 p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.B = (const __bf16*)wD16; p.Out = dx; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_dgrad;
+    p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
+    p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
+    p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
+    p.Ncols = g.Cin; p.ldB = pl->Cout_p;
+    p.a_mul = 1; p.o_mul = g.stride;
+    p.act = act; p.slope = slope; p.accumulate = accumulate;
+    int Mmax = 0;
+    const int np = (int)pl->ph_dgrad.size();
+    for (int i = 0; i < np; ++i) {
+        p.ph[i] = pl->ph_dgrad[i];
+        Mmax = std::max(Mmax, g.n_img * p.ph[i].Pa * p.ph[i].Pb);
+    }
+    p.Mmax = Mmax;
+    return launch_bf16(p, np, (hipStream_t)stream);
+}

@@ -43,9 +43,24 @@ class PackedWeights:
         cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
         self.wF = torch.empty(cout * self.taps * cin_p, dtype=torch.float32, device=w.device)
         self.wD = w if cout % 4 == 0 else torch.empty(self.taps * cin * cout_p, dtype=torch.float32, device=w.device)
+        self._wF16 = self._wD16 = None
+        self._bf16_stale = True
         self.refresh()
 
+    def bf16(self):
+        """(wF16, wD16): bf16 copies of the packed layouts for the inference-precision kernels (lazy)."""
+        if self._wF16 is None:
+            self._wF16 = torch.empty(self.wF.numel(), dtype=torch.bfloat16, device=self.w.device)
+            self._wD16 = torch.empty(self.wD.numel(), dtype=torch.bfloat16, device=self.w.device)
+        if self._bf16_stale:
+            lib, st = self.ops.lib, self.ops.stream
+            native.check(lib.wdg_convert_bf16(self.wF.data_ptr(), self._wF16.data_ptr(), self.wF.numel(), st), "convert_bf16")
+            native.check(lib.wdg_convert_bf16(self.wD.data_ptr(), self._wD16.data_ptr(), self.wD.numel(), st), "convert_bf16")
+            self._bf16_stale = False
+        return self._wF16, self._wD16
+
     def refresh(self):
+        self._bf16_stale = True
         lib = self.ops.lib
         native.check(lib.wdg_weight_pack(self.w.data_ptr(), self.wF.data_ptr(),
                                          0 if self.wD is self.w else self.wD.data_ptr(),
@@ -138,6 +153,17 @@ class HipOps:
         native.check(self.lib.wdg_conv_dgrad(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(),
                                              int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                              self.stream), "conv_dgrad")
+
+    def conv_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, accumulate=False, slope=0.2):
+        """Inference precision: y = affine(act(conv(bf16(x), bf16(W)) + bias)), fp32 accumulation."""
+        plan, _, _ = self._plan(x, y, pk.cin, pk.cout, g)
+        native.check(self.lib.wdg_conv_fwd_bf16(plan, x.data_ptr(), pk.bf16()[0].data_ptr(), _ptr(bias), _ptr(affine),
+                                                y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_bf16")
+
+    def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2):
+        plan, _, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
+        native.check(self.lib.wdg_conv_dgrad_bf16(plan, dy.data_ptr(), pk.bf16()[1].data_ptr(), _ptr(bias), _ptr(affine),
+                                                  dx.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_dgrad_bf16")
 
     def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
         """y = act(convT(bilinear_x2(x_low), W) + bias) without materialising the upsampled tensor.

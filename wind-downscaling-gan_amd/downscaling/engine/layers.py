@@ -58,6 +58,13 @@ class Conv:
         else:
             self.ops.conv_fwd(x, self.pk, self.b.value, y, self.g, act=self.act, slope=LRELU)
 
+    def forward_bf16(self, x, y, affine=None):
+        """Inference precision (bf16 operands, fp32 accumulate); `affine` = fused inference BatchNorm."""
+        if self.transposed:
+            self.ops.conv_dgrad_bf16(x, self.pk, y, self.g, bias=self.b.value, act=self.act, affine=affine, slope=LRELU)
+        else:
+            self.ops.conv_fwd_bf16(x, self.pk, self.b.value, y, self.g, act=self.act, affine=affine, slope=LRELU)
+
     def backward_weights(self, x, dpre):
         if self.transposed:
             self.ops.conv_wgrad(dpre, x, self.pk, self.w.grad, self.g, accumulate=True)
@@ -106,6 +113,11 @@ class BatchNorm:
         else:
             o.bn_finalize_infer(self.gamma.value, self.beta.value, self.mmean.value, self.mvar.value, BN_EPS, self.ss)
         o.bn_apply(y, self.ss, z)
+
+    def infer_affine(self):
+        """[scale | shift] of the inference-mode normalisation (moving statistics), for epilogue fusion."""
+        self.ops.bn_finalize_infer(self.gamma.value, self.beta.value, self.mmean.value, self.mvar.value, BN_EPS, self.ss)
+        return self.ss
 
     def backward(self, dz, y, dpre, dbias, act_slope=LRELU):
         """dpre = BN-backward(dz) * lrelu'(y); accumulates dgamma, dbeta and (fused) the conv bias grad."""
@@ -188,20 +200,22 @@ class ConvLSTM:
         """Single timestep + few channels: the fused, gate-recomputing kernels (convlstm1.hip)."""
         return T == 1 and self.ops.convlstm1_supported(self.cin, self.F)
 
-    def forward(self, x, h, B, T):
-        """x: [T*B,H,W,>=cin] view; h: [T*B,H,W,round4(F)] output buffer (pad channels stay zero)."""
+    def forward(self, x, h, B, T, bf16=False):
+        """x: [T*B,H,W,>=cin] view; h: [T*B,H,W,round4(F)] output buffer (pad channels stay zero).
+        bf16=True: the two convolutions run at inference precision (the cell math stays fp32)."""
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
         if self._fused1(T):
             o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
             return
         self._buffers(N, H, W)
-        o.conv_fwd(x, self.pkx, self.b.value, self.gates, self.g, act=False)
+        conv = o.conv_fwd_bf16 if bf16 else o.conv_fwd
+        conv(x, self.pkx, self.b.value, self.gates, self.g, act=False)
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             if t > 0:
                 pv = slice((t - 1) * B, t * B)
-                o.conv_fwd(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
+                conv(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
                 o.lstm_fwd(v2(self.gates[sl]), v2(self.c[pv]), v2(self.c[sl]), v2(h[sl]), F)
             else:
                 o.lstm_fwd(v2(self.gates[sl]), None, v2(self.c[sl]), v2(h[sl]), F)

@@ -144,8 +144,10 @@ class GeneratorNet(_Net):
         return v2(self.buffers(B)["x0"][..., self.in_channels:self.cin])
 
     # ---- forward -----------------------------------------------------------------------------------
-    def forward(self, B, training, need_backward=None):
+    def forward(self, B, training, need_backward=None, precision="fp32"):
         """Runs on the resident input buffer; returns the [T*B,S,S,round4(out)] time-major output.
+        precision="bf16" (inference only): the implicit-GEMM layers use bf16 MFMA operands with fp32
+        accumulation and fuse the inference BatchNorm into their epilogue.
         Only a forward that will be back-propagated (the generator step, ganbase.py:50-61) materialises
         the bilinear-upsampled tensor (it is the weight-gradient operand); every other forward fuses the
         upsampling into the transposed conv's input staging."""
@@ -156,6 +158,20 @@ class GeneratorNet(_Net):
         self._prepare(training)
         res2 = b["cat2"][..., F // 4:]
         res4 = b["cat4"][..., F // 2:]
+        if precision == "bf16":
+            if training:
+                raise ValueError("the bf16 path is inference-only")
+            self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine())
+            self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine())
+            self.lstm.forward(res4, b["h"], B, T, bf16=True)
+            self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine())
+            self.c7.forward_bf16(b["cat4"], b["cat2"][..., :F // 4], affine=self.bn8.infer_affine())
+            self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)
+            self.bn10.forward(v2(b["y9"]), v2(b["z9"]), False)
+            self.c11.forward(b["z9"], b["out"])
+            return b["out"]
+        if precision != "fp32":
+            raise ValueError(f"unknown precision {precision!r}")
         self.c0.forward(b["x0"], b["y0"])
         self.bn1.forward(v2(b["y0"]), v2(res2), training)
         self.c2.forward(res2, b["y2"])

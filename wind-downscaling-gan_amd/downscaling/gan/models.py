@@ -114,8 +114,9 @@ class _Model:
 
 class Generator(_Model):
     name = "generator"
+    inference_precision = "fp32"   # "bf16": bf16-operand MFMA for the inference forward (BASELINE configs[3])
 
-    def __call__(self, inputs, training=False, mask=None):
+    def __call__(self, inputs, training=False, mask=None, precision=None):
         image, noise = inputs
         ops, net = self.ops, self.net
         image, noise = _to_dev(image, ops), _to_dev(noise, ops)
@@ -124,19 +125,21 @@ class Generator(_Model):
         assert tuple(noise.shape) == (B, net.T, net.S, net.S, net.noise_channels), noise.shape
         net.set_image(image)
         net.set_noise(noise)
-        out_tm = net.forward(B, bool(training))
+        precision = precision or ("fp32" if training else self.inference_precision)
+        out_tm = net.forward(B, bool(training), precision=precision)
         out = torch.empty(B, T, net.S, net.S, net.out_channels, dtype=ops.dtype, device=ops.device)
         net.from_time_major(out_tm, out)
         return out
 
     call = __call__
 
-    def predict(self, inputs, batch_size=32, **kwargs):
+    def predict(self, inputs, batch_size=32, precision=None, **kwargs):
         image, noise = inputs
         n = len(image)
         outs = []
         for i in range(0, n, batch_size):
-            outs.append(self([image[i:i + batch_size], noise[i:i + batch_size]], training=False).cpu().numpy())
+            outs.append(self([image[i:i + batch_size], noise[i:i + batch_size]], training=False,
+                             precision=precision).cpu().numpy())
         return np.concatenate(outs, axis=0)
 
 
