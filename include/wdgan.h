@@ -121,6 +121,14 @@ int wdg_conv_fwd_bf16(const wdg_conv_plan* plan, const float* x, const void* wF1
 int wdg_conv_dgrad_bf16(const wdg_conv_plan* plan, const float* dy, const void* wD16, const float* bias,
                         const float* affine, float* dx, int act, float slope, int accumulate, wdg_stream stream);
 
+/* bf16 halo-tile kernels for the generator's last two layers (stride 1, <= 64 output channels, channels % 8 == 0):
+ * the thin forward conv, and the fused UpSampling2D(bilinear) + Conv2DTranspose forward (two-stage LDS staging). */
+int wdg_conv_halo_fwd_bf16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,
+                           const float* affine, float* y, int act, float slope, wdg_stream stream);
+int wdg_upconv_fwd_bf16(const wdg_conv_plan* plan, const float* x_low, int ld_low, int64_t img_stride_low,
+                        const void* wD16, const float* bias, const float* affine, float* y, int act, float slope,
+                        wdg_stream stream);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum_pixels x (*) dy  — HWIO, the master layout.   ganbase.py:46,60 */
 int wdg_conv_wgrad(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw,
                    int accumulate, void* ws, size_t ws_bytes, wdg_stream stream);

@@ -164,6 +164,15 @@ class TorchOps:
             out = out * affine[:pk.cin] + affine[pk.cin:]
         dx[..., :pk.cin] = out + (dx[..., :pk.cin] if accumulate else 0)
 
+    def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2):
+        self.conv_fwd_bf16(x, pk, bias, y, g, act=act, affine=affine, slope=slope)
+
+    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2):
+        # bilinear interpolation in full precision, then bf16 rounding of the conv operands
+        up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
+        self.upsample2x_fwd(x_low, up)
+        self.conv_dgrad_bf16(up, pk, y, g, bias=bias, act=act, affine=affine, slope=slope)
+
     def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
         self.upsample2x_fwd(x_low, up)

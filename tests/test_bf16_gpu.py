@@ -54,6 +54,34 @@ def test_bf16_conv_kernels(case, hip_ops, ref_ops):
         assert rel_err(dx_g, dx_r) < 1e-4, "transposed"
 
 
+def test_bf16_halo_kernels(hip_ops, ref_ops):
+    """bf16 fused upsample + transposed 5x5 conv (two-stage LDS staging) and the thin 16 -> 2 conv."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    gen = torch.Generator().manual_seed(9)
+    dev = hip_ops.device
+    x = torch.randn(3, 60, 68, 160, generator=gen, dtype=torch.float64).float().double()
+    w = torch.randn(5, 5, 16, 160, generator=gen, dtype=torch.float64) * 0.05
+    b = torch.randn(16, generator=gen, dtype=torch.float64)
+    aff = torch.cat([torch.rand(16, generator=gen, dtype=torch.float64) + 0.5, torch.randn(16, generator=gen, dtype=torch.float64)])
+    y_r, y_g = torch.zeros(3, 120, 136, 16, dtype=torch.float64), hip_ops.zeros(3, 120, 136, 16)
+    ref_ops.upconv_fwd_bf16(x, ref_ops.pack_weights(w), b, y_r, RG(5, 5, 1, 2), act=True, affine=aff)
+    hip_ops.upconv_fwd_bf16(x.float().to(dev), hip_ops.pack_weights(w.float().to(dev).contiguous()), b.float().to(dev), y_g,
+                            ConvGeom(5, 5, 1, 2), act=True, affine=aff.float().to(dev))
+    # the interpolated value is rounded to bf16 after fp32 (HIP) vs fp64 (oracle) interpolation: a value that sits
+    # on a rounding boundary may round the other way, so the bound is one bf16 ulp of a few of the 4000 products
+    assert rel_err(y_g, y_r) < 2e-3
+    x2 = torch.randn(2, 70, 50, 16, generator=gen, dtype=torch.float64).float().double()
+    w2 = torch.randn(3, 3, 16, 2, generator=gen, dtype=torch.float64) * 0.2
+    b2 = torch.randn(2, generator=gen, dtype=torch.float64)
+    o_r, o_g = torch.zeros(2, 70, 50, 4, dtype=torch.float64), hip_ops.zeros(2, 70, 50, 4)
+    ref_ops.conv_halo_fwd_bf16(x2, ref_ops.pack_weights(w2), b2, o_r, RG(3, 3, 1, 1))
+    hip_ops.conv_halo_fwd_bf16(x2.float().to(dev), hip_ops.pack_weights(w2.float().to(dev).contiguous()), b2.float().to(dev),
+                               o_g, ConvGeom(3, 3, 1, 1))
+    assert rel_err(o_g, o_r) < 1e-4
+    assert float(o_g[..., 2:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("S,T,F", [(32, 2, 128), (48, 1, 64)])
 def test_bf16_generator_forward(hip_ops, S, T, F):
     from downscaling.engine.networks import GeneratorNet

@@ -165,6 +165,21 @@ class HipOps:
         native.check(self.lib.wdg_conv_dgrad_bf16(plan, dy.data_ptr(), pk.bf16()[1].data_ptr(), _ptr(bias), _ptr(affine),
                                                   dx.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_dgrad_bf16")
 
+    def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2):
+        """bf16 thin stride-1 conv (<= 64 output channels) through the halo-tile kernel."""
+        plan, _, _ = self._plan(x, y, pk.cin, pk.cout, g)
+        native.check(self.lib.wdg_conv_halo_fwd_bf16(plan, x.data_ptr(), pk.bf16()[0].data_ptr(), _ptr(bias), _ptr(affine),
+                                                     y.data_ptr(), int(act), slope, self.stream), "conv_halo_fwd_bf16")
+
+    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2):
+        px, ldl, isl = _v4(x_low)
+        py, ldy, isy = _v4(y)
+        n, H, W, _ = y.shape
+        cp = (pk.cout + 3) // 4 * 4
+        plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
+        native.check(self.lib.wdg_upconv_fwd_bf16(plan, px, ldl, isl, pk.bf16()[1].data_ptr(), _ptr(bias), _ptr(affine),
+                                                  py, int(act), slope, self.stream), "upconv_fwd_bf16")
+
     def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
         """y = act(convT(bilinear_x2(x_low), W) + bias) without materialising the upsampled tensor.
         pk/g describe the transposed conv as the conv it is the adjoint of (cin = y channels)."""

@@ -166,9 +166,9 @@ class GeneratorNet(_Net):
             self.lstm.forward(res4, b["h"], B, T, bf16=True)
             self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine())
             self.c7.forward_bf16(b["cat4"], b["cat2"][..., :F // 4], affine=self.bn8.infer_affine())
-            self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)
-            self.bn10.forward(v2(b["y9"]), v2(b["z9"]), False)
-            self.c11.forward(b["z9"], b["out"])
+            self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
+                                     affine=self.bn10.infer_affine())
+            self.ops.conv_halo_fwd_bf16(b["z9"], self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False)
             return b["out"]
         if precision != "fp32":
             raise ValueError(f"unknown precision {precision!r}")
