@@ -3,8 +3,9 @@
   configs[0]  generator-only forward, one 2-ch 16x16 ERA5 patch (x8 nearest) + 128x128 DEM -> 128x128 wind,
               checked against the CPU oracle (plumbing);
   configs[3]  tiled inference of a synthetic 1200x1200x24h field with the shipped network shape
-              G(96,3,20,2,T=24): 225 tiles, groups of 16, overlap blend (fp32 here; bf16 is a later round);
-  configs[4]  stochastic ensemble: 8 tiles x 64 noise realisations (fp32 here; fp16 is a later round).
+              G(96,3,20,2,T=24): 225 tiles, groups of 16, overlap blend — fp32 and bf16-operand paths;
+  configs[4]  stochastic ensemble: 8 tiles x 64 noise realisations — fp32 and bf16-operand paths (the fp16
+              variant is not built).
 Prints one JSON object."""
 import json
 import sys
@@ -71,6 +72,24 @@ def main():
     gf = 3.799e9  # SURVEY §8 d: S=96, T=24 algorithmic forward FLOPs per tile-timestep
     out["config3_generator_only_16tiles_T24"] = {"ms_per_group": 1e3 * dt, "tile_timesteps_per_s": 16 * 24 / dt,
                                                  "tflops": 16 * 24 * gf / dt * 1e-12}
+    gen.inference_precision = "bf16"
+    ref32 = gen([tiles, nz], precision="fp32")
+    got16 = gen([tiles, nz])
+    rel = float((got16 - ref32).abs().max() / ref32.abs().max())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gen([tiles, network.noise_generator(bs=16, channels=20)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    out["config3_generator_only_16tiles_T24_bf16"] = {"ms_per_group": 1e3 * dt, "tile_timesteps_per_s": 16 * 24 / dt,
+                                                      "rel_err_vs_fp32_path": rel}
+    t0 = time.perf_counter()
+    pred16 = api.predict_array(fields, overlap_factor=0.05, network=network)
+    torch.cuda.synchronize()
+    out["config3_tiled_inference_1200x1200x24_bf16"] = {"seconds_end_to_end": time.perf_counter() - t0,
+                                                        "finite": bool(np.isfinite(pred16[:, cnt[0] > 0]).all())}
+    gen.inference_precision = "fp32"
     # ---- configs[4]: 8 tiles x 64 noise realisations
     tiles8 = tiles[:8]
     t0 = time.perf_counter()
@@ -81,6 +100,13 @@ def main():
     dt = time.perf_counter() - t0
     spread = float(torch.stack(ens).std(0).mean())
     out["config4_ensemble_8tiles_x64_fp32_1gpu"] = {"seconds": dt, "realisations_per_s": 64 * 8 / dt, "mean_spread": spread}
+    gen.inference_precision = "bf16"     # (the fp16 MFMA variant of configs[4] is not built; bf16 operands here)
+    t0 = time.perf_counter()
+    for r in range(64):
+        gen([tiles8, network.noise_generator(bs=8, channels=20)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["config4_ensemble_8tiles_x64_bf16_1gpu"] = {"seconds": dt, "realisations_per_s": 64 * 8 / dt}
     print(json.dumps(out, indent=1))
 
 
