@@ -45,6 +45,9 @@ class PackedWeights:
     def refresh(self):
         pass
 
+    def column_slice(self, n0, n1):
+        return PackedWeights(self.ops, self.w[..., n0:n1])
+
 
 def _lrelu(x, slope):
     return torch.where(x > 0, x, x * slope)

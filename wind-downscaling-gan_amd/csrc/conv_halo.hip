@@ -35,6 +35,7 @@ struct WdgHalo {
     int act, accumulate, upsample;
     float slope;
     int tiles_h, tiles_w;
+    int lr_h, lr_w;   // low-res staging tile (upsample mode): rows/cols of the source covering the halo
 };
 
 // WG = 1: the weight fragments are read straight from global memory (they are a few hundred KB, L1/L2
@@ -44,7 +45,8 @@ template <int NT, int WG>
 __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, const float* __restrict__ Bw) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     f32x4* lds_a = smem;                 // [4][npix]
-    f32x4* lds_w = smem + 4 * p.npix;    // [ntaps][4][NT*16]
+    f32x4* lds_w = smem + 4 * p.npix;    // [ntaps][4][NT*16]   (WG = 0 only)
+    f32x4* lds_lr = smem + 4 * p.npix + (WG ? 0 : p.ntaps * 4 * NT * 16);   // [lr_h*lr_w][4] low-res tile (upsample)
     constexpr int NW = NT * 16;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -58,6 +60,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
     const int hy0 = oy0 + p.dh_min, hx0 = ox0 + p.dw_min;
     const int npr = p.halo_h * p.halo_w;
     const float* Aimg = p.A + (long long)img * p.imgStrideA;
+    const int ly0 = (hy0 >> 1) - 1, lx0 = (hx0 >> 1) - 1;   // low-res origin of the staging tile
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -70,6 +73,44 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
     for (int ck = 0; ck < nchunk; ++ck) {
         const int kgs = min(4, p.C4 - 4 * ck);
         __syncthreads();  // previous chunk's fragment reads are done
+        if (p.upsample) {
+            // ---- two-stage staging (the fill, not the MFMA, bounds this layer): (1) the low-resolution source tile
+            // (coordinates clamped = bilinear edge clamp) goes to LDS once, (2) the upsampled halo is interpolated
+            // LDS -> LDS: 4 LDS reads per slot instead of 4 dependent global loads
+            const int nl = p.lr_h * p.lr_w;
+            for (int idx = t; idx < nl * kgs; idx += 256) {
+                const int kg = idx % kgs;
+                const int pix = idx / kgs;
+                const int y = pix / p.lr_w, x = pix - y * p.lr_w;
+                const int gy = min(max(ly0 + y, 0), p.H - 1), gx = min(max(lx0 + x, 0), p.W - 1);
+                lds_lr[pix * 4 + kg] = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + (4 * ck + kg) * 4);
+            }
+            __syncthreads();
+            for (int idx = t; idx < kgs * npr; idx += 256) {
+                const int kg = idx / npr;
+                const int pix = idx - kg * npr;
+                const int hy = pix / p.halo_w, hx = pix - hy * p.halo_w;
+                const int gy = hy0 + hy, gx = hx0 + hx;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc) {
+                    // bilinear x2, half-pixel centres, edge clamp (same arithmetic as wdg_up2_fwd_kernel)
+                    const int jh = gy >> 1, jw = gx >> 1;
+                    const int h0 = (gy & 1) ? jh : max(jh - 1, 0), h1 = (gy & 1) ? min(jh + 1, p.H - 1) : jh;
+                    const int w0 = (gx & 1) ? jw : max(jw - 1, 0), w1 = (gx & 1) ? min(jw + 1, p.W - 1) : jw;
+                    const float fh = (gy & 1) ? 0.25f : 0.75f, fw = (gx & 1) ? 0.25f : 0.75f;
+                    const int r0 = (h0 - ly0) * p.lr_w, r1 = (h1 - ly0) * p.lr_w, c0 = w0 - lx0, c1 = w1 - lx0;
+                    const f32x4 a00 = lds_lr[(r0 + c0) * 4 + kg], a01 = lds_lr[(r0 + c1) * 4 + kg];
+                    const f32x4 a10 = lds_lr[(r1 + c0) * 4 + kg], a11 = lds_lr[(r1 + c1) * 4 + kg];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float top = a00[j] + (a01[j] - a00[j]) * fw;
+                        const float bot = a10[j] + (a11[j] - a10[j]) * fw;
+                        v[j] = top + (bot - top) * fh;
+                    }
+                }
+                lds_a[kg * p.npix + pix] = v;
+            }
+        } else
         // ---- stage the input halo: lanes run over pixels (conflict-free ds_write_b128)
         for (int idx = t; idx < kgs * npr; idx += 256) {
             const int kg = idx / npr;
@@ -78,29 +119,8 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
             const int hx = pix - hy * p.halo_w;
             const int gy = hy0 + hy, gx = hx0 + hx;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc) {
-                const int c = (4 * ck + kg) * 4;
-                if (!p.upsample) {
-                    v = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + c);
-                } else {
-                    // bilinear x2, half-pixel centres, edge clamp (same arithmetic as wdg_up2_fwd_kernel)
-                    const int jh = gy >> 1, jw = gx >> 1;
-                    const int h0 = (gy & 1) ? jh : max(jh - 1, 0), h1 = (gy & 1) ? min(jh + 1, p.H - 1) : jh;
-                    const int w0 = (gx & 1) ? jw : max(jw - 1, 0), w1 = (gx & 1) ? min(jw + 1, p.W - 1) : jw;
-                    const float fh = (gy & 1) ? 0.25f : 0.75f, fw = (gx & 1) ? 0.25f : 0.75f;
-                    const float* xb = Aimg + c;
-                    const f32x4 a00 = *reinterpret_cast<const f32x4*>(xb + ((long long)h0 * p.W + w0) * p.ldA);
-                    const f32x4 a01 = *reinterpret_cast<const f32x4*>(xb + ((long long)h0 * p.W + w1) * p.ldA);
-                    const f32x4 a10 = *reinterpret_cast<const f32x4*>(xb + ((long long)h1 * p.W + w0) * p.ldA);
-                    const f32x4 a11 = *reinterpret_cast<const f32x4*>(xb + ((long long)h1 * p.W + w1) * p.ldA);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float top = a00[j] + (a01[j] - a00[j]) * fw;
-                        const float bot = a10[j] + (a11[j] - a10[j]) * fw;
-                        v[j] = top + (bot - top) * fh;
-                    }
-                }
-            }
+            if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc)
+                v = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + (4 * ck + kg) * 4);
             lds_a[kg * p.npix + pix] = v;
         }
         // ---- stage this chunk's weights: [tap][kg][n] (kg < kgs only)
@@ -214,9 +234,11 @@ static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols
 static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
 void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
 
-static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0) {
-    const int npix = wdg_round_up((HALO_TH + kh - 1) * (HALO_TW + kw - 1), 16);
-    return (size_t)(4 * npix + (wg ? 0 : kh * kw * 4 * nt * 16)) * sizeof(f32x4);
+static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 0) {
+    const int hh = HALO_TH + kh - 1, hw = HALO_TW + kw - 1;
+    const int npix = wdg_round_up(hh * hw, 16);
+    const int lr = upsample ? (hh / 2 + 3) * (hw / 2 + 3) * 4 : 0;
+    return (size_t)(4 * npix + (wg ? 0 : kh * kw * 4 * nt * 16) + lr) * sizeof(f32x4);
 }
 
 int wdg_halo_plan_init(wdg_conv_plan* pl) {
@@ -299,8 +321,9 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     p.npix = wdg_round_up(p.halo_h * p.halo_w, 16);
     p.tiles_h = (p.Ho + HALO_TH - 1) / HALO_TH;
     p.tiles_w = (p.Wo + HALO_TW - 1) / HALO_TW;
-    const int wg = g_halo_wg;
-    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg);
+    const int wg = upsample ? 1 : g_halo_wg;   // the low-res staging tile takes the LDS of the weight stage
+    p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
+    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg, upsample);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
 #define WDG_HALO_CASE(NT_)                                                                             \
     if (nt == NT_) {                                                                                   \

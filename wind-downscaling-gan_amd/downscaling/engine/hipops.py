@@ -59,6 +59,16 @@ class PackedWeights:
             self._bf16_stale = False
         return self._wF16, self._wD16
 
+    def column_slice(self, n0, n1):
+        """Forward-only view of output channels [n0, n1): the rows of wF are contiguous per output channel."""
+        sub = object.__new__(PackedWeights)
+        sub.ops, sub.w, sub.taps, sub.cin, sub.cout = self.ops, None, self.taps, self.cin, n1 - n0
+        ld = self.taps * ((self.cin + 3) // 4 * 4)
+        sub.wF = self.wF[n0 * ld:n1 * ld]
+        sub.wD = None
+        sub._parent, sub._range = self, (n0 * ld, n1 * ld)
+        return sub
+
     def refresh(self):
         self._bf16_stale = True
         lib = self.ops.lib

@@ -180,6 +180,7 @@ class ConvLSTM:
         self.pkh = self.ops.pack_weights(self.wh.value)
         self._packed_version = self.net.params.version
         self._shape = None
+        self._pk_i = None
 
     def prepare(self, training):
         if self._packed_version != self.net.params.version:
@@ -194,6 +195,7 @@ class ConvLSTM:
             self.c = o.empty(N, H, W, F)
             self.dgates = None
             self.dgates1 = None
+            self._pk_i = None
             self._shape = (N, H, W)
 
     def _fused1(self, T):
@@ -210,7 +212,16 @@ class ConvLSTM:
             return
         self._buffers(N, H, W)
         conv = o.conv_fwd_bf16 if bf16 else o.conv_fwd
-        conv(x, self.pkx, self.b.value, self.gates, self.g, act=False)
+        if T == 1 and not bf16:
+            # h_0 = c_0 = 0: the forget gate is never read at t = 0 -> skip its quarter of the input convolution
+            # (the slab keeps zeros there, so the backward's dgates_f = dc * c_prev * hs' = 0 is consistent)
+            if self._pk_i is None:
+                self._pk_i, self._pk_co = self.pkx.column_slice(0, F), self.pkx.column_slice(2 * F, 4 * F)
+                self.gates[..., F:2 * F].zero_()
+            conv(x, self._pk_i, self.b.value[:F], self.gates[..., :F], self.g, act=False)
+            conv(x, self._pk_co, self.b.value[2 * F:], self.gates[..., 2 * F:], self.g, act=False)
+        else:
+            conv(x, self.pkx, self.b.value, self.gates, self.g, act=False)
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             if t > 0:
