@@ -84,12 +84,11 @@ def main():
         label = ops.conv_kernel_label(which, x, y, pk, g)
         nbytes = 4.0 * (n * H * W * ((cin + 3) // 4 * 4) + n * Ho * Wo * ((cout + 3) // 4 * 4))
         cases.append((name, fn, flops, label, nbytes))
-    pipes = (0, 1, 2)   # column meaning below: 0 = xcd_swizzle on, 1 = xcd_swizzle off, 2 = pipe 1 (double-buffered)
+    pipes = (0, 1, 2)   # igemm_pipe tuning values: 0 = single LDS stage, 1 = double-buffered, 2 = 1 + fragment prefetch
     times = {(c[0], pp): [] for c in cases for pp in pipes}
     for r in range(reps + 1):
         for pp in pipes:
-            lib.wdg_set_tuning(b"igemm_pipe", 1 if pp == 2 else 0)
-            lib.wdg_set_tuning(b"halo_weights_global", 0 if pp == 1 else 1)
+            lib.wdg_set_tuning(b"igemm_pipe", pp)
             for name, fn, flops, label, nbytes in cases:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -98,7 +97,7 @@ def main():
                 torch.cuda.synchronize()
                 if r > 0:
                     times[(name, pp)].append(e0.elapsed_time(e1))
-    print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"{n}: ms (TF/s)  " for n in ("halo wg1", "halo wg0", "dbuf    ")))
+    print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"{n}: ms (TF/s)  " for n in ("pipe0   ", "pipe1   ", "pipe2   ")))
     for name, fn, flops, label, nbytes in cases:
         row = f"{name:32s} {label:28s} "
         for pp in pipes:

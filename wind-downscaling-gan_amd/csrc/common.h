@@ -36,8 +36,26 @@ void wdg_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// exact unsigned division n / d for n < 2^31 by a multiply-high and a shift (d >= 1)
+struct wdg_fastdiv {
+    unsigned m, s;   // m == 0 marks d == 1
+};
+static inline wdg_fastdiv wdg_fastdiv_make(unsigned d) {
+    wdg_fastdiv f = {0u, 0u};
+    if (d <= 1) return f;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;                       // s = ceil(log2 d) >= 1
+    f.m = (unsigned)(((1ull << (31 + s)) / d) + 1);    // < 2^32 because d > 2^(s-1)
+    f.s = s - 1;
+    return f;
+}
+
 static inline int wdg_round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t wdg_ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ unsigned wdg_fastdiv_do(unsigned n, wdg_fastdiv f) {
+    return f.m ? __umulhi(n, f.m) >> f.s : n;
+}
 
 __device__ __forceinline__ float wdg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
@@ -52,3 +70,20 @@ __device__ __forceinline__ double wdg_wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// ---- buffer (SRD) loads: 32-bit byte offsets relative to a wave-uniform base, hardware range check.
+// The descriptor spans 2 GiB; an offset of WDG_SRD_OOB is out of range and the load returns zeros
+// (cdna_hip_programming.md T8/T20: build the descriptor only from kernel arguments / blockIdx values).
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+typedef __amdgpu_buffer_rsrc_t wdg_srd;
+#define WDG_SRD_BYTES 0x7FFFFFFF
+#define WDG_SRD_OOB 0x80000000u
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wdg_srd wdg_make_srd(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, WDG_SRD_BYTES, 0x00020000);
+}
+__device__ __forceinline__ f32x4 wdg_buffer_load_f32x4(wdg_srd srd, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+#endif

@@ -85,8 +85,15 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     if (k4_end > ph.K4) k4_end = ph.K4;
     const int nk = k4_end > k4_begin ? (k4_end - k4_begin) >> 3 : 0;
 
-    // ---- per-thread A row state
-    long long a_base[A_LOADS];
+    // ---- buffer descriptors (wave-uniform: kernel arguments and blockIdx only).  Every operand load is a
+    // buffer_load_dwordx4 whose byte offset is pushed out of range for padding / out-of-image / tail lanes,
+    // so the hardware range check returns the zeros and the load sequence has no branches.
+    const int img0 = m0 / PaPb;
+    const wdg_srd srdA = wdg_make_srd(p.A + (long long)img0 * p.imgStrideA);
+    const wdg_srd srdB = wdg_make_srd(p.B);
+
+    // ---- per-thread A row state (element offsets relative to image img0)
+    int a_off[A_LOADS];
     int a_ih0[A_LOADS], a_iw0[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
@@ -100,22 +107,22 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
             const int iw0 = pb * p.a_mul + ph.a_off_w;
             a_ih0[i] = ih0;
             a_iw0[i] = iw0;
-            a_base[i] = (long long)img * p.imgStrideA + ((long long)ih0 * p.W + iw0) * p.ldA;
+            a_off[i] = (int)((long long)(img - img0) * p.imgStrideA) + (ih0 * p.W + iw0) * p.ldA;
         } else {
             a_ih0[i] = -(1 << 28);
             a_iw0[i] = -(1 << 28);
-            a_base[i] = 0;
+            a_off[i] = 0;
         }
     }
     // ---- per-thread B row state
-    long long b_base[B_LOADS];
+    int b_off[B_LOADS];
     bool b_ok[B_LOADS];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int nl = lrow + 32 * i;
         const int n = n0 + nl;
         b_ok[i] = (nl < BN) && (n < p.Ncols);
-        b_base[i] = (long long)n * p.ldB;
+        b_off[i] = n * p.ldB;
     }
 
     f32x4 acc[MT][NT];
@@ -127,21 +134,23 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     f32x4 ra[A_LOADS], rb[B_LOADS];
     const int4* tab = p.ktab + ph.tab_off + k4_begin + kg;
 
+    // the table entry of the NEXT tile is fetched together with this tile's operands, so no load_tile ever
+    // waits on its own table read
+    int4 e_cur = nk > 0 ? tab[0] : (int4){0, 0, 0, -1};
     auto load_tile = [&](int kt) {
-        const int4 e = tab[kt * 8];
+        const int4 e = e_cur;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int ih = a_ih0[i] + e.y, iw = a_iw0[i] + e.z;
             const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (e.w >= 0);
-            ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.A + a_base[i] + e.x)
-                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ra[i] = wdg_buffer_load_f32x4(srdA, ok ? (unsigned)(a_off[i] + e.x) << 2 : WDG_SRD_OOB);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const bool ok = b_ok[i] && (e.w >= 0);
-            rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.B + b_base[i] + e.w)
-                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rb[i] = wdg_buffer_load_f32x4(srdB, ok ? (unsigned)(b_off[i] + e.w) << 2 : WDG_SRD_OOB);
         }
+        e_cur = tab[(kt + 1 < nk ? kt + 1 : kt) * 8];
     };
 
     auto store_tile = [&](f32x4* ldsA, f32x4* ldsB) {
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int row = lrow + 32 * i;
-            if (row < BN) ldsB[kg * BN + (row ^ kg)] = rb[i];
+            if (32 * (i + 1) <= BN || row < BN) ldsB[kg * BN + (row ^ kg)] = rb[i];
         }
     };
     auto read_frags = [&](const f32x4* ldsA, const f32x4* ldsB, int h, f32x4 (&af)[MT], f32x4 (&bf)[NT]) {
@@ -313,6 +322,7 @@ struct WdgWgrad {
     int accumulate;
     int splitk;
     long long pix_per_split, Ptot;
+    wdg_fastdiv div_howo, div_wo;   // pixel index -> (image, row, column) without integer division
 };
 
 template <int BN, int WGM, int WGN>
@@ -357,30 +367,30 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // operands come through buffer loads relative to the first image of this pixel split; lanes that fall
+    // on padding, outside the image or past the end of the split get an out-of-range offset (-> zeros)
+    const int img0 = (int)(pix_begin / HoWo);
+    const wdg_srd srdX = wdg_make_srd(p.X + (long long)img0 * p.imgStrideX);
+    const wdg_srd srdY = wdg_make_srd(p.DY + (long long)img0 * p.imgStrideY);
+    const unsigned q0 = (unsigned)(pix_begin - (long long)img0 * HoWo);   // pixel index relative to image img0
+    const unsigned q_end = (unsigned)(pix_end - (long long)img0 * HoWo);
     f32x4 ra[4], rb[4];
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long q = pix_begin + (long long)kt * 32 + ps + 8 * i;
-            f32x4 va = (f32x4){0.f, 0.f, 0.f, 0.f}, vb = va;
-            if (q < pix_end) {
-                const int img = (int)(q / HoWo);
-                const int rem = (int)(q - (long long)img * HoWo);
-                const int oh = rem / p.Wo;
-                const int ow = rem - oh * p.Wo;
-                if (a_row_ok) {
-                    const int ih0 = oh * p.stride - p.pad_h, iw0 = ow * p.stride - p.pad_w;
-                    const int ih = ih0 + e.y, iw = iw0 + e.z;
-                    if (((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))
-                        va = *reinterpret_cast<const f32x4*>(
-                            p.X + (long long)img * p.imgStrideX + ((long long)ih0 * p.W + iw0) * p.ldx + e.x);
-                }
-                if (b_col_ok)
-                    vb = *reinterpret_cast<const f32x4*>(
-                        p.DY + (long long)img * p.imgStrideY + ((long long)oh * p.Wo + ow) * p.ldy + nb);
-            }
-            ra[i] = va;
-            rb[i] = vb;
+            const unsigned q = q0 + (unsigned)(kt * 32 + ps + 8 * i);
+            const unsigned im = wdg_fastdiv_do(q, p.div_howo);
+            const unsigned rem = q - im * (unsigned)HoWo;
+            const int oh = (int)wdg_fastdiv_do(rem, p.div_wo);
+            const int ow = (int)rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - p.pad_h, iw0 = ow * p.stride - p.pad_w;
+            const int ih = ih0 + e.y, iw = iw0 + e.z;
+            const bool in = q < q_end;
+            const bool okx = in && a_row_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+            const int offx = (int)im * (int)p.imgStrideX + (ih0 * p.W + iw0) * p.ldx + e.x;
+            const int offy = (int)im * (int)p.imgStrideY + (int)rem * p.ldy + nb;
+            ra[i] = wdg_buffer_load_f32x4(srdX, okx ? (unsigned)offx << 2 : WDG_SRD_OOB);
+            rb[i] = wdg_buffer_load_f32x4(srdY, (in && b_col_ok) ? (unsigned)offy << 2 : WDG_SRD_OOB);
         }
     };
 
@@ -857,6 +867,16 @@ extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const flo
     split = (int)((p.Ptot + per - 1) / per);
     p.splitk = split;
     p.pix_per_split = per;
+    p.div_howo = wdg_fastdiv_make((unsigned)(g.Ho * g.Wo));
+    p.div_wo = wdg_fastdiv_make((unsigned)g.Wo);
+    {
+        // 32-bit buffer offsets are relative to the first image of a split
+        const long long imgs = per / ((long long)g.Ho * g.Wo) + 2;
+        if (imgs * std::max(g.img_stride_x, g.img_stride_y) * 4 >= (1LL << 31) || per + (long long)g.Ho * g.Wo >= (1LL << 31)) {
+            wdg_set_error("wgrad: a pixel split spans more than 2 GiB of x or dy");
+            return WDG_ERR_ARG;
+        }
+    }
     if (split > 1) {
         const size_t need = (size_t)split * p.K4 * 4 * p.Cout * sizeof(float);
         if (!ws || ws_bytes < need) {
