@@ -325,14 +325,42 @@ struct WdgWgrad {
     wdg_fastdiv div_howo, div_wo;   // pixel index -> (image, row, column) without integer division
 };
 
+// Fragment layout.  A lane's LDS read is ONE vector of MT (NT) consecutive rows (columns) of one pixel:
+// element j of it is the operand of accumulator tile j, i.e. MFMA tile j of a wave owns the rows
+// {base + MT*i + j : i = 0..15} — a strided row set instead of 16 consecutive rows, which costs nothing
+// (the epilogue undoes the permutation) and turns 2*(MT+NT) ds_read_b32 per 4 pixels into one
+// ds_read_b128/b64 per operand.  Pixel-row strides are chosen per read width so that the reads are
+// bank-conflict free (MI355X_MICROARCH.md, LDS: b128 -> stride = 0 mod 64 words, b64 -> 32 mod 64,
+// b32 -> 16 mod 32).  The fragments of pixel group s+1 are read before the MFMAs of group s.
+template <int W>
+struct WdgFrag {
+    float v[W];
+};
+template <int W>
+__device__ __forceinline__ WdgFrag<W> wdg_lds_frag(const float* q) {
+    WdgFrag<W> f;
+    if constexpr (W == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(q);
+        f.v[0] = t[0]; f.v[1] = t[1]; f.v[2] = t[2]; f.v[3] = t[3];
+    } else if constexpr (W == 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 t = *reinterpret_cast<const f32x2*>(q);
+        f.v[0] = t[0]; f.v[1] = t[1];
+    } else {
+        f.v[0] = *q;
+    }
+    return f;
+}
+
 template <int BN, int WGM, int WGN>
 __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
     constexpr int BM = 128;
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;
-    constexpr int RSA = BM + 16;
-    constexpr int RSB = BN + 16;
     static_assert(WGM * WGN == 4, "4 waves");
+    static_assert((MT == 4 || MT == 2) && (NT == 4 || NT == 2 || NT == 1), "fragment widths");
+    constexpr int RSA = MT == 4 ? BM : BM + 32;
+    constexpr int RSB = NT == 4 ? (BN + 63) / 64 * 64 : NT == 2 ? (BN % 64 == 32 ? BN : BN + 32) : (BN % 32 == 16 ? BN : BN + 16);
     __shared__ __attribute__((aligned(16))) float ldsA[32 * RSA];
     __shared__ __attribute__((aligned(16))) float ldsB[32 * RSB];
 
@@ -343,9 +371,11 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
     const int g4 = t & 31;   // row group (A) / column group (B) handled by this thread
     const int ps = t >> 5;   // pixel slot 0..7
 
+    // (an XCD-aware split -> XCD assignment was measured 3-15 % SLOWER here: profiles/r01t_perf_conv_wgrad_xcd_negative.log)
+    const int bx = blockIdx.x, split_id = blockIdx.y;
     const int tiles_m = (p.K4 * 4 + BM - 1) / BM;
-    const int tm = blockIdx.x % tiles_m;
-    const int tn = blockIdx.x / tiles_m;
+    const int tm = bx % tiles_m;
+    const int tn = bx / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int r4 = (m0 >> 2) + g4;
@@ -355,7 +385,7 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
     const int nb = n0 + 4 * g4;
     const bool b_col_ok = (4 * g4 < BN) && (nb < p.Cout_p);
 
-    const long long pix_begin = (long long)blockIdx.y * p.pix_per_split;
+    const long long pix_begin = (long long)split_id * p.pix_per_split;
     long long pix_end = pix_begin + p.pix_per_split;
     if (pix_end > p.Ptot) pix_end = p.Ptot;
     const int nk = pix_end > pix_begin ? (int)((pix_end - pix_begin + 31) >> 5) : 0;
@@ -394,61 +424,69 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
         }
     };
 
+    const float* fragA = ldsA + (lane >> 4) * RSA + wm * (BM / WGM) + MT * (lane & 15);
+    const float* fragB = ldsB + (lane >> 4) * RSB + wn * (BN / WGN) + NT * (lane & 15);
+
     if (nk > 0) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = ps + 8 * i;
             *reinterpret_cast<f32x4*>(&ldsA[px * RSA + 4 * g4]) = ra[i];
-            if (4 * g4 < BN) *reinterpret_cast<f32x4*>(&ldsB[px * RSB + 4 * g4]) = rb[i];
+            if (BN >= 128 || 4 * g4 < BN) *reinterpret_cast<f32x4*>(&ldsB[px * RSB + 4 * g4]) = rb[i];
         }
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
+        WdgFrag<MT> af[2];
+        WdgFrag<NT> bf[2];
+        af[0] = wdg_lds_frag<MT>(fragA);
+        bf[0] = wdg_lds_frag<NT>(fragB);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int px = 4 * s + (lane >> 4);
-            float af[MT], bf[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) af[a] = ldsA[px * RSA + wm * (BM / WGM) + a * 16 + (lane & 15)];
-#pragma unroll
-            for (int b = 0; b < NT; ++b) bf[b] = ldsB[px * RSB + wn * (BN / WGN) + b * 16 + (lane & 15)];
+            if (s + 1 < 8) {
+                af[(s + 1) & 1] = wdg_lds_frag<MT>(fragA + 4 * (s + 1) * RSA);
+                bf[(s + 1) & 1] = wdg_lds_frag<NT>(fragB + 4 * (s + 1) * RSB);
+            }
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1].v[a], bf[s & 1].v[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    const int col = lane & 15;
+    // ---- epilogue.  Accumulator (a, reg r) of lane (i = lane & 15, q = lane >> 4) is logical row 4q + r of
+    // tile a = tile row MT*(4q + r) + a, and column NT*i + b of the wave's column block.
+    const int q = lane >> 4;
+    const int ncol0 = n0 + wn * (BN / WGN) + NT * (lane & 15);
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
-        const int rg = ((m0 + wm * (BM / WGM) + a * 16) >> 2) + (lane >> 4);  // k4 group of this lane's 4 rows
-        if (rg >= p.K4) continue;
-        if (p.splitk > 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* dst = p.partial + ((long long)blockIdx.y * p.K4 * 4 + rg * 4 + r) * p.Cout;
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * (BM / WGM) + MT * (4 * q + r) + a;
+            const int rg = row >> 2, rr = row & 3;
+            if (rg >= p.K4) continue;
+            if (p.splitk > 1) {
+                float* dst = p.partial + ((long long)split_id * p.K4 * 4 + row) * p.Cout + ncol0;
+                if (NT == 4 && (p.Cout & 3) == 0) {
+                    if (ncol0 < p.Cout)
+                        *reinterpret_cast<f32x4*>(dst) = (f32x4){acc[a][0][r], acc[a][NT > 1 ? 1 : 0][r], acc[a][NT > 2 ? 2 : 0][r], acc[a][NT > 3 ? 3 : 0][r]};
+                } else {
 #pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
-                    if (n < p.Cout) dst[n] = acc[a][b][r];
+                    for (int b = 0; b < NT; ++b)
+                        if (ncol0 + b < p.Cout) dst[b] = acc[a][b][r];
                 }
-            }
-        } else {
-            const int2 wr = p.wrow[rg];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r >= wr.y) continue;
-                float* dst = p.dW + wr.x + (long long)r * p.Cout;
+            } else {
+                const int2 wr = p.wrow[rg];
+                if (rr >= wr.y) continue;
+                float* dst = p.dW + wr.x + (long long)rr * p.Cout + ncol0;
 #pragma unroll
                 for (int b = 0; b < NT; ++b) {
-                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
-                    if (n < p.Cout) {
+                    if (ncol0 + b < p.Cout) {
                         float v = acc[a][b][r];
-                        if (p.accumulate) v += dst[n];
-                        dst[n] = v;
+                        if (p.accumulate) v += dst[b];
+                        dst[b] = v;
                     }
                 }
             }
@@ -536,17 +574,39 @@ static TileCfg pick_tile(int ncols) {
     return cand[3];
 }
 static int pick_wgrad_bn(int ncols) { return pick_tile(ncols).BN; }
-static int wgrad_blocks_per_cu(int bn) { return bn >= 128 ? 3 : bn >= 64 ? 4 : 6; }
+// wdg_set_tuning("force_{fwd,dgrad,wgrad}_split", n): n > 0 overrides the split chosen at plan creation (sweeps)
+static int g_force_split[3] = {0, 0, 0};
+// resident workgroups per CU (512 unified VGPRs per lane and SIMD: 244 -> 2 waves, 156 -> 3, ...)
+static int igemm_blocks_per_cu(int bn) { return bn >= 128 ? 2 : bn >= 64 ? 3 : bn >= 32 ? 2 : 3; }
+static int wgrad_blocks_per_cu(int bn) { return bn >= 128 ? 2 : bn >= 64 ? 4 : 5; }
 
-// choose a split-K factor so that roughly >= 2 blocks per CU exist, keeping >= 16 k4 groups per split
-static int pick_split(long long tiles, int K4, int cus) {
-    if (tiles >= 2LL * cus || K4 < 32) return 1;
-    long long want = (2LL * cus + tiles - 1) / tiles;
-    long long maxs = K4 / 16;
-    if (maxs < 1) maxs = 1;
-    if (want > maxs) want = maxs;
-    if (want > 64) want = 64;
-    return (int)std::max<long long>(1, want);
+// Split factor from a wave-quantisation model: `tiles * s` equal workgroups run in rounds of `cap` = CUs x
+// resident workgroups; a last round that leaves at most one workgroup per CU finishes in ~0.65 of a full
+// round (no sharing of the matrix pipe).  Relative time = rounds / s, plus 0.3 % per split for the slab
+// write + reduce.  Constants fitted to profiles/r01u_sweep_split.log (multiples of the resident capacity win;
+// 1.5 rounds lose 20-25 %).
+static int pick_split_model(long long tiles, int max_split, int cus, int per_cu) {
+    const long long cap = (long long)cus * per_cu;
+    if (tiles >= cap || max_split <= 1) return 1;   // a full round exists already: the slab traffic would cost more than the tail
+    double best_t = 1e30;
+    int best = 1;
+    for (int s = 1; s <= max_split && s <= 256; ++s) {
+        const long long blocks = tiles * s;
+        const long long rounds = (blocks + cap - 1) / cap;
+        const long long rem = blocks - (rounds - 1) * cap;
+        double t = ((double)(rounds - 1) + (rem <= cus ? 0.55 : 1.0)) / s;
+        t *= 1.0 + 0.003 * (s - 1);
+        if (t < best_t * 0.999) {
+            best_t = t;
+            best = s;
+        }
+    }
+    return best;
+}
+// implicit GEMM: at least 16 k4 groups (two K-steps) per split
+static int pick_split(long long tiles, int K4, int cus, int bn) {
+    if (K4 < 32) return 1;
+    return pick_split_model(tiles, std::max(1, K4 / 16), cus, igemm_blocks_per_cu(bn));
 }
 
 extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g) {
@@ -635,7 +695,8 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         const long long M = (long long)g->n_img * g->Ho * g->Wo;
         TileCfg tc = pick_tile(g->Cout);
         long long tiles = ((M + tc.BM - 1) / tc.BM) * ((g->Cout + tc.BN - 1) / tc.BN);
-        pl->fwd_split = pick_split(tiles, pl->K4_fwd, pl->cus);
+        pl->fwd_split = pick_split(tiles, pl->K4_fwd, pl->cus, tc.BN);
+        if (g_force_split[0] > 0) pl->fwd_split = std::min(g_force_split[0], std::max(1, pl->K4_fwd / 8));
         if (pl->fwd_split > 1) pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->fwd_split * M * g->Cout * 4));
     }
     {
@@ -643,7 +704,8 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g->n_img * ph.Pa * ph.Pb);
         TileCfg tc = pick_tile(g->Cin);
         long long tiles = ((Mmax + tc.BM - 1) / tc.BM) * ((g->Cin + tc.BN - 1) / tc.BN) * (long long)pl->ph_dgrad.size();
-        pl->dgrad_split = pick_split(tiles, pl->K4_dgrad_max, pl->cus);
+        pl->dgrad_split = pick_split(tiles, pl->K4_dgrad_max, pl->cus, tc.BN);
+        if (g_force_split[1] > 0) pl->dgrad_split = std::min(g_force_split[1], std::max(1, pl->K4_dgrad_max / 8));
         if (pl->dgrad_split > 1)
             pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->dgrad_split * pl->ph_dgrad.size() * Mmax * g->Cin * 4));
     }
@@ -651,12 +713,9 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         const long long P = (long long)g->n_img * g->Ho * g->Wo;
         const int bn = pick_wgrad_bn(g->Cout);
         long long tiles = (long long)((pl->K4_fwd * 4 + 127) / 128) * ((g->Cout + bn - 1) / bn);
-        // enough resident blocks to hide the (single-stage) global-load latency of the pixel reduction
-        const long long target = (long long)pl->cus * wgrad_blocks_per_cu(bn);
-        long long want = tiles >= target ? 1 : (target + tiles - 1) / tiles;
         long long maxs = std::max<long long>(1, P / 512);  // >= 512 pixels (16 steps) per split
-        want = std::min(want, maxs);
-        want = std::min<long long>(want, 2048);
+        long long want = pick_split_model(tiles, (int)std::min<long long>(maxs, 256), pl->cus, wgrad_blocks_per_cu(bn));
+        if (g_force_split[2] > 0) want = std::min<long long>(g_force_split[2], std::max<long long>(1, P / 64));
         pl->wgrad_split = (int)std::max<long long>(1, want);
         if (pl->wgrad_split > 1)
             pl->ws_bytes = std::max(pl->ws_bytes, (size_t)pl->wgrad_split * pl->K4_fwd * 4 * g->Cout * 4);
@@ -715,6 +774,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "halo_weights_global")) {
         wdg_halo_set_wg(value);
+        return WDG_OK;
+    }
+    if (key && (!strcmp(key, "force_fwd_split") || !strcmp(key, "force_dgrad_split") || !strcmp(key, "force_wgrad_split"))) {
+        g_force_split[key[6] == 'f' ? 0 : key[6] == 'd' ? 1 : 2] = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "xcd_swizzle")) {
