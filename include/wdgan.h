@@ -148,6 +148,28 @@ int wdg_weight_pack(const float* w_hwio, float* wF, float* wD, int taps, int Cin
 size_t wdg_sn_scratch_floats(int rows, int cols);
 int wdg_sn_power_iter(float* w, float* u, int rows, int cols, float* scratch, wdg_stream stream);
 
+/* Batched weight preparation of one network: what every `training=True` call of a Keras model with
+ * SpectralNormalization wrappers does before its first layer runs (all power iterations + in-place
+ * w <- w / sigma, models.py:33-134 through tfa), plus the refresh of the kernel-layout copies — one
+ * launch per stage for ALL layers instead of five launches per layer.  Per-layer arithmetic and
+ * summation order equal wdg_sn_power_iter / wdg_weight_pack (bit-identical results). */
+typedef struct wdg_prep_layer {
+    float* w;            /* master HWIO weights                                               */
+    float* u;            /* sn_u [cols] (NULL when sn == 0)                                   */
+    float* wF;           /* forward layout copy, or NULL                                      */
+    float* wD;           /* data-gradient layout copy, or NULL (Cout % 4 == 0: master is used) */
+    int32_t rows, cols;  /* SN matrix view of w (cols = last kernel axis)                     */
+    int32_t taps, cin, cout;
+    int32_t sn;          /* 1: layer is wrapped in SpectralNormalization                      */
+} wdg_prep_layer;
+typedef struct wdg_prep_batch wdg_prep_batch;
+#define WDG_PREP_SN 1        /* power iteration + w /= sigma on the SN layers, then repack them */
+#define WDG_PREP_PACK_ALL 2  /* repack every layer (after an optimizer step / weight load)      */
+int wdg_prep_batch_create(wdg_prep_batch** out, const wdg_prep_layer* layers, int n);
+size_t wdg_prep_batch_scratch_floats(const wdg_prep_batch* b);
+int wdg_prep_batch_run(const wdg_prep_batch* b, float* scratch, int flags, wdg_stream stream);
+int wdg_prep_batch_destroy(wdg_prep_batch* b);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNormalization (axis -1, eps 1e-3, momentum 0.99) over P = B*T*H*W pixels.   models.py:34,40,50,56,69
  * Statistics are accumulated in fp64 so the SyncBN all-reduce can be inserted between

@@ -191,6 +191,19 @@ class TorchOps:
         else:
             dw.copy_(gw)
 
+    def make_prep_batch(self, entries):
+        """Restatement of HipOps.make_prep_batch: layer by layer (the batching is a launch-count optimisation)."""
+        ops = self
+
+        class _Batch:
+            def run(self, sn, pack_all):
+                for pk, u in entries:
+                    if sn and u is not None:
+                        ops.sn_power_iter(pk.w.view(-1, pk.cout), u.view(-1))
+                    if pack_all or (sn and u is not None):
+                        pk.refresh()
+        return _Batch()
+
     def sn_power_iter(self, w2d, u):
         # tfa.layers.SpectralNormalization.normalize_weights, power_iterations=1
         def l2n(v):

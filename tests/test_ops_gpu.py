@@ -229,6 +229,39 @@ def test_sn_power_iter(hip_ops, ref_ops):
         assert rel_err(w_g, w) < TOL and rel_err(u_g, u) < TOL, (rows, cols)
 
 
+def test_prep_batch_equals_layerwise(hip_ops):
+    """The batched network preparation (all SN power iterations + repacks in one launch per stage) is
+    bit-identical to the layer-by-layer entry points, for SN and plain layers, Cout % 4 != 0 included."""
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(8, 8, 23, 128, True), (3, 3, 16, 2, False), (7, 7, 64, 128, True), (2, 2, 32, 192, True),
+              (3, 3, 5, 64, False), (3, 3, 2, 16, True)]
+    dev = hip_ops.device
+    ws = [(torch.randn(kh, kw, ci, co, generator=gen) * 0.05).to(dev) for kh, kw, ci, co, _ in shapes]
+    us = [(torch.randn(co, generator=gen) * 0.02).to(dev) if sn else None for _, _, _, co, sn in shapes]
+    wa, ua = [w.clone() for w in ws], [None if u is None else u.clone() for u in us]
+    pka = [hip_ops.pack_weights(w) for w in wa]
+    pkb = [hip_ops.pack_weights(w) for w in ws]
+    batch = hip_ops.make_prep_batch(list(zip(pkb, us)))
+    for _ in range(2):
+        for pk, u in zip(pka, ua):          # layer by layer
+            if u is not None:
+                hip_ops.sn_power_iter(pk.w.view(-1, pk.cout), u)
+                pk.refresh()
+        batch.run(sn=True, pack_all=False)
+    for pk_a, pk_b, u_a, u_b in zip(pka, pkb, ua, us):
+        assert torch.equal(pk_a.w, pk_b.w) and torch.equal(pk_a.wF, pk_b.wF) and torch.equal(pk_a.wD, pk_b.wD)
+        if u_a is not None:
+            assert torch.equal(u_a, u_b)
+    # optimizer-step path: masters change, everything is repacked, no SN
+    for pk_a, pk_b in zip(pka, pkb):
+        pk_a.w.mul_(1.5)
+        pk_b.w.mul_(1.5)
+        pk_a.refresh()
+    batch.run(sn=False, pack_all=True)
+    for pk_a, pk_b in zip(pka, pkb):
+        assert torch.equal(pk_a.wF, pk_b.wF) and torch.equal(pk_a.wD, pk_b.wD)
+
+
 @pytest.mark.parametrize("C,P", [(128, 5000), (64, 777), (32, 4096), (16, 70000)])
 def test_batchnorm(C, P, hip_ops, ref_ops):
     gen = torch.Generator().manual_seed(2)

@@ -8,6 +8,7 @@
 #include "common.h"
 #include <algorithm>
 #include <stdarg.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 void wdg_set_error(const char* fmt, ...) {
@@ -20,15 +21,14 @@ extern "C" const char* wdg_last_error(void) { return g_err; }
 extern "C" const char* wdg_version(void) { return "wdgan 0.1 gfx950"; }
 
 // ---- SN step 1: vraw[r] = <u, W[r,:]>, per-block partial sum of squares ---------------------------
-__global__ void __launch_bounds__(256) wdg_sn_rowdot_kernel(const float* __restrict__ w,
-                                                            const float* __restrict__ u, int rows, int cols,
-                                                            float* vraw, float* part1) {
+__device__ __forceinline__ void wdg_sn_rowdot_block(int blk, const float* __restrict__ w, const float* __restrict__ u,
+                                                    int rows, int cols, float* vraw, float* part1) {
     __shared__ float red[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float sq = 0.f;
-    // each wave owns rows blockIdx.x*32 + wave*8 .. +8
+    // each wave owns rows blk*32 + wave*8 .. +8
     for (int i = 0; i < 8; ++i) {
-        const int r = blockIdx.x * 32 + wave * 8 + i;
+        const int r = blk * 32 + wave * 8 + i;
         if (r >= rows) break;
         float s = 0.f;
         for (int c = lane; c < cols; c += 64) s += u[c] * w[(size_t)r * cols + c];
@@ -40,14 +40,13 @@ __global__ void __launch_bounds__(256) wdg_sn_rowdot_kernel(const float* __restr
     }
     if (lane == 0) red[wave] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) part1[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) part1[blk] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---- SN step 2: per 64-row chunk, part2[chunk][c] = sum_r v[r] W[r][c] ----------------------------
-__global__ void __launch_bounds__(256) wdg_sn_colpart_kernel(const float* __restrict__ w,
-                                                             const float* __restrict__ vraw,
-                                                             const float* __restrict__ part1, int nb1, int rows,
-                                                             int cols, float* part2) {
+__device__ __forceinline__ void wdg_sn_colpart_block(int blk, const float* __restrict__ w, const float* __restrict__ vraw,
+                                                     const float* __restrict__ part1, int nb1, int rows, int cols,
+                                                     float* part2) {
     __shared__ float vs[64];
     __shared__ float s_scale;
     if (threadIdx.x == 0) {
@@ -56,20 +55,20 @@ __global__ void __launch_bounds__(256) wdg_sn_colpart_kernel(const float* __rest
         s_scale = 1.f / sqrtf(fmaxf(n2, 1e-12f));      // tf.math.l2_normalize
     }
     __syncthreads();
-    const int r0 = blockIdx.x * 64;
+    const int r0 = blk * 64;
     if (threadIdx.x < 64) vs[threadIdx.x] = (r0 + threadIdx.x < rows) ? vraw[r0 + threadIdx.x] * s_scale : 0.f;
     __syncthreads();
     const int nr = min(64, rows - r0);
     for (int c = threadIdx.x; c < cols; c += 256) {
         float s = 0.f;
         for (int r = 0; r < nr; ++r) s += vs[r] * w[(size_t)(r0 + r) * cols + c];
-        part2[(size_t)blockIdx.x * cols + c] = s;
+        part2[(size_t)blk * cols + c] = s;
     }
 }
 
-// ---- SN step 3 (one block): u_raw, its norm, sigma; writes u and 1/sigma -------------------------
-__global__ void __launch_bounds__(1024) wdg_sn_finish_kernel(const float* __restrict__ part2, int nchunks,
-                                                             int cols, float* u, float* inv_sigma) {
+// ---- SN step 3 (one block of 1024): u_raw, its norm, sigma; writes u and 1/sigma ------------------
+__device__ __forceinline__ void wdg_sn_finish_block(const float* __restrict__ part2, int nchunks, int cols, float* u,
+                                                    float* inv_sigma) {
     __shared__ float red[1024];
     __shared__ float s_norm2;
     // each thread owns columns t, t+1024, ...
@@ -93,6 +92,22 @@ __global__ void __launch_bounds__(1024) wdg_sn_finish_kernel(const float* __rest
     for (int c = threadIdx.x; c < cols; c += 1024) u[c] = u[c] * sc;
     // sigma = <u_raw, u_new> = n2 * sc
     if (threadIdx.x == 0) inv_sigma[0] = 1.f / (n2 * sc);
+}
+
+__global__ void __launch_bounds__(256) wdg_sn_rowdot_kernel(const float* __restrict__ w,
+                                                            const float* __restrict__ u, int rows, int cols,
+                                                            float* vraw, float* part1) {
+    wdg_sn_rowdot_block(blockIdx.x, w, u, rows, cols, vraw, part1);
+}
+__global__ void __launch_bounds__(256) wdg_sn_colpart_kernel(const float* __restrict__ w,
+                                                             const float* __restrict__ vraw,
+                                                             const float* __restrict__ part1, int nb1, int rows,
+                                                             int cols, float* part2) {
+    wdg_sn_colpart_block(blockIdx.x, w, vraw, part1, nb1, rows, cols, part2);
+}
+__global__ void __launch_bounds__(1024) wdg_sn_finish_kernel(const float* __restrict__ part2, int nchunks,
+                                                             int cols, float* u, float* inv_sigma) {
+    wdg_sn_finish_block(part2, nchunks, cols, u, inv_sigma);
 }
 
 __global__ void __launch_bounds__(256) wdg_scale_inplace_kernel(float* w, int64_t n, const float* __restrict__ s) {
@@ -124,6 +139,176 @@ extern "C" int wdg_sn_power_iter(float* w, float* u, int rows, int cols, float* 
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096));
     hipLaunchKernelGGL(wdg_scale_inplace_kernel, dim3(blocks), dim3(256), 0, st, w, n, inv_sigma);
     WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- Batched weight preparation of one network ----------------------------------------------------
+// Every training-mode forward of the reference first runs the SN power iteration of ALL its wrapped layers
+// (w <- w / sigma, u updated in place) and then needs the kernel-layout copies of the changed weights.  Layer
+// by layer that is 5 tiny launches per layer (~400 per train step, a third of all launches, each followed by
+// the ~5 us inter-kernel drain).  A batch object holds the layer table on the device; one launch per STAGE
+// covers all layers (blockIdx -> layer through block-offset prefixes).  Per-layer arithmetic and summation
+// order are exactly those of wdg_sn_power_iter, so results are bit-identical to the layer-by-layer path and
+// across data-parallel ranks.
+struct WdgPrepLayer {
+    float* w;
+    float* u;
+    float* wF;
+    float* wD;
+    long long s_off;        // scratch offset of this layer (floats)
+    int rows, cols;         // SN matrix view
+    int taps, cin, cout;    // packing geometry
+    int sn;
+    int nb1, nchunks;
+    int b1, b2, b3, b4, b5; // first block of this layer in the rowdot / colpart / finish / scale / pack grids
+    int nb4, nb5;
+};
+struct wdg_prep_batch {
+    std::vector<WdgPrepLayer> h;
+    WdgPrepLayer* d = nullptr;
+    int n = 0, n_sn = 0;
+    int g1 = 0, g2 = 0, g4 = 0;      // SN-stage grids (SN layers are sorted first)
+    int g5_sn = 0, g5_all = 0;       // pack grids: SN layers only / every layer
+    size_t scratch_floats = 0;
+};
+
+__device__ __forceinline__ int wdg_prep_find(const WdgPrepLayer* L, int n, int blk, int which) {
+    int l = 0;
+    for (int i = 1; i < n; ++i) {
+        const int b = which == 1 ? L[i].b1 : which == 2 ? L[i].b2 : which == 4 ? L[i].b4 : L[i].b5;
+        if (blk >= b) l = i;
+    }
+    return l;
+}
+
+__global__ void __launch_bounds__(256) wdg_prep_rowdot_kernel(const WdgPrepLayer* __restrict__ L, int n, float* scratch) {
+    const int l = wdg_prep_find(L, n, blockIdx.x, 1);
+    const WdgPrepLayer q = L[l];
+    float* vraw = scratch + q.s_off;
+    wdg_sn_rowdot_block(blockIdx.x - q.b1, q.w, q.u, q.rows, q.cols, vraw, vraw + q.rows);
+}
+__global__ void __launch_bounds__(256) wdg_prep_colpart_kernel(const WdgPrepLayer* __restrict__ L, int n, float* scratch) {
+    const int l = wdg_prep_find(L, n, blockIdx.x, 2);
+    const WdgPrepLayer q = L[l];
+    float* vraw = scratch + q.s_off;
+    float* part1 = vraw + q.rows;
+    wdg_sn_colpart_block(blockIdx.x - q.b2, q.w, vraw, part1, q.nb1, q.rows, q.cols, part1 + q.nb1);
+}
+__global__ void __launch_bounds__(1024) wdg_prep_finish_kernel(const WdgPrepLayer* __restrict__ L, float* scratch) {
+    const WdgPrepLayer q = L[blockIdx.x];
+    float* part2 = scratch + q.s_off + q.rows + q.nb1;
+    wdg_sn_finish_block(part2, q.nchunks, q.cols, q.u, part2 + (size_t)q.nchunks * q.cols);
+}
+__global__ void __launch_bounds__(256) wdg_prep_scale_kernel(const WdgPrepLayer* __restrict__ L, int n, const float* scratch) {
+    const int l = wdg_prep_find(L, n, blockIdx.x, 4);
+    const WdgPrepLayer q = L[l];
+    const float k = scratch[q.s_off + q.rows + q.nb1 + (size_t)q.nchunks * q.cols];
+    const long long tot = (long long)q.rows * q.cols;
+    for (long long i = (long long)(blockIdx.x - q.b4) * 256 + threadIdx.x; i < tot; i += (long long)q.nb4 * 256) q.w[i] *= k;
+}
+// master HWIO -> wF [Cout][taps][Cin_p] and wD [taps][Cin][Cout_p] (same maps as wdg_weight_pack_kernel)
+__global__ void __launch_bounds__(256) wdg_prep_pack_kernel(const WdgPrepLayer* __restrict__ L, int n) {
+    const int l = wdg_prep_find(L, n, blockIdx.x, 5);
+    const WdgPrepLayer q = L[l];
+    const int Cin_p = (q.cin + 3) & ~3, Cout_p = (q.cout + 3) & ~3;
+    const long long nF = q.wF ? (long long)q.cout * q.taps * Cin_p : 0;
+    const long long nD = q.wD ? (long long)q.taps * q.cin * Cout_p : 0;
+    for (long long idx = (long long)(blockIdx.x - q.b5) * 256 + threadIdx.x; idx < nF + nD; idx += (long long)q.nb5 * 256) {
+        if (idx < nF) {
+            const int ci = (int)(idx % Cin_p);
+            const long long r = idx / Cin_p;
+            const int tap = (int)(r % q.taps);
+            const int co = (int)(r / q.taps);
+            q.wF[idx] = ci < q.cin ? q.w[((long long)tap * q.cin + ci) * q.cout + co] : 0.f;
+        } else {
+            const long long j = idx - nF;
+            const int co = (int)(j % Cout_p);
+            const long long r = j / Cout_p;  // tap*Cin + ci
+            q.wD[j] = co < q.cout ? q.w[r * q.cout + co] : 0.f;
+        }
+    }
+}
+
+extern "C" int wdg_prep_batch_create(wdg_prep_batch** out, const wdg_prep_layer* layers, int n) {
+    WDG_CHECK_ARG(out && layers && n > 0 && n <= 64, "bad argument");
+    wdg_prep_batch* b = new wdg_prep_batch();
+    // SN layers first (the SN stages index only them), original order otherwise
+    std::vector<int> order;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < n; ++i)
+            if ((layers[i].sn != 0) == (pass == 0)) order.push_back(i);
+    long long soff = 0;
+    int b1 = 0, b2 = 0, b4 = 0, b5 = 0;
+    for (int idx : order) {
+        const wdg_prep_layer& s = layers[idx];
+        if (!s.w || s.taps <= 0 || s.cin <= 0 || s.cout <= 0 || (s.sn && (!s.u || s.rows <= 0 || s.cols <= 0))) {
+            delete b;
+            wdg_set_error("wdg_prep_batch_create: bad layer %d", idx);
+            return WDG_ERR_ARG;
+        }
+        WdgPrepLayer q;
+        memset(&q, 0, sizeof(q));
+        q.w = s.w; q.u = s.u; q.wF = s.wF; q.wD = s.wD;
+        q.rows = s.rows; q.cols = s.cols; q.taps = s.taps; q.cin = s.cin; q.cout = s.cout; q.sn = s.sn != 0;
+        q.s_off = soff;
+        q.b1 = b1; q.b2 = b2; q.b3 = b->n_sn; q.b4 = b4; q.b5 = b5;
+        if (q.sn) {
+            q.nb1 = (q.rows + 31) / 32;
+            q.nchunks = (q.rows + 63) / 64;
+            const long long tot = (long long)q.rows * q.cols;
+            q.nb4 = (int)std::max<long long>(1, std::min<long long>((tot + 1023) / 1024, 512));
+            soff += (long long)wdg_sn_scratch_floats(q.rows, q.cols);
+            b1 += q.nb1; b2 += q.nchunks; b4 += q.nb4;
+            b->n_sn++;
+        }
+        const long long Cin_p = (q.cin + 3) & ~3, Cout_p = (q.cout + 3) & ~3;
+        const long long np = (q.wF ? (long long)q.cout * q.taps * Cin_p : 0) + (q.wD ? (long long)q.taps * q.cin * Cout_p : 0);
+        q.nb5 = np ? (int)std::max<long long>(1, std::min<long long>((np + 1023) / 1024, 512)) : 0;
+        b5 += q.nb5;
+        if (q.sn) b->g5_sn = b5;
+        b->h.push_back(q);
+    }
+    b->n = n;
+    b->g1 = b1; b->g2 = b2; b->g4 = b4; b->g5_all = b5;
+    b->scratch_floats = (size_t)soff + 8;
+    if (hipMalloc((void**)&b->d, sizeof(WdgPrepLayer) * n) != hipSuccess ||
+        hipMemcpy(b->d, b->h.data(), sizeof(WdgPrepLayer) * n, hipMemcpyHostToDevice) != hipSuccess) {
+        delete b;
+        wdg_set_error("wdg_prep_batch_create: device allocation failed");
+        return WDG_ERR_HIP;
+    }
+    *out = b;
+    return WDG_OK;
+}
+
+extern "C" size_t wdg_prep_batch_scratch_floats(const wdg_prep_batch* b) { return b ? b->scratch_floats : 0; }
+
+extern "C" int wdg_prep_batch_destroy(wdg_prep_batch* b) {
+    if (!b) return WDG_OK;
+    if (b->d) (void)hipFree(b->d);
+    delete b;
+    return WDG_OK;
+}
+
+// flags: WDG_PREP_SN = power iteration + in-place w / sigma on the SN layers, then repack them;
+//        WDG_PREP_PACK_ALL = repack every layer (after an optimizer step or a weight load).
+extern "C" int wdg_prep_batch_run(const wdg_prep_batch* b, float* scratch, int flags, wdg_stream stream) {
+    WDG_CHECK_ARG(b, "null batch");
+    hipStream_t st = (hipStream_t)stream;
+    const bool sn = (flags & WDG_PREP_SN) && b->n_sn > 0;
+    if (sn) {
+        WDG_CHECK_ARG(scratch, "scratch required");
+        hipLaunchKernelGGL(wdg_prep_rowdot_kernel, dim3(b->g1), dim3(256), 0, st, b->d, b->n_sn, scratch);
+        hipLaunchKernelGGL(wdg_prep_colpart_kernel, dim3(b->g2), dim3(256), 0, st, b->d, b->n_sn, scratch);
+        hipLaunchKernelGGL(wdg_prep_finish_kernel, dim3(b->n_sn), dim3(1024), 0, st, b->d, scratch);
+        hipLaunchKernelGGL(wdg_prep_scale_kernel, dim3(b->g4), dim3(256), 0, st, b->d, b->n_sn, scratch);
+        WDG_LAUNCH_CHECK();
+    }
+    const int g5 = (flags & WDG_PREP_PACK_ALL) ? b->g5_all : (sn ? b->g5_sn : 0);
+    if (g5 > 0) {
+        hipLaunchKernelGGL(wdg_prep_pack_kernel, dim3(g5), dim3(256), 0, st, b->d, (flags & WDG_PREP_PACK_ALL) ? b->n : b->n_sn);
+        WDG_LAUNCH_CHECK();
+    }
     return WDG_OK;
 }
 

@@ -77,6 +77,36 @@ class PackedWeights:
                                          self.taps, self.cin, self.cout, self.ops.stream), "weight_pack")
 
 
+class _PrepBatch:
+    def __init__(self, ops, entries):
+        self.ops, self.entries = ops, entries
+        arr = (native.PrepLayer * len(entries))()
+        for i, (pk, u) in enumerate(entries):
+            kh_kw_cin, cout = pk.w.numel() // pk.cout, pk.cout
+            arr[i] = native.PrepLayer(pk.w.data_ptr(), _ptr(u), pk.wF.data_ptr(), 0 if pk.wD is pk.w else pk.wD.data_ptr(),
+                                      kh_kw_cin, cout, pk.taps, pk.cin, pk.cout, int(u is not None))
+        self.handle = C.c_void_p()
+        native.check(ops.lib.wdg_prep_batch_create(C.byref(self.handle), arr, len(entries)), "prep_batch_create")
+        self.scratch = ops.empty(max(int(ops.lib.wdg_prep_batch_scratch_floats(self.handle)), 4))
+        self.any_sn = any(u is not None for _, u in entries)
+
+    def run(self, sn, pack_all):
+        flags = (native.PREP_SN if sn and self.any_sn else 0) | (native.PREP_PACK_ALL if pack_all else 0)
+        if not flags:
+            return
+        native.check(self.ops.lib.wdg_prep_batch_run(self.handle, self.scratch.data_ptr(), flags, self.ops.stream),
+                     "prep_batch_run")
+        for pk, u in self.entries:
+            if pack_all or (sn and u is not None):
+                pk._bf16_stale = True
+
+    def __del__(self):
+        try:
+            self.ops.lib.wdg_prep_batch_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class HipOps:
     name = "hip"
     dtype = torch.float32
@@ -217,6 +247,11 @@ class HipOps:
             self._sn_scratch = self.empty(max(need, 1 << 16))
         native.check(self.lib.wdg_sn_power_iter(w2d.data_ptr(), u.data_ptr(), rows, cols,
                                                 self._sn_scratch.data_ptr(), self.stream), "sn_power_iter")
+
+    def make_prep_batch(self, entries):
+        """entries: [(PackedWeights, u or None)] of one network -> object with run(sn, pack_all): all spectral-norm
+        power iterations and all weight repacks of the network in one launch per stage."""
+        return _PrepBatch(self, entries)
 
     # ---- batch norm -------------------------------------------------------------------------
     def bn_stats(self, x, stats):

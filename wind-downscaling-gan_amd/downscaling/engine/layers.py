@@ -36,21 +36,13 @@ class Conv:
         self.b = store.add(bname, (cin if transposed else cout,), P.zeros_init)
         self.u = store.add(f"{name}/{prefix}/sn_u", (1, cout), P.sn_u_init, trainable=False) if sn else None
         self.pk = None
-        self._packed_version = -1
 
     def build(self):
         self.pk = self.ops.pack_weights(self.w.value)
-        self._packed_version = self.net.params.version
 
-    def prepare(self, training):
-        """SN power iteration (training only, in place on w and u) and refresh of the packed copies."""
-        if self.sn and training:
-            self.ops.sn_power_iter(self.w.value.view(-1, self.cout), self.u.value.view(-1))
-            self.pk.refresh()
-            self._packed_version = self.net.params.version
-        elif self._packed_version != self.net.params.version:
-            self.pk.refresh()
-            self._packed_version = self.net.params.version
+    def prep_entries(self):
+        """(packed weights, sn_u or None) for the network's batched SN / repack stage (_Net._prepare)."""
+        return [(self.pk, self.u.value.view(-1) if self.sn else None)]
 
     def forward(self, x, y):
         if self.transposed:
@@ -173,20 +165,15 @@ class ConvLSTM:
         self.wh = st.add(f"{name}/cell/recurrent_kernel", (3, 3, F, 4 * F), P.orthogonal)
         self.b = st.add(f"{name}/cell/bias", (4 * F,), P.lstm_bias(F))
         self.g = ConvGeom(3, 3, 1, 1)
-        self._packed_version = -1
 
     def build(self):
         self.pkx = self.ops.pack_weights(self.wx.value)
         self.pkh = self.ops.pack_weights(self.wh.value)
-        self._packed_version = self.net.params.version
         self._shape = None
         self._pk_i = None
 
-    def prepare(self, training):
-        if self._packed_version != self.net.params.version:
-            self.pkx.refresh()
-            self.pkh.refresh()
-            self._packed_version = self.net.params.version
+    def prep_entries(self):
+        return [(self.pkx, None), (self.pkh, None)]
 
     def _buffers(self, N, H, W):
         if self._shape != (N, H, W):

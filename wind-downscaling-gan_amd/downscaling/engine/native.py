@@ -21,6 +21,15 @@ class ConvGeom(C.Structure):
     ]
 
 
+class PrepLayer(C.Structure):
+    _fields_ = [
+        ("w", c_fp), ("u", c_fp), ("wF", c_fp), ("wD", c_fp),
+        ("rows", i32), ("cols", i32), ("taps", i32), ("cin", i32), ("cout", i32), ("sn", i32),
+    ]
+
+
+PREP_SN, PREP_PACK_ALL = 1, 2
+
 # name -> (restype, argtypes); every symbol of include/wdgan.h
 SIGNATURES = {
     "wdg_last_error": (C.c_char_p, []),
@@ -43,6 +52,10 @@ SIGNATURES = {
     "wdg_weight_pack": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
     "wdg_sn_scratch_floats": (szt, [i32, i32]),
     "wdg_sn_power_iter": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp]),
+    "wdg_prep_batch_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(PrepLayer), i32]),
+    "wdg_prep_batch_scratch_floats": (szt, [C.c_void_p]),
+    "wdg_prep_batch_run": (i32, [C.c_void_p, c_fp, i32, c_fp]),
+    "wdg_prep_batch_destroy": (i32, [C.c_void_p]),
     "wdg_bn_stats": (i32, [c_fp, i64, i32, i32, c_fp, c_fp]),
     "wdg_bn_finalize_train": (i32, [c_fp, f64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, c_fp, i32, c_fp]),
     "wdg_bn_finalize_infer": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),

@@ -19,6 +19,8 @@ class _Net:
         self.params = ParamStore(ops)
         self._layers = []
         self._bufs = {}
+        self._prep = None
+        self._packed_version = -1
 
     def _add(self, layer):
         self._layers.append(layer)
@@ -29,11 +31,20 @@ class _Net:
         for l in self._layers:
             if hasattr(l, "build"):
                 l.build()
+        self._packed_version = self.params.version
 
     def _prepare(self, training):
-        for l in self._layers:
-            if hasattr(l, "prepare"):
-                l.prepare(training)
+        """What a Keras call does before the first layer runs: SN power iteration of every wrapped layer
+        (training only: w <- w / sigma and u in place, tfa SpectralNormalization) and refresh of the
+        kernel-layout weight copies that are stale — batched over the whole network."""
+        if self._prep is None:
+            entries = []
+            for l in self._layers:
+                if hasattr(l, "prep_entries"):
+                    entries += l.prep_entries()
+            self._prep = self.ops.make_prep_batch(entries)
+        self._prep.run(sn=training, pack_all=self._packed_version != self.params.version)
+        self._packed_version = self.params.version
 
     # ---- [B,T,...] <-> time-major ---------------------------------------------------------------
     def to_time_major(self, src, dst):
