@@ -15,7 +15,26 @@
 #include "common.h"
 #include <algorithm>
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two features per instruction: v_pk_fma_f32 (x broadcast to both halves, weights as an SGPR pair) doubles the
+// fp32 FMA rate of the vector unit
+__device__ __forceinline__ f32x2 cl_pk_fma(float x, f32x2 w, f32x2 acc) {
+    return __builtin_elementwise_fma((f32x2){x, x}, w, acc);
+}
+
 constexpr int CL_TH = 4, CL_TW = 32;   // backward tile: 128 centre pixels, 2 threads (feature halves) per pixel
+
+// tanh in ~12 branch-free instructions (ocml's tanhf is ~35 with a divergent range split, and the cell evaluates two
+// per feature): |x| < 0.1: odd Taylor polynomial to x^7 (rel. error < 3e-10); otherwise (1 - e) / (1 + e) with
+// e = exp(-2|x|) <= 0.82 through v_exp_f32 / v_rcp_f32 (rel. error < 5e-7, no cancellation).
+__device__ __forceinline__ float cl_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float e = __expf(-2.f * ax);
+    const float big = copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
+    return ax < 0.1f ? poly : big;
+}
 
 __device__ __forceinline__ float cl_hsig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); }
 __device__ __forceinline__ float cl_hsig_grad(float x) {
@@ -72,11 +91,20 @@ __device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const flo
                     const int c = 4 * c4 + j;
                     if (c < CIN) {
                         const float* w = Wx + (tap * CIN + c) * 4 * F + f0;
+                        if constexpr (FH % 2 == 0) {
 #pragma unroll
-                        for (int f = 0; f < FH; ++f) {
-                            gi[f] = fmaf(cur[c4][j], w[f], gi[f]);
-                            gc[f] = fmaf(cur[c4][j], w[2 * F + f], gc[f]);
-                            go[f] = fmaf(cur[c4][j], w[3 * F + f], go[f]);
+                            for (int f = 0; f < FH; f += 2) {
+                                *(f32x2*)&gi[f] = cl_pk_fma(cur[c4][j], *(const f32x2*)&w[f], *(f32x2*)&gi[f]);
+                                *(f32x2*)&gc[f] = cl_pk_fma(cur[c4][j], *(const f32x2*)&w[2 * F + f], *(f32x2*)&gc[f]);
+                                *(f32x2*)&go[f] = cl_pk_fma(cur[c4][j], *(const f32x2*)&w[3 * F + f], *(f32x2*)&go[f]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int f = 0; f < FH; ++f) {
+                                gi[f] = fmaf(cur[c4][j], w[f], gi[f]);
+                                gc[f] = fmaf(cur[c4][j], w[2 * F + f], gc[f]);
+                                go[f] = fmaf(cur[c4][j], w[3 * F + f], go[f]);
+                            }
                         }
                     }
                 }
@@ -93,11 +121,20 @@ __device__ __forceinline__ void cl_gates(const float* __restrict__ Wx, const flo
                 const int c = 4 * c4 + j;
                 if (c < CIN) {
                     const float* w = Wx + (tap * CIN + c) * 4 * F + f0;   // wave-uniform address -> scalar loads
+                    if constexpr (FH % 2 == 0) {
 #pragma unroll
-                    for (int f = 0; f < FH; ++f) {
-                        gi[f] = fmaf(xv[j], w[f], gi[f]);
-                        gc[f] = fmaf(xv[j], w[2 * F + f], gc[f]);
-                        go[f] = fmaf(xv[j], w[3 * F + f], go[f]);
+                        for (int f = 0; f < FH; f += 2) {
+                            *(f32x2*)&gi[f] = cl_pk_fma(xv[j], *(const f32x2*)&w[f], *(f32x2*)&gi[f]);
+                            *(f32x2*)&gc[f] = cl_pk_fma(xv[j], *(const f32x2*)&w[2 * F + f], *(f32x2*)&gc[f]);
+                            *(f32x2*)&go[f] = cl_pk_fma(xv[j], *(const f32x2*)&w[3 * F + f], *(f32x2*)&go[f]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < FH; ++f) {
+                            gi[f] = fmaf(xv[j], w[f], gi[f]);
+                            gc[f] = fmaf(xv[j], w[2 * F + f], gc[f]);
+                            go[f] = fmaf(xv[j], w[3 * F + f], go[f]);
+                        }
                     }
                 }
             }
@@ -125,11 +162,11 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
             return *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4);
         return (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    float gi[FH], gc[FH], go[FH];
+    __attribute__((aligned(8))) float gi[FH], gc[FH], go[FH];
     cl_gates<CIN, F, FH, true>(Wx, bias, f0, load, gi, gc, go);
     float* hp = p.Hout + (long long)img * p.imgStrideH + ((long long)oy * p.W + ox) * p.ldh + f0;
 #pragma unroll
-    for (int f = 0; f < FH; ++f) hp[f] = cl_hsig(go[f]) * tanhf(cl_hsig(gi[f]) * tanhf(gc[f]));
+    for (int f = 0; f < FH; ++f) hp[f] = cl_hsig(go[f]) * cl_tanh(cl_hsig(gi[f]) * cl_tanh(gc[f]));
 }
 
 // ---- backward: 4x32 centre tile; dgates recomputed on the 6x34 halo into LDS, dx gathered from it --------
@@ -182,14 +219,14 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
             for (int f = 0; f < FH; ++f) dgi[f] = dgc[f] = dgo[f] = 0.f;
             if (inside) {
                 auto load = [&](int th, int tw, int c4) -> f32x4 { return xs[((hy + th) * XW + hx + tw) * C4 + c4]; };
-                float gi[FH], gc[FH], go[FH];
+                __attribute__((aligned(8))) float gi[FH], gc[FH], go[FH];
                 cl_gates<CIN, F, FH, false>(Wx, bias, f0, load, gi, gc, go);
                 const float* dhp = DHimg + ((long long)gy * p.W + gx) * p.lddh + f0;
 #pragma unroll
                 for (int f = 0; f < FH; ++f) {
-                    const float si = cl_hsig(gi[f]), tc_ = tanhf(gc[f]), so = cl_hsig(go[f]);
+                    const float si = cl_hsig(gi[f]), tc_ = cl_tanh(gc[f]), so = cl_hsig(go[f]);
                     const float c = si * tc_;
-                    const float th = tanhf(c);
+                    const float th = cl_tanh(c);
                     const float dh = dhp[f];
                     const float dc = dh * so * (1.f - th * th);
                     dgi[f] = dc * tc_ * cl_hsig_grad(gi[f]);
@@ -226,11 +263,14 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
 #pragma unroll
     for (int c = 0; c < CIN; ++c) dx[c] = 0.f;
     if (half_on) {
+        f32x2 dx2[CIN];   // packed partial sums over even / odd features
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dx2[c] = (f32x2){0.f, 0.f};
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int th = tap / 3, tw = tap % 3;
             const float* dgp = &dgs[((py + 2 - th) * GW + px + 2 - tw) * G3 + f0];
-            float v[3][FH];
+            __attribute__((aligned(8))) float v[3][FH];
 #pragma unroll
             for (int f = 0; f < FH; ++f) {
                 v[0][f] = dgp[f];
@@ -240,14 +280,25 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
                 const float* w = Wx + (tap * CIN + c) * 4 * F + f0;
+                if constexpr (FH % 2 == 0) {
 #pragma unroll
-                for (int f = 0; f < FH; ++f) {
-                    dx[c] = fmaf(v[0][f], w[f], dx[c]);
-                    dx[c] = fmaf(v[1][f], w[2 * F + f], dx[c]);
-                    dx[c] = fmaf(v[2][f], w[3 * F + f], dx[c]);
+                    for (int f = 0; f < FH; f += 2) {
+                        dx2[c] = __builtin_elementwise_fma(*(const f32x2*)&v[0][f], *(const f32x2*)&w[f], dx2[c]);
+                        dx2[c] = __builtin_elementwise_fma(*(const f32x2*)&v[1][f], *(const f32x2*)&w[2 * F + f], dx2[c]);
+                        dx2[c] = __builtin_elementwise_fma(*(const f32x2*)&v[2][f], *(const f32x2*)&w[3 * F + f], dx2[c]);
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < FH; ++f) {
+                        dx[c] = fmaf(v[0][f], w[f], dx[c]);
+                        dx[c] = fmaf(v[1][f], w[2 * F + f], dx[c]);
+                        dx[c] = fmaf(v[2][f], w[3 * F + f], dx[c]);
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dx[c] += dx2[c][0] + dx2[c][1];
     }
     if (half == 1) {
 #pragma unroll
