@@ -132,6 +132,10 @@ int wdg_upconv_fwd_bf16(const wdg_conv_plan* plan, const float* x_low, int ld_lo
 /* dw[kh][kw][Cin][Cout] (+)= sum_pixels x (*) dy  — HWIO, the master layout.   ganbase.py:46,60 */
 int wdg_conv_wgrad(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw,
                    int accumulate, void* ws, size_t ws_bytes, wdg_stream stream);
+/* Same, plus the bias gradient dbias[Cout] += sum_pixels dy (always accumulated; NULL to skip): the
+ * ConvLSTM2D kernel/bias gradients of models.py:93,101 in one pass over dgates. */
+int wdg_conv_wgrad_bias(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw, float* dbias,
+                        int accumulate, void* ws, size_t ws_bytes, wdg_stream stream);
 
 /* Repack master HWIO weights into the two kernel layouts.
  * wD may be NULL when Cout%4==0 (the master is then used directly as wD). */

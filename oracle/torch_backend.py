@@ -181,7 +181,7 @@ class TorchOps:
         self.upsample2x_fwd(x_low, up)
         self.conv_dgrad(up, pk, y, g, bias=bias, act=act, slope=slope)
 
-    def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True):
+    def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True, dbias=None):
         xin = x[..., :pk.cin].permute(0, 3, 1, 2).contiguous()
         gout = dy[..., :pk.cout].permute(0, 3, 1, 2).contiguous()
         gw = torch.nn.grad.conv2d_weight(xin, (pk.cout, pk.cin, g.kh, g.kw), gout, stride=g.stride, padding=g.pad)
@@ -190,6 +190,8 @@ class TorchOps:
             dw += gw
         else:
             dw.copy_(gw)
+        if dbias is not None:   # bias gradient of the same layer (always accumulated)
+            dbias += dy[..., :pk.cout].reshape(-1, pk.cout).sum(0)
 
     def make_prep_batch(self, entries):
         """Restatement of HipOps.make_prep_batch: layer by layer (the batching is a launch-count optimisation)."""

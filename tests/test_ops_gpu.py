@@ -50,6 +50,11 @@ CONV_CASES = [
     ("halo_5x5_8to16", 4, 128, 128, 8, 16, 5, 1, 2),
     ("halo_3x3_12to24", 4, 128, 132, 12, 24, 3, 1, 1),
     ("n160_tile32", 2, 24, 24, 16, 160, 5, 1, 2),
+    # thin 3x3 weight-gradient kernel: ragged tile edges, every built row-tile count, 32 output channels
+    ("thin_3to32", 3, 150, 150, 3, 32, 3, 1, 1),
+    ("thin_4to8", 3, 150, 151, 4, 8, 3, 1, 1),
+    ("thin_8to16", 3, 149, 150, 8, 16, 3, 1, 1),
+    ("thin_1to4", 5, 120, 130, 1, 4, 3, 1, 1),
 ]
 
 
@@ -112,6 +117,13 @@ def test_conv_fwd_dgrad_wgrad(case, hip_ops, ref_ops):
     ref_ops.conv_wgrad(d["x"], d["dy"], pk_r, dw_r, rg, accumulate=True)
     hip_ops.conv_wgrad(x_g, dy_g, pk_g, dw_g, g, accumulate=True)
     assert rel_err(dw_g, dw_r) < TOL, "wgrad accumulate"
+    # weight + bias gradient in one call (thin 3x3 layers: ones-row by-product; others: column-sum pass)
+    db_r = torch.linspace(-2, 2, d["cout"], dtype=torch.float64)
+    db_g = db_r.float().to(dev)
+    ref_ops.conv_wgrad(d["x"], d["dy"], pk_r, dw_r, rg, accumulate=True, dbias=db_r)
+    hip_ops.conv_wgrad(x_g, dy_g, pk_g, dw_g, g, accumulate=True, dbias=db_g)
+    assert rel_err(dw_g, dw_r) < TOL, "wgrad+bias: dw"
+    assert rel_err(db_g, db_r) < TOL, "wgrad+bias: dbias"
 
 
 def test_conv_on_concat_and_time_views(hip_ops, ref_ops):

@@ -732,6 +732,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     if ((rc = upload(td.data(), td.size() * sizeof(int4), (void**)&pl->d_tab_dgrad)) != WDG_OK) { delete pl; return rc; }
     if ((rc = wdg_halo_plan_init(pl)) != WDG_OK) { delete pl; return rc; }
     pl->ws_bytes = std::max(pl->ws_bytes, wdg_wgrad_halo_ws_bytes(pl));
+    pl->ws_bytes = std::max(pl->ws_bytes, wdg_wgrad_thin_ws_bytes(pl));
     *out = pl;
     return WDG_OK;
 }
@@ -756,6 +757,7 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
     info[3] = d.BM; info[4] = d.BN; info[5] = pl->dgrad_split;
     info[6] = pick_wgrad_bn(pl->g.Cout); info[7] = pl->wgrad_split;
     if (wdg_wgrad_halo_eligible(pl)) { info[6] = 0; info[7] = 1; }   // BN = 0 marks the halo weight-gradient kernel
+    if (wdg_wgrad_thin_eligible(pl)) { info[6] = -1; info[7] = 1; }  // BN = -1 marks the thin 3x3 weight-gradient kernel
     if (pl->halo_auto && pl->halo_fwd_nt) { info[0] = 0; info[1] = 16 * pl->halo_fwd_nt; info[2] = 1; }     // BM = 0 marks the halo kernel
     if (pl->halo_auto && pl->halo_dgrad_nt) { info[3] = 0; info[4] = 16 * pl->halo_dgrad_nt; info[5] = 1; }
     return WDG_OK;
@@ -778,6 +780,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && (!strcmp(key, "force_fwd_split") || !strcmp(key, "force_dgrad_split") || !strcmp(key, "force_wgrad_split"))) {
         g_force_split[key[6] == 'f' ? 0 : key[6] == 'd' ? 1 : 2] = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "wgrad_thin")) {
+        wdg_wgrad_thin_enable(value);
         return WDG_OK;
     }
     if (key && !strcmp(key, "xcd_swizzle")) {
@@ -907,12 +913,34 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
     return launch_igemm(p, np, pl->K4_dgrad_max, pl->dgrad_split, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out, int accumulate, wdg_stream stream);
+
+// weight gradient + bias gradient (dbias[co] += sum_pixels dy[pixel][co]) in one call: the thin 3x3 kernel gets
+// the column sums as a by-product of a constant-1 row; every other geometry runs the column-sum pass after it.
+extern "C" int wdg_conv_wgrad_bias(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw, float* dbias,
+                                   int accumulate, void* ws, size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && dy && dw, "null argument");
+    if (dbias && wdg_wgrad_thin_has_bias_row(pl)) {
+        WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "x / dy must be 16-byte aligned");
+        return wdg_wgrad_thin_launch(pl, x, dy, dw, dbias, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    }
+    const int rc = wdg_conv_wgrad(pl, x, dy, dw, accumulate, ws, ws_bytes, stream);
+    if (rc != WDG_OK || !dbias) return rc;
+    const wdg_conv_geom& g = pl->g;
+    if (g.img_stride_y != (int64_t)g.Ho * g.Wo * g.ldy) {
+        wdg_set_error("wdg_conv_wgrad_bias: dy images must be contiguous for the column-sum pass");
+        return WDG_ERR_ARG;
+    }
+    return wdg_colsum(dy, g.ldy, (int64_t)g.n_img * g.Ho * g.Wo, g.Cout, dbias, 1, stream);
+}
+
 extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw,
                               int accumulate, void* ws, size_t ws_bytes, wdg_stream stream) {
     WDG_CHECK_ARG(pl && x && dy && dw, "null argument");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "x / dy must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
     hipStream_t st = (hipStream_t)stream;
+    if (wdg_wgrad_thin_eligible(pl)) return wdg_wgrad_thin_launch(pl, x, dy, dw, nullptr, accumulate, ws, ws_bytes, st);
     if (wdg_wgrad_halo_eligible(pl)) return wdg_wgrad_halo_launch(pl, x, dy, dw, accumulate, ws, ws_bytes, st);
     WdgWgrad p;
     memset(&p, 0, sizeof(p));

@@ -45,5 +45,11 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
 // wgrad_halo.hip
 int wdg_wgrad_halo_eligible(const wdg_conv_plan* pl);
 size_t wdg_wgrad_halo_ws_bytes(const wdg_conv_plan* pl);
+int wdg_wgrad_thin_eligible(const wdg_conv_plan* pl);
+int wdg_wgrad_thin_has_bias_row(const wdg_conv_plan* pl);
+size_t wdg_wgrad_thin_ws_bytes(const wdg_conv_plan* pl);
+void wdg_wgrad_thin_enable(int v);
+int wdg_wgrad_thin_launch(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw, float* dbias,
+                          int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 int wdg_wgrad_halo_launch(const wdg_conv_plan* pl, const float* x, const float* dy, float* dw, int accumulate,
                           void* ws, size_t ws_bytes, hipStream_t st);

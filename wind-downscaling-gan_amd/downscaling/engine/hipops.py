@@ -175,6 +175,8 @@ class HipOps:
             return self._label(info[0], info[1])
         if which == "dgrad":
             return self._label(info[3], info[4])
+        if info[6] < 0:
+            return "wdg_wgrad_thin_kernel"
         return "wdg_wgrad_halo_kernel" if info[6] == 0 else "wdg_wgrad_kernel<%d>" % info[6]
 
     # ---- convolution family -----------------------------------------------------------------
@@ -231,11 +233,16 @@ class HipOps:
         native.check(self.lib.wdg_upconv_fwd(plan, px, ldl, isl, pk.wD.data_ptr(), _ptr(bias), py, int(act), slope,
                                              self.stream), "upconv_fwd")
 
-    def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True):
-        """dw[kh,kw,Cin,Cout] (+)= x (*) dy."""
+    def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True, dbias=None):
+        """dw[kh,kw,Cin,Cout] (+)= x (*) dy;  dbias[Cout] += sum_pixels dy when given."""
         plan, wsb, _ = self._plan(x, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         assert dw.is_contiguous()
+        if dbias is not None:
+            native.check(self.lib.wdg_conv_wgrad_bias(plan, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), dbias.data_ptr(),
+                                                      int(accumulate), ws.data_ptr(), ws.numel(), self.stream),
+                         "conv_wgrad_bias")
+            return
         native.check(self.lib.wdg_conv_wgrad(plan, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), int(accumulate),
                                              ws.data_ptr(), ws.numel(), self.stream), "conv_wgrad")
 

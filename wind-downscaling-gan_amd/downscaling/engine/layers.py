@@ -228,9 +228,8 @@ class ConvLSTM:
                 self.dgates1 = o.empty(N, H, W, 4 * F)
             dg = self.dgates1 if need_wgrad else None
             o.convlstm1_bwd(x, self.wx.value, self.b.value, dh, dg, dx, self.cin, F, accumulate_dx=accumulate_dx)
-            if need_wgrad:
-                o.conv_wgrad(x, dg, self.pkx, self.wx.grad, self.g, accumulate=True)
-                o.colsum(v2(dg), self.b.grad, accumulate=True)
+            if need_wgrad:   # kernel and bias gradient in one pass over dgates
+                o.conv_wgrad(x, dg, self.pkx, self.wx.grad, self.g, accumulate=True, dbias=self.b.grad)
             return
         if self.dgates is None:
             self.dgates = o.empty(N, H, W, 4 * F)

@@ -49,6 +49,7 @@ SIGNATURES = {
     "wdg_conv_halo_fwd_bf16": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     "wdg_upconv_fwd_bf16": (i32, [C.c_void_p, c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     "wdg_conv_wgrad": (i32, [C.c_void_p, c_fp, c_fp, c_fp, i32, c_fp, szt, c_fp]),
+    "wdg_conv_wgrad_bias": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, c_fp, szt, c_fp]),
     "wdg_weight_pack": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
     "wdg_sn_scratch_floats": (szt, [i32, i32]),
     "wdg_sn_power_iter": (i32, [c_fp, c_fp, i32, i32, c_fp, c_fp]),
