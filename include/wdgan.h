@@ -129,6 +129,19 @@ int wdg_upconv_fwd_bf16(const wdg_conv_plan* plan, const float* x_low, int ld_lo
                         const void* wD16, const float* bias, const float* affine, float* y, int act, float slope,
                         wdg_stream stream);
 
+/* UpSampling2D(2,'bilinear') + Conv2DTranspose(5x5, stride 1, 'same') (models.py:62-64) evaluated as four 4x4
+ * convolutions on the low-resolution grid with composite kernels (csrc/upconv4.hip): 16 instead of 25 taps per
+ * output pixel, results equal to the two-step definition up to fp32 re-association (~1e-7 relative).
+ * w_hwio: the layer's kernel as stored, [5][5][N][C] (N <= 16 layer outputs, C layer inputs);
+ * wc: wdg_upconv4_weight_floats(N, C) floats, rebuilt by wdg_upconv4_pack whenever w changes.
+ * x_low: [n_img][H][W][ld_low] (C channels used), y: [n_img][2H][2W][ldy] (N channels written). */
+size_t wdg_upconv4_weight_floats(int N, int C);
+int wdg_upconv4_supported(int N, int C, int H, int W);
+int wdg_upconv4_pack(const float* w_hwio, int N, int C, float* wc, wdg_stream stream);
+int wdg_upconv4_fwd(const float* x_low, int ld_low, int64_t img_stride_low, int n_img, int H, int W, int C,
+                    const float* wc, const float* bias, float* y, int ldy, int64_t img_stride_y, int N,
+                    int act, float slope, wdg_stream stream);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum_pixels x (*) dy  — HWIO, the master layout.   ganbase.py:46,60 */
 int wdg_conv_wgrad(const wdg_conv_plan* plan, const float* x, const float* dy, float* dw,
                    int accumulate, void* ws, size_t ws_bytes, wdg_stream stream);

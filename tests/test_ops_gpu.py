@@ -150,22 +150,37 @@ def test_conv_on_concat_and_time_views(hip_ops, ref_ops):
     assert rel_err(buf_g, buf) < TOL
 
 
-def test_fused_upsample_conv_transpose(hip_ops, ref_ops):
-    """UpSampling2D(bilinear) + Conv2DTranspose(5x5,'same') + bias + LeakyReLU in one kernel (models.py:62-64),
-    input taken from a channel-concat view, odd tile boundaries."""
+@pytest.mark.parametrize("n,H,W,C,N,ld", [(3, 60, 68, 160, 16, 160), (2, 19, 35, 40, 4, 48), (2, 3, 3, 20, 8, 20),
+                                          (1, 9, 50, 160, 16, 192), (2, 4, 17, 8, 2, 8)])
+@pytest.mark.parametrize("composite", [True, False])
+def test_fused_upsample_conv_transpose(n, H, W, C, N, ld, composite, hip_ops, ref_ops):
+    """UpSampling2D(bilinear) + Conv2DTranspose(5x5,'same') + bias + LeakyReLU fused (models.py:62-64), input taken
+    from a channel-concat view, ragged tiles, tiny maps (every pixel on the border ring), few outputs / channels.
+    composite=True: the four-phase 4x4 composite-kernel path (upconv4.hip); False: the 25-tap halo kernel."""
     from downscaling.engine.hipops import ConvGeom
     from oracle.torch_backend import ConvGeom as RG
     g, rg = ConvGeom(5, 5, 1, 2), RG(5, 5, 1, 2)
     gen = torch.Generator().manual_seed(9)
     dev = hip_ops.device
-    x = torch.randn(3, 60, 68, 160, generator=gen, dtype=torch.float64)
-    w = torch.randn(5, 5, 16, 160, generator=gen, dtype=torch.float64) * 0.05
-    b = torch.randn(16, generator=gen, dtype=torch.float64)
-    y_r = torch.zeros(3, 120, 136, 16, dtype=torch.float64)
-    y_g = hip_ops.zeros(3, 120, 136, 16)
+    x = torch.randn(n, H, W, C, generator=gen, dtype=torch.float64)
+    w = torch.randn(5, 5, N, C, generator=gen, dtype=torch.float64) * 0.05
+    b = torch.randn(N, generator=gen, dtype=torch.float64)
+    Np = (N + 3) // 4 * 4
+    y_r = torch.zeros(n, 2 * H, 2 * W, Np, dtype=torch.float64)
+    y_g = hip_ops.zeros(n, 2 * H, 2 * W, Np)
     ref_ops.upconv_fwd(x, ref_ops.pack_weights(w), b, y_r, rg, act=True)
-    hip_ops.upconv_fwd(x.float().to(dev), hip_ops.pack_weights(w.float().to(dev).contiguous()), b.float().to(dev), y_g, g, act=True)
+    xg = hip_ops.zeros(n, H, W, ld)
+    xg[..., :C] = x.float().to(dev)
+    if ld > C:
+        xg[..., C:] = 7.0   # neighbouring channels of the concat buffer must not leak in
+    hip_ops.upconv4 = composite
+    try:
+        hip_ops.upconv_fwd(xg[..., :C], hip_ops.pack_weights(w.float().to(dev).contiguous()), b.float().to(dev), y_g, g, act=True)
+    finally:
+        hip_ops.upconv4 = True
     assert rel_err(y_g, y_r) < TOL
+    if Np != N:
+        assert float(y_g[..., N:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("cin,F_,n,H,W", [(2, 2, 3, 37, 45), (5, 16, 2, 33, 70), (5, 16, 1, 4, 32)])

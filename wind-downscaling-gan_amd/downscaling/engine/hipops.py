@@ -45,7 +45,22 @@ class PackedWeights:
         self.wD = w if cout % 4 == 0 else torch.empty(self.taps * cin * cout_p, dtype=torch.float32, device=w.device)
         self._wF16 = self._wD16 = None
         self._bf16_stale = True
+        self._up4 = None
         self.refresh()
+
+    def up4(self):
+        """Composite 4x4 kernels of the fused bilinear-x2 + 5x5 transposed conv (csrc/upconv4.hip), rebuilt lazily
+        after the master weights changed."""
+        lib = self.ops.lib
+        if self._up4 is None:
+            self._up4 = torch.empty(int(lib.wdg_upconv4_weight_floats(self.cin, self.cout)), dtype=torch.float32,
+                                    device=self.w.device)
+            self._up4_stale = True
+        if self._up4_stale:
+            native.check(lib.wdg_upconv4_pack(self.w.data_ptr(), self.cin, self.cout, self._up4.data_ptr(),
+                                              self.ops.stream), "upconv4_pack")
+            self._up4_stale = False
+        return self._up4
 
     def bf16(self):
         """(wF16, wD16): bf16 copies of the packed layouts for the inference-precision kernels (lazy)."""
@@ -71,6 +86,7 @@ class PackedWeights:
 
     def refresh(self):
         self._bf16_stale = True
+        self._up4_stale = True
         lib = self.ops.lib
         native.check(lib.wdg_weight_pack(self.w.data_ptr(), self.wF.data_ptr(),
                                          0 if self.wD is self.w else self.wD.data_ptr(),
@@ -99,6 +115,7 @@ class _PrepBatch:
         for pk, u in self.entries:
             if pack_all or (sn and u is not None):
                 pk._bf16_stale = True
+                pk._up4_stale = True
 
     def __del__(self):
         try:
@@ -121,6 +138,7 @@ class HipOps:
         self._plans = {}
         self._ws = None
         self._sn_scratch = None
+        self.upconv4 = True   # fused upsample + 5x5 transposed conv through the composite-kernel path
 
     # ---- plumbing ---------------------------------------------------------------------------
     @property
@@ -228,6 +246,12 @@ class HipOps:
         px, ldl, isl = _v4(x_low)
         py, ldy, isy = _v4(y)
         n, H, W, _ = y.shape
+        if self.upconv4 and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
+                self.lib.wdg_upconv4_supported(pk.cin, pk.cout, H // 2, W // 2):
+            # four composite 4x4 convolutions on the low-res grid (16 instead of 25 taps per output pixel)
+            native.check(self.lib.wdg_upconv4_fwd(px, ldl, isl, n, H // 2, W // 2, pk.cout, pk.up4().data_ptr(), _ptr(bias),
+                                                  py, ldy, isy, pk.cin, int(act), slope, self.stream), "upconv4_fwd")
+            return
         cp = (pk.cout + 3) // 4 * 4
         plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
         native.check(self.lib.wdg_upconv_fwd(plan, px, ldl, isl, pk.wD.data_ptr(), _ptr(bias), py, int(act), slope,

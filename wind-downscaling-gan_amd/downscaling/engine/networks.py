@@ -192,11 +192,9 @@ class GeneratorNet(_Net):
         self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), training)
         self.c7.forward(b["cat4"], b["y7"])
         self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), training)
-        if need_backward:
+        if need_backward:   # the upsampled tensor itself is only needed as the weight-gradient operand
             self.ops.upsample2x_fwd(b["cat2"], self._up(B))                           # models.py:62
-            self.c9.forward(self._up(B), b["y9"])
-        else:
-            self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)   # :62-64 fused
+        self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)       # :62-64 fused
         self.bn10.forward(v2(b["y9"]), v2(b["z9"]), training)
         self.c11.forward(b["z9"], b["out"])
         return b["out"]
