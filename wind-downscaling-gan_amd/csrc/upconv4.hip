@@ -202,22 +202,34 @@ __global__ void __launch_bounds__(256) wdg_upconv4_border_kernel(const WdgUp4 p)
     const float* Wv = p.Wc + ((long long)((rc * 3 + cc) * 4 + wave) * 16 * 16 + li) * p.Cp;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int ngrp = (p.C4 + 3) >> 2;   // 16-channel chunks
+    // four independent accumulator chains and batches of four chunks per tap: 8 loads in flight per lane
+    f32x4 acc4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc4[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int tap = 0; tap < 16; ++tap) {
         const int gy = min(max(i + (tap >> 2) + ph - 2, 0), p.H - 1), gx = min(max(j + (tap & 3) + pw - 2, 0), p.W - 1);
         const float* xp = Ximg + ((long long)gy * p.W + gx) * p.ldA;
         const float* wp = Wv + (long long)tap * 16 * p.Cp;
-#pragma unroll 2
-        for (int ck = 0; ck < ngrp; ++ck) {
-            const int g = 4 * ck + lg;
-            f32x4 af = (f32x4){0.f, 0.f, 0.f, 0.f}, bf = af;
-            if (g < p.C4) {
-                af = *reinterpret_cast<const f32x4*>(xp + 4 * g);
-                bf = *reinterpret_cast<const f32x4*>(wp + 4 * g);
+        for (int ck = 0; ck < ngrp; ck += 4) {
+            f32x4 af[4], bf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = 4 * (ck + u) + lg;
+                af[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                bf[u] = af[u];
+                if (g < p.C4) {
+                    af[u] = *reinterpret_cast<const f32x4*>(xp + 4 * g);
+                    bf[u] = *reinterpret_cast<const f32x4*>(wp + 4 * g);
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q], bf[q], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][q], bf[u][q], acc4[u], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (acc4[0][q] + acc4[1][q]) + (acc4[2][q] + acc4[3][q]);
     // accumulator reg q of lane (li, lg): segment pixel 4*lg + q, output channel li
     if (li < p.N) {
         const float bv = p.bias ? p.bias[li] : 0.f;
