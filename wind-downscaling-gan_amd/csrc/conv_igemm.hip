@@ -198,6 +198,33 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
             }
             __syncthreads();
         }
+    } else if (PIPE == 3) {
+        // rotated single-stage loop, ONE basic block per K-step: the operand loads of the next tile (address
+        // arithmetic + 8 buffer loads) and its LDS stores sit in the same block as the MFMAs, so the scheduler can
+        // interleave them with the matrix instructions instead of running them as separate phases
+        f32x4* ldsA = lds_all;
+        f32x4* ldsB = lds_all + 8 * BM;
+        if (nk > 0) {
+            load_tile(0);
+            store_tile(ldsA, ldsB);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            load_tile(kt + 1 < nk ? kt + 1 : kt);   // unconditional (the last one is redundant)
+            {
+                f32x4 af[MT], bf[NT];
+                read_frags(ldsA, ldsB, 0, af, bf);
+                mfma_block(af, bf);
+            }
+            {
+                f32x4 af[MT], bf[NT];
+                read_frags(ldsA, ldsB, 1, af, bf);
+                __syncthreads();   // every wave has read this tile: the stage may be overwritten
+                mfma_block(af, bf);
+            }
+            store_tile(ldsA, ldsB);
+            __syncthreads();
+        }
     } else {
         // double-buffered LDS: the next tile is written into the other stage right after this wave's own
         // MFMAs, one barrier per K-step
@@ -436,7 +463,8 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
             if (BN >= 128 || 4 * g4 < BN) *reinterpret_cast<f32x4*>(&ldsB[px * RSB + 4 * g4]) = rb[i];
         }
         __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
+        load_tile(kt + 1);   // unconditional (past the end every lane is out of range -> no memory traffic): keeps the
+                             // address arithmetic and the loads in the MFMA basic block, where they interleave
         WdgFrag<MT> af[2];
         WdgFrag<NT> bf[2];
         af[0] = wdg_lds_frag<MT>(fragA);
@@ -766,11 +794,11 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
 static int g_xcd_swizzle = 1;
-static int g_igemm_pipe = 0;   // measured: the single-stage form is 2-10 % faster (profiles/r01e_perf_conv.log)
+static int g_igemm_pipe = 3;   // measured (profiles/r02d_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
 extern "C" int wdg_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "igemm_pipe")) {
-        if (value < 0 || value > 2) return WDG_ERR_ARG;
+        if (value < 0 || value > 3) return WDG_ERR_ARG;
         g_igemm_pipe = value;
         return WDG_OK;
     }
@@ -796,7 +824,7 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
 
 template <int BM, int BN, int WGM, int WGN, int PIPE>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
-    constexpr size_t lds = (size_t)(PIPE == 0 ? 1 : 2) * 8 * (BM + BN) * sizeof(f32x4);
+    constexpr size_t lds = (size_t)((PIPE == 0 || PIPE == 3) ? 1 : 2) * 8 * (BM + BN) * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 48 * 1024)
@@ -841,6 +869,7 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     if (tc.BM == BM_ && tc.BN == BN_) {                                                                 \
         if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);                  \
         else if (pipe == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 1>(grid, block, st, p);             \
+        else if (pipe == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3>(grid, block, st, p);             \
         else rc = launch_variant<BM_, BN_, WM_, WN_, 2>(grid, block, st, p);                            \
     }
     WDG_IGEMM_CASE(128, 128, 2, 2)
