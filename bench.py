@@ -73,7 +73,16 @@ class ConvTimer:
         def conv_wgrad(x, dy, pk, dw, g, **k):
             timed(ops.conv_kernel_label("wgrad", x, dy, pk, g), flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g, **k)
 
-        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
+        orig_up = ops.upconv_fwd
+
+        def upconv_fwd(x_low, pk, bias, y, g, **k):
+            # algorithmic FLOPs of the reference layer (bilinear x2, then 25 taps); the composite-kernel path
+            # (csrc/upconv4.hip) executes 16/25 of these MACs
+            n, Ho, Wo = y.shape[0], y.shape[1], y.shape[2]
+            timed("wdg_upconv4_kernel (fused upsample + 5x5 transposed conv; executes 0.64 of the algorithmic MACs)",
+                  2.0 * n * Ho * Wo * pk.cin * g.kh * g.kw * pk.cout, orig_up, x_low, pk, bias, y, g, **k)
+
+        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad, ops.upconv_fwd = conv_fwd, conv_dgrad, conv_wgrad, upconv_fwd
 
     def summary(self):
         agg = {}
@@ -85,7 +94,7 @@ class ConvTimer:
         return agg
 
 
-def cpu_baseline(batch=1):
+def cpu_baseline(batch=4):
     """The CPU restatement of the same train step (torch-CPU fp32, all host cores) on a bounded sample."""
     from oracle import torch_model as TM
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
@@ -261,7 +270,9 @@ def main():
                          "launches": dom[1][2], "avg_launch_ms": 1e3 * dom[1][1] / dom[1][2],
                          "all_conv_kernels": {k: {"tflops": v[0] / v[1] * 1e-12, "ms_per_step": 1e3 * v[1] / args.steps,
                                                    "launches_per_step": v[2] / args.steps} for k, v in agg.items()},
-                         "conv_share_of_step": conv_time / dt, "all_conv_tflops": conv_flops / conv_time * 1e-12},
+                         "conv_share_of_step": conv_time / dt, "all_conv_tflops": conv_flops / conv_time * 1e-12,
+                         "measured_mfma_issue_ceiling_tflops": {"constant_operands": 155.7, "random_operands": 151.2,
+                                                                "source": "tools/mfma_peak.hip, profiles/r01q_mfma_peak_probe.log"}},
             "losses": {k: float(v) for k, v in logs.items() if v is not None},
         }
         # HBM traffic of the dominant kernel comes from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc passes (counter_collection.csv, one counter group per pass) into a per-kernel summary
+and the dominant kernel's HBM traffic per launch for bench.py's `roofline.traffic`.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py ...
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ... -d gpurun_out/pmc_sq ...
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq profiles/<tag>_pmc_summary.csv
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are reported in KB;
+on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes -> doubled here (column *_x2).  The counters sit on
+the L2's fabric side, i.e. Infinity-Cache hits are included.
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([\w:]+(?:<[^(]*>)?)\(", name)
+    return (m.group(1) if m else name)[:70]
+
+
+def read(dirname):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    dur = defaultdict(list)
+    for f in glob.glob(str(Path(dirname) / "**" / "*counter_collection.csv"), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+    return acc, cnt, dur
+
+
+def main():
+    dirs, out = sys.argv[1:-1], sys.argv[-1]
+    tot, n, dur = defaultdict(dict), defaultdict(dict), {}
+    for d in dirs:
+        a, c, du = read(d)
+        for k in a:
+            for name, v in a[k].items():
+                tot[k][name] = v
+                n[k][name] = c[k][name]
+            dur.setdefault(k, du[k])
+    rows = []
+    for k in tot:
+        t = tot[k]
+        launches = max(n[k].values())
+        per = lambda name: t.get(name, float("nan")) / n[k].get(name, 1)
+        row = {"kernel": k, "launches": launches, "avg_us_under_pmc": sum(dur[k]) / max(len(dur[k]), 1)}
+        if "FETCH_SIZE" in t:
+            row["fetch_kb_per_launch_raw"] = per("FETCH_SIZE")
+            row["fetch_mb_per_launch_x2"] = 2 * per("FETCH_SIZE") * 1024 / 1e6
+        if "WRITE_SIZE" in t:
+            row["write_mb_per_launch"] = per("WRITE_SIZE") * 1024 / 1e6
+        if "TCC_HIT_sum" in t:
+            row["l2_hit"] = t["TCC_HIT_sum"] / max(t["TCC_HIT_sum"] + t.get("TCC_MISS_sum", 0.0), 1.0)
+        if "SQ_WAVE_CYCLES" in t:
+            wc = max(t["SQ_WAVE_CYCLES"], 1.0)
+            for cname, col in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac"),
+                               ("SQ_ACTIVE_INST_ANY", "active_frac")):
+                if cname in t:
+                    row[col] = t[cname] / wc
+            if "SQ_LDS_BANK_CONFLICT" in t and "SQ_LDS_IDX_ACTIVE" in t:
+                row["lds_bank_conflict_frac"] = t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0)
+        row["_total_us"] = sum(dur[k])
+        rows.append(row)
+    rows.sort(key=lambda r: -r["_total_us"])
+    cols = ["kernel", "launches", "avg_us_under_pmc", "fetch_kb_per_launch_raw", "fetch_mb_per_launch_x2", "write_mb_per_launch",
+            "l2_hit", "wait_any_frac", "wait_inst_frac", "active_frac", "lds_bank_conflict_frac"]
+    with open(out, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore")
+        w.writeheader()
+        for r in rows[:40]:
+            w.writerow({c: (f"{r[c]:.4g}" if isinstance(r.get(c), float) else r.get(c, "")) for c in cols})
+    dom = next((r for r in rows if r["kernel"].startswith("wdg_igemm_kernel<128, 128")), None)
+    if dom and "fetch_mb_per_launch_x2" in dom and "write_mb_per_launch" in dom:
+        tj = {"source": f"{out} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0)",
+              "kernel": "wdg_igemm_kernel<128,128>",
+              "hbm_bytes_per_launch": (dom["fetch_mb_per_launch_x2"] + dom["write_mb_per_launch"]) * 1e6,
+              "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream); counts fabric "
+                      "requests incl. Infinity-Cache hits; mean over all launches of the kernel in one train step"}
+        Path(out).with_name("pmc_traffic.json").write_text(json.dumps(tj, indent=1))
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()

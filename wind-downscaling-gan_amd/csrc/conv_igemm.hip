@@ -794,7 +794,7 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
 static int g_xcd_swizzle = 1;
-static int g_igemm_pipe = 3;   // measured (profiles/r02d_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
+static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
 extern "C" int wdg_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "igemm_pipe")) {

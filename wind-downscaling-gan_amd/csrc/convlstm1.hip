@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     constexpr int C4 = (CIN + 3) / 4;
     constexpr int XH = CL_TH + 4, XW = CL_TW + 4;    // x halo (two 3x3 stages)
     constexpr int GH = CL_TH + 2, GW = CL_TW + 2;    // dgates halo
-    constexpr int G3 = 3 * F;                        // compact dgates: [i | c~ | o]
+    constexpr int G3 = 3 * F + 1;                    // compact dgates [i | c~ | o] + 1 pad: an odd pixel stride keeps the per-pixel b32 accesses of a wave on distinct banks (3F = 48 was a 16-way conflict)
     __shared__ __attribute__((aligned(16))) f32x4 xs[XH * XW * C4];
     __shared__ __attribute__((aligned(16))) float dgs[GH * GW * G3];
     __shared__ float dxp[128 * CIN];
