@@ -18,13 +18,28 @@ __device__ __forceinline__ void wdg_block_colreduce(const float (&v)[NV][4], int
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds[(k * 256 + t) * 4 + j] = active ? v[k][j] : 0.f;
     __syncthreads();
+    int live = rows;
+    if ((rows & (rows - 1)) == 0) {
+        // tree over the pixel rows with all threads (rows is a power of two whenever C/4 is): log2(rows) steps instead
+        // of a serial loop by c4n threads (for 16 channels that loop was 4 threads x 64 rows)
+        for (int sft = rows >> 1; sft > 0; sft >>= 1) {
+            if (active && t < sft * c4n) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lds[(k * 256 + t) * 4 + j] += lds[(k * 256 + t + sft * c4n) * 4 + j];
+            }
+            __syncthreads();
+        }
+        live = 1;
+    }
     if (t < c4n) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 OutT s = 0;
-                for (int r = 0; r < rows; ++r) s += (OutT)lds[(k * 256 + r * c4n + t) * 4 + j];
+                for (int r = 0; r < live; ++r) s += (OutT)lds[(k * 256 + r * c4n + t) * 4 + j];
                 atomicAdd(&out[(size_t)k * C + 4 * t + j], s);
             }
         }
@@ -57,13 +72,21 @@ __global__ void __launch_bounds__(256) wdg_bn_stats_kernel(const float* __restri
     const bool active = prow < rows;
     float v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if (active) {
-        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += (int64_t)gridDim.x * rows) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(x + p * ldx + 4 * c4);
+        // eight pixels per trip, loads first (pure stream: keep several 16-byte loads in flight per lane)
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += 8 * stride) {
+            f32x4 a[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[0][j] += a[j];
-                v[1][j] += a[j] * a[j];
-            }
+            for (int u = 0; u < 8; ++u)
+                a[u] = p + u * stride < P ? *reinterpret_cast<const f32x4*>(x + (p + u * stride) * ldx + 4 * c4)
+                                          : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[0][j] += a[u][j];
+                    v[1][j] += a[u][j] * a[u][j];
+                }
         }
     }
     wdg_block_colreduce<2, double>(v, c4, c4n, rows, active, stats, C, lds);
@@ -72,8 +95,9 @@ __global__ void __launch_bounds__(256) wdg_bn_stats_kernel(const float* __restri
 extern "C" int wdg_bn_stats(const float* x, int64_t P, int C, int ldx, double* stats, wdg_stream stream) {
     WDG_CHECK_ARG(x && stats && C % 4 == 0 && C <= 1024 && ldx % 4 == 0, "bad argument");
     ColGeom g = col_geom(C);
-    // keep per-thread fp32 partial sums short: many blocks, each thread sees <= ~P/(blocks*rows) pixels
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 8192));
+    // few blocks: every block ends with 2*C fp64 atomics on the same addresses, and 2048-8192 blocks made that
+    // serialised tail longer than the streaming pass (profiles/r01ah); fp32 partials stay short enough (<= ~512 values)
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 512));
     hipLaunchKernelGGL(wdg_bn_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ldx,
                        stats, g.c4n, g.rows);
     WDG_LAUNCH_CHECK();
@@ -170,15 +194,26 @@ __global__ void __launch_bounds__(256) wdg_bn_bwd_reduce_kernel(const float* __r
     if (active) {
         const f32x4 mean = *reinterpret_cast<const f32x4*>(saved + 4 * c4);
         const f32x4 inv = *reinterpret_cast<const f32x4*>(saved + C + 4 * c4);
-        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += (int64_t)gridDim.x * rows) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
-            const f32x4 a = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += 4 * stride) {
+            f32x4 g[4], a[4];   // four pixels per trip, loads first
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xh = (a[j] - mean[j]) * inv[j];
-                v[0][j] += g[j];
-                v[1][j] += g[j] * xh;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = p + u * stride;
+                g[u] = a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q < P) {
+                    g[u] = *reinterpret_cast<const f32x4*>(dz + q * lddz + 4 * c4);
+                    a[u] = *reinterpret_cast<const f32x4*>(y + q * ldy + 4 * c4);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (a[u][j] - mean[j]) * inv[j];
+                    v[0][j] += g[u][j];
+                    v[1][j] += g[u][j] * xh;
+                }
         }
     }
     wdg_block_colreduce<2, double>(v, c4, c4n, rows, active, red, C, lds);
@@ -190,7 +225,7 @@ extern "C" int wdg_bn_bwd_reduce(const float* dz, int lddz, const float* y, int 
     WDG_CHECK_ARG(dz && y && saved_mean_invstd && red && C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0,
                   "bad argument");
     ColGeom g = col_geom(C);
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 8192));
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 512));   // see wdg_bn_stats
     hipLaunchKernelGGL(wdg_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
                        ldy, saved_mean_invstd, P, C, red, g.c4n, g.rows);
     WDG_LAUNCH_CHECK();
@@ -217,19 +252,34 @@ __global__ void __launch_bounds__(256) wdg_bn_bwd_apply_kernel(
             mdz[j] = (float)(red_mean[4 * c4 + j] / count);
             mdzx[j] = (float)(red_mean[C + 4 * c4 + j] / count);
         }
-        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += (int64_t)gridDim.x * rows) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
-            const f32x4 a = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
-            f32x4 r;
+        // four pixels per trip with the loads first (dpre may alias dz: each thread only touches its own slots)
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += 4 * stride) {
+            f32x4 g[4], a[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xh = (a[j] - mean[j]) * inv[j];
-                float d = k0[j] * (g[j] - mdz[j] - xh * mdzx[j]);
-                if (act_slope >= 0.f) d *= (a[j] > 0.f ? 1.f : act_slope);
-                r[j] = d;
-                v[0][j] += d;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = p + u * stride;
+                g[u] = a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q < P) {
+                    g[u] = *reinterpret_cast<const f32x4*>(dz + q * lddz + 4 * c4);
+                    a[u] = *reinterpret_cast<const f32x4*>(y + q * ldy + 4 * c4);
+                }
             }
-            *reinterpret_cast<f32x4*>(dpre + p * lddpre + 4 * c4) = r;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = p + u * stride;
+                if (q >= P) continue;
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (a[u][j] - mean[j]) * inv[j];
+                    float d = k0[j] * (g[u][j] - mdz[j] - xh * mdzx[j]);
+                    if (act_slope >= 0.f) d *= (a[u][j] > 0.f ? 1.f : act_slope);
+                    r[j] = d;
+                    v[0][j] += d;
+                }
+                *reinterpret_cast<f32x4*>(dpre + q * lddpre + 4 * c4) = r;
+            }
         }
     }
     if (dbias) wdg_block_colreduce<1, float>(v, c4, c4n, rows, active, dbias, C, lds);
@@ -253,7 +303,7 @@ extern "C" int wdg_bn_bwd_apply(const float* dz, int lddz, const float* y, int l
     WDG_CHECK_ARG(dz && y && saved_mean_invstd && gamma && red_mean && dpre, "null argument");
     WDG_CHECK_ARG(C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0 && lddpre % 4 == 0, "bad sizes");
     ColGeom g = col_geom(C);
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 16 - 1) / (g.rows * 16), 8192));
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 16 - 1) / (g.rows * 16), 1024));
     hipLaunchKernelGGL(wdg_bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
                        ldy, saved_mean_invstd, gamma, red_mean, red_param, count, act_slope, dpre, lddpre,
                        dgamma, dbeta, dbias, P, C, g.c4n, g.rows);
@@ -367,79 +417,115 @@ __global__ void __launch_bounds__(256) wdg_ln_bwd_kernel(const float* __restrict
         gm[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (c4 < c4n) gm[k] = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
     }
-    for (int64_t p = (int64_t)blockIdx.x * ppb + t / L; p < P; p += (int64_t)gridDim.x * ppb) {
-        const float mean = mean_rstd[2 * p], rstd = mean_rstd[2 * p + 1];
-        f32x4 a[MAXCH], g[MAXCH];
-        float s1 = 0.f, s2 = 0.f;
+    // U pixels per trip with all their loads issued first: the kernel is a pure stream (two reads, one write per
+    // element) and one pixel per trip left it latency-bound at < 2 TB/s.  dpre may alias dz (in-place), which is safe
+    // because a thread only ever touches its own (pixel, channel-group) slots — but it is also why the compiler cannot
+    // batch the loads by itself.
+    constexpr int U = MAXCH == 1 ? 4 : 1;
+    const int64_t stride = (int64_t)gridDim.x * ppb;
+    for (int64_t p0 = (int64_t)blockIdx.x * ppb + t / L; p0 < P; p0 += U * stride) {
+        f32x4 a[U][MAXCH], g[U][MAXCH];
+        float mean[U], rstd[U];
 #pragma unroll
-        for (int k = 0; k < MAXCH; ++k) {
-            const int c4 = sub + k * L;
-            a[k] = g[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c4 < c4n) {
-                a[k] = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
-                g[k] = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + u * stride;
+            const bool on = p < P;
+            mean[u] = on ? mean_rstd[2 * p] : 0.f;
+            rstd[u] = on ? mean_rstd[2 * p + 1] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (a[k][j] - mean) * rstd;
-                    const float gg = g[k][j] * gm[k][j];
-                    s1 += gg;
-                    s2 += gg * xh;
-                    ag[k][j] += g[k][j] * xh;
-                    ab[k][j] += g[k][j];
+            for (int k = 0; k < MAXCH; ++k) {
+                const int c4 = sub + k * L;
+                a[u][k] = g[u][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (on && c4 < c4n) {
+                    a[u][k] = *reinterpret_cast<const f32x4*>(y + p * ldy + 4 * c4);
+                    g[u][k] = *reinterpret_cast<const f32x4*>(dz + p * lddz + 4 * c4);
                 }
             }
         }
-        for (int o = L >> 1; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-        }
-        s1 *= invC;
-        s2 *= invC;
 #pragma unroll
-        for (int k = 0; k < MAXCH; ++k) {
-            const int c4 = sub + k * L;
-            if (c4 < c4n) {
-                f32x4 r;
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + u * stride;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXCH; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xh = (a[k][j] - mean) * rstd;
-                    float d = rstd * (g[k][j] * gm[k][j] - s1 - xh * s2);
-                    if (act_slope >= 0.f) d *= (a[k][j] > 0.f ? 1.f : act_slope);
-                    r[j] = d;
-                    abias[k][j] += d;
+                    const float xh = (a[u][k][j] - mean[u]) * rstd[u];
+                    const float gg = g[u][k][j] * gm[k][j];
+                    s1 += gg;
+                    s2 += gg * xh;
+                    ag[k][j] += g[u][k][j] * xh;
+                    ab[k][j] += g[u][k][j];
                 }
-                *reinterpret_cast<f32x4*>(dpre + p * lddpre + 4 * c4) = r;
+            for (int o = L >> 1; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            s1 *= invC;
+            s2 *= invC;
+            if (p < P) {
+#pragma unroll
+                for (int k = 0; k < MAXCH; ++k) {
+                    const int c4 = sub + k * L;
+                    if (c4 < c4n) {
+                        f32x4 r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xh = (a[u][k][j] - mean[u]) * rstd[u];
+                            float d = rstd[u] * (g[u][k][j] * gm[k][j] - s1 - xh * s2);
+                            if (act_slope >= 0.f) d *= (a[u][k][j] > 0.f ? 1.f : act_slope);
+                            r[j] = d;
+                            abias[k][j] += d;
+                        }
+                        *reinterpret_cast<f32x4*>(dpre + p * lddpre + 4 * c4) = r;
+                    }
+                }
             }
         }
     }
-    // reduce the three per-channel accumulators over the ppb pixel slots of the block
+    // reduce the three per-channel accumulators over the ppb pixel slots of the block: lanes of a wave that share a
+    // channel group differ in the lane bits >= log2(L) -> xor-shuffles, then the four waves through LDS; one atomic
+    // per (block, channel).  (The former serial LDS loop by L threads plus one atomic per block from 2048 blocks on
+    // the same 3*C addresses cost more than the streaming pass itself.)
+    if (!dgamma && !dbeta && !dbias) return;
 #pragma unroll
     for (int k = 0; k < MAXCH; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            lds[((0 * MAXCH + k) * 256 + t) * 4 + j] = ag[k][j];
-            lds[((1 * MAXCH + k) * 256 + t) * 4 + j] = ab[k][j];
-            lds[((2 * MAXCH + k) * 256 + t) * 4 + j] = abias[k][j];
+            float v0 = ag[k][j], v1 = ab[k][j], v2 = abias[k][j];
+            for (int o = L; o < 64; o <<= 1) {
+                v0 += __shfl_xor(v0, o, 64);
+                v1 += __shfl_xor(v1, o, 64);
+                v2 += __shfl_xor(v2, o, 64);
+            }
+            ag[k][j] = v0; ab[k][j] = v1; abias[k][j] = v2;
         }
-    __syncthreads();
-    if (t < L) {
+    const int lane = t & 63, wave = t >> 6;
+    // L <= 64 divides 64, so `sub` = lane % L inside a wave
+    if (lane < L) {
 #pragma unroll
-        for (int k = 0; k < MAXCH; ++k) {
-            const int c4 = t + k * L;
-            if (c4 >= c4n) continue;
+        for (int k = 0; k < MAXCH; ++k)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-                for (int r = 0; r < ppb; ++r) {
-                    s0 += lds[((0 * MAXCH + k) * 256 + r * L + t) * 4 + j];
-                    s1 += lds[((1 * MAXCH + k) * 256 + r * L + t) * 4 + j];
-                    s2 += lds[((2 * MAXCH + k) * 256 + r * L + t) * 4 + j];
-                }
-                if (dgamma) atomicAdd(&dgamma[4 * c4 + j], s0);
-                if (dbeta) atomicAdd(&dbeta[4 * c4 + j], s1);
-                if (dbias) atomicAdd(&dbias[4 * c4 + j], s2);
+                lds[(((wave * 3 + 0) * MAXCH + k) * 64 + lane) * 4 + j] = ag[k][j];
+                lds[(((wave * 3 + 1) * MAXCH + k) * 64 + lane) * 4 + j] = ab[k][j];
+                lds[(((wave * 3 + 2) * MAXCH + k) * 64 + lane) * 4 + j] = abias[k][j];
             }
-        }
+    }
+    __syncthreads();
+    // thread -> (which, k, sub, j)
+    for (int idx = t; idx < 3 * MAXCH * L * 4; idx += 256) {
+        const int j = idx & 3;
+        const int sub2 = (idx >> 2) % L;
+        const int k = ((idx >> 2) / L) % MAXCH;
+        const int which = (idx >> 2) / (L * MAXCH);
+        const int c4 = sub2 + k * L;
+        if (c4 >= c4n) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += lds[(((w * 3 + which) * MAXCH + k) * 64 + sub2) * 4 + j];
+        float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dbias;
+        if (dst) atomicAdd(&dst[4 * c4 + j], v);
     }
 }
 
@@ -450,7 +536,7 @@ extern "C" int wdg_ln_bwd(const float* dz, int lddz, const float* y, int ldy, co
     WDG_CHECK_ARG(C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0 && lddpre % 4 == 0, "bad sizes");
     const int L = ln_lanes(C);
     const int ppb = 256 / L;
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + ppb * 8 - 1) / (ppb * 8), 2048));
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + ppb * 8 - 1) / (ppb * 8), 1024));
     const int chunks = (C / 4 + L - 1) / L;
     if (chunks <= 1)
         hipLaunchKernelGGL(wdg_ln_bwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
