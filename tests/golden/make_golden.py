@@ -7,6 +7,10 @@ only: /root/reference does not exist on the GPU box).
   generator_index.json  variable names / shapes decoded from
                         /root/reference/src/downscaling/weights-55.ckpt/generator.index
   discriminator_index.json  same for the discriminator (shortcut variant, SURVEY §8 a2 note 2)
+  data_pipeline.json    the numpy-only members of /root/reference/src/downscaling/data/data_generator.py
+                        (`_BatchGenerator.transform_sequence` :271-290, `NaiveDecoder` :338-360,
+                        `WindSpeedDecoder` / `WindComponentDecoder` :363-417) imported with TensorFlow, xarray,
+                        parse stubbed by MagicMock and run on seeded inputs
 """
 import ast
 import json
@@ -68,5 +72,50 @@ def main():
         (HERE / f"{name}_index.json").write_text(json.dumps(dict(variables=var, variable_bytes=nbytes), indent=1))
 
 
+def reference_data_pipeline():
+    """Import the reference's data_generator with its heavy imports stubbed and record what its numpy code does."""
+    import importlib.util
+    from unittest.mock import MagicMock
+    for m in ("tensorflow", "xarray", "parse", "silence_tensorflow", "tensorflow.keras", "tensorflow.keras.utils"):
+        sys.modules.setdefault(m, MagicMock())
+    sys.modules["tensorflow"].keras.utils.Sequence = object
+    spec = importlib.util.spec_from_file_location("ref_data_generator", REF / "data" / "data_generator.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {"transform_sequence": [], "naive": {}, "wind_speed": {}, "wind_component": {}}
+    bg = mod._BatchGenerator.__new__(mod._BatchGenerator)
+    for seed in (0, 1, 2, 3, 5, 7, 11, 123):
+        bg.prng = np.random.RandomState(seed)
+        X = np.arange(2 * 4 * 4 * 2, dtype=np.float64).reshape(2, 4, 4, 2)
+        Y = -np.arange(2 * 4 * 4 * 1, dtype=np.float64).reshape(2, 4, 4, 1)
+        x2, y2 = bg.transform_sequence(X, Y)
+        x3 = bg.transform_sequence(X)       # the same RandomState keeps drawing
+        out["transform_sequence"].append(dict(seed=seed, X=np.asarray(x2).tolist(), Y=np.asarray(y2).tolist(),
+                                              X_only=np.asarray(x3).tolist()))
+    rng = np.random.default_rng(42)
+    img = rng.standard_normal((3, 4, 4, 2)) * 3 + 1
+    img[1, 2, 3, 0] = np.nan
+    nd = mod.NaiveDecoder()
+    out["naive"] = dict(input=img.tolist(), normalize=nd.normalize(img).tolist(),
+                        normalize_positive=nd.normalize_positive(img).tolist(), denormalize=nd.denormalize(img).tolist(),
+                        denormalize_positive=nd.denormalize_positive(img).tolist(), call=nd(img).tolist(),
+                        call_off=mod.NaiveDecoder(False)(img).tolist())
+    w = rng.standard_normal((2, 3, 3, 1)) * 2
+    w[0, 0, 0, 0] = 0.0
+    w[1, 1, 1, 0] = 5.0
+    w[1, 2, 2, 0] = -3.0
+    ws, wsn = mod.WindSpeedDecoder(below_val=-2.0), mod.WindSpeedDecoder(below_val=-2.0, normalize=True)
+    dec = ws(w)
+    out["wind_speed"] = dict(input=w.tolist(), call=dec.tolist(), call_normalized=wsn(w).tolist(),
+                             denormalize=ws.denormalize(wsn(w).copy()).tolist(), default_nan=mod.WindSpeedDecoder()(w).tolist())
+    c = rng.standard_normal((2, 3, 3, 2)) * 6
+    c[0, 1, 1, 1] = 0.0
+    wc, wcr = mod.WindComponentDecoder(below_val=-10.0), mod.WindComponentDecoder(below_val=-10.0, normalize=False)
+    out["wind_component"] = dict(input=c.tolist(), call=wc(c).tolist(), call_raw=wcr(c).tolist(),
+                                 denormalize=wc.denormalize(wcr(c).copy(), set_nan=False).tolist())
+    (HERE / "data_pipeline.json").write_text(json.dumps(out))
+
+
 if __name__ == "__main__":
     main()
+    reference_data_pipeline()

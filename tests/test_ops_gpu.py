@@ -456,3 +456,22 @@ def test_philox_noise(hip_ops, ref_ops):
     ref_ops.philox_uniform(u_r, 99, 5)
     hip_ops.philox_uniform(u_g, 99, 5)
     assert float((u_g.double().cpu() - u_r).abs().max()) == 0.0
+
+
+def test_structured_noise_generator(hip_ops):
+    """NoiseGenerator (data_generator.py:296-316) on the Philox kernel: shape, scale, and the reference's layout (the
+    time-varying channel is constant over (x, y); every draw fills a run of consecutive elements)."""
+    from downscaling.data.data_generator import NoiseGenerator
+    from downscaling.engine import runtime
+    runtime.set_ops(hip_ops)
+    gen = NoiseGenerator((4, 6, 8, 10, 4), std=0.5, random_seed=11)
+    n = gen()
+    assert tuple(n.shape) == (4, 6, 8, 10, 4) and n.is_cuda
+    tv = n[..., 0]
+    assert float((tv - tv[:, :, :1, :1]).abs().max()) == 0.0
+    lon = n[..., 1].reshape(4, -1)
+    runs = lon.view(4, 8, 60)                      # bs x draws x run length t*y
+    assert float((runs - runs[:, :, :1]).abs().max()) == 0.0
+    assert 0.3 < float(n[..., 3].std()) < 0.7
+    n2 = NoiseGenerator((4, 6, 8, 10, 4), std=0.5, random_seed=11)(bs=2)
+    assert tuple(n2.shape) == (2, 6, 8, 10, 4)
