@@ -165,6 +165,10 @@ int wdg_weight_pack(const float* w_hwio, float* wF, float* wD, int taps, int Cin
 size_t wdg_sn_scratch_floats(int rows, int cols);
 int wdg_sn_power_iter(float* w, float* u, int rows, int cols, float* scratch, wdg_stream stream);
 
+/* Host utility: CRC-32C (Castagnoli) continued from `crc` (0 to start) — the checksum of the TF tensor-bundle
+ * checkpoint format that GAN.save_weights / load_weights of the reference go through (ganbase.py:132-140). */
+uint32_t wdg_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* Batched weight preparation of one network: what every `training=True` call of a Keras model with
  * SpectralNormalization wrappers does before its first layer runs (all power iterations + in-place
  * w <- w / sigma, models.py:33-134 through tfa), plus the refresh of the kernel-layout copies — one

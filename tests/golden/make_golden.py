@@ -70,6 +70,8 @@ def main():
         nbytes = sum(size for (k, dt, shape, shard, off, size) in ents
                      if k.endswith(suffix) and k.startswith("layer_with_weights") and ".OPTIMIZER_SLOT" not in k)
         (HERE / f"{name}_index.json").write_text(json.dumps(dict(variables=var, variable_bytes=nbytes), indent=1))
+        # the shipped index file itself (5 KB of data): the bundle WRITER is checked by re-encoding it byte for byte
+        (HERE / f"weights-55_{name}.index").write_bytes((REF / "weights-55.ckpt" / f"{name}.index").read_bytes())
 
 
 def reference_data_pipeline():

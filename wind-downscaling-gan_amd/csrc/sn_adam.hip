@@ -18,6 +18,26 @@ void wdg_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* wdg_last_error(void) { return g_err; }
+
+// CRC-32C (Castagnoli), the checksum of TensorFlow's tensor-bundle checkpoint format (per-tensor and per-block
+// checksums of <prefix>.index / .data-*; /root/reference/src/downscaling/gan/ganbase.py:132-140 saves through it).
+// Host code: table-driven, byte at a time (checkpoints are tens of MB and written rarely).
+extern "C" uint32_t wdg_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
 extern "C" const char* wdg_version(void) { return "wdgan 0.1 gfx950"; }
 
 // ---- SN step 1: vraw[r] = <u, W[r,:]>, per-block partial sum of squares ---------------------------

@@ -35,6 +35,7 @@ SIGNATURES = {
     "wdg_last_error": (C.c_char_p, []),
     "wdg_version": (C.c_char_p, []),
     "wdg_device_cus": (i32, []),
+    "wdg_crc32c": (C.c_uint32, [C.c_void_p, szt, C.c_uint32]),
     "wdg_set_tuning": (i32, [C.c_char_p, i32]),
     "wdg_conv_plan_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom)]),
     "wdg_conv_plan_destroy": (i32, [C.c_void_p]),

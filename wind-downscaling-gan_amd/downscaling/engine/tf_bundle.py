@@ -1,4 +1,4 @@
-"""Reader for TensorFlow tensor-bundle checkpoints (`<prefix>.index` + `<prefix>.data-00000-of-00001`),
+"""Reader and writer for TensorFlow tensor-bundle checkpoints (`<prefix>.index` + `<prefix>.data-00000-of-00001`),
 the format of the reference's weights-55.ckpt (/root/reference/src/downscaling/gan/ganbase.py:132-140,
 api.py:21,85).  The index is a LevelDB-style SSTable: 48-byte footer (metaindex + index block handles,
 magic), prefix-compressed key blocks with a restart array, values = BundleEntryProto
@@ -103,4 +103,136 @@ def read_bundle(prefix, include_optimizer_slots=False):
             f.seek(off)
             arr = np.frombuffer(f.read(size), dtype=_DTYPES[dt]).reshape(shape)
             out[key[:-len(_SUFFIX)]] = arr
+    return out
+
+
+# ---- writer -------------------------------------------------------------------------------------------------------------
+_MAGIC = 0xdb4775248b80fb57
+_RESTART_INTERVAL = 16
+_NP2DT = {np.dtype(np.float32): 1, np.dtype(np.float64): 2, np.dtype(np.int32): 3, np.dtype(np.int64): 9}
+
+
+def crc32c(data, crc=0):
+    """CRC-32C of a bytes-like object through the library's host routine (wdg_crc32c)."""
+    import ctypes as C
+    from . import native
+    buf = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+    return int(native.load().wdg_crc32c(C.c_char_p(bytes(buf)), len(buf), crc))
+
+
+def _mask(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
+def _pv(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def encode_entry(dtype, shape, shard=0, offset=0, size=0, crc=0):
+    """BundleEntryProto bytes: zero-valued scalar fields are omitted (proto3), the shape message always written."""
+    dims = b"".join(b"\x12" + _pv(len(d)) + d for d in (b"\x08" + _pv(int(n)) for n in shape))
+    out = b"\x08" + _pv(dtype) + b"\x12" + _pv(len(dims)) + dims
+    if shard:
+        out += b"\x18" + _pv(shard)
+    if offset:
+        out += b"\x20" + _pv(offset)
+    if size:
+        out += b"\x28" + _pv(size)
+    return out + b"\x35" + struct.pack("<I", crc)
+
+
+def _build_block(items):
+    """LevelDB block: prefix-compressed entries, a restart point every 16 entries, restart array, count."""
+    out, restarts, last = bytearray(), [], b""
+    for n, (key, val) in enumerate(items):
+        shared = 0
+        if n % _RESTART_INTERVAL == 0:
+            restarts.append(len(out))
+        else:
+            m = min(len(key), len(last))
+            while shared < m and key[shared] == last[shared]:
+                shared += 1
+        out += _pv(shared) + _pv(len(key) - shared) + _pv(len(val)) + key[shared:] + val
+        last = key
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        out += struct.pack("<I", r)
+    out += struct.pack("<I", len(restarts))
+    return bytes(out)
+
+
+def _short_successor(key):
+    """LevelDB BytewiseComparator::FindShortSuccessor: first byte that can be incremented, truncated after it."""
+    for i, c in enumerate(key):
+        if c != 0xFF:
+            return key[:i] + bytes([c + 1])
+    return key
+
+
+def encode_index(items):
+    """items: [(key bytes, value bytes)] sorted by key, first key b"" = BundleHeaderProto -> bytes of `<prefix>.index`
+    (one data block, as TensorFlow writes for bundles below its 256 KB table block size)."""
+    out = bytearray()
+
+    def emit(block):
+        off = len(out)
+        out.extend(block)
+        out.extend(b"\x00" + struct.pack("<I", _mask(crc32c(block + b"\x00"))))
+        return _pv(off) + _pv(len(block))
+
+    data_handle = emit(_build_block(items))
+    meta_handle = emit(_build_block([]))
+    index_handle = emit(_build_block([(_short_successor(items[-1][0]), data_handle)]))
+    footer = meta_handle + index_handle
+    out.extend(footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC))
+    return bytes(out)
+
+
+HEADER = b"\x08\x01\x1a\x02\x08\x01"    # BundleHeaderProto{num_shards: 1, version{producer: 1}}
+
+
+def write_bundle(prefix, tensors):
+    """{variable name: array} -> `<prefix>.index` + `<prefix>.data-00000-of-00001`, keys
+    `<name>/.ATTRIBUTES/VARIABLE_VALUE` as Keras' TF-format `save_weights` names them (ganbase.py:132-135).
+    Readable by `read_bundle` and by TensorFlow's checkpoint reader (`tf.train.load_checkpoint`); Keras'
+    `load_weights` additionally wants the `_CHECKPOINTABLE_OBJECT_GRAPH` entry, which is not written."""
+    prefix = str(prefix)
+    items, offset = [(b"", HEADER)], 0
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        for name in sorted(tensors, key=lambda k: (k + _SUFFIX).encode()):
+            arr = np.ascontiguousarray(tensors[name])
+            if arr.dtype not in _NP2DT:
+                arr = arr.astype(np.float32)
+            raw = arr.astype(arr.dtype.newbyteorder("<"), copy=False).tobytes()
+            f.write(raw)
+            items.append(((name + _SUFFIX).encode(), encode_entry(_NP2DT[arr.dtype], arr.shape, 0, offset, len(raw),
+                                                                  _mask(crc32c(raw)))))
+            offset += len(raw)
+    with open(prefix + ".index", "wb") as f:
+        f.write(encode_index(items))
+
+
+def read_raw_items(index_path):
+    """[(key bytes, value bytes)] of every entry of an index file, in file order (tests re-encode these)."""
+    data = open(index_path, "rb").read()
+    footer, i = data[-48:], 0
+    _, i = _varint(footer, i)
+    _, i = _varint(footer, i)
+    ioff, i = _varint(footer, i)
+    isize, i = _varint(footer, i)
+    out = []
+    for _, handle in _block(data, ioff, isize):
+        j = 0
+        boff, j = _varint(handle, j)
+        bsize, j = _varint(handle, j)
+        out += [(bytes(k), bytes(v)) for k, v in _block(data, boff, bsize)]
     return out

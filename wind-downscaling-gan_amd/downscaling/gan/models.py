@@ -93,11 +93,20 @@ class _Model:
     def set_weights_dict(self, mapping, strict=True):
         self.net.params.set_weights(mapping, strict=strict)
 
-    def save_weights(self, filepath, *args, **kwargs):
-        """Writes `<filepath>.npz` keyed by the TF checkpoint variable names (layer_with_weights-N/...)."""
+    def save_weights(self, filepath, overwrite=True, save_format=None, **kwargs):
+        """Keras `Model.save_weights(prefix)` of the reference (ganbase.py:132-135) writes the TF tensor-bundle format
+        `<prefix>.index` + `<prefix>.data-00000-of-00001`; so does this (keys `<variable>/.ATTRIBUTES/VARIABLE_VALUE`,
+        the names of weights-55.ckpt).  `save_format="npz"` (or a path ending in .npz) writes one `<prefix>.npz`."""
         filepath = os.fspath(filepath)
         Path(filepath).parent.mkdir(parents=True, exist_ok=True)
-        np.savez(filepath + ".npz", **{k.replace("/", "|"): v for k, v in self.get_weights_dict().items()})
+        if save_format == "npz" or filepath.endswith(".npz"):
+            base = filepath[:-4] if filepath.endswith(".npz") else filepath
+            np.savez(base + ".npz", **{k.replace("/", "|"): v for k, v in self.get_weights_dict().items()})
+            return
+        if save_format not in (None, "tf"):
+            raise ValueError(f"save_format {save_format!r}: only 'tf' (tensor bundle) and 'npz' are available")
+        from downscaling.engine.tf_bundle import write_bundle
+        write_bundle(filepath, self.get_weights_dict())
 
     def load_weights(self, filepath, *args, **kwargs):
         filepath = os.fspath(filepath)
