@@ -228,11 +228,139 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
     }
 }
 
+// ---- persistent single-chunk variant ----------------------------------------------------------------
+// 3x3 layers with exactly 16 (padded) input channels and <= 16 outputs on large maps (the discriminator's 16->16
+// full-resolution conv and its data gradient, the generator's 16->2 output conv) are latency-bound in the kernel
+// above (PMC: 42 % of wave cycles waiting, 1.9 TB/s): one tile per block, the halo staged by dependent loads between
+// two barriers.  Here a block walks tiles with a grid stride, the NEXT tile's halo is fetched into registers while
+// the current one is multiplied (one barrier pair per tile, no exposed load latency), and the nine taps' weight
+// fragments stay in registers for the block's whole life.
+template <int TAPS>
+__global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, const float* __restrict__ Bw) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem1[];
+    f32x4* lds_a = smem1;   // [4][npix]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int npr = p.halo_h * p.halo_w;
+    constexpr int NLMAX = 6;                      // (8+2)*(32+2)*4 / 256 = 5.3 slots per thread for 3x3
+    const int nslots = 4 * npr;
+
+    // weight fragments of all taps in LDS for the block's whole life: slot [tap][lg][li]
+    f32x4* lds_w = lds_a + 4 * p.npix;
+    for (int idx = t; idx < TAPS * 64; idx += 256) {
+        const int tap = idx >> 6, l = idx & 63;
+        const int wli = l & 15, wlg = l >> 4;
+        lds_w[idx] = wli < p.Ncols ? *reinterpret_cast<const f32x4*>(Bw + (long long)wli * p.ldB + p.taps[tap].z + wlg * 4)
+                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int rowoff[TAPS];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const int4 e = p.taps[tap];
+        rowoff[tap] = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
+    }
+    const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
+    f32x4 rs[NLMAX];
+    // slot geometry is tile independent: halo row / column and the in-image element offset of every staging slot
+    int shy[NLMAX], shx[NLMAX], soff[NLMAX];
+#pragma unroll
+    for (int i = 0; i < NLMAX; ++i) {
+        const int idx = t + 256 * i;
+        const int kg = idx & 3, pix = idx >> 2;     // 4 consecutive lanes = the 64 contiguous bytes of one pixel
+        shy[i] = idx < nslots ? pix / p.halo_w : (1 << 28);
+        shx[i] = pix - (pix / p.halo_w) * p.halo_w;
+        soff[i] = ((pix / p.halo_w) * p.W + shx[i]) * p.ldA + kg * 4;
+    }
+    auto load_tile = [&](int tile) {
+        const int img = tile / (p.tiles_h * p.tiles_w);
+        const int rem = tile - img * (p.tiles_h * p.tiles_w);
+        const int ty = rem / p.tiles_w, tx = rem - ty * p.tiles_w;
+        const int hy0 = ty * HALO_TH + p.dh_min, hx0 = tx * HALO_TW + p.dw_min;
+        const float* Aorg = p.A + (long long)img * p.imgStrideA + ((long long)hy0 * p.W + hx0) * p.ldA;
+#pragma unroll
+        for (int i = 0; i < NLMAX; ++i) {
+            const int gy = hy0 + shy[i], gx = hx0 + shx[i];
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc)
+                v = *reinterpret_cast<const f32x4*>(Aorg + soff[i]);
+            rs[i] = v;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < NLMAX; ++i) {
+            const int idx = t + 256 * i;
+            // slot = kg*npix + (pixel ^ 2kg): the XOR keeps the 4 lanes of a pixel (kg = 0..3) on distinct banks for the
+            // write and permutes inside aligned 8-pixel groups only, so the fragment reads stay conflict-free
+            if (idx < nslots) lds_a[(idx & 3) * p.npix + ((idx >> 2) ^ (2 * (idx & 3)))] = rs[i];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        f32x4 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int pbase = 2 * wave * p.halo_w + li;
+        const f32x4* lds_g = lds_a + lg * p.npix;
+        // fragments of tap+1 are read while tap is multiplied; the scheduling barrier per tap keeps the compiler from
+        // hoisting all 36 fragment reads (144 registers, 2 waves/SIMD) in front of the MFMAs
+        f32x4 af[2][4], bfr[2];
+        auto read_tap = [&](int tap, f32x4 (&a4)[4], f32x4& b1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) a4[a] = lds_g[(pbase + (a >> 1) * p.halo_w + (a & 1) * 16 + rowoff[tap]) ^ (2 * lg)];
+            b1 = lds_w[tap * 64 + lane];
+        };
+        read_tap(0, af[0], bfr[0]);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap + 1 < TAPS) read_tap(tap + 1, af[(tap + 1) & 1], bfr[(tap + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    // operands swapped (A = weights, B = pixels): the accumulator is the TRANSPOSED tile, lane (li, lg)
+                    // holds channels 4lg..4lg+3 of pixel li -> one 16-byte store per row tile instead of four 4-byte ones
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[tap & 1][j], af[tap & 1][a][j], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int b = tile;
+        const int tx = b % p.tiles_w;
+        b /= p.tiles_w;
+        const int ty = b % p.tiles_h;
+        const int img = b / p.tiles_h;
+        if (4 * lg < ((p.Ncols + 3) & ~3)) {
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = 4 * lg + r < p.Ncols ? p.bias[4 * lg + r] : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int oy = ty * HALO_TH + 2 * wave + (a >> 1);
+                const int ox = tx * HALO_TW + (a & 1) * 16 + li;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                f32x4* dst = reinterpret_cast<f32x4*>(p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO + 4 * lg);
+                f32x4 v = acc[a] + bv;
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
+                }
+                if (p.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols <= 64 ? 4 : 0; }
 
 static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
 void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
+static int g_halo_persistent = 1;   // wdg_set_tuning("halo_persistent", 0/1)
+void wdg_halo_set_persistent(int v) { g_halo_persistent = v != 0; }
 
 static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 0) {
     const int hh = HALO_TH + kh - 1, hw = HALO_TW + kw - 1;
@@ -325,6 +453,14 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
     const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg, upsample);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
+    if (g_halo_persistent && !upsample && nt == 1 && p.C4 == 4 && pl->taps == 9 && g.kh == 3) {
+        // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
+        const size_t lds1 = ((size_t)4 * p.npix + 9 * 64) * sizeof(f32x4);
+        const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * 2);   // 220 registers -> 2 resident blocks per CU
+        hipLaunchKernelGGL((wdg_conv_halo1_kernel<9>), dim3(nb), block, lds1, st, p, Bw);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
 #define WDG_HALO_CASE(NT_)                                                                             \
     if (nt == NT_) {                                                                                   \
         if (wg) hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 1>), grid, block, lds, st, p, Bw);       \

@@ -179,7 +179,9 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+                    // A = weights, B = pixels: the accumulator holds the TRANSPOSED tile — reg r of lane (i = lane & 15,
+                    // q = lane >> 4) is output channel 4q + r of pixel i — so the epilogue writes 16 bytes per lane
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);
     };
 
     if (PIPE == 0) {
@@ -260,41 +262,43 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
         }
     }
 
-    // ---- epilogue
-    const int col = lane & 15;
+    // ---- epilogue: one pixel per (row tile a), four consecutive output channels per (column tile b)
+    const int q4 = 4 * (lane >> 4);
+    const int NcP = (p.Ncols + 3) & ~3;
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
+        const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
+        if (m >= Mph) continue;
+        if (p.splitk > 1) {
+            float* dst = p.partial + (((long long)blockIdx.z * p.splitk + blockIdx.y) * p.Mmax + m) * NcP;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * (BM / WGM) + a * 16 + (lane >> 4) * 4 + r;
-            if (m >= Mph) continue;
-            if (p.splitk > 1) {
-                float* dst = p.partial +
-                             (((long long)blockIdx.z * p.splitk + blockIdx.y) * p.Mmax + m) * p.Ncols;
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+                if (n < NcP) *reinterpret_cast<f32x4*>(dst + n) = acc[a][b];
+            }
+        } else {
+            const int img = m / PaPb;
+            const int rem = m - img * PaPb;
+            const int pa = rem / ph.Pb;
+            const int pb = rem - pa * ph.Pb;
+            const int oh = pa * p.o_mul + ph.o_off_h;
+            const int ow = pb * p.o_mul + ph.o_off_w;
+            float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
 #pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
-                    if (n < p.Ncols) dst[n] = acc[a][b][r];
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+                if (n >= NcP) continue;
+                f32x4 v = acc[a][b];
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += n + r < p.Ncols ? p.bias[n + r] : 0.f;
                 }
-            } else {
-                const int img = m / PaPb;
-                const int rem = m - img * PaPb;
-                const int pa = rem / ph.Pb;
-                const int pb = rem - pa * ph.Pb;
-                const int oh = pa * p.o_mul + ph.o_off_h;
-                const int ow = pb * p.o_mul + ph.o_off_w;
-                float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
+                if (p.act) {
 #pragma unroll
-                for (int b = 0; b < NT; ++b) {
-                    const int n = n0 + wn * (BN / WGN) + b * 16 + col;
-                    if (n < p.Ncols) {
-                        float v = acc[a][b][r];
-                        if (p.bias) v += p.bias[n];
-                        if (p.act) v = wdg_lrelu(v, p.slope);
-                        if (p.accumulate) v += dst[n];
-                        dst[n] = v;
-                    }
+                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
                 }
+                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst + n);
+                *reinterpret_cast<f32x4*>(dst + n) = v;   // channels Ncols .. round4(Ncols)-1 receive zeros (padding)
             }
         }
     }
@@ -305,14 +309,15 @@ __global__ void __launch_bounds__(256) wdg_igemm_reduce_kernel(const WdgIgemm p)
     const WdgPhase ph = p.ph[blockIdx.z];
     const int PaPb = ph.Pa * ph.Pb;
     const int Mph = p.n_img * PaPb;
+    const int NcP = (p.Ncols + 3) & ~3;     // slab rows are padded to 4 columns (16-byte stores of the main kernel)
     const long long total = (long long)Mph * p.Ncols;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * 256) {
         const int m = (int)(idx / p.Ncols);
         const int n = (int)(idx - (long long)m * p.Ncols);
-        const float* src = p.partial + (((long long)blockIdx.z * p.splitk) * p.Mmax + m) * p.Ncols + n;
+        const float* src = p.partial + (((long long)blockIdx.z * p.splitk) * p.Mmax + m) * NcP + n;
         float v = 0.f;
-        for (int s = 0; s < p.splitk; ++s) v += src[(long long)s * p.Mmax * p.Ncols];
+        for (int s = 0; s < p.splitk; ++s) v += src[(long long)s * p.Mmax * NcP];
         const int img = m / PaPb;
         const int rem = m - img * PaPb;
         const int pa = rem / ph.Pb;
@@ -725,7 +730,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         long long tiles = ((M + tc.BM - 1) / tc.BM) * ((g->Cout + tc.BN - 1) / tc.BN);
         pl->fwd_split = pick_split(tiles, pl->K4_fwd, pl->cus, tc.BN);
         if (g_force_split[0] > 0) pl->fwd_split = std::min(g_force_split[0], std::max(1, pl->K4_fwd / 8));
-        if (pl->fwd_split > 1) pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->fwd_split * M * g->Cout * 4));
+        if (pl->fwd_split > 1) pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->fwd_split * M * pl->Cout_p * 4));
     }
     {
         long long Mmax = 0;
@@ -735,7 +740,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         pl->dgrad_split = pick_split(tiles, pl->K4_dgrad_max, pl->cus, tc.BN);
         if (g_force_split[1] > 0) pl->dgrad_split = std::min(g_force_split[1], std::max(1, pl->K4_dgrad_max / 8));
         if (pl->dgrad_split > 1)
-            pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->dgrad_split * pl->ph_dgrad.size() * Mmax * g->Cin * 4));
+            pl->ws_bytes = std::max(pl->ws_bytes, (size_t)((size_t)pl->dgrad_split * pl->ph_dgrad.size() * Mmax * pl->Cin_p * 4));
     }
     {
         const long long P = (long long)g->n_img * g->Ho * g->Wo;
@@ -810,6 +815,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_force_split[key[6] == 'f' ? 0 : key[6] == 'd' ? 1 : 2] = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "halo_persistent")) {
+        wdg_halo_set_persistent(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "wgrad_thin")) {
         wdg_wgrad_thin_enable(value);
         return WDG_OK;
@@ -852,7 +861,7 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     split = (K4max + per - 1) / per;
     p.splitk = split;
     if (split > 1) {
-        const size_t need = (size_t)split * nphase * p.Mmax * p.Ncols * sizeof(float);
+        const size_t need = (size_t)split * nphase * p.Mmax * wdg_round_up(p.Ncols, 4) * sizeof(float);
         if (!ws || ws_bytes < need) {
             wdg_set_error("igemm: workspace too small (%zu < %zu)", ws_bytes, need);
             return WDG_ERR_WORKSPACE;
@@ -892,7 +901,7 @@ extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float
                             float* y, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
                             wdg_stream stream) {
     WDG_CHECK_ARG(pl && x && wF && y, "null argument");
-    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0, "x / wF must be 16-byte aligned");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0 && ((uintptr_t)y & 15) == 0, "x / wF / y must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
     if (pl->halo_auto && pl->halo_fwd_nt)
         return wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, accumulate,
@@ -918,7 +927,7 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
                               float* dx, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
                               wdg_stream stream) {
     WDG_CHECK_ARG(pl && dy && wD && dx, "null argument");
-    WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0, "dy / wD must be 16-byte aligned");
+    WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0 && ((uintptr_t)dx & 15) == 0, "dy / wD / dx must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
     if (pl->halo_auto && pl->halo_dgrad_nt)
         return wdg_halo_launch(pl, true, dy, g.ldy, g.img_stride_y, 0, wD, bias, dx, act, slope, accumulate,

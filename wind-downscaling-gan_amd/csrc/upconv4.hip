@@ -144,25 +144,30 @@ __global__ void __launch_bounds__(256) wdg_upconv4_kernel(const WdgUp4 p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < U4_TH; ++r)
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], bf[j], acc[r], 0, 0, 0);
+                    // A = weights, B = pixels: transposed accumulator, reg q of lane (li, lg) = output channel 4*lg + q of
+                    // low-res column j0 + li -> one 16-byte store per row instead of four 4-byte ones
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[r][j], acc[r], 0, 0, 0);
         }
     }
 
-    // epilogue: accumulator reg q of lane (li, lg) = low-res column j0 + 4*lg + q, output channel li
-    if (li < p.N) {
-        const float bv = p.bias ? p.bias[li] : 0.f;
+    const int j = j0 + li;
+    if (4 * lg < ((p.N + 3) & ~3) && j <= p.W - 2) {
+        f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = 4 * lg + q < p.N ? p.bias[4 * lg + q] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < U4_TH; ++r) {
             const int i = i0 + r;
             if (i > p.H - 2) continue;
+            f32x4 v = acc[r] + bv;
+            if (p.act) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + 4 * lg + q;
-                if (j > p.W - 2) continue;
-                float v = acc[r][q] + bv;
-                if (p.act) v = wdg_lrelu(v, p.slope);
-                p.Out[(long long)img * p.imgStrideO + ((long long)(2 * i + ph) * (2 * p.W) + (2 * j + pw)) * p.ldO + li] = v;
+                for (int q = 0; q < 4; ++q) v[q] = wdg_lrelu(v[q], p.slope);
             }
+            *reinterpret_cast<f32x4*>(p.Out + (long long)img * p.imgStrideO +
+                                      ((long long)(2 * i + ph) * (2 * p.W) + (2 * j + pw)) * p.ldO + 4 * lg) = v;
         }
     }
 }
@@ -225,23 +230,22 @@ __global__ void __launch_bounds__(256) wdg_upconv4_border_kernel(const WdgUp4 p)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][q], bf[u][q], acc4[u], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[u][q], af[u][q], acc4[u], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = (acc4[0][q] + acc4[1][q]) + (acc4[2][q] + acc4[3][q]);
-    // accumulator reg q of lane (li, lg): segment pixel 4*lg + q, output channel li
-    if (li < p.N) {
-        const float bv = p.bias ? p.bias[li] : 0.f;
+    // transposed accumulator: reg q of lane (li, lg) = output channel 4*lg + q of segment pixel li
+    if (4 * lg < ((p.N + 3) & ~3) && li < cnt) {
+        f32x4 v = acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int kk = 4 * lg + q;
-            if (kk >= cnt) continue;
-            const int oi = si + kk * di, oj = sj + kk * dj;
-            float v = acc[q] + bv;
-            if (p.act) v = wdg_lrelu(v, p.slope);
-            p.Out[(long long)img * p.imgStrideO + ((long long)(2 * oi + ph) * (2 * p.W) + (2 * oj + pw)) * p.ldO + li] = v;
+            v[q] += (p.bias && 4 * lg + q < p.N) ? p.bias[4 * lg + q] : 0.f;
+            if (p.act) v[q] = wdg_lrelu(v[q], p.slope);
         }
+        const int oi = si + li * di, oj = sj + li * dj;
+        *reinterpret_cast<f32x4*>(p.Out + (long long)img * p.imgStrideO +
+                                  ((long long)(2 * oi + ph) * (2 * p.W) + (2 * oj + pw)) * p.ldO + 4 * lg) = v;
     }
 }
 
@@ -269,6 +273,7 @@ extern "C" int wdg_upconv4_fwd(const float* x_low, int ld_low, int64_t img_strid
     WDG_CHECK_ARG(x_low && wc && y, "null argument");
     WDG_CHECK_ARG(wdg_upconv4_supported(N, C, H, W), "unsupported shape");
     WDG_CHECK_ARG(((uintptr_t)x_low & 15) == 0 && ld_low % 4 == 0 && ld_low >= wdg_round_up(C, 4), "x_low alignment / ld");
+    WDG_CHECK_ARG(((uintptr_t)y & 15) == 0 && ldy % 4 == 0 && ldy >= wdg_round_up(N, 4), "y alignment / ld");
     WDG_CHECK_ARG((long long)H * W * ld_low < (1LL << 31), "low-res image too large for 32-bit offsets");
     WdgUp4 p;
     memset(&p, 0, sizeof(p));

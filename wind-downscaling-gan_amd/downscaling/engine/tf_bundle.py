@@ -101,7 +101,7 @@ def read_bundle(prefix, include_optimizer_slots=False):
             if ".OPTIMIZER_SLOT" in key and not include_optimizer_slots:
                 continue
             f.seek(off)
-            arr = np.frombuffer(f.read(size), dtype=_DTYPES[dt]).reshape(shape)
+            arr = np.frombuffer(f.read(size), dtype=_DTYPES[dt]).reshape(shape).copy()   # writable, detached from the buffer
             out[key[:-len(_SUFFIX)]] = arr
     return out
 
