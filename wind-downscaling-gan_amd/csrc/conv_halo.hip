@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);   // transposed tile
             }
         } else {
             // ---- flattened (tap, channel-group) entries, 4 per MFMA k-group: lane group lg takes entry 4q+lg
@@ -198,32 +198,32 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][j], bf[b][j], acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);   // transposed tile
             }
         }
     }
 
-    // ---- epilogue: accumulator reg r of lane (li, lg) is pixel column 4*lg + r, channel li
+    // ---- epilogue: the MFMA operands are swapped (A = weights, B = pixels), so accumulator reg r of lane (li, lg) is
+    // output channel b*16 + 4*lg + r of pixel column li: one 16-byte store per lane and tile
+    const int NcP = (p.Ncols + 3) & ~3;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int oy = oy0 + 2 * wave + (a >> 1);
-        if (oy >= p.Ho) continue;
+        const int ox = ox0 + (a & 1) * 16 + li;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ox = ox0 + (a & 1) * 16 + lg * 4 + r;
-            if (ox >= p.Wo) continue;
-            float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO;
+        for (int b = 0; b < NT; ++b) {
+            const int n = b * 16 + 4 * lg;
+            if (n >= NcP) continue;
+            f32x4 v = acc[a][b];
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int n = b * 16 + li;
-                if (n < p.Ncols) {
-                    float v = acc[a][b][r];
-                    if (p.bias) v += p.bias[n];
-                    if (p.act) v = wdg_lrelu(v, p.slope);
-                    if (p.accumulate) v += dst[n];
-                    dst[n] = v;
-                }
+            for (int r = 0; r < 4; ++r) {
+                if (p.bias && n + r < p.Ncols) v[r] += p.bias[n + r];
+                if (p.act) v[r] = wdg_lrelu(v[r], p.slope);
             }
+            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst + n);
+            *reinterpret_cast<f32x4*>(dst + n) = v;
         }
     }
 }
