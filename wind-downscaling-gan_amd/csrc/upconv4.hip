@@ -122,31 +122,45 @@ __global__ void __launch_bounds__(256) wdg_upconv4_kernel(const WdgUp4 p) {
     const int abase = lg * U4_NPIX + li + (ph * U4_HW + pw);   // + (th*HW + tw) + r*HW per tap / row
 
     const int nchunk = (p.C4 + 3) >> 2;
+    // Weight fragments come straight from global memory (L1/L2 resident), four taps per batch, double buffered.  Order
+    // matters for the in-order vmcnt queue: the first batch of a chunk is issued BEFORE the next chunk's halo prefetch,
+    // so waiting for it never waits for the prefetch; later batches are issued behind the prefetch, which has landed by
+    // the time they are needed (4 taps = 128 MFMAs later).
+    f32x4 bw[2][4];
+    auto load_w = [&](int ck, int g, f32x4 (&dst)[4]) {
+        const bool kvalid = lg < min(4, p.C4 - 4 * ck);
+        const float* Wk = Wph + 16 * ck + (long long)(4 * g) * 16 * p.Cp;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            dst[u] = kvalid ? *reinterpret_cast<const f32x4*>(Wk + (long long)u * 16 * p.Cp) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     load_chunk(0);
     for (int ck = 0; ck < nchunk; ++ck) {
         f32x4* st = lds[ck & 1];
 #pragma unroll
         for (int i = 0; i < NL; ++i)
             if (sdst[i] >= 0) st[sdst[i]] = rs[i];
+        load_w(ck, 0, bw[0]);
         __syncthreads();   // one barrier per chunk: the other stage is only rewritten after the next barrier
         if (ck + 1 < nchunk) load_chunk(ck + 1);
-        const bool kvalid = lg < min(4, p.C4 - 4 * ck);
-        const float* Wk = Wph + 16 * ck;
-#pragma unroll 4
-        for (int tap = 0; tap < 16; ++tap) {
-            const f32x4 bf = kvalid ? *reinterpret_cast<const f32x4*>(Wk + (long long)tap * 16 * p.Cp)
-                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int ao = abase + (tap >> 2) * U4_HW + (tap & 3);
-            f32x4 af[U4_TH];
 #pragma unroll
-            for (int r = 0; r < U4_TH; ++r) af[r] = st[ao + r * U4_HW];
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load_w(ck, g + 1, bw[(g + 1) & 1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int u = 0; u < 4; ++u) {
+                const int tap = 4 * g + u;
+                const int ao = abase + (tap >> 2) * U4_HW + (tap & 3);
+                f32x4 af[U4_TH];
 #pragma unroll
-                for (int r = 0; r < U4_TH; ++r)
-                    // A = weights, B = pixels: transposed accumulator, reg q of lane (li, lg) = output channel 4*lg + q of
-                    // low-res column j0 + li -> one 16-byte store per row instead of four 4-byte ones
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[r][j], acc[r], 0, 0, 0);
+                for (int r = 0; r < U4_TH; ++r) af[r] = st[ao + r * U4_HW];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < U4_TH; ++r)
+                        // A = weights, B = pixels: transposed accumulator, reg q of lane (li, lg) = output channel 4*lg + q of
+                        // low-res column j0 + li -> one 16-byte store per row instead of four 4-byte ones
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g & 1][u][j], af[r][j], acc[r], 0, 0, 0);
+            }
         }
     }
 
