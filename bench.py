@@ -153,7 +153,7 @@ def bench_generator_forward(args, generator, gan, low, world, rank, dev):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         dist.destroy_process_group()
@@ -192,10 +192,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # one process per GPU over RCCL ("nccl").  For a functional check of the multi-rank path on a single-GPU box:
+    # WDG_DIST_BACKEND=gloo WDG_DEVICE=0 runs every rank on cuda:0 with host-staged reductions (not a benchmark).
+    backend = os.environ.get("WDG_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("WDG_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from downscaling.data.data_generator import FlexibleNoiseGenerator
     from downscaling.engine import runtime
@@ -233,7 +240,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

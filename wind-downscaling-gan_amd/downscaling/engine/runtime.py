@@ -10,7 +10,7 @@ def get_ops():
     global _ops
     if _ops is None:
         from .hipops import HipOps
-        _ops = HipOps(f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+        _ops = HipOps(f"cuda:{int(os.environ.get('WDG_DEVICE', os.environ.get('LOCAL_RANK', 0)))}")
     return _ops
 
 

@@ -63,7 +63,16 @@ class DistSync:
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+        # gloo has no device collectives in every build: stage device tensors through the host there (tests that
+        # run two ranks on one GPU; the production backend is "nccl" = RCCL, which reduces in place on the device)
+        self._stage = self.dist.get_backend(group) == "gloo"
+
     def all_reduce_sum(self, t):
+        if self._stage and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
