@@ -164,7 +164,7 @@ def bench_generator_forward(args, generator, gan, low, world, rank, dev):
             "metric": "generator forward samples/s, 32x32->256x256 wind tiles", "value": world * B * args.steps / dt,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 operands / f32 accumulate", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else f"{args.precision} operands / f32 accumulate", "data": "synthetic",
             "config": {"workload": f"make_generator(256,3,20,2,T=1) forward, inference mode, batch {B}/GPU", "per_gpu_batch": B},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="gen_fwd only: inference precision")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp16"], default="fp32", help="gen_fwd only: inference precision")
     ap.add_argument("--workload", choices=["train", "gen_fwd"], default="train",
                     help="train: the headline GAN train step (default); gen_fwd: generator-only forward (inference "
                          "mode) at --batch tiles, the 'generator conv stack at batch 64' figure of BASELINE.json")

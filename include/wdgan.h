@@ -129,6 +129,19 @@ int wdg_upconv_fwd_bf16(const wdg_conv_plan* plan, const float* x_low, int ld_lo
                         const void* wD16, const float* bias, const float* affine, float* y, int act, float slope,
                         wdg_stream stream);
 
+/* The same five entry points with IEEE fp16 operands (v_mfma_f32_16x16x32_f16; BASELINE configs[4], the stochastic
+ * ensemble): identical kernels instantiated for the other 16-bit format, w*16 = fp16 copies (wdg_convert_f16). */
+int wdg_convert_f16(const float* src, void* dst_f16, int64_t n, wdg_stream stream);
+int wdg_conv_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,
+                     const float* affine, float* y, int act, float slope, int accumulate, wdg_stream stream);
+int wdg_conv_dgrad_f16(const wdg_conv_plan* plan, const float* dy, const void* wD16, const float* bias,
+                       const float* affine, float* dx, int act, float slope, int accumulate, wdg_stream stream);
+int wdg_conv_halo_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,
+                          const float* affine, float* y, int act, float slope, wdg_stream stream);
+int wdg_upconv_fwd_f16(const wdg_conv_plan* plan, const float* x_low, int ld_low, int64_t img_stride_low,
+                       const void* wD16, const float* bias, const float* affine, float* y, int act, float slope,
+                       wdg_stream stream);
+
 /* UpSampling2D(2,'bilinear') + Conv2DTranspose(5x5, stride 1, 'same') (models.py:62-64) evaluated as four 4x4
  * convolutions on the low-resolution grid with composite kernels (csrc/upconv4.hip): 16 instead of 25 taps per
  * output pixel, results equal to the two-step definition up to fp32 re-association (~1e-7 relative).

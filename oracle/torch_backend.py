@@ -148,33 +148,33 @@ class TorchOps:
             out = out + dx[..., :pk.cin]
         dx[..., :pk.cin] = out
 
-    # inference precision: operands rounded to bf16 (round-to-nearest-even), exact accumulation
+    # inference precision: operands rounded to a 16-bit format (bf16 or IEEE fp16, round-to-nearest-even), exact accumulation
     @staticmethod
-    def _r16(t):
-        return t.to(torch.bfloat16).to(t.dtype)
+    def _r16(t, fmt="bf16"):
+        return t.to(torch.bfloat16 if fmt == "bf16" else torch.float16).to(t.dtype)
 
-    def conv_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, accumulate=False, slope=0.2):
+    def conv_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
         out = torch.zeros(y.shape[:3] + (pk.cout,), dtype=x.dtype)
-        self.conv_fwd(self._r16(x), PackedWeights(self, self._r16(pk.w)), bias, out, g, act=act, slope=slope)
+        self.conv_fwd(self._r16(x, fmt), PackedWeights(self, self._r16(pk.w, fmt)), bias, out, g, act=act, slope=slope)
         if affine is not None:
             out = out * affine[:pk.cout] + affine[pk.cout:]
         y[..., :pk.cout] = out + (y[..., :pk.cout] if accumulate else 0)
 
-    def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2):
+    def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
         out = torch.zeros(dx.shape[:3] + (pk.cin,), dtype=dy.dtype)
-        self.conv_dgrad(self._r16(dy), PackedWeights(self, self._r16(pk.w)), out, g, bias=bias, act=act, slope=slope)
+        self.conv_dgrad(self._r16(dy, fmt), PackedWeights(self, self._r16(pk.w, fmt)), out, g, bias=bias, act=act, slope=slope)
         if affine is not None:
             out = out * affine[:pk.cin] + affine[pk.cin:]
         dx[..., :pk.cin] = out + (dx[..., :pk.cin] if accumulate else 0)
 
-    def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2):
-        self.conv_fwd_bf16(x, pk, bias, y, g, act=act, affine=affine, slope=slope)
+    def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2, fmt="bf16"):
+        self.conv_fwd_bf16(x, pk, bias, y, g, act=act, affine=affine, slope=slope, fmt=fmt)
 
-    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2):
-        # bilinear interpolation in full precision, then bf16 rounding of the conv operands
+    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16"):
+        # bilinear interpolation in full precision, then 16-bit rounding of the conv operands
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
         self.upsample2x_fwd(x_low, up)
-        self.conv_dgrad_bf16(up, pk, y, g, bias=bias, act=act, affine=affine, slope=slope)
+        self.conv_dgrad_bf16(up, pk, y, g, bias=bias, act=act, affine=affine, slope=slope, fmt=fmt)
 
     def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)

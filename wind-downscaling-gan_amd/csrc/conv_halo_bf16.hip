@@ -10,7 +10,17 @@
 #include "conv_plan.h"
 #include <algorithm>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// operand format FMT: 0 = bf16, 1 = IEEE fp16 (same kernels, see conv_igemm_bf16.hip)
+template <int FMT> struct WdgH16;
+template <> struct WdgH16<0> { typedef __bf16 T; };
+template <> struct WdgH16<1> { typedef _Float16 T; };
+template <int FMT> using wdg_h16 = typename WdgH16<FMT>::T;
+template <int FMT> using wdg_h16x8 = wdg_h16<FMT> __attribute__((ext_vector_type(8)));
+template <int FMT>
+__device__ __forceinline__ f32x4 wdg_mfma16(const wdg_h16x8<FMT>& a, const wdg_h16x8<FMT>& b, const f32x4& c) {
+    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 constexpr int HB_TH = 8, HB_TW = 32;
 
 struct WdgHaloBf16 {
@@ -32,18 +42,21 @@ struct WdgHaloBf16 {
     int lr_h, lr_w;         // low-res staging tile (upsample mode)
 };
 
-__device__ __forceinline__ bf16x8 hb_pack(const f32x4& a, const f32x4& b) {
-    bf16x8 v;
+template <int FMT>
+__device__ __forceinline__ wdg_h16x8<FMT> hb_pack_t(const f32x4& a, const f32x4& b) {
+    wdg_h16x8<FMT> v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        v[j] = (__bf16)a[j];
-        v[4 + j] = (__bf16)b[j];
+        v[j] = (wdg_h16<FMT>)a[j];
+        v[4 + j] = (wdg_h16<FMT>)b[j];
     }
     return v;
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256) wdg_conv_halo_bf16_kernel(const WdgHaloBf16 p, const __bf16* __restrict__ Bw) {
+template <int NT, int FMT>
+__global__ void __launch_bounds__(256) wdg_conv_halo_bf16_kernel(const WdgHaloBf16 p, const wdg_h16<FMT>* __restrict__ Bw) {
+    typedef wdg_h16x8<FMT> bf16x8;
+    auto hb_pack = [](const f32x4& a, const f32x4& b) { return hb_pack_t<FMT>(a, b); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);                       // [4][npix] bf16 halo
     f32x4* lds_lr = reinterpret_cast<f32x4*>(smem_raw + (size_t)4 * p.npix * 16);  // [lr_h*lr_w][8] fp32 low-res tile
@@ -152,7 +165,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_bf16_kernel(const WdgHaloBf
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = wdg_mfma16<FMT>(af[a], bf[b], acc[a][b]);
         }
     }
 
@@ -183,7 +196,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_bf16_kernel(const WdgHaloBf
 
 static int launch_halo_bf16(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA,
                             int upsample, const void* B16, const float* bias, const float* affine, float* Out, int act,
-                            float slope, int accumulate, hipStream_t st) {
+                            float slope, int accumulate, int fmt, hipStream_t st) {
     const wdg_conv_geom& g = pl->g;
     WdgHaloBf16 p;
     memset(&p, 0, sizeof(p));
@@ -226,30 +239,48 @@ static int launch_halo_bf16(const wdg_conv_plan* pl, bool dgrad, const float* A,
     p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
     const size_t lds = (size_t)4 * p.npix * 16 + (upsample ? (size_t)p.lr_h * p.lr_w * 8 * 16 : 0);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
-    if (nt == 1)
-        hipLaunchKernelGGL(wdg_conv_halo_bf16_kernel<1>, grid, block, lds, st, p, (const __bf16*)B16);
-    else if (nt == 2)
-        hipLaunchKernelGGL(wdg_conv_halo_bf16_kernel<2>, grid, block, lds, st, p, (const __bf16*)B16);
-    else
-        hipLaunchKernelGGL(wdg_conv_halo_bf16_kernel<4>, grid, block, lds, st, p, (const __bf16*)B16);
+#define WDG_HB_CASE(NT_)                                                                                              \
+    if (nt == NT_) {                                                                                              \
+        if (fmt == 0) hipLaunchKernelGGL((wdg_conv_halo_bf16_kernel<NT_, 0>), grid, block, lds, st, p, (const __bf16*)B16);   \
+        else hipLaunchKernelGGL((wdg_conv_halo_bf16_kernel<NT_, 1>), grid, block, lds, st, p, (const _Float16*)B16);          \
+    }
+    WDG_HB_CASE(1) WDG_HB_CASE(2) WDG_HB_CASE(4)
+#undef WDG_HB_CASE
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
 
-// bf16 forward of a thin stride-1 conv (<= 64 output channels): y = affine(act(conv(x, wF16) + bias))
-extern "C" int wdg_conv_halo_fwd_bf16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
-                                      const float* affine, float* y, int act, float slope, wdg_stream stream) {
+// 16-bit forward of a thin stride-1 conv (<= 64 output channels): y = affine(act(conv(x, wF16) + bias))
+static int halo_fwd_h16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias, const float* affine,
+                        float* y, int act, float slope, int fmt, wdg_stream stream) {
     WDG_CHECK_ARG(pl && x && wF16 && y, "null argument");
-    return launch_halo_bf16(pl, false, x, pl->g.ldx, pl->g.img_stride_x, 0, wF16, bias, affine, y, act, slope, 0,
+    return launch_halo_bf16(pl, false, x, pl->g.ldx, pl->g.img_stride_x, 0, wF16, bias, affine, y, act, slope, 0, fmt,
                             (hipStream_t)stream);
 }
+extern "C" int wdg_conv_halo_fwd_bf16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
+                                      const float* affine, float* y, int act, float slope, wdg_stream stream) {
+    return halo_fwd_h16(pl, x, wF16, bias, affine, y, act, slope, 0, stream);
+}
+extern "C" int wdg_conv_halo_fwd_f16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
+                                     const float* affine, float* y, int act, float slope, wdg_stream stream) {
+    return halo_fwd_h16(pl, x, wF16, bias, affine, y, act, slope, 1, stream);
+}
 
-// bf16 counterpart of wdg_upconv_fwd: y = affine(act(convT(upsample2x(x_low), wD16) + bias))
+// 16-bit counterpart of wdg_upconv_fwd: y = affine(act(convT(upsample2x(x_low), wD16) + bias))
+static int upconv_fwd_h16(const wdg_conv_plan* pl, const float* x_low, int ld_low, int64_t img_stride_low, const void* wD16,
+                          const float* bias, const float* affine, float* y, int act, float slope, int fmt, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x_low && wD16 && y, "null argument");
+    WDG_CHECK_ARG(((uintptr_t)x_low & 15) == 0 && ld_low % 4 == 0, "x_low must be 16-byte aligned, ld % 4 == 0");
+    return launch_halo_bf16(pl, true, x_low, ld_low, img_stride_low, 1, wD16, bias, affine, y, act, slope, 0, fmt,
+                            (hipStream_t)stream);
+}
 extern "C" int wdg_upconv_fwd_bf16(const wdg_conv_plan* pl, const float* x_low, int ld_low, int64_t img_stride_low,
                                    const void* wD16, const float* bias, const float* affine, float* y, int act,
                                    float slope, wdg_stream stream) {
-    WDG_CHECK_ARG(pl && x_low && wD16 && y, "null argument");
-    WDG_CHECK_ARG(((uintptr_t)x_low & 15) == 0 && ld_low % 4 == 0, "x_low must be 16-byte aligned, ld % 4 == 0");
-    return launch_halo_bf16(pl, true, x_low, ld_low, img_stride_low, 1, wD16, bias, affine, y, act, slope, 0,
-                            (hipStream_t)stream);
+    return upconv_fwd_h16(pl, x_low, ld_low, img_stride_low, wD16, bias, affine, y, act, slope, 0, stream);
+}
+extern "C" int wdg_upconv_fwd_f16(const wdg_conv_plan* pl, const float* x_low, int ld_low, int64_t img_stride_low,
+                                  const void* wD16, const float* bias, const float* affine, float* y, int act,
+                                  float slope, wdg_stream stream) {
+    return upconv_fwd_h16(pl, x_low, ld_low, img_stride_low, wD16, bias, affine, y, act, slope, 1, stream);
 }

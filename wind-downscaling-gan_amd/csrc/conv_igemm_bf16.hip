@@ -14,11 +14,23 @@
 #include "conv_plan.h"
 #include <algorithm>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// Two 16-bit operand formats share every kernel of this file (template parameter FMT): 0 = bf16
+// (v_mfma_f32_16x16x32_bf16), 1 = IEEE fp16 (v_mfma_f32_16x16x32_f16, BASELINE.json configs[4]).  Both round to
+// nearest even from the fp32 activations while staging and accumulate in fp32.
+template <int FMT> struct WdgH16;
+template <> struct WdgH16<0> { typedef __bf16 T; };
+template <> struct WdgH16<1> { typedef _Float16 T; };
+template <int FMT> using wdg_h16 = typename WdgH16<FMT>::T;
+template <int FMT> using wdg_h16x8 = wdg_h16<FMT> __attribute__((ext_vector_type(8)));
+template <int FMT>
+__device__ __forceinline__ f32x4 wdg_mfma16(const wdg_h16x8<FMT>& a, const wdg_h16x8<FMT>& b, const f32x4& c) {
+    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 struct WdgIgemmBf16 {
     const float* A;
-    const __bf16* B;
+    const void* B;         // 16-bit weights (format = the kernel's FMT)
     float* Out;
     const float* bias;
     const float* affine;   // optional [2*Ncols]: scale | shift applied after the activation
@@ -34,8 +46,11 @@ struct WdgIgemmBf16 {
     WdgPhase ph[9];
 };
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int FMT>
 __global__ void __launch_bounds__(256) wdg_igemm_bf16_kernel(const WdgIgemmBf16 p) {
+    typedef wdg_h16<FMT> h16;
+    typedef wdg_h16x8<FMT> bf16x8;
+    const h16* Bp = static_cast<const h16*>(p.B);
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;
     constexpr int A_SLOTS = BM / 32;                // slots (8 channels of one row) per thread per K-step
@@ -112,9 +127,9 @@ __global__ void __launch_bounds__(256) wdg_igemm_bf16_kernel(const WdgIgemmBf16 
         for (int i = 0; i < B_SLOTS; ++i) {
             bf16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            for (int j = 0; j < 8; ++j) v[j] = (h16)0.f;
             // the weight rows are K-contiguous and zero-padded, and e1 directly follows e0 (Cin_p % 8 == 0)
-            if (b_ok[i] && e0.w >= 0) v = *reinterpret_cast<const bf16x8*>(p.B + b_base[i] + e0.w);
+            if (b_ok[i] && e0.w >= 0) v = *reinterpret_cast<const bf16x8*>(Bp + b_base[i] + e0.w);
             rb[i] = v;
         }
     };
@@ -126,8 +141,8 @@ __global__ void __launch_bounds__(256) wdg_igemm_bf16_kernel(const WdgIgemmBf16 
             bf16x8 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = (__bf16)ra[i][0][j];
-                v[4 + j] = (__bf16)ra[i][1][j];
+                v[j] = (h16)ra[i][0][j];
+                v[4 + j] = (h16)ra[i][1][j];
             }
             const int row = lrow + 32 * i;
             ldsA[kg * BM + (row ^ kg)] = v;
@@ -151,7 +166,7 @@ __global__ void __launch_bounds__(256) wdg_igemm_bf16_kernel(const WdgIgemmBf16 
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = wdg_mfma16<FMT>(af[a], bf[b], acc[a][b]);
         }
         __syncthreads();
     }
@@ -184,46 +199,60 @@ __global__ void __launch_bounds__(256) wdg_igemm_bf16_kernel(const WdgIgemmBf16 
     }
 }
 
-__global__ void __launch_bounds__(256) wdg_convert_bf16_kernel(const float* __restrict__ src, __bf16* dst, long long n) {
+template <int FMT>
+__global__ void __launch_bounds__(256) wdg_convert_h16_kernel(const float* __restrict__ src, wdg_h16<FMT>* dst, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        dst[i] = (__bf16)src[i];
+        dst[i] = (wdg_h16<FMT>)src[i];
 }
 
-extern "C" int wdg_convert_bf16(const float* src, void* dst_bf16, int64_t n, wdg_stream stream) {
-    WDG_CHECK_ARG(src && dst_bf16 && n >= 0, "bad argument");
+static int convert_h16(const float* src, void* dst, int64_t n, int fmt, wdg_stream stream) {
+    WDG_CHECK_ARG(src && dst && n >= 0, "bad argument");
     if (n == 0) return WDG_OK;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192));
-    hipLaunchKernelGGL(wdg_convert_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst_bf16, n);
+    if (fmt == 0)
+        hipLaunchKernelGGL(wdg_convert_h16_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, n);
+    else
+        hipLaunchKernelGGL(wdg_convert_h16_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, n);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+extern "C" int wdg_convert_bf16(const float* src, void* dst_bf16, int64_t n, wdg_stream stream) {
+    return convert_h16(src, dst_bf16, n, 0, stream);
+}
+extern "C" int wdg_convert_f16(const float* src, void* dst_f16, int64_t n, wdg_stream stream) {
+    return convert_h16(src, dst_f16, n, 1, stream);
+}
 
-static int launch_bf16(WdgIgemmBf16& p, int nphase, hipStream_t st) {
+static int launch_bf16(WdgIgemmBf16& p, int nphase, int fmt, hipStream_t st) {
     if (p.Mmax <= 0) return WDG_OK;
     p.nphase = nphase;
     const bool wide = p.Ncols > 64;
     const int BM = 128, BN = wide ? 128 : 64;
     const int tiles_m = (p.Mmax + BM - 1) / BM, tiles_n = (p.Ncols + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, nphase), block(256);
-    if (wide)
-        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    if (wide && fmt == 0)
+        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 128, 2, 2, 0>), grid, block, 0, st, p);
+    else if (wide)
+        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 128, 2, 2, 1>), grid, block, 0, st, p);
+    else if (fmt == 0)
+        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 64, 2, 2, 0>), grid, block, 0, st, p);
     else
-        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 64, 2, 2, 1>), grid, block, 0, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
 
 // y = affine(act(conv(x, wF16) + bias)); wF16 = bf16 copy of the forward-packed weights [Cout][taps][Cin_p]
-extern "C" int wdg_conv_fwd_bf16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
-                                 const float* affine, float* y, int act, float slope, int accumulate,
-                                 wdg_stream stream) {
+static int conv_fwd_h16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
+                        const float* affine, float* y, int act, float slope, int accumulate, int fmt,
+                        wdg_stream stream) {
     WDG_CHECK_ARG(pl && x && wF16 && y, "null argument");
     WDG_CHECK_ARG(pl->Cin_p % 8 == 0, "bf16 path needs the padded input channel count to be a multiple of 8");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF16 & 15) == 0, "alignment");
     const wdg_conv_geom& g = pl->g;
     WdgIgemmBf16 p;
     memset(&p, 0, sizeof(p));
-    p.A = x; p.B = (const __bf16*)wF16; p.Out = y; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_fwd;
+    p.A = x; p.B = wF16; p.Out = y; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_fwd;
     p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
     p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
     p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
@@ -235,20 +264,30 @@ extern "C" int wdg_conv_fwd_bf16(const wdg_conv_plan* pl, const float* x, const 
     ph.Pa = g.Ho; ph.Pb = g.Wo; ph.a_off_h = -g.pad_h; ph.a_off_w = -g.pad_w;
     ph.o_off_h = 0; ph.o_off_w = 0; ph.K4 = pl->K4_fwd; ph.tab_off = 0;
     p.ph[0] = ph;
-    return launch_bf16(p, 1, (hipStream_t)stream);
+    return launch_bf16(p, 1, fmt, (hipStream_t)stream);
+}
+extern "C" int wdg_conv_fwd_bf16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
+                                 const float* affine, float* y, int act, float slope, int accumulate,
+                                 wdg_stream stream) {
+    return conv_fwd_h16(pl, x, wF16, bias, affine, y, act, slope, accumulate, 0, stream);
+}
+extern "C" int wdg_conv_fwd_f16(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias,
+                                const float* affine, float* y, int act, float slope, int accumulate,
+                                wdg_stream stream) {
+    return conv_fwd_h16(pl, x, wF16, bias, affine, y, act, slope, accumulate, 1, stream);
 }
 
 // dx = affine(act(conv_transpose(dy, wD16) + bias)) — the Conv2DTranspose forward in bf16.
-extern "C" int wdg_conv_dgrad_bf16(const wdg_conv_plan* pl, const float* dy, const void* wD16, const float* bias,
-                                   const float* affine, float* dx, int act, float slope, int accumulate,
-                                   wdg_stream stream) {
+static int conv_dgrad_h16(const wdg_conv_plan* pl, const float* dy, const void* wD16, const float* bias,
+                          const float* affine, float* dx, int act, float slope, int accumulate, int fmt,
+                          wdg_stream stream) {
     WDG_CHECK_ARG(pl && dy && wD16 && dx, "null argument");
     WDG_CHECK_ARG(pl->Cout_p % 8 == 0, "bf16 path needs the padded channel count of dy to be a multiple of 8");
     WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD16 & 15) == 0, "alignment");
     const wdg_conv_geom& g = pl->g;
     WdgIgemmBf16 p;
     memset(&p, 0, sizeof(p));
-    p.A = dy; p.B = (const __bf16*)wD16; p.Out = dx; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_dgrad;
+    p.A = dy; p.B = wD16; p.Out = dx; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_dgrad;
     p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
     p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
     p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
@@ -262,5 +301,15 @@ extern "C" int wdg_conv_dgrad_bf16(const wdg_conv_plan* pl, const float* dy, con
         Mmax = std::max(Mmax, g.n_img * p.ph[i].Pa * p.ph[i].Pb);
     }
     p.Mmax = Mmax;
-    return launch_bf16(p, np, (hipStream_t)stream);
+    return launch_bf16(p, np, fmt, (hipStream_t)stream);
+}
+extern "C" int wdg_conv_dgrad_bf16(const wdg_conv_plan* pl, const float* dy, const void* wD16, const float* bias,
+                                   const float* affine, float* dx, int act, float slope, int accumulate,
+                                   wdg_stream stream) {
+    return conv_dgrad_h16(pl, dy, wD16, bias, affine, dx, act, slope, accumulate, 0, stream);
+}
+extern "C" int wdg_conv_dgrad_f16(const wdg_conv_plan* pl, const float* dy, const void* wD16, const float* bias,
+                                  const float* affine, float* dx, int act, float slope, int accumulate,
+                                  wdg_stream stream) {
+    return conv_dgrad_h16(pl, dy, wD16, bias, affine, dx, act, slope, accumulate, 1, stream);
 }

@@ -43,7 +43,8 @@ class PackedWeights:
         cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
         self.wF = torch.empty(cout * self.taps * cin_p, dtype=torch.float32, device=w.device)
         self.wD = w if cout % 4 == 0 else torch.empty(self.taps * cin * cout_p, dtype=torch.float32, device=w.device)
-        self._wF16 = self._wD16 = None
+        self._half = {}
+        self._hver = 0
         self._bf16_stale = True
         self._up4 = None
         self.refresh()
@@ -63,16 +64,26 @@ class PackedWeights:
         return self._up4
 
     def bf16(self):
-        """(wF16, wD16): bf16 copies of the packed layouts for the inference-precision kernels (lazy)."""
-        if self._wF16 is None:
-            self._wF16 = torch.empty(self.wF.numel(), dtype=torch.bfloat16, device=self.w.device)
-            self._wD16 = torch.empty(self.wD.numel(), dtype=torch.bfloat16, device=self.w.device)
-        if self._bf16_stale:
-            lib, st = self.ops.lib, self.ops.stream
-            native.check(lib.wdg_convert_bf16(self.wF.data_ptr(), self._wF16.data_ptr(), self.wF.numel(), st), "convert_bf16")
-            native.check(lib.wdg_convert_bf16(self.wD.data_ptr(), self._wD16.data_ptr(), self.wD.numel(), st), "convert_bf16")
+        return self.half("bf16")
+
+    def half(self, fmt="bf16"):
+        """(wF16, wD16): 16-bit copies (fmt "bf16" or "fp16") of the packed layouts for the inference-precision
+        kernels, converted lazily and again after the master weights changed."""
+        cache = self._half.setdefault(fmt, {"wF": None, "wD": None, "ver": -1})
+        tdt = torch.bfloat16 if fmt == "bf16" else torch.float16
+        if cache["wF"] is None:
+            cache["wF"] = torch.empty(self.wF.numel(), dtype=tdt, device=self.w.device)
+            cache["wD"] = torch.empty(self.wD.numel(), dtype=tdt, device=self.w.device)
+        if self._bf16_stale:            # the packed fp32 layouts changed since the last conversion of any format
+            self._hver += 1
             self._bf16_stale = False
-        return self._wF16, self._wD16
+        if cache["ver"] != self._hver:
+            lib, st = self.ops.lib, self.ops.stream
+            conv = lib.wdg_convert_bf16 if fmt == "bf16" else lib.wdg_convert_f16
+            native.check(conv(self.wF.data_ptr(), cache["wF"].data_ptr(), self.wF.numel(), st), "convert_16")
+            native.check(conv(self.wD.data_ptr(), cache["wD"].data_ptr(), self.wD.numel(), st), "convert_16")
+            cache["ver"] = self._hver
+        return cache["wF"], cache["wD"]
 
     def column_slice(self, n0, n1):
         """Forward-only view of output channels [n0, n1): the rows of wF are contiguous per output channel."""
@@ -214,31 +225,35 @@ class HipOps:
                                              int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                              self.stream), "conv_dgrad")
 
-    def conv_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, accumulate=False, slope=0.2):
-        """Inference precision: y = affine(act(conv(bf16(x), bf16(W)) + bias)), fp32 accumulation."""
+    def conv_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
+        """Inference precision: y = affine(act(conv(r16(x), r16(W)) + bias)), fp32 accumulation; fmt "bf16" | "fp16"."""
         plan, _, _ = self._plan(x, y, pk.cin, pk.cout, g)
-        native.check(self.lib.wdg_conv_fwd_bf16(plan, x.data_ptr(), pk.bf16()[0].data_ptr(), _ptr(bias), _ptr(affine),
-                                                y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_bf16")
+        fn = self.lib.wdg_conv_fwd_bf16 if fmt == "bf16" else self.lib.wdg_conv_fwd_f16
+        native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
+                        y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_16")
 
-    def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2):
+    def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
         plan, _, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
-        native.check(self.lib.wdg_conv_dgrad_bf16(plan, dy.data_ptr(), pk.bf16()[1].data_ptr(), _ptr(bias), _ptr(affine),
-                                                  dx.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_dgrad_bf16")
+        fn = self.lib.wdg_conv_dgrad_bf16 if fmt == "bf16" else self.lib.wdg_conv_dgrad_f16
+        native.check(fn(plan, dy.data_ptr(), pk.half(fmt)[1].data_ptr(), _ptr(bias), _ptr(affine),
+                        dx.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_dgrad_16")
 
-    def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2):
-        """bf16 thin stride-1 conv (<= 64 output channels) through the halo-tile kernel."""
+    def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2, fmt="bf16"):
+        """16-bit thin stride-1 conv (<= 64 output channels) through the halo-tile kernel."""
         plan, _, _ = self._plan(x, y, pk.cin, pk.cout, g)
-        native.check(self.lib.wdg_conv_halo_fwd_bf16(plan, x.data_ptr(), pk.bf16()[0].data_ptr(), _ptr(bias), _ptr(affine),
-                                                     y.data_ptr(), int(act), slope, self.stream), "conv_halo_fwd_bf16")
+        fn = self.lib.wdg_conv_halo_fwd_bf16 if fmt == "bf16" else self.lib.wdg_conv_halo_fwd_f16
+        native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
+                        y.data_ptr(), int(act), slope, self.stream), "conv_halo_fwd_16")
 
-    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2):
+    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16"):
         px, ldl, isl = _v4(x_low)
         py, ldy, isy = _v4(y)
         n, H, W, _ = y.shape
         cp = (pk.cout + 3) // 4 * 4
         plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
-        native.check(self.lib.wdg_upconv_fwd_bf16(plan, px, ldl, isl, pk.bf16()[1].data_ptr(), _ptr(bias), _ptr(affine),
-                                                  py, int(act), slope, self.stream), "upconv_fwd_bf16")
+        fn = self.lib.wdg_upconv_fwd_bf16 if fmt == "bf16" else self.lib.wdg_upconv_fwd_f16
+        native.check(fn(plan, px, ldl, isl, pk.half(fmt)[1].data_ptr(), _ptr(bias), _ptr(affine),
+                        py, int(act), slope, self.stream), "upconv_fwd_16")
 
     def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
         """y = act(convT(bilinear_x2(x_low), W) + bias) without materialising the upsampled tensor.

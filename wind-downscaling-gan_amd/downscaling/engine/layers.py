@@ -50,12 +50,12 @@ class Conv:
         else:
             self.ops.conv_fwd(x, self.pk, self.b.value, y, self.g, act=self.act, slope=LRELU)
 
-    def forward_bf16(self, x, y, affine=None):
-        """Inference precision (bf16 operands, fp32 accumulate); `affine` = fused inference BatchNorm."""
+    def forward_bf16(self, x, y, affine=None, fmt="bf16"):
+        """Inference precision (bf16 or fp16 operands, fp32 accumulate); `affine` = fused inference BatchNorm."""
         if self.transposed:
-            self.ops.conv_dgrad_bf16(x, self.pk, y, self.g, bias=self.b.value, act=self.act, affine=affine, slope=LRELU)
+            self.ops.conv_dgrad_bf16(x, self.pk, y, self.g, bias=self.b.value, act=self.act, affine=affine, slope=LRELU, fmt=fmt)
         else:
-            self.ops.conv_fwd_bf16(x, self.pk, self.b.value, y, self.g, act=self.act, affine=affine, slope=LRELU)
+            self.ops.conv_fwd_bf16(x, self.pk, self.b.value, y, self.g, act=self.act, affine=affine, slope=LRELU, fmt=fmt)
 
     def backward_weights(self, x, dpre):
         if self.transposed:
@@ -189,7 +189,7 @@ class ConvLSTM:
         """Single timestep + few channels: the fused, gate-recomputing kernels (convlstm1.hip)."""
         return T == 1 and self.ops.convlstm1_supported(self.cin, self.F)
 
-    def forward(self, x, h, B, T, bf16=False):
+    def forward(self, x, h, B, T, bf16=False, fmt="bf16"):
         """x: [T*B,H,W,>=cin] view; h: [T*B,H,W,round4(F)] output buffer (pad channels stay zero).
         bf16=True: the two convolutions run at inference precision (the cell math stays fp32)."""
         o, F = self.ops, self.F
@@ -198,7 +198,7 @@ class ConvLSTM:
             o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
             return
         self._buffers(N, H, W)
-        conv = o.conv_fwd_bf16 if bf16 else o.conv_fwd
+        conv = (lambda *a, **k: o.conv_fwd_bf16(*a, fmt=fmt, **k)) if bf16 else o.conv_fwd
         if T == 1 and not bf16:
             # h_0 = c_0 = 0: the forget gate is never read at t = 0 -> skip its quarter of the input convolution
             # (the slab keeps zeros there, so the backward's dgates_f = dc * c_prev * hs' = 0 is consistent)

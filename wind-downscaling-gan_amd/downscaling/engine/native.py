@@ -53,6 +53,11 @@ SIGNATURES = {
     "wdg_conv_dgrad_bf16": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp]),
     "wdg_conv_halo_fwd_bf16": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     "wdg_upconv_fwd_bf16": (i32, [C.c_void_p, c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
+    "wdg_convert_f16": (i32, [c_fp, c_fp, i64, c_fp]),
+    "wdg_conv_fwd_f16": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp]),
+    "wdg_conv_dgrad_f16": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp]),
+    "wdg_conv_halo_fwd_f16": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
+    "wdg_upconv_fwd_f16": (i32, [C.c_void_p, c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     "wdg_conv_wgrad": (i32, [C.c_void_p, c_fp, c_fp, c_fp, i32, c_fp, szt, c_fp]),
     "wdg_conv_wgrad_bias": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, c_fp, szt, c_fp]),
     "wdg_weight_pack": (i32, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

@@ -157,7 +157,7 @@ class GeneratorNet(_Net):
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, B, training, need_backward=None, precision="fp32"):
         """Runs on the resident input buffer; returns the [T*B,S,S,round4(out)] time-major output.
-        precision="bf16" (inference only): the implicit-GEMM layers use bf16 MFMA operands with fp32
+        precision="bf16" / "fp16" (inference only): the implicit-GEMM layers use 16-bit MFMA operands with fp32
         accumulation and fuse the inference BatchNorm into their epilogue.
         Only a forward that will be back-propagated (the generator step, ganbase.py:50-61) materialises
         the bilinear-upsampled tensor (it is the weight-gradient operand); every other forward fuses the
@@ -169,17 +169,18 @@ class GeneratorNet(_Net):
         self._prepare(training)
         res2 = b["cat2"][..., F // 4:]
         res4 = b["cat4"][..., F // 2:]
-        if precision == "bf16":
+        if precision in ("bf16", "fp16"):
             if training:
-                raise ValueError("the bf16 path is inference-only")
-            self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine())
-            self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine())
-            self.lstm.forward(res4, b["h"], B, T, bf16=True)
-            self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine())
-            self.c7.forward_bf16(b["cat4"], b["cat2"][..., :F // 4], affine=self.bn8.infer_affine())
+                raise ValueError("the 16-bit operand path is inference-only")
+            f = precision
+            self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine(), fmt=f)
+            self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine(), fmt=f)
+            self.lstm.forward(res4, b["h"], B, T, bf16=True, fmt=f)
+            self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
+            self.c7.forward_bf16(b["cat4"], b["cat2"][..., :F // 4], affine=self.bn8.infer_affine(), fmt=f)
             self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
-                                     affine=self.bn10.infer_affine())
-            self.ops.conv_halo_fwd_bf16(b["z9"], self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False)
+                                     affine=self.bn10.infer_affine(), fmt=f)
+            self.ops.conv_halo_fwd_bf16(b["z9"], self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
             return b["out"]
         if precision != "fp32":
             raise ValueError(f"unknown precision {precision!r}")

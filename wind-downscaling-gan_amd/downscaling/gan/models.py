@@ -123,7 +123,7 @@ class _Model:
 
 class Generator(_Model):
     name = "generator"
-    inference_precision = "fp32"   # "bf16": bf16-operand MFMA for the inference forward (BASELINE configs[3])
+    inference_precision = "fp32"   # "bf16" / "fp16": 16-bit-operand MFMA for the inference forward (BASELINE configs[3] / [4])
 
     def __call__(self, inputs, training=False, mask=None, precision=None):
         image, noise = inputs
