@@ -143,40 +143,57 @@ def _tile_lat_index(sy):
 def predict_array(fields, overlap_factor=0.05, network=None, return_count=False):
     """Array core of predict (api.py:96-151).  fields: (time, lat, lon, 3) float array with channels
     [u10, v10, elevation in metres].  Returns (ntimeseq*24, lat, lon, 2) with NaN where no tile
-    contributes (the reference's dataframe simply has no such rows)."""
-    fields = np.asarray(fields, dtype=np.float32).copy()
-    fields[..., 2] = fields[..., 2] / 1e3                                         # api.py:96
-    time_window, pixels_lat, pixels_lon = fields.shape[:3]
-    plan = tile_plan(pixels_lat, pixels_lon, time_window, overlap_factor)
+    contributes (the reference's dataframe simply has no such rows).
+
+    The whole driver runs on the generator's device: the field is uploaded once, tiles are gathered there (latitude
+    flip and the sy == 0 off-by-one included), the nanmean / nanstd normalisation over axes (0, 1, 2) is a device
+    reduction (accumulated in fp64), every group of 16 tiles goes through the generator without leaving HBM, and the
+    2-pixel-cropped tiles are summed / counted into the output grid there; one download at the end.  (The reference
+    does this part with numpy / pandas on the host: 3.3 of the 3.5 s of a 1200 x 1200 x 24 h field.)"""
+    import torch
     network = network or get_network()
+    gen = network.generator
+    ops = gen.ops
+    dev, dt = getattr(ops, "device", "cpu"), ops.dtype
+    f = torch.as_tensor(np.asarray(fields, dtype=np.float32)).to(dev)
+    f[..., 2] = f[..., 2] / 1e3                                                    # api.py:96
+    time_window, pixels_lat, pixels_lon = f.shape[:3]
+    plan = tile_plan(pixels_lat, pixels_lon, time_window, overlap_factor)
     keys = [(sx, sy, k) for sx in plan['slices_start_x'] for sy in plan['slices_start_y'] for k in range(plan['ntimeseq'])]
     print(f'Applying model to {len(keys)} patches')
     lat_ok = pixels_lat > IMG_SIZE or all(sy != 0 for sy in plan['slices_start_y'])
     if not lat_ok:
         raise RuntimeError('the sy == 0 tile needs lat row 96 (reference slice(IMG_SIZE, 0, -1)): lat dimension too small')
-    tensors = np.stack([fields[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH][:, _tile_lat_index(sy)][:, :, sx:sx + IMG_SIZE]
-                        for (sx, sy, k) in keys], axis=0)                         # (N, T, H, W, C)
-    tensors = (tensors - np.nanmean(tensors, axis=(0, 1, 2), keepdims=True)) / np.nanstd(tensors, axis=(0, 1, 2), keepdims=True)
-    gen = network.generator
-    preds = []
+    rows = {sy: torch.as_tensor(_tile_lat_index(sy).copy(), device=dev) for sy in plan['slices_start_y']}
+    tensors = torch.stack([f[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH].index_select(1, rows[sy])[:, :, sx:sx + IMG_SIZE]
+                           for (sx, sy, k) in keys], dim=0)                         # (N, T, H, W, C)
+    # nanmean / nanstd over axes (0, 1, 2), keepdims: one statistic per (lon index inside the tile, channel) — api.py:126-129
+    valid = ~torch.isnan(tensors)
+    n_valid = valid.sum(dim=(0, 1, 2), keepdim=True).double()
+    t64 = torch.where(valid, tensors, torch.zeros((), dtype=tensors.dtype, device=dev)).double()
+    mean = t64.sum(dim=(0, 1, 2), keepdim=True) / n_valid
+    var = (torch.where(valid, t64 - mean, torch.zeros((), dtype=torch.float64, device=dev)) ** 2).sum(dim=(0, 1, 2), keepdim=True) / n_valid
+    del t64
+    tensors = ((tensors - mean.to(tensors.dtype)) / var.sqrt().to(tensors.dtype)).to(dt)
+    nt = plan['ntimeseq'] * SEQUENCE_LENGTH
+    acc = torch.zeros(nt, pixels_lat, pixels_lon, NB_OUTPUTS, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(nt, pixels_lat, pixels_lon, dtype=torch.int32, device=dev)
     group_size = BATCH_SIZE * 2
     num_groups = math.ceil(tensors.shape[0] / group_size)
-    for t in range(num_groups):
-        tensor = tensors[t * group_size:(t + 1) * group_size, ...]
-        noise = network.noise_generator(bs=tensor.shape[0], channels=NOISE_CHANNELS)
-        preds.append(gen.predict([tensor, noise]))
-        print(f'Predicted {(t + 1) / num_groups:.0%}')
-    predictions = np.concatenate(preds, axis=0)
-    nt = plan['ntimeseq'] * SEQUENCE_LENGTH
-    acc = np.zeros((nt, pixels_lat, pixels_lon, NB_OUTPUTS), dtype=np.float64)
-    cnt = np.zeros((nt, pixels_lat, pixels_lon), dtype=np.int32)
-    for i, (sx, sy, k) in enumerate(keys):
-        rows = _tile_lat_index(sy)[2:-2]                                          # api.py:148
-        ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
-        acc[ts, rows[:, None], np.arange(sx + 2, sx + IMG_SIZE - 2)[None, :]] += predictions[i][:, 2:-2, 2:-2]
-        cnt[ts, rows[:, None], np.arange(sx + 2, sx + IMG_SIZE - 2)[None, :]] += 1
-    with np.errstate(invalid='ignore', divide='ignore'):
-        out = (acc / cnt[..., None]).astype(np.float32)                           # api.py:149-150 (uniform mean)
+    with torch.no_grad():
+        for t in range(num_groups):
+            tensor = tensors[t * group_size:(t + 1) * group_size, ...]
+            noise = network.noise_generator(bs=tensor.shape[0], channels=NOISE_CHANNELS)
+            pred = gen([tensor, noise])                                            # stays on the device (api.py:137)
+            for j, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):
+                r = _tile_lat_index(sy)[2:-2]                                      # api.py:148: descending, contiguous
+                ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
+                rs, cs = slice(int(r[-1]), int(r[0]) + 1), slice(sx + 2, sx + IMG_SIZE - 2)
+                acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
+                cnt[ts, rs, cs] += 1
+            print(f'Predicted {(t + 1) / num_groups:.0%}')
+    out = (acc / cnt[..., None].double()).float()                                  # api.py:149-150 (uniform mean); 0/0 -> NaN
+    out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
     return (out, cnt) if return_count else out
 
 
