@@ -92,3 +92,42 @@ def test_two_rank_step_equals_global_batch_reference():
     for net, w in (("g", gw), ("d", dw)):
         for k in w:
             assert rel_err(r[0][net][k], w[k]) < 1e-7, (net, k)
+
+
+def _predict_worker(rank, port, outdir):
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    from downscaling.engine import runtime
+    from downscaling.engine.trainer import DistSync
+    from oracle.torch_backend import TorchOps
+    import downscaling.api as api
+    runtime.set_ops(TorchOps(torch.float64))
+    api.IMG_SIZE, api.SEQUENCE_LENGTH, api.NOISE_CHANNELS, api.BATCH_SIZE = 20, 2, 5, 1
+    network = api.get_network(allow_random_init=True, random_seed=11)
+    network.noise_generator.std = 0.0                    # deterministic generator: the blend must not depend on the sharding
+    rng = np.random.default_rng(0)
+    fields = rng.standard_normal((4, 40, 50, 3)).astype(np.float32)
+    fields[..., 2] = fields[..., 2] * 800 + 1500
+    out, cnt = api.predict_array(fields, overlap_factor=0.3, network=network, return_count=True, sync=DistSync())
+    np.savez(os.path.join(outdir, f"pred{rank}.npz"), out=out, cnt=cnt)
+    if rank == 0:
+        network2 = api.get_network(allow_random_init=True, random_seed=11)
+        network2.noise_generator.std = 0.0
+        o1, c1 = api.predict_array(fields, overlap_factor=0.3, network=network2, return_count=True)
+        np.savez(os.path.join(outdir, "single.npz"), out=o1, cnt=c1)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_tile_sharded_inference_equals_single_process():
+    """configs[3]/[4] multi-GPU path: groups of tiles dealt round-robin to the ranks, sum / count grids all-reduced."""
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_predict_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+        r = [np.load(os.path.join(out, f"pred{i}.npz")) for i in range(WORLD)]
+        single = np.load(os.path.join(out, "single.npz"))
+        for x in r:
+            np.testing.assert_array_equal(x["cnt"], single["cnt"])
+            np.testing.assert_allclose(x["out"], single["out"], rtol=1e-6, atol=1e-6, equal_nan=True)

@@ -140,7 +140,7 @@ def _tile_lat_index(sy):
     return np.arange(IMG_SIZE, 0, -1)
 
 
-def predict_array(fields, overlap_factor=0.05, network=None, return_count=False):
+def predict_array(fields, overlap_factor=0.05, network=None, return_count=False, sync=None):
     """Array core of predict (api.py:96-151).  fields: (time, lat, lon, 3) float array with channels
     [u10, v10, elevation in metres].  Returns (ntimeseq*24, lat, lon, 2) with NaN where no tile
     contributes (the reference's dataframe simply has no such rows).
@@ -149,7 +149,11 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False)
     flip and the sy == 0 off-by-one included), the nanmean / nanstd normalisation over axes (0, 1, 2) is a device
     reduction (accumulated in fp64), every group of 16 tiles goes through the generator without leaving HBM, and the
     2-pixel-cropped tiles are summed / counted into the output grid there; one download at the end.  (The reference
-    does this part with numpy / pandas on the host: 3.3 of the 3.5 s of a 1200 x 1200 x 24 h field.)"""
+    does this part with numpy / pandas on the host: 3.3 of the 3.5 s of a 1200 x 1200 x 24 h field.)
+
+    `sync` (engine.trainer.DistSync, one process per GPU): tiles are independent, so the groups of 16 are dealt
+    round-robin to the ranks and the per-rank sum / count grids are all-reduced once at the end — no exchange
+    inside the model (SURVEY §8 e).  Every rank returns the full blended field."""
     import torch
     network = network or get_network()
     gen = network.generator
@@ -180,8 +184,9 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False)
     cnt = torch.zeros(nt, pixels_lat, pixels_lon, dtype=torch.int32, device=dev)
     group_size = BATCH_SIZE * 2
     num_groups = math.ceil(tensors.shape[0] / group_size)
+    rank, world = (sync.rank, sync.world_size) if sync is not None else (0, 1)
     with torch.no_grad():
-        for t in range(num_groups):
+        for t in range(rank, num_groups, world):
             tensor = tensors[t * group_size:(t + 1) * group_size, ...]
             noise = network.noise_generator(bs=tensor.shape[0], channels=NOISE_CHANNELS)
             pred = gen([tensor, noise])                                            # stays on the device (api.py:137)
@@ -192,6 +197,9 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False)
                 acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
                 cnt[ts, rs, cs] += 1
             print(f'Predicted {(t + 1) / num_groups:.0%}')
+    if world > 1:
+        sync.all_reduce_sum(acc)
+        sync.all_reduce_sum(cnt)
     out = (acc / cnt[..., None].double()).float()                                  # api.py:149-150 (uniform mean); 0/0 -> NaN
     out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
     return (out, cnt) if return_count else out
