@@ -344,7 +344,14 @@ class DiscriminatorNet(_Net):
     def set_high_tm(self, high_tm, B):
         """high_tm: time-major [T*B,S,S,>=ch] view (e.g. the generator's output buffer)."""
         b = self.buffers(B)
-        self.ops.copy_channels(high_tm[..., :self.ch], b["hi"][..., :self.ch])
+        chp = round4(self.ch)
+        if high_tm.shape[-1] == chp and high_tm.stride(-1) == 1:
+            # the caller's buffer already has the layout of the high-res branch input (channels padded to 4 with zeros)
+            # and stays untouched until this pass' backward has run: read it in place instead of copying it
+            b["hi_view"] = high_tm
+        else:
+            self.ops.copy_channels(high_tm[..., :self.ch], b["hi"][..., :self.ch])
+            b["hi_view"] = b["hi"]
         self.ops.copy_channels(high_tm[..., :self.ch], b["mix"][..., self.cl:self.cl + self.ch])
 
     def forward(self, B, training):
@@ -352,7 +359,7 @@ class DiscriminatorNet(_Net):
         b = self.buffers(B)
         o, Fd, T = self.ops, self.Fd, self.T
         self._prepare(training)
-        self.lstm_a.forward(b["hi"], b["ha"], B, T)
+        self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
         self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
         self.lstm_b.forward(b["mix"], b["hb"], B, T)
         self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
@@ -416,7 +423,7 @@ class DiscriminatorNet(_Net):
             conv.backward_input(dz, b["dzs"][i - 1] if i > 0 else b["dcat"])
         # branch A (high-res only)
         self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
-        self.lstm_a.backward(b["hi"], b["ha"], b["dha"], b["dhi"], B, T, need_wgrad)
+        self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"], B, T, need_wgrad)
         # branch B (low + high)
         self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dpre"], b["dhb"], need_wgrad)
         self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"], B, T, need_wgrad)
