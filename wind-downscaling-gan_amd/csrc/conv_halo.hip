@@ -293,9 +293,10 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
 #pragma unroll
         for (int i = 0; i < NLMAX; ++i) {
             const int idx = t + 256 * i;
-            // slot = kg*npix + (pixel ^ 2kg): the XOR keeps the 4 lanes of a pixel (kg = 0..3) on distinct banks for the
-            // write and permutes inside aligned 8-pixel groups only, so the fragment reads stay conflict-free
-            if (idx < nslots) lds_a[(idx & 3) * p.npix + ((idx >> 2) ^ (2 * (idx & 3)))] = rs[i];
+            // slot = kg*npix + pixel (npix = 0 mod 16): conflict-free fragment reads (36 per tile); the 6 staging writes
+            // per tile are 4-way conflicted, the price of coalesced 64-byte-per-pixel global loads (an XOR swizzle that
+            // fixed the writes made 30 % of the read cycles conflicts: profiles/r01aq_pmc_summary.csv)
+            if (idx < nslots) lds_a[(idx & 3) * p.npix + (idx >> 2)] = rs[i];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
         f32x4 af[2][4], bfr[2];
         auto read_tap = [&](int tap, f32x4 (&a4)[4], f32x4& b1) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) a4[a] = lds_g[(pbase + (a >> 1) * p.halo_w + (a & 1) * 16 + rowoff[tap]) ^ (2 * lg)];
+            for (int a = 0; a < 4; ++a) a4[a] = lds_g[pbase + (a >> 1) * p.halo_w + (a & 1) * 16 + rowoff[tap]];
             b1 = lds_w[tap * 64 + lane];
         };
         read_tap(0, af[0], bfr[0]);
