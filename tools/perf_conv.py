@@ -88,7 +88,7 @@ def main():
     times = {(c[0], pp): [] for c in cases for pp in pipes}
     for r in range(reps + 1):
         for pp in pipes:
-            lib.wdg_set_tuning(b"igemm_pipe", (0, 3, 1)[pp])
+            lib.wdg_set_tuning(b"igemm_pipe", (3, 0, 1)[pp])
             for name, fn, flops, label, nbytes in cases:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -97,7 +97,7 @@ def main():
                 torch.cuda.synchronize()
                 if r > 0:
                     times[(name, pp)].append(e0.elapsed_time(e1))
-    print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"{n}: ms (TF/s)  " for n in ("pipe0   ", "pipe3   ", "pipe1   ")))
+    print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"{n}: ms (TF/s)  " for n in ("pipe3   ", "pipe0   ", "pipe1   ")))
     for name, fn, flops, label, nbytes in cases:
         row = f"{name:32s} {label:28s} "
         for pp in pipes:
