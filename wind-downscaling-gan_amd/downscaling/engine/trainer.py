@@ -67,6 +67,16 @@ class DistSync:
         # run two ranks on one GPU; the production backend is "nccl" = RCCL, which reduces in place on the device)
         self._stage = self.dist.get_backend(group) == "gloo"
 
+    def all_reduce_sum_async(self, t):
+        """Start the all-reduce and return a zero-argument `finish()`; the collective runs on RCCL's own stream, so
+        kernels enqueued on the compute stream before `finish()` overlap with it (`finish` makes the compute stream
+        wait for the result)."""
+        if self._stage and t.is_cuda:
+            self.all_reduce_sum(t)          # host-staged test path: nothing to overlap
+            return lambda: None
+        work = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work.wait
+
     def all_reduce_sum(self, t):
         if self._stage and t.is_cuda:
             h = t.cpu()
@@ -87,6 +97,7 @@ class GanEngine:
         if sync is not None and sync_bn:
             gen.sync = sync
         self._tmp = {}
+        self._pending = {}
 
     def _buf(self, key, *shape):
         t = self._tmp.get(key)
@@ -96,12 +107,26 @@ class GanEngine:
         return t
 
     def _reduce_and_step(self, net, opt):
+        """Gradient all-reduce + optimizer step.  With several ranks the all-reduce is started asynchronously and the
+        optimizer step is deferred until the network is next touched (`_flush`): the generator forward that opens the
+        next critic iteration does not depend on the discriminator's weights (and the discriminator pass that opens the
+        metrics recompute not on the generator's), so that compute hides the exchange."""
         scale = 1.0
         if self.sync is not None and self.sync.world_size > 1:
-            self.sync.all_reduce_sum(net.params.grads)
             scale = 1.0 / self.sync.world_size
+            finish = self.sync.all_reduce_sum_async(net.params.grads)
+            self._pending[id(net)] = (net, opt, scale, finish)
+            return scale
         opt.apply_gradients(net.params, grad_scale=scale)
         return scale
+
+    def _flush(self, net):
+        """Complete a deferred exchange + optimizer step of `net` (no-op when nothing is pending)."""
+        pend = self._pending.pop(id(net), None)
+        if pend is not None:
+            _, opt, scale, finish = pend
+            finish()
+            opt.apply_gradients(net.params, grad_scale=scale)
 
     def _grad_param_metric(self, net, scale):
         st = net.params
@@ -131,6 +156,7 @@ class GanEngine:
             fake = gen.forward(B, training=True, need_backward=False)             # :29 (outside any tape)
             noise.uniform_into(eps)                                               # :30
             ops.lerp_batch(v2(real), v2(fake), eps, v2(comb), ppi, B)             # :31
+            self._flush(disc)                                                     # previous iteration's D update lands here
             disc.set_high_tm(comb, B)
             disc.forward(B, training=True)                                        # :32-34
             dcomb = disc.backward(B, ones, need_wgrad=False)                      # :35
@@ -150,11 +176,12 @@ class GanEngine:
             disc.backward(B, dscore, need_wgrad=True)
             disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45, train.py:11-12
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
-        d_gradient_param = self._grad_param_metric(disc, dscale)
-
         gen.params.zero_grad()                                                    # generator step, :50-61
         noise.normal_into(gen.noise_view(B), self.noise_std)
-        fake = gen.forward(B, training=True, need_backward=True)
+        fake = gen.forward(B, training=True, need_backward=True)                  # overlaps the last D exchange
+        self._flush(disc)
+        d_gradient_param = self._grad_param_metric(disc, dscale)
+
         disc.set_high_tm(fake, B)
         gen_disc_loss = -disc.forward(B, training=True).mean()                    # :54
         dscore.fill_(-1.0 / B)
@@ -166,10 +193,11 @@ class GanEngine:
             ops.copy_channels(dreco, dfake[..., :ch], accumulate=True)
         gen.backward(B, dfake)
         gscale = self._reduce_and_step(gen, g_opt)
-        g_gradient_param = self._grad_param_metric(gen, gscale)
 
         disc.set_high_tm(real, B)                                                 # metrics recompute, :63-68
-        real_mean = disc.forward(B, training=False).mean()
+        real_mean = disc.forward(B, training=False).mean()                        # overlaps the generator's exchange
+        self._flush(gen)
+        g_gradient_param = self._grad_param_metric(gen, gscale)
         noise.normal_into(gen.noise_view(B), self.noise_std)
         fake = gen.forward(B, training=False)
         disc.set_high_tm(fake, B)
