@@ -84,11 +84,13 @@ def main():
         label = ops.conv_kernel_label(which, x, y, pk, g)
         nbytes = 4.0 * (n * H * W * ((cin + 3) // 4 * 4) + n * Ho * Wo * ((cout + 3) // 4 * 4))
         cases.append((name, fn, flops, label, nbytes))
-    pipes = (0, 1, 2)   # columns: 0 = defaults (igemm_pipe 0, xcd_swizzle 1), 1 = xcd_swizzle off, 2 = igemm_pipe 1 (double-buffered LDS)
+    pipes = (0, 1, 2)   # columns: 0 = defaults, 1 = 128x160 tile off, 2 = K-loop variant 0 (plain single-stage loop)
+    knobs = {0: ((b"tile160", 1), (b"igemm_pipe", 3)), 1: ((b"tile160", 0), (b"igemm_pipe", 3)), 2: ((b"tile160", 1), (b"igemm_pipe", 0))}
     times = {(c[0], pp): [] for c in cases for pp in pipes}
     for r in range(reps + 1):
         for pp in pipes:
-            lib.wdg_set_tuning(b"igemm_pipe", (3, 0, 1)[pp])
+            for k_, v_ in knobs[pp]:
+                lib.wdg_set_tuning(k_, v_)
             for name, fn, flops, label, nbytes in cases:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -97,7 +99,7 @@ def main():
                 torch.cuda.synchronize()
                 if r > 0:
                     times[(name, pp)].append(e0.elapsed_time(e1))
-    print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"{n}: ms (TF/s)  " for n in ("pipe3   ", "pipe0   ", "pipe1   ")))
+    print(f"{'layer':32s} {'kernel':28s} " + " ".join(f"{n}: ms (TF/s)  " for n in ("default ", "no160   ", "pipe0   ")))
     for name, fn, flops, label, nbytes in cases:
         row = f"{name:32s} {label:28s} "
         for pp in pipes:
