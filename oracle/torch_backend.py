@@ -181,6 +181,16 @@ class TorchOps:
         self.upsample2x_fwd(x_low, up)
         self.conv_dgrad(up, pk, y, g, bias=bias, act=act, slope=slope)
 
+    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g):
+        """Backward of upconv_fwd as the reference's tape computes it: through the materialised upsampled tensor."""
+        n, Hl, Wl, C = x_low.shape
+        up = torch.zeros(n, 2 * Hl, 2 * Wl, C, dtype=x_low.dtype)
+        dup = torch.zeros(n, 2 * Hl, 2 * Wl, C, dtype=x_low.dtype)
+        self.upsample2x_fwd(x_low, up)
+        self.conv_wgrad(dpre, up, pk, dw, g, accumulate=True)
+        self.conv_fwd(dpre, pk, None, dup, g, act=False)
+        self.upsample2x_bwd(dup, dx_low)
+
     def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True, dbias=None):
         xin = x[..., :pk.cin].permute(0, 3, 1, 2).contiguous()
         gout = dy[..., :pk.cout].permute(0, 3, 1, 2).contiguous()

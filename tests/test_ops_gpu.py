@@ -183,6 +183,44 @@ def test_fused_upsample_conv_transpose(n, H, W, C, N, ld, composite, hip_ops, re
         assert float(y_g[..., N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,H,W,C,N,ld", [(3, 60, 68, 160, 16, 160), (2, 19, 35, 40, 4, 48), (2, 3, 3, 20, 8, 20),
+                                          (1, 9, 50, 160, 16, 192), (2, 4, 17, 8, 2, 8), (1, 2, 2, 12, 16, 12)])
+@pytest.mark.parametrize("column", [True, False])
+def test_upsample_conv_transpose_backward(n, H, W, C, N, ld, column, hip_ops, ref_ops):
+    """Backward of UpSampling2D(bilinear) + Conv2DTranspose(5x5,'same') (models.py:60-64): weight gradient
+    (accumulated) and low-res input gradient written into a channel-concat view.  column=True: column form on the
+    replicate-extended low-res grid (upconv_col.hip; N = 2 falls back), False: via the materialised upsampled tensor.
+    Ragged tiles and maps so small that every pixel touches the border masks."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    g, rg = ConvGeom(5, 5, 1, 2), RG(5, 5, 1, 2)
+    gen = torch.Generator().manual_seed(21)
+    dev = hip_ops.device
+    Np = (N + 3) // 4 * 4
+    x = torch.randn(n, H, W, C, generator=gen, dtype=torch.float64)
+    w = torch.randn(5, 5, N, C, generator=gen, dtype=torch.float64) * 0.05
+    dy = torch.zeros(n, 2 * H, 2 * W, Np, dtype=torch.float64)
+    dy[..., :N] = torch.randn(n, 2 * H, 2 * W, N, generator=gen, dtype=torch.float64)
+    dw0 = torch.randn(5, 5, N, C, generator=gen, dtype=torch.float64)
+    dw_r, dx_r = dw0.clone(), torch.zeros(n, H, W, C, dtype=torch.float64)
+    ref_ops.upconv_bwd(x, dy, ref_ops.pack_weights(w), dw_r, dx_r, rg)
+    xg = hip_ops.zeros(n, H, W, ld)
+    xg[..., :C] = x.float().to(dev)
+    dxg = hip_ops.zeros(n, H, W, ld)
+    dxg.fill_(3.0)
+    dw_g = dw0.float().to(dev).contiguous()
+    hip_ops.upconv_col = column
+    try:
+        hip_ops.upconv_bwd(xg[..., :C], dy.float().to(dev), hip_ops.pack_weights(w.float().to(dev).contiguous()), dw_g,
+                           dxg[..., :C], g)
+    finally:
+        hip_ops.upconv_col = True
+    assert rel_err(dxg[..., :C], dx_r) < TOL
+    assert rel_err(dw_g, dw_r) < TOL
+    if ld > C:
+        assert float((dxg[..., C:] - 3.0).abs().max()) == 0.0   # neighbouring channels of the concat buffer untouched
+
+
 @pytest.mark.parametrize("cin,F_,n,H,W", [(2, 2, 3, 37, 45), (5, 16, 2, 33, 70), (5, 16, 1, 4, 32)])
 def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
     """convlstm1.hip: x -> h and (x, dh) -> (dgates, dx) with gate recomputation, against

@@ -85,6 +85,17 @@ class PackedWeights:
             cache["ver"] = self._hver
         return cache["wF"], cache["wD"]
 
+    def as_1x1(self):
+        """The same weights as a 1x1 convolution with taps*cin input channels: w[t][i][o] viewed as [t*cin + i][o].
+        Both kernel layouts coincide with this object's (wF is [cout][taps][cin], wD is w itself), so the view shares
+        them and needs no packing of its own (cin % 4 == 0 and cout % 4 == 0 only)."""
+        assert self.cin % 4 == 0 and self.cout % 4 == 0 and self.wD is self.w
+        sub = object.__new__(PackedWeights)
+        sub.ops, sub.taps, sub.cin, sub.cout = self.ops, 1, self.taps * self.cin, self.cout
+        sub.w = self.w.view(1, 1, self.taps * self.cin, self.cout)
+        sub.wF, sub.wD = self.wF, sub.w
+        return sub
+
     def column_slice(self, n0, n1):
         """Forward-only view of output channels [n0, n1): the rows of wF are contiguous per output channel."""
         sub = object.__new__(PackedWeights)
@@ -150,6 +161,8 @@ class HipOps:
         self._ws = None
         self._sn_scratch = None
         self.upconv4 = True   # fused upsample + 5x5 transposed conv through the composite-kernel path
+        self.upconv_col = True   # its backward in column form on the low-res grid
+        self._scratch_bufs = {}
 
     # ---- plumbing ---------------------------------------------------------------------------
     @property
@@ -271,6 +284,41 @@ class HipOps:
         plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
         native.check(self.lib.wdg_upconv_fwd(plan, px, ldl, isl, pk.wD.data_ptr(), _ptr(bias), py, int(act), slope,
                                              self.stream), "upconv_fwd")
+
+    def _scratch(self, key, *shape):
+        t = self._scratch_bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._scratch_bufs[key] = self.empty(*shape)
+        return t
+
+    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g):
+        """Backward of y = convT(bilinear_x2(x_low), W) given dpre = dL/dy (before bias/activation):
+        dw += dL/dW, dx_low = dL/dx_low.  pk/g as in upconv_fwd.  5x5 layers with 4/8/16 output channels run in
+        column form on the low-res grid (csrc/upconv_col.hip: a quarter of the multiply-adds); anything else
+        through the materialised upsampled tensor."""
+        n, Hl, Wl, C = x_low.shape
+        lib = self.lib
+        if self.upconv_col and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
+                C == pk.cout and pk.cout % 4 == 0 and lib.wdg_upconv_col_supported(pk.cin) and pk.wD is pk.w:
+            px, ldx, isx = _v4(x_low)
+            pdy, lddy, isdy = _v4(dpre)
+            pdx, lddx, isdx = _v4(dx_low)
+            xe = self._scratch("upc_xe", n, Hl + 2, Wl + 2, C)
+            col = self._scratch("upc_col", n, Hl + 2, Wl + 2, 25 * pk.cin)
+            dxe = self._scratch("upc_dxe", n, Hl + 2, Wl + 2, C)
+            native.check(lib.wdg_up2_pad(px, ldx, isx, xe.data_ptr(), n, Hl, Wl, C, self.stream), "up2_pad")
+            native.check(lib.wdg_upconv_col(pdy, lddy, isdy, col.data_ptr(), n, Hl, Wl, pk.cin, self.stream), "upconv_col")
+            pk1, g1 = pk.as_1x1(), ConvGeom(1, 1, 1, 0)
+            self.conv_fwd(col, pk1, None, dxe, g1, act=False)
+            native.check(lib.wdg_up2_fold(dxe.data_ptr(), pdx, lddx, isdx, n, Hl, Wl, C, 0, self.stream), "up2_fold")
+            self.conv_wgrad(col, xe, pk1, dw.view(1, 1, 25 * pk.cin, pk.cout), g1, accumulate=True)
+            return
+        up = self._scratch("upc_up", n, 2 * Hl, 2 * Wl, C)
+        dup = self._scratch("upc_dup", n, 2 * Hl, 2 * Wl, C)
+        self.upsample2x_fwd(x_low, up)
+        self.conv_wgrad(dpre, up, pk, dw, g, accumulate=True)
+        self.conv_fwd(dpre, pk, None, dup, g, act=False)
+        self.upsample2x_bwd(dup, dx_low)
 
     def conv_wgrad(self, x, dy, pk, dw, g, accumulate=True, dbias=None):
         """dw[kh,kw,Cin,Cout] (+)= x (*) dy;  dbias[Cout] += sum_pixels dy when given."""

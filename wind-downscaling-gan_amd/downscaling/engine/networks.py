@@ -118,20 +118,12 @@ class GeneratorNet(_Net):
         self._grad_bufs = None
         return b
 
-    def _up(self, B):
-        """The materialised upsampled tensor (only the back-propagated forward needs it)."""
-        b = self.buffers(B)
-        if "up" not in b:
-            b["up"] = self.ops.empty(self.T * B, self.S, self.S, self.F // 4 + self.IF)
-        return b["up"]
-
     def grad_buffers(self, B):
         if self._grad_bufs is None:
             o, S, F, IF, T = self.ops, self.S, self.F, self.IF, self.T
             N, S2, S4 = T * B, S // 2, S // 4
             self._grad_bufs = dict(
                 dz9=o.empty(N, S, S, F // 8),
-                dup=o.empty(N, S, S, F // 4 + IF),
                 dcat2=o.empty(N, S2, S2, F // 4 + IF),
                 dcat4=o.empty(N, S4, S4, F // 2 + F),
                 dh=o.zeros(N, S4, S4, F),
@@ -159,9 +151,8 @@ class GeneratorNet(_Net):
         """Runs on the resident input buffer; returns the [T*B,S,S,round4(out)] time-major output.
         precision="bf16" / "fp16" (inference only): the implicit-GEMM layers use 16-bit MFMA operands with fp32
         accumulation and fuse the inference BatchNorm into their epilogue.
-        Only a forward that will be back-propagated (the generator step, ganbase.py:50-61) materialises
-        the bilinear-upsampled tensor (it is the weight-gradient operand); every other forward fuses the
-        upsampling into the transposed conv's input staging."""
+        need_backward is kept for interface stability: no forward materialises the bilinear-upsampled tensor any
+        more (the backward of the upsample + transposed-conv block works on the low-res grid, ops.upconv_bwd)."""
         if need_backward is None:
             need_backward = training
         b = self.buffers(B)
@@ -193,8 +184,6 @@ class GeneratorNet(_Net):
         self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), training)
         self.c7.forward(b["cat4"], b["y7"])
         self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), training)
-        if need_backward:   # the upsampled tensor itself is only needed as the weight-gradient operand
-            self.ops.upsample2x_fwd(b["cat2"], self._up(B))                           # models.py:62
         self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)       # :62-64 fused
         self.bn10.forward(v2(b["y9"]), v2(b["z9"]), training)
         self.c11.forward(b["z9"], b["out"])
@@ -213,9 +202,7 @@ class GeneratorNet(_Net):
         self.c11.backward_input(dout, g["dz9"])
         # bn10 + LeakyReLU of c9
         self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad)
-        self.c9.backward_weights(self._up(B), g["dz9"])
-        self.c9.backward_input(g["dz9"], g["dup"])
-        o.upsample2x_bwd(g["dup"], g["dcat2"])
+        o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g)   # :60-64 backward
         # bn8 + c7
         d7 = g["dcat2"][..., :F // 4]
         self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad)
