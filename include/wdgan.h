@@ -306,16 +306,12 @@ int wdg_upsample2x_bwd(const float* dy, int lddy, int64_t img_stride_dy, float* 
 
 /* ------------------------------------------------------------------------------------------
  * Backward of "UpSampling2D(2,'bilinear') -> Conv2DTranspose(5x5)" (models.py:60-64) on the low-resolution
- * grid (csrc/upconv_col.hip): x_ext = replicate_pad(x, 1); col = masked 4x4-smoothed, tap-shifted output gradient
- * [n, Hl+2, Wl+2, 25*C] (C = the layer's output channels: 4, 8 or 16); the two GEMMs
- * dx_ext = col * W and dW += col^T * x_ext run through wdg_conv_fwd / wdg_conv_wgrad as 1x1 convolutions with the
- * layer's weight tensor viewed as [25*C][C_in]; dx = fold(dx_ext).  A quarter of the multiply-adds of the
+ * grid (csrc/upconv_col.hip): col [n, Hl, Wl, 25*C] = the output gradient pulled through the tap shifts and the
+ * adjoint of the clamped bilinear stencil (C = the layer's output channels: 4, 8 or 16; dy is [n, 2Hl, 2Wl, >=C]);
+ * the two GEMMs dx = col * W and dW += col^T * x then run through wdg_conv_fwd / wdg_conv_wgrad as 1x1
+ * convolutions with the layer's weight tensor viewed as [25*C][C_in].  A quarter of the multiply-adds of the
  * full-resolution formulation (tf.GradientTape through the two Keras layers, ganbase.py:55-61).
  * ------------------------------------------------------------------------------------------ */
-int wdg_up2_pad(const float* x, int ldx, int64_t img_stride_x, float* xe, int n_img, int H, int W, int C,
-                wdg_stream stream);
-int wdg_up2_fold(const float* dxe, float* dx, int lddx, int64_t img_stride_dx, int n_img, int H, int W, int C,
-                 int accumulate, wdg_stream stream);
 int wdg_upconv_col_supported(int C);
 int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, float* col, int n_img, int Hl, int Wl, int C,
                    wdg_stream stream);

@@ -300,18 +300,12 @@ class HipOps:
         lib = self.lib
         if self.upconv_col and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
                 C == pk.cout and pk.cout % 4 == 0 and lib.wdg_upconv_col_supported(pk.cin) and pk.wD is pk.w:
-            px, ldx, isx = _v4(x_low)
             pdy, lddy, isdy = _v4(dpre)
-            pdx, lddx, isdx = _v4(dx_low)
-            xe = self._scratch("upc_xe", n, Hl + 2, Wl + 2, C)
-            col = self._scratch("upc_col", n, Hl + 2, Wl + 2, 25 * pk.cin)
-            dxe = self._scratch("upc_dxe", n, Hl + 2, Wl + 2, C)
-            native.check(lib.wdg_up2_pad(px, ldx, isx, xe.data_ptr(), n, Hl, Wl, C, self.stream), "up2_pad")
+            col = self._scratch("upc_col", n, Hl, Wl, 25 * pk.cin)
             native.check(lib.wdg_upconv_col(pdy, lddy, isdy, col.data_ptr(), n, Hl, Wl, pk.cin, self.stream), "upconv_col")
             pk1, g1 = pk.as_1x1(), ConvGeom(1, 1, 1, 0)
-            self.conv_fwd(col, pk1, None, dxe, g1, act=False)
-            native.check(lib.wdg_up2_fold(dxe.data_ptr(), pdx, lddx, isdx, n, Hl, Wl, C, 0, self.stream), "up2_fold")
-            self.conv_wgrad(col, xe, pk1, dw.view(1, 1, 25 * pk.cin, pk.cout), g1, accumulate=True)
+            self.conv_fwd(col, pk1, None, dx_low, g1, act=False)
+            self.conv_wgrad(col, x_low, pk1, dw.view(1, 1, 25 * pk.cin, pk.cout), g1, accumulate=True)
             return
         up = self._scratch("upc_up", n, 2 * Hl, 2 * Wl, C)
         dup = self._scratch("upc_dup", n, 2 * Hl, 2 * Wl, C)

@@ -90,8 +90,6 @@ SIGNATURES = {
                               c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upsample2x_fwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "wdg_upsample2x_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
-    "wdg_up2_pad": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, c_fp]),
-    "wdg_up2_fold": (i32, [c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upconv_col_supported": (i32, [i32]),
     "wdg_upconv_col": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, c_fp]),
     "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
