@@ -361,7 +361,8 @@ static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols
 static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
 void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
 static int g_halo_persistent = 1;   // wdg_set_tuning("halo_persistent", 0/1)
-void wdg_halo_set_persistent(int v) { g_halo_persistent = v != 0; }
+static int g_halo1_bpc = 4;         // resident workgroups per CU of the persistent kernel (126 registers -> 4 waves per SIMD; measured 2: 122, 3: 113, 4: 111, 5: 127 us)
+void wdg_halo_set_persistent(int v) { g_halo_persistent = v != 0; if (v > 1) g_halo1_bpc = v; }
 
 static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 0) {
     const int hh = HALO_TH + kh - 1, hw = HALO_TW + kw - 1;
@@ -457,7 +458,7 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     if (g_halo_persistent && !upsample && nt == 1 && p.C4 == 4 && pl->taps == 9 && g.kh == 3) {
         // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
         const size_t lds1 = ((size_t)4 * p.npix + 9 * 64) * sizeof(f32x4);
-        const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * 2);   // 220 registers -> 2 resident blocks per CU
+        const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * g_halo1_bpc);
         hipLaunchKernelGGL((wdg_conv_halo1_kernel<9>), dim3(nb), block, lds1, st, p, Bw);
         WDG_LAUNCH_CHECK();
         return WDG_OK;
