@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1,
                     help="train only: sequence length T (headline 1; 24 = the shipped SEQUENCE_LENGTH, which exercises the "
                          "ConvLSTM recurrence; reported as tile-timesteps/s, SURVEY 8d)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="wdg_set_tuning(KEY, INT) before anything is planned (A/B evidence runs; repeatable)")
     args = ap.parse_args()
     global S, T
     S, T = args.size, args.timesteps
@@ -222,6 +224,10 @@ def main():
 
     ops = runtime.get_ops()
     dev = ops.device
+    for kv in args.tune:
+        key, val = kv.split("=")
+        if ops.lib.wdg_set_tuning(key.encode(), int(val)) != 0:
+            raise SystemExit(f"--tune {kv}: rejected by wdg_set_tuning")
     B = args.batch
     generator = make_generator(S, CIN, NZ, CH, T)
     discriminator = make_discriminator(S, S, CIN, CH, T)

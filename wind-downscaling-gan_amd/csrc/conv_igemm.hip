@@ -599,7 +599,16 @@ struct TileCfg {
     int BM, BN;
 };
 // largest tile whose padded column count stays within 13 % of the best achievable padding
-static TileCfg pick_tile(int ncols, bool igemm = true) {
+// Wide layers on small maps (the discriminator's 84->27->8 stages): when the 128x128 tiling yields between 16 and
+// g_small_m tiles — less than one workgroup per CU — the 128x64 tile doubles the tile count and needs a smaller
+// split-K factor (64->128 forward 211 -> 189 us, 128->256 forward 82 -> 77 us); with only a handful of tiles (the
+// 8->2 stage) the split factor dominates either way and 128x128 stays.  wdg_set_tuning("small_m", n): n = 0 disables.
+static int g_small_m = 256;
+static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
+    if (igemm && M >= 0 && ncols >= 128) {
+        const long long t128 = ((M + 127) / 128) * ((ncols + 127) / 128);
+        if (t128 >= 16 && t128 <= g_small_m) return TileCfg{128, 64};
+    }
     // 160 columns (the generator's widest decoder layer): one 128 x 160 tile, five column fragments per wave,
     // instead of five 256 x 32 tiles (2.2 instead of 1.3 MFMAs per LDS fragment read)
     if (igemm && g_tile160 && ncols % 160 == 0) return TileCfg{128, 160};
@@ -730,7 +739,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     // ---- split-K choices and workspace
     {
         const long long M = (long long)g->n_img * g->Ho * g->Wo;
-        TileCfg tc = pick_tile(g->Cout);
+        TileCfg tc = pick_tile(g->Cout, true, M);
         long long tiles = ((M + tc.BM - 1) / tc.BM) * ((g->Cout + tc.BN - 1) / tc.BN);
         pl->fwd_split = pick_split(tiles, pl->K4_fwd, pl->cus, tc.BN);
         if (g_force_split[0] > 0) pl->fwd_split = std::min(g_force_split[0], std::max(1, pl->K4_fwd / 8));
@@ -739,7 +748,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     {
         long long Mmax = 0;
         for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g->n_img * ph.Pa * ph.Pb);
-        TileCfg tc = pick_tile(g->Cin);
+        TileCfg tc = pick_tile(g->Cin, true, Mmax);
         long long tiles = ((Mmax + tc.BM - 1) / tc.BM) * ((g->Cin + tc.BN - 1) / tc.BN) * (long long)pl->ph_dgrad.size();
         pl->dgrad_split = pick_split(tiles, pl->K4_dgrad_max, pl->cus, tc.BN);
         if (g_force_split[1] > 0) pl->dgrad_split = std::min(g_force_split[1], std::max(1, pl->K4_dgrad_max / 8));
@@ -789,7 +798,9 @@ extern "C" size_t wdg_conv_ws_bytes(const wdg_conv_plan* pl) { return pl ? pl->w
 // info[0..7] = {fwd BM, fwd BN, fwd split, dgrad BM, dgrad BN, dgrad split, wgrad BN, wgrad split}
 extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
     WDG_CHECK_ARG(pl && info, "null argument");
-    TileCfg f = pick_tile(pl->g.Cout), d = pick_tile(pl->g.Cin);
+    long long Mf = (long long)pl->g.n_img * pl->g.Ho * pl->g.Wo, Md = 0;
+    for (auto& ph : pl->ph_dgrad) Md = std::max(Md, (long long)pl->g.n_img * ph.Pa * ph.Pb);
+    TileCfg f = pick_tile(pl->g.Cout, true, Mf), d = pick_tile(pl->g.Cin, true, Md);
     info[0] = f.BM; info[1] = f.BN; info[2] = pl->fwd_split;
     info[3] = d.BM; info[4] = d.BN; info[5] = pl->dgrad_split;
     info[6] = pick_wgrad_bn(pl->g.Cout); info[7] = pl->wgrad_split;
@@ -824,6 +835,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         return WDG_OK;
     }
 
+    if (key && !strcmp(key, "small_m")) {   // takes effect for plans created afterwards
+        g_small_m = value;
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "halo_persistent")) {
         wdg_halo_set_persistent(value);
         return WDG_OK;
@@ -857,7 +872,7 @@ static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm&
 
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
                         hipStream_t st) {
-    TileCfg tc = pick_tile(p.Ncols);
+    TileCfg tc = pick_tile(p.Ncols, true, p.Mmax);
     const int tiles_m = (p.Mmax + tc.BM - 1) / tc.BM;
     const int tiles_n = (p.Ncols + tc.BN - 1) / tc.BN;
     if (p.Mmax <= 0) return WDG_OK;
