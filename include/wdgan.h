@@ -335,6 +335,14 @@ int wdg_dense_gap_bwd(const float* x, const float* w, const float* dscore, float
 int wdg_copy_channels(const float* src, int lds, int64_t img_stride_src, float* dst, int ldd,
                       int64_t img_stride_dst, int n_img, int64_t pixels_per_img, int C,
                       int accumulate, wdg_stream stream);
+/* Window patches of a strided grid — shortcut_convolution (tf_utils.py:15-32; stride >= kernel, so the windows are
+ * disjoint): out[n][oy][ox][(ky*k + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside), t x t
+ * windows per image; the conv becomes a 1x1 convolution on `out` with the weights viewed as [k*k*C][Cout].
+ * wdg_patch_scatter is the adjoint: dx (+)= the window gradient at each pixel's (unique) window position, 0 elsewhere. */
+int wdg_patch_gather(const float* x, int ldx, int64_t img_stride_x, float* out, int n_img, int H, int W, int C,
+                     int k, int stride, int pad, int t, wdg_stream stream);
+int wdg_patch_scatter(const float* dpatch, float* dx, int lddx, int64_t img_stride_dx, int n_img, int H, int W, int C,
+                      int k, int stride, int pad, int t, int accumulate, wdg_stream stream);
 /* out[c] (+)= sum_p x[p][c]                                      (bias gradients) */
 int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out, int accumulate,
                wdg_stream stream);

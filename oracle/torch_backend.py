@@ -48,6 +48,9 @@ class PackedWeights:
     def column_slice(self, n0, n1):
         return PackedWeights(self.ops, self.w[..., n0:n1])
 
+    def as_1x1(self):
+        return PackedWeights(self.ops, self.w.view(1, 1, self.taps * self.cin, self.cout))
+
 
 def _lrelu(x, slope):
     return torch.where(x > 0, x, x * slope)
@@ -391,6 +394,28 @@ class TorchOps:
             dx += gx
         else:
             dx.copy_(gx)
+
+    def patch_gather(self, x, out, k, stride, pad):
+        n, H, W, Cc = x.shape
+        t = out.shape[1]
+        xp = F.pad(x, (0, 0, pad, max(0, (t - 1) * stride + k - pad - W), pad, max(0, (t - 1) * stride + k - pad - H)))
+        for oy in range(t):
+            for ox in range(t):
+                out[:, oy, ox] = xp[:, oy * stride:oy * stride + k, ox * stride:ox * stride + k, :].reshape(n, -1)
+
+    def patch_scatter(self, dpatch, dx, k, stride, pad, accumulate=False):
+        n, H, W, Cc = dx.shape
+        t = dpatch.shape[1]
+        Hp, Wp = max(H + pad, (t - 1) * stride + k), max(W + pad, (t - 1) * stride + k)
+        buf = torch.zeros(n, Hp, Wp, Cc, dtype=dx.dtype)
+        for oy in range(t):
+            for ox in range(t):
+                buf[:, oy * stride:oy * stride + k, ox * stride:ox * stride + k, :] += dpatch[:, oy, ox].reshape(n, k, k, Cc)
+        g = buf[:, pad:pad + H, pad:pad + W, :]
+        if accumulate:
+            dx += g
+        else:
+            dx.copy_(g)
 
     def dense_gap_fwd(self, x, w, b, score, B, T):
         s = (x @ w + b[0]).reshape(T, B)  # rows are time-major

@@ -165,26 +165,47 @@ def generator_forward(w, image, noise, training=False, new_state=None):
     return _untd(xf, bt)
 
 
-def discriminator_layout(size, channels):
-    """Loop structure of models.py:111-136 -> [(key index, k, stride, pad)], final index."""
+def shortcut_geometry(src_size, target):
+    """kernel / stride / padding of shortcut_convolution (tf_utils.py:15-32) from a src_size map to a target map."""
+    if target == 1:
+        return src_size, 1, 0                                                           # :18-21: one full-size valid conv
+    stride = math.ceil((2 + src_size) / (target - 1))                                  # :23
+    pad = math.ceil((stride * (target - 1) - src_size) / 2) + 1 + 2                    # :24-25
+    return stride * (1 - target) + src_size + 2 * pad, stride, pad                     # :26
+
+
+def discriminator_layout(size, channels, shortcut_variant=False):
+    """Loop structure of models.py:111-136 -> ([(conv key index, LN key index, k, stride, pad)], final index, shortcut).
+    shortcut_variant=True is the graph the shipped weights-55 discriminator was trained with (SURVEY 8 a2 note 2): the
+    split connection of models.py:127-130 taken when the `>= 4` loop ran once (the published test `i > 1` can never
+    succeed).  shortcut = None or dict(src=number of blocks before the tap, conv=key index, ln=key index, k, s, p)."""
     blocks, idx = [], 6
     while size >= 16:
-        blocks.append((idx, 7, 3, 1)); size = (size + 2 - 7) // 3 + 1; idx += 2
+        blocks.append((idx, idx + 1, 7, 3, 1)); size = (size + 2 - 7) // 3 + 1; idx += 2
+    n_src, src_size = len(blocks), size
     i = 0
     while size >= 4:
-        blocks.append((idx, 7, 3, 1)); size = (size + 2 - 7) // 3 + 1; idx += 2; i += 1
-    assert i <= 1, "shortcut branch is unreachable in the published code"
+        blocks.append((idx, idx + 1, 7, 3, 1)); size = (size + 2 - 7) // 3 + 1; idx += 2; i += 1
+    assert i <= 1, "two passes of the `>= 4` loop cannot happen (the second conv would have zero output)"
+    shortcut = None
+    if shortcut_variant and i == 1:
+        # checkpoint numbering: conv_<size> idx-2, shortcut_conv idx-1, LN(main) idx, LN(shortcut) idx+1
+        ci, _, k, s, p = blocks[-1]
+        blocks[-1] = (ci, ci + 2, k, s, p)
+        sk, ss, sp = shortcut_geometry(src_size, size)
+        shortcut = dict(src=n_src, conv=ci + 1, ln=ci + 3, k=sk, s=ss, p=sp)
+        idx = ci + 4
     while size > 2:
-        blocks.append((idx, 3, 2, 0)); size = (size - 3) // 2 + 1; idx += 2
-    return blocks, idx
+        blocks.append((idx, idx + 1, 3, 2, 0)); size = (size - 3) // 2 + 1; idx += 2
+    return blocks, idx, shortcut
 
 
-def discriminator_sn_keys(size):
-    blocks, _ = discriminator_layout(size, 0)
-    return [L + "2/layer", L + "3/layer"] + [L + f"{i}/layer" for (i, _, _, _) in blocks]
+def discriminator_sn_keys(size, shortcut_variant=False):
+    blocks, _, sc = discriminator_layout(size, 0, shortcut_variant)
+    return [L + "2/layer", L + "3/layer"] + [L + f"{b[0]}/layer" for b in blocks] + ([L + f"{sc['conv']}/layer"] if sc else [])
 
 
-def discriminator_forward(w, low, high):
+def discriminator_forward(w, low, high, shortcut_variant=False):
     """make_discriminator graph, models.py:93-140 -> scores [B,1].  (LayerNorm has no train/infer split.)"""
     hr = conv_lstm(high, w[L + "0/cell/kernel"], w[L + "0/cell/recurrent_kernel"], w[L + "0/cell/bias"])   # :93
     hf, bt = _td(hr)
@@ -196,11 +217,17 @@ def discriminator_forward(w, low, high):
     mf = conv2d(mf, w[L + "3/layer/w"], w[L + "3/layer/layer/bias"], 1, 1)             # :102-104
     mix = layer_norm(_untd(mf, bt), w, L + "5")                                        # :105
     x = torch.cat([hr, mix], -1)                                                       # :108
-    blocks, idx = discriminator_layout(x.shape[2], x.shape[-1])
-    for (i, k, s, p) in blocks:                                                        # :111-136
+    blocks, idx, sc = discriminator_layout(x.shape[2], x.shape[-1], shortcut_variant)
+    for n, (i, j, k, s, p) in enumerate(blocks):                                       # :111-136
+        if sc and n == sc["src"]:
+            shortcut = x                                                               # :118
         xf, _ = _td(x)
         xf = conv2d(xf, w[L + f"{i}/layer/w"], w[L + f"{i}/layer/layer/bias"], s, p)
-        x = layer_norm(_untd(xf, bt), w, L + f"{i + 1}")
+        x = layer_norm(_untd(xf, bt), w, L + f"{j}")
+        if sc and n == sc["src"]:                                                      # :127-130, tf_utils.py:15-32
+            sf, _ = _td(shortcut)
+            sf = conv2d(sf, w[L + f"{sc['conv']}/layer/w"], w[L + f"{sc['conv']}/layer/layer/bias"], sc["s"], sc["p"])
+            x = x + layer_norm(_untd(sf, bt), w, L + f"{sc['ln']}")
     xf, _ = _td(x)
     xf = xf.reshape(xf.shape[0], -1)                                                   # :137 Flatten (H,W,C)
     s = xf @ w[L + f"{idx}/layer/kernel"] + w[L + f"{idx}/layer/bias"]                 # :138 Dense(1)

@@ -49,8 +49,11 @@ def test_reference_signatures_and_errors(cpu_backend):
     from downscaling.data.data_generator import FlexibleNoiseGenerator
     assert list(inspect.signature(models.make_generator).parameters) == [
         "image_size", "in_channels", "noise_channels", "out_channels", "n_timesteps", "batch_size", "feature_channels"]
-    assert list(inspect.signature(models.make_discriminator).parameters) == [
+    dpar = inspect.signature(models.make_discriminator).parameters
+    assert [k for k, v in dpar.items() if v.kind is not v.KEYWORD_ONLY] == [
         "low_res_size", "high_res_size", "low_res_channels", "high_res_channels", "n_timesteps", "batch_size", "feature_channels"]
+    # the one extension is keyword-only and off by default (the published graph)
+    assert [k for k, v in dpar.items() if v.kind is v.KEYWORD_ONLY] == ["shortcut_variant"] and dpar["shortcut_variant"].default is False
     assert inspect.signature(models.make_generator).parameters["feature_channels"].default == 128
     assert inspect.signature(models.make_discriminator).parameters["feature_channels"].default == 16
     assert list(inspect.signature(ganbase.GAN.__init__).parameters)[:6] == [
@@ -81,6 +84,24 @@ def test_checkpoint_variable_names_match_shipped_index(cpu_backend):
     # 7,182,688 B in SURVEY §8 a1 = these variables + 24 B of optimizer scalars (iter, lr, decay, momentum, rho)
     assert sum(int(np.prod(s)) for s in mine.values()) * 4 == fixture["variable_bytes"] == 7182688 - 24
     assert gen.net.params.num_trainable() == 1794418
+
+
+def test_shipped_discriminator_checkpoint_is_the_shortcut_variant(cpu_backend):
+    """SURVEY §8 a2 note 2 / f1: weights-55.ckpt/discriminator.index holds `layer_with_weights-11/layer/w [6,6,128,256]`
+    and two LayerNorms before the Dense — the split connection of models.py:127-130 that the published `i > 1` test
+    never builds.  make_discriminator(..., shortcut_variant=True) produces exactly the checkpoint's variables; the
+    published graph produces a strict subset by NAME with a shifted numbering (which is why Keras' lazy restore
+    cannot load it completely)."""
+    import json
+    from downscaling.gan.models import make_discriminator
+    fixture = json.loads((ROOT / "tests" / "golden" / "discriminator_index.json").read_text())
+    disc = make_discriminator(96, 96, 3, 2, 1, shortcut_variant=True)
+    mine = {v.name: list(v.shape) for v in disc.net.params.vars}
+    assert mine == fixture["variables"]
+    assert sum(int(np.prod(s)) for s in mine.values()) * 4 == fixture["variable_bytes"]
+    published = {v.name: list(v.shape) for v in make_discriminator(96, 96, 3, 2, 1).net.params.vars}
+    assert "layer_with_weights-13/gamma" not in published and published != fixture["variables"]
+    assert published["layer_with_weights-12/layer/kernel"] == [1024, 1]     # the Dense sits where the ckpt has a LayerNorm
 
 
 def test_gan_api_train_save_load_predict(cpu_backend, tmp_path):

@@ -68,11 +68,16 @@ def test_generator_forward_backward(ops, S, T, training):
         assert rel_err(g[k], gref[k]) < 1e-8, k
 
 
-@pytest.mark.parametrize("S,T,Fd", [(12, 2, 8), (20, 1, 8), (32, 2, 8), (24, 1, 8), (20, 1, 16)])
-def test_discriminator_forward_backward(ops, S, T, Fd):
-    """(.., T=1, Fd=16) takes the fused single-timestep ConvLSTM ops (convlstm1_*), the others the general path."""
+@pytest.mark.parametrize("S,T,Fd,variant", [(12, 2, 8, False), (20, 1, 8, False), (32, 2, 8, False), (24, 1, 8, False),
+                                            (20, 1, 16, False), (12, 2, 8, True), (20, 1, 8, True), (32, 2, 8, True)])
+def test_discriminator_forward_backward(ops, S, T, Fd, variant):
+    """(.., T=1, Fd=16) takes the fused single-timestep ConvLSTM ops (convlstm1_*), the others the general path.
+    variant=True: the split connection of models.py:127-130 (shortcut_convolution, tf_utils.py:15-32) as the shipped
+    discriminator checkpoint has it — tapped from the concat (S=12, 6x6 stride 7), as one full-size window (S=20) and
+    from a 10x10 map with 6x6 windows at stride 12 (S=32)."""
     B, cl, ch = 2, 3, 2
-    net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=Fd, seed=4)
+    net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=Fd, seed=4, shortcut_variant=variant)
+    assert (net.shortcut is not None) == variant
     w = randomize(net, 12)
     low, _, high = _inputs(B, T, S, cl, 1, ch, seed=1)
     keys = TM.trainable_keys(w)
@@ -84,14 +89,14 @@ def test_discriminator_forward_backward(ops, S, T, Fd):
     net.set_high_tm(high_tm, B)
     score = net.forward(B, training=True).clone()
 
-    TM.apply_sn(w, TM.discriminator_sn_keys(S), True)
+    TM.apply_sn(w, TM.discriminator_sn_keys(S, variant), True)
     hreq = high.clone().requires_grad_(True)
-    ref = TM.discriminator_forward(w, low, hreq)
+    ref = TM.discriminator_forward(w, low, hreq, variant)
     assert rel_err(score, ref.reshape(-1)) < TOL
     dscore = torch.randn(B, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
     loss = (ref.reshape(-1) * dscore).sum()
     gref = TM._grads(loss, w, keys + [])
-    (ghigh,) = torch.autograd.grad((TM.discriminator_forward(w, low, hreq).reshape(-1) * dscore).sum(), hreq)
+    (ghigh,) = torch.autograd.grad((TM.discriminator_forward(w, low, hreq, variant).reshape(-1) * dscore).sum(), hreq)
 
     net.params.zero_grad()
     dhigh_tm = net.backward(B, dscore.clone(), need_wgrad=True)

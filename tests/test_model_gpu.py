@@ -59,12 +59,15 @@ def test_generator(hip_ops, S, T, F, nz, training):
         assert rel_err(g[k], gref[k]) < TOL, k
 
 
-@pytest.mark.parametrize("S,T,Fd", [(32, 2, 16), (12, 2, 8), (40, 1, 16), (96, 1, 16)])
-def test_discriminator(hip_ops, S, T, Fd):
+@pytest.mark.parametrize("S,T,Fd,variant", [(32, 2, 16, False), (12, 2, 8, False), (40, 1, 16, False), (96, 1, 16, False),
+                                            (96, 2, 16, True), (12, 2, 8, True), (20, 1, 8, True)])
+def test_discriminator(hip_ops, S, T, Fd, variant):
+    """variant=True: the shipped checkpoint's graph (split connection, models.py:127-130 / tf_utils.py:15-32);
+    (96, ., 16) is the shipped shape: 6x6 windows at stride 11 from the 9x9 map."""
     from downscaling.engine.networks import DiscriminatorNet
     B, cl, ch = 2, 3, 2
     dev = hip_ops.device
-    net = DiscriminatorNet(hip_ops, S, S, cl, ch, T, feature_channels=Fd, seed=4)
+    net = DiscriminatorNet(hip_ops, S, S, cl, ch, T, feature_channels=Fd, seed=4, shortcut_variant=variant)
     w = randomize(net, 12)
     low, _, high = _inputs(B, T, S, cl, 1, ch, seed=1)
     keys = TM.trainable_keys(w)
@@ -75,9 +78,9 @@ def test_discriminator(hip_ops, S, T, Fd):
     net.to_time_major(high.float().to(dev), high_tm)
     net.set_high_tm(high_tm, B)
     score = net.forward(B, training=True).clone()
-    TM.apply_sn(w, TM.discriminator_sn_keys(S), True)
+    TM.apply_sn(w, TM.discriminator_sn_keys(S, variant), True)
     hreq = high.clone().requires_grad_(True)
-    ref = TM.discriminator_forward(w, low, hreq).reshape(-1)
+    ref = TM.discriminator_forward(w, low, hreq, variant).reshape(-1)
     assert float((score.double().cpu() - ref).abs().max()) < TOL * max(1.0, float(ref.abs().max()))
     dscore = torch.randn(B, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
     gs = torch.autograd.grad((ref * dscore).sum(), [w[k] for k in keys] + [hreq])

@@ -183,6 +183,36 @@ def test_fused_upsample_conv_transpose(n, H, W, C, N, ld, composite, hip_ops, re
         assert float(y_g[..., N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,H,C,ld,k,s,p,t", [(3, 9, 128, 128, 6, 11, 4, 2), (2, 13, 8, 12, 7, 8, 5, 3), (2, 6, 16, 16, 6, 6, 0, 1),
+                                              (1, 12, 4, 8, 6, 7, 4, 3)])
+def test_window_patches_gather_and_adjoint(n, H, C, ld, k, s, p, t, hip_ops, ref_ops):
+    """wdg_patch_gather / wdg_patch_scatter (shortcut_convolution as a 1x1 conv on disjoint windows, tf_utils.py:15-32):
+    against the oracle's slicing loops, the scatter accumulating into a strided channel view; and the adjoint identity
+    <gather(x), g> = <x, scatter(g)>."""
+    gen = torch.Generator().manual_seed(3)
+    dev = hip_ops.device
+    x = torch.randn(n, H, H, C, generator=gen, dtype=torch.float64)
+    g = torch.randn(n, t, t, k * k * C, generator=gen, dtype=torch.float64)
+    base = torch.randn(n, H, H, C, generator=gen, dtype=torch.float64)
+    out_r, dx_r = torch.zeros(n, t, t, k * k * C, dtype=torch.float64), base.clone()
+    ref_ops.patch_gather(x, out_r, k, s, p)
+    ref_ops.patch_scatter(g, dx_r, k, s, p, accumulate=True)
+    xg = hip_ops.zeros(n, H, H, ld)
+    xg[..., :C] = x.float().to(dev)
+    out_g = hip_ops.empty(n, t, t, k * k * C)
+    hip_ops.patch_gather(xg[..., :C], out_g, k, s, p)
+    dxg = hip_ops.zeros(n, H, H, ld)
+    dxg.fill_(5.0)
+    dxg[..., :C] = base.float().to(dev)
+    hip_ops.patch_scatter(g.float().to(dev).contiguous(), dxg[..., :C], k, s, p, accumulate=True)
+    assert rel_err(out_g, out_r) < TOL and rel_err(dxg[..., :C], dx_r) < TOL
+    if ld > C:
+        assert float((dxg[..., C:] - 5.0).abs().max()) == 0.0
+    lhs = float((out_r * g).sum())
+    rhs = float((x * (dx_r - base)).sum())
+    assert abs(lhs - rhs) < 1e-9 * max(1.0, abs(lhs))
+
+
 @pytest.mark.parametrize("n,H,W,C,N,ld", [(3, 60, 68, 160, 16, 160), (2, 19, 35, 40, 4, 48), (2, 3, 3, 20, 8, 20),
                                           (1, 9, 50, 160, 16, 192), (2, 4, 17, 8, 2, 8), (1, 2, 2, 12, 16, 12)])
 @pytest.mark.parametrize("column", [True, False])

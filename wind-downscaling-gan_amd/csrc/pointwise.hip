@@ -556,3 +556,70 @@ extern "C" int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+
+// ---- window patches of a strided grid (shortcut_convolution, tf_utils.py:15-32) -----------------
+// A convolution whose stride is at least its kernel size reads disjoint windows: gathering them turns it into a
+// 1x1 convolution (GEMM) on a t x t map with k*k*C channels — forward, data gradient and weight gradient then run
+// in the implicit-GEMM kernels with the layer's weights viewed as [k*k*C][Cout] — and the adjoint of the gather is
+// a gather as well (every input pixel lies in at most one window).
+__global__ void __launch_bounds__(256) wdg_patch_gather_kernel(const float* __restrict__ x, int ldx, long long isx,
+                                                               float* __restrict__ out, int H, int W, int CQ, int k,
+                                                               int s, int p, int t, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % CQ);
+        long long r = i / CQ;
+        const int kx = (int)(r % k); r /= k;
+        const int ky = (int)(r % k); r /= k;
+        const int ox = (int)(r % t); r /= t;
+        const int oy = (int)(r % t);
+        const long long n = r / t;
+        const int y = oy * s - p + ky, xx = ox * s - p + kx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+            v = *reinterpret_cast<const f32x4*>(x + n * isx + ((long long)y * W + xx) * ldx + 4 * cq);
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) wdg_patch_scatter_kernel(const float* __restrict__ dpatch, float* __restrict__ dx,
+                                                                int lddx, long long isdx, int H, int W, int CQ, int k,
+                                                                int s, int p, int t, int accumulate, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i % CQ);
+        long long r = i / CQ;
+        const int xx = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const long long n = r / H;
+        const int oy = (y + p) / s, ky = (y + p) - oy * s, ox = (xx + p) / s, kx = (xx + p) - ox * s;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (oy < t && ox < t && ky < k && kx < k)
+            v = reinterpret_cast<const f32x4*>(dpatch)[((((n * t + oy) * t + ox) * k + ky) * k + kx) * CQ + cq];
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + n * isdx + ((long long)y * W + xx) * lddx + 4 * cq);
+        if (accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+extern "C" int wdg_patch_gather(const float* x, int ldx, int64_t img_stride_x, float* out, int n_img, int H, int W, int C,
+                                int k, int stride, int pad, int t, wdg_stream stream) {
+    WDG_CHECK_ARG(x && out && n_img > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0, "bad argument");
+    WDG_CHECK_ARG(k > 0 && stride > 0 && pad >= 0 && t > 0, "bad window geometry");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "x / out must be 16-byte aligned");
+    const long long total = (long long)n_img * t * t * k * k * (C / 4);
+    hipLaunchKernelGGL(wdg_patch_gather_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (long long)img_stride_x, out, H, W, C / 4, k, stride, pad, t, total);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+extern "C" int wdg_patch_scatter(const float* dpatch, float* dx, int lddx, int64_t img_stride_dx, int n_img, int H, int W,
+                                 int C, int k, int stride, int pad, int t, int accumulate, wdg_stream stream) {
+    WDG_CHECK_ARG(dpatch && dx && n_img > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && lddx % 4 == 0, "bad argument");
+    WDG_CHECK_ARG(k > 0 && stride >= k && pad >= 0 && t > 0, "windows must not overlap (stride >= k)");
+    WDG_CHECK_ARG(((uintptr_t)dpatch & 15) == 0 && ((uintptr_t)dx & 15) == 0, "dpatch / dx must be 16-byte aligned");
+    const long long total = (long long)n_img * H * W * (C / 4);
+    hipLaunchKernelGGL(wdg_patch_scatter_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dpatch, dx,
+                       lddx, (long long)img_stride_dx, H, W, C / 4, k, stride, pad, t, accumulate, total);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}

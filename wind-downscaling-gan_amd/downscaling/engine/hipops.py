@@ -470,6 +470,21 @@ class HipOps:
         native.check(self.lib.wdg_upsample2x_bwd(pdy, lddy, isdy, pdx, lddx, isdx, n, H, W, Cc, int(accumulate),
                                                  self.stream), "upsample_bwd")
 
+    def patch_gather(self, x, out, k, stride, pad):
+        """out [n,t,t,k*k*C] = the t x t grid of k x k windows of x [n,H,W,C] (zero padded); see wdg_patch_gather."""
+        px, ldx, isx = _v4(x)
+        n, H, W, Cc = x.shape
+        assert out.is_contiguous() and out.shape[0] == n and out.shape[3] == k * k * Cc
+        native.check(self.lib.wdg_patch_gather(px, ldx, isx, out.data_ptr(), n, H, W, Cc, k, stride, pad, out.shape[1],
+                                               self.stream), "patch_gather")
+
+    def patch_scatter(self, dpatch, dx, k, stride, pad, accumulate=False):
+        pdx, lddx, isdx = _v4(dx)
+        n, H, W, Cc = dx.shape
+        assert dpatch.is_contiguous() and dpatch.shape[3] == k * k * Cc
+        native.check(self.lib.wdg_patch_scatter(dpatch.data_ptr(), pdx, lddx, isdx, n, H, W, Cc, k, stride, pad,
+                                                dpatch.shape[1], int(accumulate), self.stream), "patch_scatter")
+
     def dense_gap_fwd(self, x, w, b, score, B, T):
         assert x.is_contiguous()
         native.check(self.lib.wdg_dense_gap_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), score.data_ptr(), B, T,

@@ -7,7 +7,7 @@ are zero-padded (input 23 -> 24, wind 2 -> 4, low+high 5 -> 8).
 """
 import numpy as np
 
-from .common import round4, v2
+from .common import ConvGeom, round4, v2
 from .layers import LN_EPS, LRELU, BatchNorm, Conv, ConvLSTM, LayerNorm
 from .params import ParamStore, glorot_uniform, zeros_init
 
@@ -253,11 +253,34 @@ def discriminator_plan(size, channels):
     return blocks, size, channels
 
 
+def discriminator_shortcut(size, channels):
+    """The split connection of models.py:118,127-130 as the shipped weights-55 discriminator was trained with it
+    (SURVEY 8 a2 note 2: `layer_with_weights-11/layer/w [6,6,128,256]` exists in the checkpoint although the published
+    test `i > 1` can never succeed): taken when the `>= 4` loop ran once.  Returns None or
+    (number of blocks before the tap, tap size, tap channels, k, stride, pad, target size, out channels) with the
+    geometry of shortcut_convolution (tf_utils.py:15-32)."""
+    n_src = 0
+    while size >= 16:
+        size, channels, n_src = (size + 2 - 7) // 3 + 1, channels * 2, n_src + 1
+    if size < 4:
+        return None
+    target = (size + 2 - 7) // 3 + 1
+    if target <= 0:
+        return None
+    if target == 1:                                                                    # tf_utils.py:18-21
+        k, stride, pad = size, 1, 0
+    else:
+        stride = -(-(2 + size) // (target - 1))                                        # :23 ceil
+        pad = -(-(stride * (target - 1) - size) // 2) + 1 + 2                          # :24-25
+        k = stride * (1 - target) + size + 2 * pad                                     # :26
+    return n_src, size, channels, k, stride, pad, target, channels * 2
+
+
 class DiscriminatorNet(_Net):
     """make_discriminator, gan/models.py:76-142."""
 
     def __init__(self, ops, low_res_size, high_res_size, low_res_channels, high_res_channels, n_timesteps,
-                 feature_channels=16, seed=1, sync=None):
+                 feature_channels=16, seed=1, sync=None, shortcut_variant=False):
         super().__init__(ops, sync)
         if low_res_size != high_res_size:               # models.py:89-91
             raise NotImplementedError("The discriminator assumes that the low res and high res images have the "
@@ -276,13 +299,30 @@ class DiscriminatorNet(_Net):
         self.ln_a = self._add(LayerNorm(self, L + "4", Fd))                                   # :97
         self.ln_b = self._add(LayerNorm(self, L + "5", Fd))                                   # :105
         plan, self.final_size, self.final_ch = discriminator_plan(S, 2 * Fd)
+        sc = discriminator_shortcut(S, 2 * Fd) if shortcut_variant else None
         self.blocks = []
+        self.shortcut = None
         idx = 6
-        for (k, s, p, ci, co, osz) in plan:
+        for n, (k, s, p, ci, co, osz) in enumerate(plan):
             conv = self._add(Conv(self, L + str(idx), k, ci, co, s, p, sn=True))              # :113-114,122-123,134
-            ln = self._add(LayerNorm(self, L + str(idx + 1), co))                             # :116,125,136
+            if sc is not None and n == sc[0]:
+                # checkpoint numbering: conv_<size> idx, shortcut_conv idx+1, LN(main) idx+2, LN(shortcut) idx+3
+                _, ssz, sci, sk, sstr, spad, tgt, sco = sc
+                if tgt == 1:
+                    sstr = sk           # a single full-size window: the stride is immaterial
+                if sstr < sk:
+                    raise NotImplementedError("shortcut_convolution with overlapping windows (stride < kernel)")
+                assert (tgt, sco) == (osz, co)
+                sconv = self._add(Conv(self, L + str(idx + 1), sk, sci, sco, sstr, spad, sn=True))   # tf_utils.py:27-29
+                ln = self._add(LayerNorm(self, L + str(idx + 2), co))
+                sln = self._add(LayerNorm(self, L + str(idx + 3), sco))                       # tf_utils.py:31
+                self.shortcut = dict(block=n, conv=sconv, ln=sln, size=ssz, cin=sci, k=sk, stride=sstr, pad=spad,
+                                     target=tgt, cout=sco)
+                idx += 4
+            else:
+                ln = self._add(LayerNorm(self, L + str(idx + 1), co))                         # :116,125,136
+                idx += 2
             self.blocks.append((conv, ln, osz, co))
-            idx += 2
         K = self.final_size * self.final_size * self.final_ch
         self.K = K
         self.dense_w = self.params.add(L + f"{idx}/layer/kernel", (K, 1), glorot_uniform(K, 1))   # :138
@@ -320,6 +360,11 @@ class DiscriminatorNet(_Net):
             b["ys"].append(o.empty(N, osz, osz, co))
             b["zs"].append(o.empty(N, osz, osz, co))
             b["dzs"].append(o.empty(N, osz, osz, co))
+        if self.shortcut is not None:
+            sc = self.shortcut
+            t, kc = sc["target"], sc["k"] * sc["k"] * sc["cin"]
+            b.update(sc_patch=o.empty(N, t, t, kc), sc_dpatch=o.empty(N, t, t, kc), sc_y=o.empty(N, t, t, sc["cout"]),
+                     sc_z=o.empty(N, t, t, sc["cout"]), sc_dz=o.empty(N, t, t, sc["cout"]))
         self._bufs = {B: b}
         return b
 
@@ -354,10 +399,34 @@ class DiscriminatorNet(_Net):
         for i, (conv, ln, osz, co) in enumerate(self.blocks):
             conv.forward(x, b["ys"][i])
             ln.forward(v2(b["ys"][i]), v2(b["zs"][i]))
+            if self.shortcut is not None and i == self.shortcut["block"]:
+                self._shortcut_fwd(b, x, b["zs"][i])
             x = b["zs"][i]
         self._last = x
         o.dense_gap_fwd(x.view(T * B, self.K), self.dense_w.value.view(-1), self.dense_b.value, b["score"], B, T)
         return b["score"]
+
+    # ---- split connection (models.py:118,127-130; tf_utils.py:15-32), shortcut_variant only -------------------
+    # The shortcut conv has stride >= kernel (e.g. 6x6 stride 11 from a 9x9 map): its windows are disjoint, so it
+    # runs as a 1x1 convolution on the gathered windows with the weights viewed as [k*k*Cin][Cout].
+    _G1 = ConvGeom(1, 1, 1, 0)
+
+    def _shortcut_fwd(self, b, x_src, z_main):
+        sc, o = self.shortcut, self.ops
+        o.patch_gather(x_src, b["sc_patch"], sc["k"], sc["stride"], sc["pad"])
+        o.conv_fwd(b["sc_patch"], sc["conv"].pk.as_1x1(), sc["conv"].b.value, b["sc_y"], self._G1, act=True, slope=LRELU)
+        sc["ln"].forward(v2(b["sc_y"]), v2(b["sc_z"]))
+        o.copy_channels(b["sc_z"], z_main, accumulate=True)                       # kl.add([x, shortcut]), :130
+
+    def _shortcut_bwd(self, b, dsum, x_src, dx_src, need_wgrad):
+        """dsum: gradient w.r.t. the sum (a copy: consumed); accumulates the shortcut's share into dx_src."""
+        sc, o = self.shortcut, self.ops
+        conv, pk1 = sc["conv"], sc["conv"].pk.as_1x1()
+        sc["ln"].backward(v2(dsum), v2(b["sc_y"]), v2(dsum), conv.b.grad if need_wgrad else None, need_wgrad)
+        if need_wgrad:
+            o.conv_wgrad(b["sc_patch"], dsum, pk1, conv.w.grad.view(1, 1, pk1.cin, pk1.cout), self._G1, accumulate=True)
+        o.conv_dgrad(dsum, pk1, b["sc_dpatch"], self._G1)
+        o.patch_scatter(b["sc_dpatch"], dx_src, sc["k"], sc["stride"], sc["pad"], accumulate=True)
 
     def _fused_conv_ln(self, conv):
         return self.ops.convln_supported(conv.cin, conv.cout)
@@ -403,11 +472,17 @@ class DiscriminatorNet(_Net):
         for i in range(len(self.blocks) - 1, -1, -1):
             conv, ln, osz, co = self.blocks[i]
             dz = b["dzs"][i]
+            split = self.shortcut is not None and i == self.shortcut["block"]
+            if split:
+                o.copy_channels(dz, b["sc_dz"])                                   # the sum's gradient feeds both branches
             ln.backward(v2(dz), v2(b["ys"][i]), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
             xin = b["zs"][i - 1] if i > 0 else b["cat"]
+            dxin = b["dzs"][i - 1] if i > 0 else b["dcat"]
             if need_wgrad:
                 conv.backward_weights(xin, dz)
-            conv.backward_input(dz, b["dzs"][i - 1] if i > 0 else b["dcat"])
+            conv.backward_input(dz, dxin)
+            if split:
+                self._shortcut_bwd(b, b["sc_dz"], xin, dxin, need_wgrad)
         # branch A (high-res only)
         self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
         self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"], B, T, need_wgrad)

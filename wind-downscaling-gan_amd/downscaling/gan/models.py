@@ -189,10 +189,17 @@ def make_discriminator(
         high_res_channels: int,
         n_timesteps: int,
         batch_size: int = None,
-        feature_channels: int = 16
+        feature_channels: int = 16,
+        *,
+        shortcut_variant: bool = False
 ):
+    """Reference signature (gan/models.py:76-84) plus one keyword-only extension: shortcut_variant=True builds the
+    graph the shipped weights-55 discriminator checkpoint was trained with — the split connection of models.py:127-130
+    taken after one pass of the `>= 4` loop (the published test `i > 1` can never succeed, so the published code
+    never builds it and Keras' lazy restore silently leaves `layer_with_weights-11..13` of the checkpoint unused)."""
     if low_res_size != high_res_size:
         raise NotImplementedError("The discriminator assumes that the low res and high res images have the same size."
                                   "Perhaps you should upsample your low res image first?")
     return Discriminator(DiscriminatorNet(runtime.get_ops(), low_res_size, high_res_size, low_res_channels,
-                                          high_res_channels, n_timesteps, feature_channels=feature_channels))
+                                          high_res_channels, n_timesteps, feature_channels=feature_channels,
+                                          shortcut_variant=shortcut_variant))
