@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(256) wdg_convln_bwd_kernel(const WdgConvLn p, 
         }
 #pragma unroll
         for (int o4 = 0; o4 < CN_CO / 4; ++o4)
-            *reinterpret_cast<f32x4*>(&dps[hp * CN_CO + 4 * o4]) = (f32x4){d[4 * o4], d[4 * o4 + 1], d[4 * o4 + 2], d[4 * o4 + 3]};
+            // channel-group planes [o4][halo pixel]: consecutive lanes touch consecutive 16-byte slots (the pixel-major
+            // layout was a 4-way bank conflict on every access: 37 % of the LDS cycles, profiles/r01ay_pmc_summary.csv)
+            *reinterpret_cast<f32x4*>(&dps[(o4 * (GH * GW) + hp) * 4]) = (f32x4){d[4 * o4], d[4 * o4 + 1], d[4 * o4 + 2], d[4 * o4 + 3]};
     }
     // 2. parameter-gradient partials: wave reduction, then 4 waves through LDS, one atomic per value
     if (p.dgamma) {
@@ -205,11 +207,11 @@ __global__ void __launch_bounds__(256) wdg_convln_bwd_kernel(const WdgConvLn p, 
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int th = tap / 3, tw = tap % 3;
-        const float* dp = &dps[((py + 2 - th) * GW + px + 2 - tw) * CN_CO];
+        const float* dp = &dps[((py + 2 - th) * GW + px + 2 - tw) * 4];
         float v[CN_CO];
 #pragma unroll
         for (int o4 = 0; o4 < CN_CO / 4; ++o4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(dp + 4 * o4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(dp + o4 * (GH * GW) * 4);
             v[4 * o4] = a[0]; v[4 * o4 + 1] = a[1]; v[4 * o4 + 2] = a[2]; v[4 * o4 + 3] = a[3];
         }
 #pragma unroll

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
             v = *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4);
-        xs[idx] = v;
+        xs[c4 * (XH * XW) + pix] = v;   // channel-group planes: a wave's 16-byte reads of consecutive pixels are contiguous
     }
     __syncthreads();
     // 2. dgates on the (GH x GW) halo: work item = (halo pixel, half); halves are wave-uniform
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
 #pragma unroll
             for (int f = 0; f < FH; ++f) dgi[f] = dgc[f] = dgo[f] = 0.f;
             if (inside) {
-                auto load = [&](int th, int tw, int c4) -> f32x4 { return xs[((hy + th) * XW + hx + tw) * C4 + c4]; };
+                auto load = [&](int th, int tw, int c4) -> f32x4 { return xs[c4 * (XH * XW) + (hy + th) * XW + hx + tw]; };
                 __attribute__((aligned(8))) float gi[FH], gc[FH], go[FH];
                 cl_gates<CIN, F, FH, false>(Wx, bias, f0, load, gi, gc, go);
                 const float* dhp = DHimg + ((long long)gy * p.W + gx) * p.lddh + f0;
