@@ -454,10 +454,11 @@ class DiscriminatorNet(_Net):
                 conv.backward_weights(x, dz)
             conv.backward_input(dz, dx)
 
-    def backward(self, B, dscore, need_wgrad):
+    def backward(self, B, dscore, need_wgrad, need_input_grad=True):
         """dscore [B].  Returns the time-major gradient w.r.t. the high-res input [T*B,S,S,round4(ch)].
         need_wgrad=False is the input-gradient-only pass (gradient penalty and generator step,
-        ganbase.py:35,60)."""
+        ganbase.py:35,60); need_input_grad=False the weights-only pass of the critic update (ganbase.py:46: the tape
+        asks for the discriminator's weights only), which skips the two ConvLSTMs' input gradients and returns None."""
         b = self.buffers(B)
         o, Fd, T = self.ops, self.Fd, self.T
         x = self._last
@@ -485,10 +486,12 @@ class DiscriminatorNet(_Net):
                 self._shortcut_bwd(b, b["sc_dz"], xin, dxin, need_wgrad)
         # branch A (high-res only)
         self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
-        self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"], B, T, need_wgrad)
+        self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None, B, T, need_wgrad)
         # branch B (low + high)
         self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dpre"], b["dhb"], need_wgrad)
-        self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"], B, T, need_wgrad)
+        self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
+        if not need_input_grad:
+            return None
         # d(high) = d(hi) + d(mix)[cl:cl+ch]
         o.copy_channels(b["dhi"][..., :self.ch], b["dhigh"][..., :self.ch])
         o.copy_channels(b["dmix"][..., self.cl:self.cl + self.ch], b["dhigh"][..., :self.ch], accumulate=True)

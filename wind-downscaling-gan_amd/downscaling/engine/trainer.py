@@ -168,12 +168,12 @@ class GanEngine:
             disc.set_high_tm(noisy, B)
             real_mean = disc.forward(B, training=True).mean()                     # :41
             dscore.fill_(-sw_mean / B)
-            disc.backward(B, dscore, need_wgrad=True)
+            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
             noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(fake[..., :ch]))   # :42
             disc.set_high_tm(noisy, B)
             fake_mean = disc.forward(B, training=True).mean()                     # :43
             dscore.fill_(sw_mean / B)
-            disc.backward(B, dscore, need_wgrad=True)
+            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
             disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45, train.py:11-12
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
         gen.params.zero_grad()                                                    # generator step, :50-61
