@@ -206,6 +206,19 @@ class TorchOps:
         if dbias is not None:   # bias gradient of the same layer (always accumulated)
             dbias += dy[..., :pk.cout].reshape(-1, pk.cout).sum(0)
 
+    def fork(self):
+        """HipOps.fork restated for a backend without streams: run in place."""
+        class _Inline:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *exc):
+                return False
+
+            def join(self):
+                pass
+        return _Inline()
+
     def make_prep_batch(self, entries):
         """Restatement of HipOps.make_prep_batch: layer by layer (the batching is a launch-count optimisation)."""
         ops = self

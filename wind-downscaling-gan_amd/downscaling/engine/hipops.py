@@ -146,6 +146,28 @@ class _PrepBatch:
             pass
 
 
+class _Fork:
+    def __init__(self, ops):
+        self.ops = ops
+        if getattr(ops, "_side_stream", None) is None:
+            ops._side_stream = torch.cuda.Stream(device=ops.device)
+        self.side = ops._side_stream
+        self.ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(torch.cuda.current_stream(self.ops.device))
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        torch.cuda.current_stream(self.ops.device).wait_stream(self.side)
+
+
 class HipOps:
     name = "hip"
     dtype = torch.float32
@@ -182,9 +204,20 @@ class HipOps:
         return PackedWeights(self, w)
 
     def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Split-K / split-pixel scratch of the CURRENT stream (work forked onto a side stream gets its own)."""
+        if self._ws is None:
+            self._ws = {}
+        key = self.stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return ws
+
+    def fork(self):
+        """Context manager: run the enclosed launches on a side stream that starts after everything enqueued so far;
+        `join()` on the returned object makes the main stream wait for them.  Only worth it for chains of small
+        launches (the per-timestep recurrent kernels at T > 1); full-size kernels fill the chip on their own."""
+        return _Fork(self)
 
     def _plan(self, x, y, cin, cout, g: ConvGeom):
         px, ldx, isx = _v4(x)

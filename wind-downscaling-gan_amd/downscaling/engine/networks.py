@@ -5,6 +5,8 @@ activations are TIME-MAJOR channels-last: image index n = t*B + b, shape [T*B, H
 concatenations are zero-copy views into wider buffers; channel counts that are not multiples of 4
 are zero-padded (input 23 -> 24, wind 2 -> 4, low+high 5 -> 8).
 """
+import os
+
 import numpy as np
 
 from .common import ConvGeom, round4, v2
@@ -302,6 +304,8 @@ class DiscriminatorNet(_Net):
         sc = discriminator_shortcut(S, 2 * Fd) if shortcut_variant else None
         self.blocks = []
         self.shortcut = None
+        # T > 1 only: the two input branches on two streams (WDG_OVERLAP_BRANCHES=0 disables, for A/B runs)
+        self.overlap_branches = os.environ.get("WDG_OVERLAP_BRANCHES", "1") != "0"
         idx = 6
         for n, (k, s, p, ci, co, osz) in enumerate(plan):
             conv = self._add(Conv(self, L + str(idx), k, ci, co, s, p, sn=True))              # :113-114,122-123,134
@@ -348,7 +352,8 @@ class DiscriminatorNet(_Net):
             score=o.empty(B),
             # gradients
             dcat=o.empty(N, S, S, 2 * Fd),
-            dpre=o.empty(N, S, S, Fd),                         # dense pre-activation gradient of one branch
+            dpre=o.empty(N, S, S, Fd),                         # dense pre-activation gradients of the two branches
+            dpre_b=o.empty(N, S, S, Fd),
             dha=o.zeros(N, S, S, chp),
             dhb=o.zeros(N, S, S, Fd),
             dhi=o.zeros(N, S, S, chp),
@@ -391,10 +396,20 @@ class DiscriminatorNet(_Net):
         b = self.buffers(B)
         o, Fd, T = self.ops, self.Fd, self.T
         self._prepare(training)
-        self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
-        self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
-        self.lstm_b.forward(b["mix"], b["hb"], B, T)
-        self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
+        if T > 1 and self.overlap_branches:
+            # the two input branches are independent chains of small per-timestep launches: run the high-res-only one
+            # on a side stream under the other (at T = 1 every kernel fills the chip and the overlap gains nothing)
+            with o.fork() as side:
+                self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
+                self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
+            self.lstm_b.forward(b["mix"], b["hb"], B, T)
+            self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
+            side.join()
+        else:
+            self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
+            self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
+            self.lstm_b.forward(b["mix"], b["hb"], B, T)
+            self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
         x = b["cat"]
         for i, (conv, ln, osz, co) in enumerate(self.blocks):
             conv.forward(x, b["ys"][i])
@@ -484,12 +499,22 @@ class DiscriminatorNet(_Net):
             conv.backward_input(dz, dxin)
             if split:
                 self._shortcut_bwd(b, b["sc_dz"], xin, dxin, need_wgrad)
-        # branch A (high-res only)
-        self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
-        self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None, B, T, need_wgrad)
-        # branch B (low + high)
-        self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dpre"], b["dhb"], need_wgrad)
-        self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
+        def branch_a():   # high-res only
+            self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
+            self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None, B, T, need_wgrad)
+
+        def branch_b():   # low + high
+            self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dpre_b"], b["dhb"], need_wgrad)
+            self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
+
+        if T > 1 and self.overlap_branches:
+            with o.fork() as side:
+                branch_a()
+            branch_b()
+            side.join()
+        else:
+            branch_a()
+            branch_b()
         if not need_input_grad:
             return None
         # d(high) = d(hi) + d(mix)[cl:cl+ch]
