@@ -234,6 +234,24 @@ def discriminator_forward(w, low, high, shortcut_variant=False):
     return _untd(s, bt).mean(1)                                                        # :139 GlobalAveragePooling1D
 
 
+def encoder_forward(w, x, latent):
+    """AutoEncoder.make_encoder (autoencoder/autoencoder.py:23-36), inference mode -> [B,T,latent]."""
+    idx = 0
+    bt = None
+    while x.shape[2] >= 7:                                                             # :26
+        xf, bt = _td(x)
+        xf = conv2d(xf, w[L + f"{idx}/layer/w"], w[L + f"{idx}/layer/layer/bias"], 3, 1)   # :27-29 (ZeroPadding2D(1))
+        x = layer_norm(_untd(xf, bt), w, L + f"{idx + 1}")                             # :30
+        idx += 2
+    xf, bt = _td(x)
+    xf = xf.reshape(xf.shape[0], -1)                                                   # :31 Flatten (H,W,C)
+    if xf.shape[-1] > 2 * latent:                                                      # :32-34
+        xf = xf @ w[L + f"{idx}/layer/kernel"] + w[L + f"{idx}/layer/bias"]
+        idx += 1
+    xf = xf @ w[L + f"{idx}/layer/kernel"] + w[L + f"{idx}/layer/bias"]                # :35
+    return _untd(xf, bt)
+
+
 class AdamTF:
     def __init__(self, lr, b1=0.5, b2=0.9, eps=0.1):
         self.lr, self.b1, self.b2, self.eps, self.t = lr, b1, b2, eps, 0

@@ -146,6 +146,30 @@ def test_gan_api_train_save_load_predict(cpu_backend, tmp_path):
     gan3.compile(train.generator_optimizer(), train.discriminator_optimizer(), discriminator_loss=train.discriminator_loss)
     logs3 = gan3.train_step((low, high))
     assert logs3["g_reco_loss"] is not None and float(logs3["g_reco_loss"]) > 0
+    # the reference's own feature extractor: reconstruction_loss(autoencoder.encoder, coefficient)
+    # (gan/train.py:19-26 fed from autoencoder/features_encoding.py:17-19)
+    from downscaling.autoencoder.autoencoder import AutoEncoder
+    ae = AutoEncoder(img_size=S, time_steps=T, latent_dimension=8, batch_size=B)
+    with pytest.raises(NotImplementedError):
+        ae.make_decoder()
+    reco = train.reconstruction_loss(ae.encoder, 0.5)
+    hi = torch.as_tensor(high, dtype=torch.float64).clone().requires_grad_(True)
+    lo2 = torch.as_tensor(low, dtype=torch.float64)[..., :2]
+    val = reco(lo2, hi)
+    (ghi,) = torch.autograd.grad(val, hi)
+    # the same loss through the restated encoder
+    from oracle import torch_model as TM
+    wenc = {k: torch.tensor(v, dtype=torch.float64) for k, v in ae.encoder.get_weights_dict().items()}
+    hr = hi.detach().clone().requires_grad_(True)
+    delta = TM.encoder_forward(wenc, lo2, 8) - TM.encoder_forward(wenc, hr, 8)
+    ref = 0.5 * torch.mean(torch.sqrt(torch.sum(delta ** 2, dim=-1)))
+    (gref,) = torch.autograd.grad(ref, hr)
+    assert abs(float(val.detach()) - float(ref.detach())) < 1e-6 * abs(float(ref.detach()))
+    assert float((ghi - gref).abs().max()) < 1e-5 * float(gref.abs().max())
+    gan4 = GAN(g, d, gan.noise_generator, n_critic=1, reconstruction_loss=reco)
+    gan4.compile(train.generator_optimizer(), train.discriminator_optimizer(), discriminator_loss=train.discriminator_loss)
+    logs4 = gan4.train_step((low, high))
+    assert float(logs4["g_reco_loss"]) > 0
 
 
 def test_tile_plan_golden():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from downscaling.engine.networks import DiscriminatorNet, GeneratorNet, discriminator_plan
+from downscaling.engine.networks import DiscriminatorNet, EncoderNet, GeneratorNet, discriminator_plan
 from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
 from oracle import torch_model as TM
 from oracle.torch_backend import TorchOps
@@ -144,3 +144,22 @@ def test_train_step_matches_oracle(ops, S, T):
             got = weights64(net)
             for k in w:
                 assert rel_err(got[k], w[k]) < 1e-7, (step, k)
+
+
+@pytest.mark.parametrize("S,T,latent", [(96, 2, 96), (24, 1, 4), (40, 2, 8)])
+def test_encoder_forward_and_input_gradient(ops, S, T, latent):
+    """AutoEncoder.make_encoder (autoencoder/autoencoder.py:23-36), the reconstruction-loss feature extractor: forward
+    and d/dx against the autograd restatement.  (96, ., 96) is the reference's own build (features_encoding.py:10-13:
+    three 5x5 stride-3 blocks, 144 -> 96 in one Dense); (24, ., 4) and (40, ., 8) take the two-Dense branch."""
+    B = 2
+    net = EncoderNet(ops, S, T, latent, seed=7)
+    w = randomize(net, 31)
+    x = torch.randn(B, T, S, S, 2, generator=torch.Generator().manual_seed(8), dtype=torch.float64)
+    got = net.forward(x).clone()
+    xr = x.clone().requires_grad_(True)
+    ref = TM.encoder_forward(w, xr, latent)
+    assert got.shape == ref.shape == (B, T, latent)
+    assert rel_err(got, ref) < 1e-10
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    (gref,) = torch.autograd.grad((ref * g).sum(), xr)
+    assert rel_err(net.backward_input(g), gref) < 1e-9

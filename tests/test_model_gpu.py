@@ -119,3 +119,22 @@ def test_train_step(hip_ops, S, T):
             got = weights64(net)
             for k in w:
                 assert rel_err(got[k], w[k]) < TOL, (step, k)
+
+
+@pytest.mark.parametrize("S,T,latent", [(96, 2, 96), (40, 1, 8)])
+def test_encoder_feature_extractor(hip_ops, S, T, latent):
+    """The reconstruction-loss feature extractor (autoencoder/autoencoder.py:23-36) on the HIP kernels: forward and
+    input gradient against the fp64 autograd restatement."""
+    from downscaling.engine.networks import EncoderNet
+    B = 3
+    dev = hip_ops.device
+    net = EncoderNet(hip_ops, S, T, latent, seed=7)
+    w = randomize(net, 31)
+    x = torch.randn(B, T, S, S, 2, generator=torch.Generator().manual_seed(8), dtype=torch.float64)
+    got = net.forward(x.float().to(dev)).clone()
+    xr = x.clone().requires_grad_(True)
+    ref = TM.encoder_forward(w, xr, latent)
+    assert rel_err(got, ref) < TOL
+    g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    (gref,) = torch.autograd.grad((ref * g).sum(), xr)
+    assert rel_err(net.backward_input(g.float().to(dev)), gref) < TOL

@@ -70,6 +70,31 @@ class Conv:
             self.ops.conv_dgrad(dpre, self.pk, dx, self.g, accumulate=accumulate)
 
 
+class Dense:
+    """keras.layers.Dense (linear) under TimeDistributed: rows = images, run as a 1x1 convolution on an [N,1,1,K] view
+    (kernel [K, units] viewed as HWIO [1,1,K,units])."""
+    G1 = ConvGeom(1, 1, 1, 0)
+
+    def __init__(self, net, name, K, units, prefix="layer"):
+        self.net, self.ops, self.K, self.units = net, net.ops, K, units
+        self.w = net.params.add(f"{name}/{prefix}/kernel", (K, units), P.glorot_uniform(K, units))
+        self.b = net.params.add(f"{name}/{prefix}/bias", (units,), P.zeros_init)
+        self.pk = None
+
+    def build(self):
+        self.pk = self.ops.pack_weights(self.w.value.view(1, 1, self.K, self.units))
+
+    def prep_entries(self):
+        return [(self.pk, None)]
+
+    def forward(self, x, y):
+        """x [N,1,1,>=K], y [N,1,1,round4(units)]."""
+        self.ops.conv_fwd(x, self.pk, self.b.value, y, self.G1, act=False)
+
+    def backward_input(self, dy, dx):
+        self.ops.conv_dgrad(dy, self.pk, dx, self.G1)
+
+
 class BatchNorm:
     def __init__(self, net, name, C):
         self.net, self.ops, self.C = net, net.ops, C

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 from .common import ConvGeom, round4, v2
-from .layers import LN_EPS, LRELU, BatchNorm, Conv, ConvLSTM, LayerNorm
+from .layers import LN_EPS, LRELU, BatchNorm, Conv, ConvLSTM, Dense, LayerNorm
 from .params import ParamStore, glorot_uniform, zeros_init
 
 
@@ -521,3 +521,94 @@ class DiscriminatorNet(_Net):
         o.copy_channels(b["dhi"][..., :self.ch], b["dhigh"][..., :self.ch])
         o.copy_channels(b["dmix"][..., self.cl:self.cl + self.ch], b["dhigh"][..., :self.ch], accumulate=True)
         return b["dhigh"]
+
+
+class EncoderNet(_Net):
+    """AutoEncoder.make_encoder (/root/reference/src/downscaling/autoencoder/autoencoder.py:23-36): the feature
+    extractor of `reconstruction_loss` (gan/train.py:19-26, ganbase.py:57-59).  While the map is >= 7 pixels:
+    ZeroPadding2D(1) -> SN Conv2D(2C, 5x5, stride 3) -> LeakyReLU(0.2) -> LayerNormalization; Flatten; Dense((flat +
+    latent) // 2) if flat > 2 * latent; Dense(latent).  Forward and the input gradient (the generator step
+    differentiates the loss w.r.t. the generated winds only; the extractor's weights are frozen there)."""
+
+    def __init__(self, ops, img_size, n_timesteps, latent_dimension, in_channels=2, seed=3):
+        super().__init__(ops, None)
+        self.S, self.T, self.latent, self.cin = img_size, n_timesteps, latent_dimension, in_channels
+        L = "layer_with_weights-"
+        size, ch, idx = img_size, in_channels, 0
+        self.blocks = []
+        while size >= 7:                                                               # autoencoder.py:26
+            osz = (size + 2 - 5) // 3 + 1
+            conv = self._add(Conv(self, L + str(idx), 5, ch, ch * 2, 3, 1, sn=True))   # :27-29
+            ln = self._add(LayerNorm(self, L + str(idx + 1), ch * 2))                  # :30
+            self.blocks.append((conv, ln, osz, ch * 2))
+            size, ch, idx = osz, ch * 2, idx + 2
+        if ch % 4 != 0:
+            raise NotImplementedError("encoder: the flattened map needs a channel count that is a multiple of 4")
+        self.flat = size * size * ch
+        self.final = (size, ch)
+        self.dense = []
+        K = self.flat
+        if K > 2 * latent_dimension:                                                   # :32-34
+            mid = (K + latent_dimension) // 2
+            self.dense.append(self._add(Dense(self, L + str(idx), K, mid)))
+            K, idx = mid, idx + 1
+        self.dense.append(self._add(Dense(self, L + str(idx), K, latent_dimension)))   # :35
+        self._finalize(seed)
+
+    def buffers(self, B):
+        b = self._bufs.get(B)
+        if b is not None:
+            return b
+        o, N = self.ops, self.T * B
+        b = dict(x0=o.zeros(N, self.S, self.S, round4(self.cin)), dx0=o.zeros(N, self.S, self.S, round4(self.cin)),
+                 ys=[], zs=[], dzs=[], hs=[], dhs=[])
+        for (_, _, osz, co) in self.blocks:
+            b["ys"].append(o.empty(N, osz, osz, co))
+            b["zs"].append(o.empty(N, osz, osz, co))
+            b["dzs"].append(o.empty(N, osz, osz, co))
+        for d in self.dense:
+            b["hs"].append(o.zeros(N, 1, 1, round4(d.units)))
+            b["dhs"].append(o.zeros(N, 1, 1, round4(d.units)))
+        self._bufs = {B: b}
+        return b
+
+    def forward(self, x):
+        """x [B,T,S,S,cin] -> latent [B,T,latent] (inference mode: spectral normalisation inactive)."""
+        B = x.shape[0]
+        b, N = self.buffers(B), self.T * x.shape[0]
+        self._prepare(False)
+        self.to_time_major(x, b["x0"])
+        h = b["x0"]
+        for i, (conv, ln, osz, co) in enumerate(self.blocks):
+            conv.forward(h, b["ys"][i])
+            ln.forward(v2(b["ys"][i]), v2(b["zs"][i]))
+            h = b["zs"][i]
+        h = h.view(N, 1, 1, self.flat) if self.blocks else h.reshape(N, 1, 1, -1)
+        for j, d in enumerate(self.dense):
+            d.forward(h, b["hs"][j])
+            h = b["hs"][j]
+        out = self.ops.empty(B, self.T, 1, 1, self.latent)
+        self.from_time_major(h, out)
+        return out.view(B, self.T, self.latent)
+
+    def backward_input(self, dlatent):
+        """dlatent [B,T,latent] for the activations of the LAST forward -> d/dx [B,T,S,S,cin]."""
+        B = dlatent.shape[0]
+        b, N, o = self.buffers(B), self.T * dlatent.shape[0], self.ops
+        dh = b["dhs"][-1]
+        self.to_time_major(dlatent.reshape(B, self.T, 1, 1, self.latent), dh)
+        for j in range(len(self.dense) - 1, -1, -1):
+            if j > 0:
+                dst = b["dhs"][j - 1]
+            else:
+                dst = b["dzs"][-1].view(N, 1, 1, self.flat) if self.blocks else b["dx0"].view(N, 1, 1, -1)
+            self.dense[j].backward_input(dh, dst)
+            dh = dst
+        for i in range(len(self.blocks) - 1, -1, -1):
+            conv, ln, osz, co = self.blocks[i]
+            dz = b["dzs"][i]
+            ln.backward(v2(dz), v2(b["ys"][i]), v2(dz), None, False)
+            conv.backward_input(dz, b["dzs"][i - 1] if i > 0 else b["dx0"])
+        dx = o.empty(B, self.T, self.S, self.S, self.cin)
+        self.from_time_major(b["dx0"], dx)
+        return dx
