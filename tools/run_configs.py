@@ -117,6 +117,8 @@ def main():
                                                              "ensemble_mean_rel_dev_vs_fp32_ensemble": dev}
     gen.inference_precision = "fp32"
     print(json.dumps(out, indent=1))
+    if len(sys.argv) > 1:      # also to a file: stdout carries the reference-style progress prints of predict()
+        Path(sys.argv[1]).write_text(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
