@@ -280,6 +280,15 @@ int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float
                       int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
                       wdg_stream stream);
 
+/* wdg_convlstm1_bwd plus the layer's weight and bias gradient in the same pass: dw [3][3][cin][4F] += and
+ * dbias [4F] += (MFMA over the LDS-resident x / dgates tiles, persistent blocks, block partials summed in block
+ * order by a second kernel) — no dense dgates tensor is written.  ws: wdg_convlstm1_wgrad_ws_bytes() of scratch. */
+size_t wdg_convlstm1_wgrad_ws_bytes(int n_img, int H, int W, int cin, int F);
+int wdg_convlstm1_bwd_wgrad(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                            const float* dh, int lddh, int64_t img_stride_dh, float* dx, int lddx,
+                            int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                            float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream);
+
 /* Thin 3x3 'same' conv + bias + LeakyReLU + LayerNormalization fused (models.py:94-97,102-105).
  * forward : y = lrelu(conv(x, w) + bias) (kept for the backward), z = LN(y)*gamma + beta, mean_rstd [P][2].
  * backward: dpre = LN'(dz)*lrelu'(y) (dense [P][cout], must not alias dz), dx = conv^T(dpre) (optional),

@@ -362,7 +362,7 @@ class TorchOps:
         self.lstm_fwd(gates.view(-1, 4 * F_), None, c.view(-1, F_), hh.view(-1, F_), F_)
         h[..., :F_] = hh
 
-    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False):
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False, dw=None, dbias=None):
         pk = PackedWeights(self, wx)
         gates = torch.zeros(*x.shape[:3], 4 * F_, dtype=x.dtype)
         self.conv_fwd(x, pk, bias, gates, ConvGeom(3, 3, 1, 1))
@@ -374,6 +374,8 @@ class TorchOps:
                       dg.view(-1, 4 * F_), None, F_)
         if dgates is not None:
             dgates.copy_(dg)
+        if dw is not None:
+            self.conv_wgrad(x, dg, pk, dw, ConvGeom(3, 3, 1, 1), accumulate=True, dbias=dbias)
         if dx is not None:
             self.conv_dgrad(dg, pk, dx, ConvGeom(3, 3, 1, 1), accumulate=accumulate_dx)
 

@@ -11,7 +11,7 @@ whole: size-independent properties of the domain instead.
   * the fused upsample + transposed-conv block: forward crop against the oracle, and its column-form backward through
     the same bilinear identities <y, dy> = <x, dx> = <w, dw>;
   * batch consistency of the generator (inference mode): batch 32 equals the same samples in batches of 8;
-  * reproducibility: two identical train steps from identical state agree to 1e-6 (the convolution / SN / split-K sums
+  * reproducibility: two identical train steps from identical state agree to 1e-5 (the convolution / SN / split-K sums
     are fixed-order; the BatchNorm statistics and LayerNorm parameter gradients use atomics, so not bit for bit).
 
 Tolerances are those of the operator tests (fp32 rounding: 2e-5 relative for values, 1e-4 for the inner products of
@@ -118,7 +118,7 @@ def test_upsample_conv_transpose_block_at_headline_shape(hip_ops, ref_ops):
 
 def test_generator_batch_consistency_and_train_step_reproducibility(hip_ops):
     """Inference-mode generator: batch 32 equals the same samples in batches of 8 (no cross-sample coupling, all tile /
-    split choices differ between the two runs).  Two train steps from identical state agree to 1e-6 relative."""
+    split choices differ between the two runs).  Two train steps from identical state agree to 1e-5 relative."""
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
     from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
     ops, dev = hip_ops, hip_ops.device
@@ -147,4 +147,4 @@ def test_generator_batch_consistency_and_train_step_reproducibility(hip_ops):
         finals.append((g.params.flat.clone(), d.params.flat.clone(), g.params.state.clone(), d.params.state.clone()))
         del g, d, eng
     for a, b in zip(*finals):
-        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())

@@ -275,7 +275,13 @@ def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
         ops.convlstm1_bwd(xv, ww, bb, dd, dg, dx, cin, F_, accumulate_dx=True)
         dx2 = ops.zeros(n, H, W, cp)
         ops.convlstm1_bwd(xv, ww, bb, dd, None, dx2, cin, F_, accumulate_dx=False)
-        res[name] = dict(h=h, dg=dg, dx=dx, dx2=dx2)
+        # kernel + bias gradient fused into the same pass (accumulating onto existing values), with and without dx
+        dw, db = cv(torch.full((3, 3, cin, 4 * F_), 0.5, dtype=torch.float64)).contiguous(), cv(torch.full((4 * F_,), -0.25, dtype=torch.float64))
+        dx3 = ops.zeros(n, H, W, cp)
+        ops.convlstm1_bwd(xv, ww, bb, dd, None, dx3, cin, F_, accumulate_dx=False, dw=dw, dbias=db)
+        dw2, db2 = ops.zeros(3, 3, cin, 4 * F_), ops.zeros(4 * F_)
+        ops.convlstm1_bwd(xv, ww, bb, dd, None, None, cin, F_, dw=dw2, dbias=db2)
+        res[name] = dict(h=h, dg=dg, dx=dx, dx2=dx2, dx3=dx3, dw=dw, db=db, dw2=dw2, db2=db2)
     for k in res["ref"]:
         assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
     if Fp > F_:

@@ -49,6 +49,7 @@ struct WdgCl1 {
     const float* dH;     // [.., lddh] (backward)
     float* Hout;         // forward output [.., ldh]
     float* dG;           // optional dense dgates [P][4F] (forget-gate slots zero)
+    float* dWpart;       // fused weight gradient (WG kernels): per-block partial [gridDim.x][RT*16][CT*16]
     float* dX;           // optional input gradient [.., lddx]
     long long imgStrideX, imgStrideH, imgStrideDH, imgStrideDX;
     int n_img, H, W, ldx, ldh, lddh, lddx;
@@ -170,7 +171,14 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
 }
 
 // ---- backward: 4x32 centre tile; dgates recomputed on the 6x34 halo into LDS, dx gathered from it --------
-template <int CIN, int F>
+// WG = true additionally forms the layer's weight and bias gradient in the same pass: with x and dgates of the tile
+// already in LDS, dW[(tap,ci)][gate] += sum_pixels x[p + tap - 1][ci] * dgates[p][gate] is 9 (2 for the 2-channel
+// layer) 16x16 MFMA tiles over the tile's 128 pixels (rows = 9*CIN taps-by-channels + one constant-1 row for the
+// bias gradient; columns = the 3F live gates; wave w takes the pixels of centre row w).  Blocks are persistent
+// (grid-stride over tiles, accumulators stay in registers); each block leaves one partial that a second kernel sums
+// in block order.  This replaces writing the dense 4F-channel dgates tensor (537 MB at the headline shape) and
+// reading it back in a separate weight-gradient kernel.
+template <int CIN, int F, bool WG>
 __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, const float* __restrict__ Wx,
                                                                 const float* __restrict__ bias) {
     constexpr int FH = F >= 2 ? F / 2 : 1;
@@ -178,15 +186,42 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     constexpr int XH = CL_TH + 4, XW = CL_TW + 4;    // x halo (two 3x3 stages)
     constexpr int GH = CL_TH + 2, GW = CL_TW + 2;    // dgates halo
     constexpr int G3 = 3 * F + 1;                    // compact dgates [i | c~ | o] + 1 pad: an odd pixel stride keeps the per-pixel b32 accesses of a wave on distinct banks (3F = 48 was a 16-way conflict)
+    constexpr int ROWS = 9 * CIN + 1, RT = (ROWS + 15) / 16, COLS = 3 * F, CT = (COLS + 15) / 16;
+    constexpr int WN = RT * CT * 256;                // floats of one wave's accumulator tiles
+    constexpr bool RED_IN_DGS = GH * GW * G3 >= 4 * WN;
     __shared__ __attribute__((aligned(16))) f32x4 xs[XH * XW * C4];
     __shared__ __attribute__((aligned(16))) float dgs[GH * GW * G3];
     __shared__ float dxp[128 * CIN];
+    __shared__ float red_extra[(WG && !RED_IN_DGS) ? 4 * WN : 1];
 
     const int t = threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(t >> 7);
     const int f0 = half * FH;
     const bool half_on = !(F < 2 && half);
-    int b = blockIdx.x;
+
+    // fused weight gradient: tile-invariant operand addressing of this lane
+    const int lane = t & 63, wv = t >> 6, li = lane & 15, lq = lane >> 4;
+    f32x4 wacc[WG ? RT * CT : 1];
+    int a_base[RT], a_mode[RT];
+#pragma unroll
+    for (int i = 0; i < (WG ? RT * CT : 1); ++i) wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = rt * 16 + li;
+        if (row < 9 * CIN) {
+            const int tap = row / CIN, ci = row - tap * CIN;
+            const int th = tap / 3, tw = tap - 3 * th;
+            a_base[rt] = (((ci >> 2) * (XH * XW) + (1 + th) * XW + 1 + tw) << 2) + (ci & 3);
+            a_mode[rt] = 0;
+        } else {
+            a_base[rt] = 0;
+            a_mode[rt] = row == 9 * CIN ? 1 : 2;     // the constant-1 bias row / padding rows
+        }
+    }
+
+    const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
     const int tx = b % p.tiles_w;
     b /= p.tiles_w;
     const int ty = b % p.tiles_h;
@@ -255,7 +290,28 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
         }
     }
     __syncthreads();
-    if (!p.dX) return;
+    if constexpr (WG) {
+        // 2b. weight / bias gradient of this tile: wave wv = centre row wv, 8 steps of 4 pixels
+        const float* xsf = reinterpret_cast<const float*>(xs);
+#pragma unroll 2
+        for (int sstep = 0; sstep < 8; ++sstep) {
+            const int px_ = 4 * sstep + lq;
+            const int xo = (wv * XW + px_) << 2;
+            const int go = ((wv + 1) * GW + px_ + 1) * G3;
+            float av[RT], bv[CT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                av[rt] = a_mode[rt] == 0 ? xsf[a_base[rt] + xo] : (a_mode[rt] == 1 ? 1.f : 0.f);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bv[ct] = ct * 16 + li < COLS ? dgs[go + ct * 16 + li] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    wacc[rt * CT + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[ct], wacc[rt * CT + ct], 0, 0, 0);
+        }
+    }
+    if (p.dX) {
     // 3. dx[c] = sum_tap sum_g dgates[pixel + (1 - th, 1 - tw)][g] * Wx[tap][c][g]; each half sums its own gates
     const int cp = t & 127;
     const int py = cp >> 5, px = cp & 31;
@@ -317,6 +373,48 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
             }
         }
     }
+    }   // if (p.dX)
+    if (gridDim.x < (unsigned)ntiles) __syncthreads();   // persistent blocks: the next tile overwrites xs / dgs / dxp
+    }   // tile loop
+    if constexpr (WG) {
+        // block partial: accumulator reg r of lane (li, lq) is C[row 4*lq + r][col li]; sum the four waves in wave order
+        float* red = RED_IN_DGS ? dgs : red_extra;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT * CT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv * WN + i * 256 + (4 * lq + r) * 16 + li] = wacc[i][r];
+        __syncthreads();
+        float* dst = p.dWpart + (long long)blockIdx.x * (RT * 16) * (CT * 16);
+        for (int idx = t; idx < WN; idx += 256) {
+            const float v = (red[idx] + red[WN + idx]) + (red[2 * WN + idx] + red[3 * WN + idx]);
+            const int i = idx >> 8, row = (idx >> 4) & 15, col = idx & 15;
+            dst[((i / CT) * 16 + row) * (CT * 16) + (i % CT) * 16 + col] = v;
+        }
+    }
+}
+
+// second stage of the fused weight gradient: block partials summed in block order -> dW [3][3][CIN][4F] and dbias [4F]
+// (+=; the forget-gate columns receive nothing: with h_0 = c_0 = 0 that gate has no influence at T = 1)
+template <int CIN, int F>
+__global__ void __launch_bounds__(256) wdg_convlstm1_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks,
+                                                                         float* __restrict__ dW, float* __restrict__ dbias) {
+    constexpr int ROWS = 9 * CIN + 1, RT = (ROWS + 15) / 16, COLS = 3 * F, CT = (COLS + 15) / 16;
+    // one wave per output element: lane l sums the partials of blocks l, l + 64, ... (fixed order), then a wave sum
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= ROWS * COLS) return;
+    const int row = idx / COLS, col = idx - row * COLS;
+    const float* src = part + row * (CT * 16) + col;
+    float v = 0.f;
+    for (int b = lane; b < nblocks; b += 64) v += src[(long long)b * (RT * 16) * (CT * 16)];
+    v = wdg_wave_sum(v);
+    if (lane) return;
+    const int gate = col / F, f = col - gate * F;
+    const int gcol = (gate == 0 ? 0 : gate + 1) * F + f;          // compact [i | c~ | o] -> dense [i | f | c~ | o]
+    if (row < 9 * CIN)
+        dW[row * 4 * F + gcol] += v;
+    else
+        dbias[gcol] += v;
 }
 
 // ---- host -------------------------------------------------------------------------------------------------
@@ -343,10 +441,10 @@ extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, 
     return WDG_OK;
 }
 
-extern "C" int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
-                                 const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
-                                 int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
-                                 wdg_stream stream) {
+static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                   const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
+                   int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                   float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream) {
     WDG_CHECK_ARG(x && wx && bias && dh, "null argument");
     WDG_CHECK_ARG(wdg_convlstm1_supported(cin, F), "unsupported (cin, F)");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x alignment / ld");
@@ -358,11 +456,64 @@ extern "C" int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, 
     p.accumulate_dx = accumulate_dx;
     p.tiles_h = (H + CL_TH - 1) / CL_TH;
     p.tiles_w = (W + CL_TW - 1) / CL_TW;
-    dim3 grid((unsigned)((long long)n_img * p.tiles_h * p.tiles_w)), block(256);
-    if (cin == 2)
-        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
-    else
-        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
+    const long long ntiles = (long long)n_img * p.tiles_h * p.tiles_w;
+    dim3 block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (!dw) {
+        dim3 grid((unsigned)ntiles);
+        if (cin == 2)
+            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2, false>), grid, block, 0, st, p, wx, bias);
+        else
+            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false>), grid, block, 0, st, p, wx, bias);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
+    WDG_CHECK_ARG(dbias && ws, "fused weight gradient needs dbias and scratch");
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    const int nb = (int)std::min<long long>(ntiles, (long long)cus * 3);
+    const int rows = 9 * cin + 1, cols = 3 * F;
+    const size_t slab = (size_t)((rows + 15) / 16 * 16) * ((cols + 15) / 16 * 16);
+    if (ws_bytes < (size_t)nb * slab * sizeof(float)) {
+        wdg_set_error("wdg_convlstm1_bwd_wgrad: scratch too small (%zu < %zu)", ws_bytes, (size_t)nb * slab * sizeof(float));
+        return WDG_ERR_WORKSPACE;
+    }
+    p.dWpart = (float*)ws;
+    dim3 grid((unsigned)nb), rgrid((unsigned)((rows * cols + 3) / 4));
+    if (cin == 2) {
+        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2, true>), grid, block, 0, st, p, wx, bias);
+        hipLaunchKernelGGL((wdg_convlstm1_wgrad_reduce_kernel<2, 2>), rgrid, block, 0, st, p.dWpart, nb, dw, dbias);
+    } else {
+        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, true>), grid, block, 0, st, p, wx, bias);
+        hipLaunchKernelGGL((wdg_convlstm1_wgrad_reduce_kernel<5, 16>), rgrid, block, 0, st, p.dWpart, nb, dw, dbias);
+    }
     WDG_LAUNCH_CHECK();
     return WDG_OK;
+}
+
+extern "C" int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                                 const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
+                                 int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                                 wdg_stream stream) {
+    return cl1_bwd(x, ldx, img_stride_x, wx, bias, dh, lddh, img_stride_dh, dgates, dx, lddx, img_stride_dx, accumulate_dx,
+                   n_img, H, W, cin, F, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// As wdg_convlstm1_bwd, plus dw [3][3][cin][4F] += and dbias [4F] += formed in the same pass (no dgates tensor).
+// ws: wdg_convlstm1_wgrad_ws_bytes(n_img, H, W, cin, F) bytes of scratch.
+extern "C" size_t wdg_convlstm1_wgrad_ws_bytes(int n_img, int H, int W, int cin, int F) {
+    const long long ntiles = (long long)n_img * ((H + CL_TH - 1) / CL_TH) * ((W + CL_TW - 1) / CL_TW);
+    const size_t slab = (size_t)((9 * cin + 1 + 15) / 16 * 16) * ((3 * F + 15) / 16 * 16);
+    return (size_t)std::min<long long>(ntiles, 4096) * slab * sizeof(float);
+}
+
+extern "C" int wdg_convlstm1_bwd_wgrad(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                                       const float* dh, int lddh, int64_t img_stride_dh, float* dx, int lddx,
+                                       int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                                       float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(dw && dbias, "null gradient buffers");
+    return cl1_bwd(x, ldx, img_stride_x, wx, bias, dh, lddh, img_stride_dh, nullptr, dx, lddx, img_stride_dx, accumulate_dx,
+                   n_img, H, W, cin, F, dw, dbias, ws, ws_bytes, stream);
 }

@@ -454,12 +454,21 @@ class HipOps:
         native.check(self.lib.wdg_convlstm1_fwd(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), ph, ldh, ish, n, H, W,
                                                 cin, F, self.stream), "convlstm1_fwd")
 
-    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False):
-        """dgates [N,H,W,4F] (dense, optional) and dx[..., :cin] (optional) from x and dh, recomputing the gates."""
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False, dw=None, dbias=None):
+        """dgates [N,H,W,4F] (dense, optional) and dx[..., :cin] (optional) from x and dh, recomputing the gates.
+        dw / dbias given: the kernel and bias gradient are accumulated in the same pass (no dgates tensor)."""
         px, ldx, isx = _v4(x)
         pdh, lddh, isdh = _v4(dh)
         n, H, W, _ = x.shape
         pdx, lddx, isdx = _v4(dx) if dx is not None else (0, 0, 0)
+        if dw is not None:
+            assert dgates is None and dbias is not None and dw.is_contiguous()
+            ws = self._workspace(int(self.lib.wdg_convlstm1_wgrad_ws_bytes(n, H, W, cin, F)))
+            native.check(self.lib.wdg_convlstm1_bwd_wgrad(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), pdh, lddh, isdh,
+                                                          pdx, lddx, isdx, int(accumulate_dx), n, H, W, cin, F,
+                                                          dw.data_ptr(), dbias.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                          self.stream), "convlstm1_bwd_wgrad")
+            return
         if dgates is not None:
             assert dgates.is_contiguous() and dgates.shape[-1] == 4 * F
         native.check(self.lib.wdg_convlstm1_bwd(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), pdh, lddh, isdh,

@@ -249,12 +249,10 @@ class ConvLSTM:
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
         if self._fused1(T):
-            if need_wgrad and getattr(self, "dgates1", None) is None:
-                self.dgates1 = o.empty(N, H, W, 4 * F)
-            dg = self.dgates1 if need_wgrad else None
-            o.convlstm1_bwd(x, self.wx.value, self.b.value, dh, dg, dx, self.cin, F, accumulate_dx=accumulate_dx)
-            if need_wgrad:   # kernel and bias gradient in one pass over dgates
-                o.conv_wgrad(x, dg, self.pkx, self.wx.grad, self.g, accumulate=True, dbias=self.b.grad)
+            # input gradient and (need_wgrad) kernel + bias gradient in ONE kernel: the gates are recomputed from x and
+            # the dense dgates tensor is never materialised
+            o.convlstm1_bwd(x, self.wx.value, self.b.value, dh, None, dx, self.cin, F, accumulate_dx=accumulate_dx,
+                            dw=self.wx.grad if need_wgrad else None, dbias=self.b.grad if need_wgrad else None)
             return
         if self.dgates is None:
             self.dgates = o.empty(N, H, W, 4 * F)

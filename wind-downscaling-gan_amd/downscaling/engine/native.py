@@ -83,6 +83,9 @@ SIGNATURES = {
     "wdg_convlstm1_fwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_bwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp, i32, i64, i32,
                                  i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convlstm1_wgrad_ws_bytes": (szt, [i32, i32, i32, i32, i32]),
+    "wdg_convlstm1_bwd_wgrad": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i64, i32,
+                                      i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, szt, c_fp]),
     "wdg_convln_supported": (i32, [i32, i32]),
     "wdg_convln_fwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, i64, c_fp, i32, i64,
                               c_fp, i32, i32, i32, i32, i32, c_fp]),
