@@ -304,6 +304,16 @@ int wdg_convln_bwd(const float* dz, int lddz, int64_t isdz, const float* y, int 
                    float* dpre, float* dx, int lddx, int64_t isdx, float* dgamma, float* dbeta,
                    float* dbias, int n_img, int H, int W, int cin, int cout, wdg_stream stream);
 
+/* Backward of the same fused block from x instead of y / (mean, rstd): y and its LayerNorm statistics are recomputed
+ * per pixel (the input has 2 channels, the saved tensors 18 floats per pixel), dpre stays in LDS, dx (optional),
+ * dgamma / dbeta / dbias += (all or none) and — when dw is given — the kernel gradient dw [3][3][cin][cout] += come out
+ * of the same launch.  Pair with wdg_convln_fwd(y = NULL, mean_rstd = NULL).  ws: wdg_convln_wgrad_ws_bytes(). */
+size_t wdg_convln_wgrad_ws_bytes(int n_img, int H, int W, int cin);
+int wdg_convln_bwd_x(const float* dz, int lddz, int64_t isdz, const float* x, int ldx, int64_t isx,
+                     const float* w_hwio, const float* bias, const float* gamma, float eps, float slope,
+                     float* dx, int lddx, int64_t isdx, float* dgamma, float* dbeta, float* dbias, float* dw,
+                     void* ws, size_t ws_bytes, int n_img, int H, int W, int cin, int cout, wdg_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * UpSampling2D(2, 'bilinear'): half-pixel centres, edge clamp.                     models.py:62
  * ------------------------------------------------------------------------------------------ */

@@ -383,11 +383,27 @@ class TorchOps:
         return cout == 16 and cin == 2
 
     def convln_fwd(self, x, w, bias, gamma, beta, eps, slope, y, z, mean_rstd):
-        self.conv_fwd(x, PackedWeights(self, w), bias, y, ConvGeom(3, 3, 1, 1), act=True, slope=slope)
         C = w.shape[3]
+        if y is None:       # z only: the backward (convln_bwd_x) recomputes y and the statistics from x
+            y, mean_rstd = torch.zeros(z.shape, dtype=z.dtype), torch.zeros(z.numel() // C, 2, dtype=z.dtype)
+        self.conv_fwd(x, PackedWeights(self, w), bias, y, ConvGeom(3, 3, 1, 1), act=True, slope=slope)
         zz = torch.zeros(y.shape, dtype=y.dtype)
         self.ln_fwd(y.reshape(-1, C), gamma, beta, eps, zz.view(-1, C), mean_rstd)
         z.copy_(zz)
+
+    def convln_bwd_x(self, dz, x, w, bias, gamma, eps, slope, dx, dgamma, dbeta, dbias, dw):
+        C = w.shape[3]
+        pk = PackedWeights(self, w)
+        y = torch.zeros(dz.shape, dtype=dz.dtype)
+        self.conv_fwd(x, pk, bias, y, ConvGeom(3, 3, 1, 1), act=True, slope=slope)
+        mr = torch.zeros(y.numel() // C, 2, dtype=dz.dtype)
+        self.ln_fwd(y.reshape(-1, C), gamma, torch.zeros_like(gamma), eps, torch.zeros(y.numel() // C, C, dtype=dz.dtype), mr)
+        dpre = torch.zeros(dz.shape, dtype=dz.dtype)
+        self.ln_bwd(dz.reshape(-1, C), y.reshape(-1, C), mr, gamma, slope, dpre.view(-1, C), dgamma, dbeta, dbias)
+        if dw is not None:
+            self.conv_wgrad(x, dpre, pk, dw, ConvGeom(3, 3, 1, 1), accumulate=True)
+        if dx is not None:
+            self.conv_dgrad(dpre, pk, dx, ConvGeom(3, 3, 1, 1))
 
     def convln_bwd(self, dz, y, mean_rstd, w, gamma, slope, dpre, dx, dgamma, dbeta, dbias):
         C = w.shape[3]

@@ -314,9 +314,24 @@ def test_fused_conv_layernorm(cin, n, H, W, hip_ops, ref_ops):
         dx2 = ops.zeros(n, H, W, cp)
         dpre2 = ops.empty(n, H, W, 16)
         ops.convln_bwd(dc[..., 16:], y, mr, ww, ga, 0.2, dpre2, dx2, None, None, None)
-        res[name] = dict(y=y, cat=cat, mr=mr, dpre=dpre, dx=dx, dg=dg, db=db, dbias=dbias, dx2=dx2, dpre2=dpre2)
+        # z-only forward + the backward that recomputes y / statistics from x, with the kernel gradient fused in
+        cat3 = ops.zeros(n, H, W, 32)
+        ops.convln_fwd(xx, ww, bb, ga, be, 1e-3, 0.2, None, cat3[..., 16:], None)
+        dx3 = ops.zeros(n, H, W, cp)
+        dg3, db3, dbias3 = (cv(torch.ones(16, dtype=torch.float64)) for _ in range(3))
+        dw3 = cv(torch.full((3, 3, cin, 16), 0.25, dtype=torch.float64)).contiguous()
+        ops.convln_bwd_x(dc[..., 16:], xx, ww, bb, ga, 1e-3, 0.2, dx3, dg3, db3, dbias3, dw3)
+        dx4 = ops.zeros(n, H, W, cp)
+        ops.convln_bwd_x(dc[..., 16:], xx, ww, bb, ga, 1e-3, 0.2, dx4, None, None, None, None)
+        dw5 = ops.zeros(3, 3, cin, 16)
+        dg5, db5, dbias5 = ops.zeros(16), ops.zeros(16), ops.zeros(16)
+        ops.convln_bwd_x(dc[..., 16:], xx, ww, bb, ga, 1e-3, 0.2, None, dg5, db5, dbias5, dw5)
+        res[name] = dict(y=y, cat=cat, mr=mr, dpre=dpre, dx=dx, dg=dg, db=db, dbias=dbias, dx2=dx2, dpre2=dpre2,
+                         cat3=cat3, dx3=dx3, dg3=dg3, db3=db3, dbias3=dbias3, dw3=dw3, dx4=dx4, dw5=dw5, dg5=dg5,
+                         db5=db5, dbias5=dbias5)
     for k in res["ref"]:
         assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+    assert rel_err(res["hip"]["dx3"], res["hip"]["dx"]) < TOL and rel_err(res["hip"]["cat3"], res["hip"]["cat"]) == 0.0
 
 
 def test_sn_power_iter(hip_ops, ref_ops):

@@ -479,14 +479,27 @@ class HipOps:
         return bool(self.lib.wdg_convln_supported(cin, cout))
 
     def convln_fwd(self, x, w, bias, gamma, beta, eps, slope, y, z, mean_rstd):
-        """y = lrelu(conv3x3(x, w) + bias), z = LN(y); w: master HWIO [3,3,cin,cout]."""
+        """y = lrelu(conv3x3(x, w) + bias), z = LN(y); w: master HWIO [3,3,cin,cout].  y = mean_rstd = None: only z
+        is written (the backward is then convln_bwd_x, which recomputes them from x)."""
         px, ldx, isx = _v4(x)
-        py, ldy, isy = _v4(y)
+        py, ldy, isy = _v4(y) if y is not None else (0, 0, 0)
         pz, ldz, isz = _v4(z)
-        n, H, W, _ = y.shape
+        n, H, W, _ = z.shape
         native.check(self.lib.wdg_convln_fwd(px, ldx, isx, w.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
                                              beta.data_ptr(), eps, slope, py, ldy, isy, pz, ldz, isz,
-                                             mean_rstd.data_ptr(), n, H, W, w.shape[2], w.shape[3], self.stream), "convln_fwd")
+                                             _ptr(mean_rstd), n, H, W, w.shape[2], w.shape[3], self.stream), "convln_fwd")
+
+    def convln_bwd_x(self, dz, x, w, bias, gamma, eps, slope, dx, dgamma, dbeta, dbias, dw):
+        """Backward of convln_fwd from x: dx (optional), dgamma / dbeta / dbias += (all or none), dw += (optional)."""
+        pdz, lddz, isdz = _v4(dz)
+        px, ldx, isx = _v4(x)
+        pdx, lddx, isdx = _v4(dx) if dx is not None else (0, 0, 0)
+        n, H, W, _ = dz.shape
+        ws = self._workspace(int(self.lib.wdg_convln_wgrad_ws_bytes(n, H, W, w.shape[2]))) if dw is not None else None
+        native.check(self.lib.wdg_convln_bwd_x(pdz, lddz, isdz, px, ldx, isx, w.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                                               eps, slope, pdx, lddx, isdx, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(dw),
+                                               _ptr(ws), ws.numel() if ws is not None else 0, n, H, W, w.shape[2],
+                                               w.shape[3], self.stream), "convln_bwd_x")
 
     def convln_bwd(self, dz, y, mean_rstd, w, gamma, slope, dpre, dx, dgamma, dbeta, dbias):
         pdz, lddz, isdz = _v4(dz)

@@ -91,6 +91,9 @@ SIGNATURES = {
                               c_fp, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convln_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, c_fp, c_fp, c_fp, f32, c_fp, c_fp, i32, i64,
                               c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convln_wgrad_ws_bytes": (szt, [i32, i32, i32, i32]),
+    "wdg_convln_bwd_x": (i32, [c_fp, i32, i64, c_fp, i32, i64, c_fp, c_fp, c_fp, f32, f32, c_fp, i32, i64, c_fp, c_fp, c_fp,
+                               c_fp, c_fp, szt, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upsample2x_fwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, c_fp]),
     "wdg_upsample2x_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upconv_col_supported": (i32, [i32]),

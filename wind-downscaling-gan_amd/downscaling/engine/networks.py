@@ -449,20 +449,17 @@ class DiscriminatorNet(_Net):
     def _conv_ln_fwd(self, conv, ln, x, y, z):
         """SN-Conv2D 3x3 + LeakyReLU + LayerNormalization of one branch (models.py:94-97 / 102-105)."""
         if self._fused_conv_ln(conv):
-            ln.ensure_stats(y.shape[0] * y.shape[1] * y.shape[2])
-            self.ops.convln_fwd(x, conv.w.value, conv.b.value, ln.gamma.value, ln.beta.value, LN_EPS, LRELU, y, z,
-                                ln.mean_rstd)
+            # z only: the backward recomputes the pre-norm activation and its statistics from the 2-channel input
+            self.ops.convln_fwd(x, conv.w.value, conv.b.value, ln.gamma.value, ln.beta.value, LN_EPS, LRELU, None, z, None)
         else:
             conv.forward(x, y)
             ln.forward(v2(y), v2(z))
 
     def _conv_ln_bwd(self, conv, ln, dz, y, x, dpre_dense, dx, need_wgrad):
         if self._fused_conv_ln(conv):
-            self.ops.convln_bwd(dz, y, ln.mean_rstd, conv.w.value, ln.gamma.value, LRELU, dpre_dense, dx,
-                                ln.gamma.grad if need_wgrad else None, ln.beta.grad if need_wgrad else None,
-                                conv.b.grad if need_wgrad else None)
-            if need_wgrad:
-                conv.backward_weights(x, dpre_dense)
+            self.ops.convln_bwd_x(dz, x, conv.w.value, conv.b.value, ln.gamma.value, LN_EPS, LRELU, dx,
+                                  ln.gamma.grad if need_wgrad else None, ln.beta.grad if need_wgrad else None,
+                                  conv.b.grad if need_wgrad else None, conv.w.grad if need_wgrad else None)
         else:
             ln.backward(v2(dz), v2(y), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
             if need_wgrad:
