@@ -361,6 +361,8 @@ static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols
 static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
 void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
 static int g_halo_persistent = 1;   // wdg_set_tuning("halo_persistent", 0/1)
+static int g_halo_max_cin = 64;     // reduction channels above which conv_fwd / conv_dgrad do not take the halo kernel (0 = no limit)
+void wdg_halo_set_max_cin(int v) { g_halo_max_cin = v; }
 static int g_halo1_bpc = 4;         // resident workgroups per CU of the persistent kernel (126 registers -> 4 waves per SIMD; measured 2: 122, 3: 113, 4: 111, 5: 127 us)
 void wdg_halo_set_persistent(int v) { g_halo_persistent = v != 0; if (v > 1) g_halo1_bpc = v; }
 
@@ -374,13 +376,17 @@ static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 
 int wdg_halo_plan_init(wdg_conv_plan* pl) {
     const wdg_conv_geom& g = pl->g;
     pl->halo_fwd_nt = pl->halo_dgrad_nt = 0;
-    pl->halo_auto = 0;
+    pl->halo_auto = pl->halo_auto_fwd = pl->halo_auto_dgrad = 0;
     if (g.stride != 1 || g.kh > 5 || g.kw > 5) return WDG_OK;
     // the conv entry points switch to the halo kernel only where the im2col-free gather is
     // traffic-bound (few output channels, large maps); wdg_upconv_fwd uses it at any size
     const long long pixels = (long long)g.n_img * g.Ho * g.Wo;
     pl->halo_auto = pixels >= 65536;
     int nf = halo_nt(g.Cout), nd = halo_nt(g.Cin);
+    // deep reductions (3x3 128 -> 64) are MFMA bound, not traffic bound: there the implicit GEMM's 128x64 tile wins
+    // (1.09 -> 0.79 ms per step for that layer); the kernels stay available to wdg_upconv_fwd / explicit callers
+    pl->halo_auto_fwd = pl->halo_auto && !(g_halo_max_cin > 0 && g.Cin > g_halo_max_cin);
+    pl->halo_auto_dgrad = pl->halo_auto && !(g_halo_max_cin > 0 && g.Cout > g_halo_max_cin);
     if (nf && halo_lds_bytes(g.kh, g.kw, nf) > 64 * 1024) nf = 0;
     if (nd && halo_lds_bytes(g.kh, g.kw, nd) > 64 * 1024) nd = 0;
     std::vector<int4> tf, td;

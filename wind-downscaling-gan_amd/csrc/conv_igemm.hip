@@ -806,8 +806,8 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
     info[6] = pick_wgrad_bn(pl->g.Cout); info[7] = pl->wgrad_split;
     if (wdg_wgrad_halo_eligible(pl)) { info[6] = 0; info[7] = 1; }   // BN = 0 marks the halo weight-gradient kernel
     if (wdg_wgrad_thin_eligible(pl)) { info[6] = -1; info[7] = 1; }  // BN = -1 marks the thin 3x3 weight-gradient kernel
-    if (pl->halo_auto && pl->halo_fwd_nt) { info[0] = 0; info[1] = 16 * pl->halo_fwd_nt; info[2] = 1; }     // BM = 0 marks the halo kernel
-    if (pl->halo_auto && pl->halo_dgrad_nt) { info[3] = 0; info[4] = 16 * pl->halo_dgrad_nt; info[5] = 1; }
+    if (pl->halo_auto_fwd && pl->halo_fwd_nt) { info[0] = 0; info[1] = 16 * pl->halo_fwd_nt; info[2] = 1; }     // BM = 0 marks the halo kernel
+    if (pl->halo_auto_dgrad && pl->halo_dgrad_nt) { info[3] = 0; info[4] = 16 * pl->halo_dgrad_nt; info[5] = 1; }
     return WDG_OK;
 }
 
@@ -837,6 +837,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
 
     if (key && !strcmp(key, "small_m")) {   // takes effect for plans created afterwards
         g_small_m = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "halo_max_cin")) {   // takes effect for plans created afterwards
+        wdg_halo_set_max_cin(value);
         return WDG_OK;
     }
     if (key && !strcmp(key, "halo_persistent")) {
@@ -928,7 +932,7 @@ extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float
     WDG_CHECK_ARG(pl && x && wF && y, "null argument");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0 && ((uintptr_t)y & 15) == 0, "x / wF / y must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
-    if (pl->halo_auto && pl->halo_fwd_nt)
+    if (pl->halo_auto_fwd && pl->halo_fwd_nt)
         return wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, accumulate,
                                (hipStream_t)stream);
     WdgIgemm p;
@@ -954,7 +958,7 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
     WDG_CHECK_ARG(pl && dy && wD && dx, "null argument");
     WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0 && ((uintptr_t)dx & 15) == 0, "dy / wD / dx must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
-    if (pl->halo_auto && pl->halo_dgrad_nt)
+    if (pl->halo_auto_dgrad && pl->halo_dgrad_nt)
         return wdg_halo_launch(pl, true, dy, g.ldy, g.img_stride_y, 0, wD, bias, dx, act, slope, accumulate,
                                (hipStream_t)stream);
     WdgIgemm p;

@@ -30,7 +30,8 @@ struct wdg_conv_plan {
     int4* d_taps_fwd = nullptr;
     int4* d_taps_dgrad = nullptr;
     int halo_fwd_nt = 0, halo_dgrad_nt = 0;   // 0 = not eligible; else 16-column tiles per block (1, 2, 4)
-    int halo_auto = 0;                        // conv_fwd / conv_dgrad dispatch to the halo kernel by themselves
+    int halo_auto = 0;                        // conv_fwd / conv_dgrad dispatch to the halo kernel by themselves ...
+    int halo_auto_fwd = 0, halo_auto_dgrad = 0;   // ... per direction (shallow reductions only)
 };
 
 
@@ -39,6 +40,7 @@ int wdg_halo_plan_init(wdg_conv_plan* pl);
 void wdg_halo_plan_free(wdg_conv_plan* pl);
 void wdg_halo_set_wg(int v);
 void wdg_halo_set_persistent(int v);
+void wdg_halo_set_max_cin(int v);
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
                     hipStream_t st);
