@@ -354,6 +354,12 @@ int wdg_dense_gap_bwd(const float* x, const float* w, const float* dscore, float
 int wdg_copy_channels(const float* src, int lds, int64_t img_stride_src, float* dst, int ldd,
                       int64_t img_stride_dst, int n_img, int64_t pixels_per_img, int C,
                       int accumulate, wdg_stream stream);
+/* The same with a two-level image index (image = outer * n_inner + inner, separate strides per level on both sides):
+ * one launch for the (B,T) <-> (T,B) permutation between the API layout and the time-major activations. */
+int wdg_copy_channels_2level(const float* src, int lds, int64_t inner_stride_src, int64_t outer_stride_src,
+                             float* dst, int ldd, int64_t inner_stride_dst, int64_t outer_stride_dst,
+                             int n_outer, int n_inner, int64_t pixels_per_img, int C, int accumulate,
+                             wdg_stream stream);
 /* Window patches of a strided grid — shortcut_convolution (tf_utils.py:15-32; stride >= kernel, so the windows are
  * disjoint): out[n][oy][ox][(ky*k + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside), t x t
  * windows per image; the conv becomes a 1x1 convolution on `out` with the weights viewed as [k*k*C][Cout].

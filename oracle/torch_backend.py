@@ -206,6 +206,10 @@ class TorchOps:
         if dbias is not None:   # bias gradient of the same layer (always accumulated)
             dbias += dy[..., :pk.cout].reshape(-1, pk.cout).sum(0)
 
+    def permute_bt(self, src, dst):
+        C = min(src.shape[4], dst.shape[4])
+        dst[..., :C] = src.permute(1, 0, 2, 3, 4)[..., :C]
+
     def fork(self):
         """HipOps.fork restated for a backend without streams: run in place."""
         class _Inline:

@@ -138,3 +138,46 @@ def test_encoder_feature_extractor(hip_ops, S, T, latent):
     g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
     (gref,) = torch.autograd.grad((ref * g).sum(), xr)
     assert rel_err(net.backward_input(g.float().to(dev)), gref) < TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_generator_inference_graph_replay(hip_ops, precision):
+    """Generator.__call__ in inference mode replays a captured HIP graph (GeneratorNet.forward_inference): results are
+    bit-identical to the eager launches, new inputs written into the resident buffers are picked up by the replay, and a
+    weight change re-captures."""
+    from downscaling.engine import runtime
+    from downscaling.gan.models import make_generator
+    runtime.set_ops(hip_ops)
+    dev = hip_ops.device
+    g = make_generator(32, 3, 4, 2, 3, feature_channels=64)   # 64: the 16-bit halo kernels need channels % 8 == 0
+    outs = {}
+    for mode in (False, True):
+        g.graph_inference = mode
+        res = []
+        for k in range(5):   # calls 1-2 eager, 3 captures, 4-5 replay
+            image = torch.randn(2, 3, 32, 32, 3, generator=torch.Generator().manual_seed(10 + k)).to(dev)
+            noise = torch.randn(2, 3, 32, 32, 4, generator=torch.Generator().manual_seed(20 + k)).to(dev)
+            res.append(g([image, noise], training=False, precision=precision).clone())
+        outs[mode] = res
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[True][0], outs[True][1])
+    # another batch size replaces the resident buffers: the graph captured on the old ones must not survive
+    g.graph_inference = True
+    one = g([image[:1], noise[:1]], training=False, precision=precision).clone()
+    back = [g([image, noise], training=False, precision=precision).clone() for _ in range(4)]
+    assert torch.equal(one[0], back[-1][0]) and all(torch.equal(back[0], x) for x in back)
+    # weights change -> the stale graph must not be replayed
+    w = g.get_weights_dict()
+    k0 = next(k for k in w if k.endswith("layer_with_weights-11/layer/kernel") or k.endswith("11/layer/kernel"))
+    w[k0] = w[k0] * 1.5
+    g.set_weights_dict(w)
+    image = torch.randn(2, 3, 32, 32, 3, generator=torch.Generator().manual_seed(10)).to(dev)
+    noise = torch.randn(2, 3, 32, 32, 4, generator=torch.Generator().manual_seed(20)).to(dev)
+    g.graph_inference = True
+    for _ in range(4):
+        y_graph = g([image, noise], training=False, precision=precision).clone()
+    assert any(isinstance(k, tuple) for k in g.net._graphs)      # a graph of the new weights exists and was replayed
+    g.graph_inference = False
+    y_eager = g([image, noise], training=False, precision=precision)
+    assert torch.equal(y_graph, y_eager) and not torch.equal(y_graph, outs[True][0])

@@ -340,15 +340,19 @@ extern "C" int wdg_dense_gap_bwd(const float* x, const float* w, const float* ds
 
 // ---- channel pack / unpack between views ---------------------------------------------------------
 __global__ void __launch_bounds__(256) wdg_copy_channels_kernel(const float* __restrict__ src, int lds_,
-                                                                int64_t iss, float* dst, int ldd, int64_t isd,
-                                                                int n_img, int64_t ppi, int C, int accumulate) {
+                                                                int64_t iss, int64_t oss, float* dst, int ldd, int64_t isd,
+                                                                int64_t osd, int n_inner, int n_img, int64_t ppi, int C,
+                                                                int accumulate) {
+    // image index = outer * n_inner + inner, with separate strides per level on both sides: one launch also covers the
+    // (B,T) <-> (T,B) permutation between the API layout and the time-major activations
     const int64_t total = (int64_t)n_img * ppi * C;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int64_t p = idx / C;
         const int c = (int)(idx - p * C);
         const int64_t img = p / ppi, q = p - img * ppi;
-        const float v = src[img * iss + q * lds_ + c];
-        float* d = dst + img * isd + q * ldd + c;
+        const int64_t o = img / n_inner, i = img - o * n_inner;
+        const float v = src[o * oss + i * iss + q * lds_ + c];
+        float* d = dst + o * osd + i * isd + q * ldd + c;
         *d = accumulate ? *d + v : v;
     }
 }
@@ -358,8 +362,21 @@ extern "C" int wdg_copy_channels(const float* src, int lds_, int64_t img_stride_
                                  int accumulate, wdg_stream stream) {
     WDG_CHECK_ARG(src && dst && C > 0 && n_img > 0 && pixels_per_img > 0, "bad argument");
     hipLaunchKernelGGL(wdg_copy_channels_kernel, dim3(ew_blocks((int64_t)n_img * pixels_per_img * C)), dim3(256),
-                       0, (hipStream_t)stream, src, lds_, img_stride_src, dst, ldd, img_stride_dst, n_img,
-                       pixels_per_img, C, accumulate);
+                       0, (hipStream_t)stream, src, lds_, img_stride_src, (int64_t)0, dst, ldd, img_stride_dst, (int64_t)0,
+                       n_img, n_img, pixels_per_img, C, accumulate);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+extern "C" int wdg_copy_channels_2level(const float* src, int lds_, int64_t inner_stride_src, int64_t outer_stride_src,
+                                        float* dst, int ldd, int64_t inner_stride_dst, int64_t outer_stride_dst,
+                                        int n_outer, int n_inner, int64_t pixels_per_img, int C, int accumulate,
+                                        wdg_stream stream) {
+    WDG_CHECK_ARG(src && dst && C > 0 && n_outer > 0 && n_inner > 0 && pixels_per_img > 0, "bad argument");
+    const int n_img = n_outer * n_inner;
+    hipLaunchKernelGGL(wdg_copy_channels_kernel, dim3(ew_blocks((int64_t)n_img * pixels_per_img * C)), dim3(256),
+                       0, (hipStream_t)stream, src, lds_, inner_stride_src, outer_stride_src, dst, ldd, inner_stride_dst,
+                       outer_stride_dst, n_inner, n_img, pixels_per_img, C, accumulate);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -171,6 +171,7 @@ class _Fork:
 class HipOps:
     name = "hip"
     dtype = torch.float32
+    supports_graphs = True     # launches go to torch's current stream, so torch.cuda.graph captures them
 
     def __init__(self, device=None):
         if not torch.cuda.is_available():
@@ -564,6 +565,19 @@ class HipOps:
         ldd, isd = strides(dst)
         native.check(self.lib.wdg_copy_channels(src.data_ptr(), lds, iss, dst.data_ptr(), ldd, isd, n, H * W, Cc,
                                                 int(accumulate), self.stream), "copy_channels")
+
+    def permute_bt(self, src, dst):
+        """dst[t, b, ..., :C] = src[b, t, ..., :C] for 5-D views (outer, inner, H, W, C) -> (inner, outer, H, W, >=C)
+        (or the reverse, whichever the shapes say): one launch for the API <-> time-major permutation."""
+        no, ni, H, W, Cc = src.shape
+        assert tuple(dst.shape[:4]) == (ni, no, H, W)
+        C = min(Cc, dst.shape[4])
+        lds, ldd = (src.stride(3) if W > 1 else src.stride(2)), (dst.stride(3) if W > 1 else dst.stride(2))
+        if H > 1 and W > 1:
+            assert src.stride(2) == W * lds and dst.stride(2) == W * ldd
+        native.check(self.lib.wdg_copy_channels_2level(src.data_ptr(), lds, src.stride(1), src.stride(0), dst.data_ptr(), ldd,
+                                                       dst.stride(0), dst.stride(1), no, ni, H * W, C, 0, self.stream),
+                     "copy_channels_2level")
 
     def colsum(self, x, out, accumulate=True):
         px, ld = _v2(x)

@@ -103,6 +103,7 @@ SIGNATURES = {
     "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
     "wdg_dense_gap_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
     "wdg_copy_channels": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i64, i32, i32, c_fp]),
+    "wdg_copy_channels_2level": (i32, [c_fp, i32, i64, i64, c_fp, i32, i64, i64, i32, i32, i64, i32, i32, c_fp]),
     "wdg_colsum": (i32, [c_fp, i32, i64, i32, c_fp, i32, c_fp]),
     "wdg_lerp_batch": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, i64, i64, i32, i32, c_fp]),
     "wdg_sumsq_batch_ch": (i32, [c_fp, i32, i64, i32, i32, i32, c_fp, c_fp]),

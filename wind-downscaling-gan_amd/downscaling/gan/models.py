@@ -124,6 +124,7 @@ class _Model:
 class Generator(_Model):
     name = "generator"
     inference_precision = "fp32"   # "bf16" / "fp16": 16-bit-operand MFMA for the inference forward (BASELINE configs[3] / [4])
+    graph_inference = True         # replay the inference forward from a captured HIP graph (GeneratorNet.forward_inference)
 
     def __call__(self, inputs, training=False, mask=None, precision=None):
         image, noise = inputs
@@ -135,7 +136,10 @@ class Generator(_Model):
         net.set_image(image)
         net.set_noise(noise)
         precision = precision or ("fp32" if training else self.inference_precision)
-        out_tm = net.forward(B, bool(training), precision=precision)
+        if training or not self.graph_inference:
+            out_tm = net.forward(B, bool(training), precision=precision)
+        else:
+            out_tm = net.forward_inference(B, precision=precision)
         out = torch.empty(B, T, net.S, net.S, net.out_channels, dtype=ops.dtype, device=ops.device)
         net.from_time_major(out_tm, out)
         return out
