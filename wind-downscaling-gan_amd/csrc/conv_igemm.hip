@@ -839,6 +839,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_small_m = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "h16_small_tiles")) {
+        wdg_h16_set_small_tiles(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "halo_max_cin")) {   // takes effect for plans created afterwards
         wdg_halo_set_max_cin(value);
         return WDG_OK;

@@ -223,14 +223,28 @@ extern "C" int wdg_convert_f16(const float* src, void* dst_f16, int64_t n, wdg_s
     return convert_h16(src, dst_f16, n, 1, stream);
 }
 
+static int g_h16_small_tiles = 2;   // 0 off, 1 = 128x64, 2 = 64x64 tiles for launches with few 128x128 tiles (measured 6.45 / 6.25 / 6.03 ms per T=24 forward)
+void wdg_h16_set_small_tiles(int v) { g_h16_small_tiles = v; }
 static int launch_bf16(WdgIgemmBf16& p, int nphase, int fmt, hipStream_t st) {
     if (p.Mmax <= 0) return WDG_OK;
     p.nphase = nphase;
-    const bool wide = p.Ncols > 64;
-    const int BM = 128, BN = wide ? 128 : 64;
+    bool wide = p.Ncols > 64;
+    int BM = 128, BN = wide ? 128 : 64;
+    // small maps (the per-timestep recurrent convolution at T > 1: 9,216 rows): the 16-bit MFMA finishes a 128x128 tile's
+    // K-step in ~0.2 us, so a launch with about one workgroup per CU is bound by each workgroup's own load latency chain;
+    // smaller tiles put several workgroups on every CU
+    const long long t128 = (long long)((p.Mmax + 127) / 128) * ((p.Ncols + 127) / 128) * nphase;
+    const int small = g_h16_small_tiles && wide && t128 <= 2 * 256 ? g_h16_small_tiles : 0;
+    if (small == 1) { wide = false; BN = 64; }
+    if (small == 2) { BM = 64; BN = 64; }
     const int tiles_m = (p.Mmax + BM - 1) / BM, tiles_n = (p.Ncols + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, nphase), block(256);
-    if (wide && fmt == 0)
+    if (small == 2) {
+        if (fmt == 0)
+            hipLaunchKernelGGL((wdg_igemm_bf16_kernel<64, 64, 2, 2, 0>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((wdg_igemm_bf16_kernel<64, 64, 2, 2, 1>), grid, block, 0, st, p);
+    } else if (wide && fmt == 0)
         hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 128, 2, 2, 0>), grid, block, 0, st, p);
     else if (wide)
         hipLaunchKernelGGL((wdg_igemm_bf16_kernel<128, 128, 2, 2, 1>), grid, block, 0, st, p);
