@@ -604,11 +604,11 @@ struct TileCfg {
 // split-K factor (64->128 forward 211 -> 189 us, 128->256 forward 82 -> 77 us); with only a handful of tiles (the
 // 8->2 stage) the split factor dominates either way and 128x128 stays.  wdg_set_tuning("small_m", n): n = 0 disables.
 static int g_small_m = 256;
-static int g_tile64 = 1;     // 64x64 tile when even the 128x64 tiling leaves fewer than two workgroups per CU (T=24 step 120.0 -> 118.9 ms, headline 78.4 -> 78.2)
+static int g_tile64 = 2;     // 64x64 tile when even the 128x64 tiling leaves fewer than two workgroups per CU (T=24 step 120.0 -> 118.9 ms, headline 78.4 -> 78.2); 2: also for layers with fewer than 16 tiles of 128x128 (another -0.35 ms)
 static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
     if (igemm && M >= 0 && ncols >= 128) {
         const long long t128 = ((M + 127) / 128) * ((ncols + 127) / 128);
-        if (g_tile64 && t128 >= 16 && 2 * t128 < 512) return TileCfg{64, 64};
+        if (g_tile64 && (t128 >= 16 || g_tile64 >= 2) && 2 * t128 < 512) return TileCfg{64, 64};
         if (t128 >= 16 && t128 <= g_small_m) return TileCfg{128, 64};
     }
     // 160 columns (the generator's widest decoder layer): one 128 x 160 tile, five column fragments per wave,
@@ -838,7 +838,7 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
 
     if (key && !strcmp(key, "tile64")) {   // takes effect for plans created afterwards
-        g_tile64 = value != 0;
+        g_tile64 = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "small_m")) {   // takes effect for plans created afterwards
