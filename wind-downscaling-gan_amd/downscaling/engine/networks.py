@@ -392,7 +392,7 @@ class DiscriminatorNet(_Net):
             hi=o.zeros(N, S, S, chp),                          # high-res input, padded
             mix=o.zeros(N, S, S, round4(self.cl + self.ch)),   # concat(low, high), models.py:100
             ha=o.zeros(N, S, S, chp),
-            ya=o.empty(N, S, S, Fd),
+            ya=None if self._fused_conv_ln(self.conv_a) else o.empty(N, S, S, Fd),   # the fused branch keeps no pre-norm tensor
             hb=o.zeros(N, S, S, Fd),
             yb=o.empty(N, S, S, Fd),
             cat=o.empty(N, S, S, 2 * Fd),                      # concat(hr, mix), models.py:108
@@ -400,8 +400,6 @@ class DiscriminatorNet(_Net):
             score=o.empty(B),
             # gradients
             dcat=o.empty(N, S, S, 2 * Fd),
-            dpre=o.empty(N, S, S, Fd),                         # dense pre-activation gradients of the two branches
-            dpre_b=o.empty(N, S, S, Fd),
             dha=o.zeros(N, S, S, chp),
             dhb=o.zeros(N, S, S, Fd),
             dhi=o.zeros(N, S, S, chp),
@@ -503,7 +501,7 @@ class DiscriminatorNet(_Net):
             conv.forward(x, y)
             ln.forward(v2(y), v2(z))
 
-    def _conv_ln_bwd(self, conv, ln, dz, y, x, dpre_dense, dx, need_wgrad):
+    def _conv_ln_bwd(self, conv, ln, dz, y, x, dx, need_wgrad):
         if self._fused_conv_ln(conv):
             self.ops.convln_bwd_x(dz, x, conv.w.value, conv.b.value, ln.gamma.value, LN_EPS, LRELU, dx,
                                   ln.gamma.grad if need_wgrad else None, ln.beta.grad if need_wgrad else None,
@@ -545,11 +543,11 @@ class DiscriminatorNet(_Net):
             if split:
                 self._shortcut_bwd(b, b["sc_dz"], xin, dxin, need_wgrad)
         def branch_a():   # high-res only
-            self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dpre"], b["dha"], need_wgrad)
+            self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dha"], need_wgrad)
             self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None, B, T, need_wgrad)
 
         def branch_b():   # low + high
-            self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dpre_b"], b["dhb"], need_wgrad)
+            self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad)
             self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
 
         if T > 1 and self.overlap_branches:
