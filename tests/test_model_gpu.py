@@ -95,7 +95,7 @@ def test_discriminator(hip_ops, S, T, Fd, variant):
     assert rel_err(dhigh, ghigh) < TOL
 
 
-@pytest.mark.parametrize("S,T", [(32, 2), (20, 1)])
+@pytest.mark.parametrize("S,T", [(32, 2), (20, 1), (96, 1)])
 def test_train_step(hip_ops, S, T):
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
     from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
