@@ -82,7 +82,11 @@ class ConvTimer:
             timed("wdg_upconv4_kernel (fused upsample + 5x5 transposed conv; executes 0.64 of the algorithmic MACs)",
                   2.0 * n * Ho * Wo * pk.cin * g.kh * g.kw * pk.cout, orig_up, x_low, pk, bias, y, g, **k)
 
-        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad, ops.upconv_fwd = conv_fwd, conv_dgrad, conv_wgrad, upconv_fwd
+        ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
+        if not getattr(ops, "upconv_colfwd", False):
+            # (in column form the block is a 1x1 GEMM, timed through conv_dgrad above with the FLOPs it executes, plus
+            # an untimed gather pass)
+            ops.upconv_fwd = upconv_fwd
 
     def summary(self):
         agg = {}

@@ -152,7 +152,7 @@ def test_conv_on_concat_and_time_views(hip_ops, ref_ops):
 
 @pytest.mark.parametrize("n,H,W,C,N,ld", [(3, 60, 68, 160, 16, 160), (2, 19, 35, 40, 4, 48), (2, 3, 3, 20, 8, 20),
                                           (1, 9, 50, 160, 16, 192), (2, 4, 17, 8, 2, 8)])
-@pytest.mark.parametrize("composite", [True, False])
+@pytest.mark.parametrize("composite", [True, False, "column"])
 def test_fused_upsample_conv_transpose(n, H, W, C, N, ld, composite, hip_ops, ref_ops):
     """UpSampling2D(bilinear) + Conv2DTranspose(5x5,'same') + bias + LeakyReLU fused (models.py:62-64), input taken
     from a channel-concat view, ragged tiles, tiny maps (every pixel on the border ring), few outputs / channels.
@@ -173,11 +173,12 @@ def test_fused_upsample_conv_transpose(n, H, W, C, N, ld, composite, hip_ops, re
     xg[..., :C] = x.float().to(dev)
     if ld > C:
         xg[..., C:] = 7.0   # neighbouring channels of the concat buffer must not leak in
-    hip_ops.upconv4 = composite
+    hip_ops.upconv4 = composite is True
+    hip_ops.upconv_colfwd = composite == "column"     # 1x1 GEMM + bilinear gather (N = 2 falls back)
     try:
         hip_ops.upconv_fwd(xg[..., :C], hip_ops.pack_weights(w.float().to(dev).contiguous()), b.float().to(dev), y_g, g, act=True)
     finally:
-        hip_ops.upconv4 = True
+        hip_ops.upconv4, hip_ops.upconv_colfwd = True, True
     assert rel_err(y_g, y_r) < TOL
     if Np != N:
         assert float(y_g[..., N:].abs().max()) == 0.0

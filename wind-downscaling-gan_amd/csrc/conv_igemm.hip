@@ -617,6 +617,9 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
     static const TileCfg cand[4] = {{128, 128}, {128, 64}, {256, 32}, {256, 16}};
     int best = 1 << 30;
     for (auto& c : cand) best = std::min(best, wdg_round_up(ncols, c.BN));
+    // many columns: the 128x128 tile beats the 128x64 one even with up to 30 % padding (400 columns of the column-form
+    // upsample-conv forward: 0.82 vs 0.91 ms)
+    if (igemm && ncols >= 256 && wdg_round_up(ncols, 128) * 100 <= best * 130) return cand[0];
     for (auto& c : cand)
         if (wdg_round_up(ncols, c.BN) * 100 <= best * 113) return c;
     return cand[3];

@@ -106,3 +106,123 @@ extern "C" int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, f
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+
+// ---- forward in column form: y = act(bias + gather(z)),  z[r, (t, o)] = sum_c x[r, c] * w[t][o][c]  (a 1x1 GEMM) ----
+// The adjoint of the column kernel above: y[p, o] = sum over (r, t, a, b) with 2r - 1 + (a, b) + t - 2 = p of
+// k_r(a) k_r(b) z[r, (t, o)].  Per dimension and tap there are exactly two (r, a) pairs (a = parity of p + 3 - t, or
+// that + 2), so the sum separates into a horizontal pass (10 terms) and a vertical pass (10 terms) instead of 100.
+// One workgroup = an 8x8 low-res tile = 16x16 output pixels; per tap row ty the 12x12 low-res window of z (80 floats per
+// pixel) is staged in LDS, reduced horizontally into H[12][16][C], and each thread adds its two vertical terms.
+template <int CQ>
+__global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                                float* __restrict__ y, int ldy, long long isy, int Hl,
+                                                                int Wl, int act, float slope) {
+    constexpr int ZW = TS + 4;                       // low-res window edge (12)
+    constexpr int PX = 5 * CQ;                       // float4 per window pixel and tap row
+    __shared__ f32x4 Z[ZW * ZW * PX];
+    __shared__ f32x4 Hs[ZW * 2 * TS * CQ];
+    const int tiles_x = (Wl + TS - 1) / TS;
+    const int i0 = (blockIdx.x / tiles_x) * TS, j0 = (blockIdx.x % tiles_x) * TS;
+    const long long n = blockIdx.y;
+    const int t = threadIdx.x;
+    const int qyl = t >> 4, qxl = t & 15;            // this thread's output pixel within the 16x16 tile
+    const int qy = 2 * i0 + qyl, qx = 2 * j0 + qxl;
+    const float* zimg = z + n * Hl * Wl * (100LL * CQ);
+    f32x4 acc[CQ];
+#pragma unroll
+    for (int o4 = 0; o4 < CQ; ++o4) acc[o4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // window slots of this thread (tile-invariant): element offset within a tap-row slice, or -1 outside the image
+    constexpr int NSLOT = (ZW * ZW * PX + 255) / 256;
+    long long zoff[NSLOT];
+    f32x4 zr[NSLOT];
+#pragma unroll
+    for (int s_ = 0; s_ < NSLOT; ++s_) {
+        const int i = t + 256 * s_;
+        const int k = i % PX, px = i / PX;
+        const int ry = i0 - 2 + px / ZW, rx = j0 - 2 + px % ZW;
+        zoff[s_] = (i < ZW * ZW * PX && (unsigned)ry < (unsigned)Hl && (unsigned)rx < (unsigned)Wl)
+                       ? ((long long)ry * Wl + rx) * (100LL * CQ) + 4 * k : -1;
+    }
+    auto load_slice = [&](int ty_) {
+#pragma unroll
+        for (int s_ = 0; s_ < NSLOT; ++s_)
+            zr[s_] = zoff[s_] >= 0 ? *reinterpret_cast<const f32x4*>(zimg + zoff[s_] + ty_ * (20 * CQ)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    load_slice(0);
+    for (int ty = 0; ty < 5; ++ty) {
+        // 1. window of z for this tap row (zeros outside the low-res image): staged from the registers that were
+        //    loaded under the previous tap row's passes
+#pragma unroll
+        for (int s_ = 0; s_ < NSLOT; ++s_)
+            if (t + 256 * s_ < ZW * ZW * PX) Z[t + 256 * s_] = zr[s_];
+        __syncthreads();
+        if (ty + 1 < 5) load_slice(ty + 1);
+        // 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
+        for (int i = t; i < ZW * 2 * TS * CQ; i += 256) {
+            const int o4 = i % CQ, hq = (i / CQ) % (2 * TS), ryl = i / (CQ * 2 * TS);
+            const int gq = 2 * j0 + hq;
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tx = 0; tx < 5; ++tx) {
+                const int sx = gq + 3 - tx;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int b = (sx & 1) + 2 * e;
+                    const int rx = (sx - b) >> 1;
+                    const int rxl = rx - (j0 - 2);
+                    if ((unsigned)rxl < (unsigned)ZW)
+                        h += up_adj_coef(rx, b, Wl) * Z[(ryl * ZW + rxl) * PX + tx * CQ + o4];
+                }
+            }
+            Hs[i] = h;
+        }
+        __syncthreads();
+        // 3. vertical pass: the two (ry, a) pairs of this tap row
+        {
+            const int sy = qy + 3 - ty;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int a = (sy & 1) + 2 * e;
+                const int ry = (sy - a) >> 1;
+                const int ryl = ry - (i0 - 2);
+                if ((unsigned)ryl < (unsigned)ZW) {
+                    const float c = up_adj_coef(ry, a, Hl);
+#pragma unroll
+                    for (int o4 = 0; o4 < CQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * TS + qxl) * CQ + o4];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (qy < 2 * Hl && qx < 2 * Wl) {
+        float* dst = y + n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+#pragma unroll
+        for (int o4 = 0; o4 < CQ; ++o4) {
+            f32x4 v = acc[o4];
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
+            }
+            *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
+        }
+    }
+}
+
+extern "C" int wdg_upconv_gather(const float* z, const float* bias, float* y, int ldy, int64_t img_stride_y, int n_img,
+                                 int Hl, int Wl, int C, int act, float slope, wdg_stream stream) {
+    WDG_CHECK_ARG(z && y && n_img > 0 && n_img < 65536 && Hl > 0 && Wl > 0 && ldy % 4 == 0, "bad argument");
+    WDG_CHECK_ARG(wdg_upconv_col_supported(C), "channel count must be 4, 8 or 16");
+    WDG_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0, "z / y / bias must be 16-byte aligned");
+    const int tiles = ((Hl + TS - 1) / TS) * ((Wl + TS - 1) / TS);
+    dim3 grid(tiles, n_img), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16)
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+    else if (C == 8)
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+    else
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
