@@ -334,11 +334,12 @@ int wdg_upsample2x_bwd(const float* dy, int lddy, int64_t img_stride_dy, float* 
 int wdg_upconv_col_supported(int C);
 int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, float* col, int n_img, int Hl, int Wl, int C,
                    wdg_stream stream);
-/* The forward in the same form (experimental): z [n, Hl, Wl, 25*C] = x * W as a 1x1 GEMM
- * (wdg_conv_dgrad with the weights viewed as [25*C][C_in]), then y = act(bias + gather(z)): the adjoint of
- * wdg_upconv_col with the clamped-bilinear coefficients, y [n, 2Hl, 2Wl, >= C]. */
-int wdg_upconv_gather(const float* z, const float* bias, float* y, int ldy, int64_t img_stride_y, int n_img,
-                      int Hl, int Wl, int C, int act, float slope, wdg_stream stream);
+/* The forward in the same form: z [n, Hl, Wl, 25*C] = x * W as a 1x1 GEMM
+ * (wdg_conv_dgrad / wdg_conv_dgrad_bf16 with the weights viewed as [25*C][C_in]), then
+ * y = affine(act(bias + gather(z))): the adjoint of wdg_upconv_col with the clamped-bilinear coefficients,
+ * y [n, 2Hl, 2Wl, >= C]; affine = optional [2*C] scale | shift (fused inference BatchNorm). */
+int wdg_upconv_gather(const float* z, const float* bias, const float* affine, float* y, int ldy,
+                      int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope, wdg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flatten + Dense(1) per timestep + GlobalAveragePooling1D over T.             models.py:137-140

@@ -173,9 +173,21 @@ class TorchOps:
     def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2, fmt="bf16"):
         self.conv_fwd_bf16(x, pk, bias, y, g, act=act, affine=affine, slope=slope, fmt=fmt)
 
+    upconv_colfwd = True    # mirrors HipOps.upconv_colfwd: which operand the 16-bit path rounds
+
     def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16"):
-        # bilinear interpolation in full precision, then 16-bit rounding of the conv operands
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
+        if self.upconv_colfwd and (g.kh, g.kw, g.stride, g.pad) == (5, 5, 1, 2) and pk.cout % 8 == 0 and pk.cin in (4, 8, 16):
+            # column form: the 16-bit GEMM operands are the LOW-RES input and the weights; the bilinear interpolation
+            # acts on the exact products afterwards (it commutes with the channel mixing)
+            self.upsample2x_fwd(self._r16(x_low, fmt), up)
+            out = torch.zeros(y.shape[:3] + (pk.cin,), dtype=x_low.dtype)
+            self.conv_dgrad(up, PackedWeights(self, self._r16(pk.w, fmt)), out, g, bias=bias, act=act, slope=slope)
+            if affine is not None:
+                out = out * affine[:pk.cin] + affine[pk.cin:]
+            y[..., :pk.cin] = out
+            return
+        # 25-tap halo kernel: bilinear interpolation in full precision, then 16-bit rounding of the conv operands
         self.upsample2x_fwd(x_low, up)
         self.conv_dgrad_bf16(up, pk, y, g, bias=bias, act=act, affine=affine, slope=slope, fmt=fmt)
 

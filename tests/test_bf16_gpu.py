@@ -67,12 +67,25 @@ def test_bf16_halo_kernels(fmt, hip_ops, ref_ops):
     b = torch.randn(16, generator=gen, dtype=torch.float64)
     aff = torch.cat([torch.rand(16, generator=gen, dtype=torch.float64) + 0.5, torch.randn(16, generator=gen, dtype=torch.float64)])
     y_r, y_g = torch.zeros(3, 120, 136, 16, dtype=torch.float64), hip_ops.zeros(3, 120, 136, 16)
-    ref_ops.upconv_fwd_bf16(x, ref_ops.pack_weights(w), b, y_r, RG(5, 5, 1, 2), act=True, affine=aff, fmt=fmt)
-    hip_ops.upconv_fwd_bf16(x.float().to(dev), hip_ops.pack_weights(w.float().to(dev).contiguous()), b.float().to(dev), y_g,
-                            ConvGeom(5, 5, 1, 2), act=True, affine=aff.float().to(dev), fmt=fmt)
+    pk_g = hip_ops.pack_weights(w.float().to(dev).contiguous())
+    ref_ops.upconv_colfwd = hip_ops.upconv_colfwd = False
+    try:
+        ref_ops.upconv_fwd_bf16(x, ref_ops.pack_weights(w), b, y_r, RG(5, 5, 1, 2), act=True, affine=aff, fmt=fmt)
+        hip_ops.upconv_fwd_bf16(x.float().to(dev), pk_g, b.float().to(dev), y_g,
+                                ConvGeom(5, 5, 1, 2), act=True, affine=aff.float().to(dev), fmt=fmt)
+    finally:
+        ref_ops.upconv_colfwd = hip_ops.upconv_colfwd = True
     # the interpolated value is rounded to bf16 after fp32 (HIP) vs fp64 (oracle) interpolation: a value that sits
     # on a rounding boundary may round the other way, so the bound is one bf16 ulp of a few of the 4000 products
     assert rel_err(y_g, y_r) < 2e-3
+    # column form (default): the 16-bit operands are the low-res input and the weights, products and interpolation
+    # exact / fp32 -> the same tight bound as the plain 16-bit convolutions
+    y_r2, y_g2 = torch.zeros(3, 120, 136, 16, dtype=torch.float64), hip_ops.zeros(3, 120, 136, 16)
+    ref_ops.upconv_fwd_bf16(x, ref_ops.pack_weights(w), b, y_r2, RG(5, 5, 1, 2), act=True, affine=aff, fmt=fmt)
+    hip_ops.upconv_fwd_bf16(x.float().to(dev), pk_g, b.float().to(dev), y_g2, ConvGeom(5, 5, 1, 2), act=True,
+                            affine=aff.float().to(dev), fmt=fmt)
+    assert rel_err(y_g2, y_r2) < 1e-4
+    assert rel_err(y_g2, y_g) < 1e-2        # the two roundings are both 16-bit approximations of the same layer
     x2 = torch.randn(2, 70, 50, 16, generator=gen, dtype=torch.float64).float().double()
     w2 = torch.randn(3, 3, 16, 2, generator=gen, dtype=torch.float64) * 0.2
     b2 = torch.randn(2, generator=gen, dtype=torch.float64)

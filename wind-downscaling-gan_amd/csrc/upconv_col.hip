@@ -115,8 +115,8 @@ extern "C" int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, f
 // pixel) is staged in LDS, reduced horizontally into H[12][16][C], and each thread adds its two vertical terms.
 template <int CQ>
 __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias,
-                                                                float* __restrict__ y, int ldy, long long isy, int Hl,
-                                                                int Wl, int act, float slope) {
+                                                                const float* __restrict__ affine, float* __restrict__ y,
+                                                                int ldy, long long isy, int Hl, int Wl, int act, float slope) {
     constexpr int ZW = TS + 4;                       // low-res window edge (12)
     constexpr int PX = 5 * CQ;                       // float4 per window pixel and tap row
     __shared__ f32x4 Z[ZW * ZW * PX];
@@ -204,25 +204,28 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
             }
+            if (affine)     // fused inference BatchNorm: scale | shift per channel after the activation
+                v = v * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * CQ + 4 * o4);
             *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
         }
     }
 }
 
-extern "C" int wdg_upconv_gather(const float* z, const float* bias, float* y, int ldy, int64_t img_stride_y, int n_img,
-                                 int Hl, int Wl, int C, int act, float slope, wdg_stream stream) {
+extern "C" int wdg_upconv_gather(const float* z, const float* bias, const float* affine, float* y, int ldy,
+                                 int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope,
+                                 wdg_stream stream) {
     WDG_CHECK_ARG(z && y && n_img > 0 && n_img < 65536 && Hl > 0 && Wl > 0 && ldy % 4 == 0, "bad argument");
     WDG_CHECK_ARG(wdg_upconv_col_supported(C), "channel count must be 4, 8 or 16");
-    WDG_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0, "z / y / bias must be 16-byte aligned");
+    WDG_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)affine & 15) == 0, "z / y / bias / affine must be 16-byte aligned");
     const int tiles = ((Hl + TS - 1) / TS) * ((Wl + TS - 1) / TS);
     dim3 grid(tiles, n_img), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (C == 16)
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
     else if (C == 8)
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
     else
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -298,6 +298,18 @@ class HipOps:
         px, ldl, isl = _v4(x_low)
         py, ldy, isy = _v4(y)
         n, H, W, _ = y.shape
+        if self.upconv_colfwd and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
+                x_low.shape[3] == pk.cout and pk.cout % 8 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
+                pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (affine is None or affine.data_ptr() % 16 == 0):
+            # column form with 16-bit GEMM operands: z = x * W (fp32 result), then the fp32 bilinear gather
+            z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin)
+            plan, _, _ = self._plan(z, x_low, 25 * pk.cin, pk.cout, ConvGeom(1, 1, 1, 0))
+            fn = self.lib.wdg_conv_dgrad_bf16 if fmt == "bf16" else self.lib.wdg_conv_dgrad_f16
+            native.check(fn(plan, x_low.data_ptr(), pk.half(fmt)[1].data_ptr(), 0, 0, z.data_ptr(), 0, slope, 0, self.stream),
+                         "conv_dgrad_16")
+            native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), _ptr(affine), py, ldy, isy, n, H // 2, W // 2,
+                                                    pk.cin, int(act), slope, self.stream), "upconv_gather")
+            return
         cp = (pk.cout + 3) // 4 * 4
         plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
         fn = self.lib.wdg_upconv_fwd_bf16 if fmt == "bf16" else self.lib.wdg_upconv_fwd_f16
@@ -316,7 +328,7 @@ class HipOps:
             # column form: z = x * W on the low-res grid (1x1 GEMM, 25*cin columns), then the bilinear gather
             z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin)
             self.conv_dgrad(x_low, pk.as_1x1(), z, ConvGeom(1, 1, 1, 0))
-            native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), py, ldy, isy, n, H // 2, W // 2, pk.cin,
+            native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), 0, py, ldy, isy, n, H // 2, W // 2, pk.cin,
                                                     int(act), slope, self.stream), "upconv_gather")
             return
         if self.upconv4 and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \

@@ -98,7 +98,7 @@ SIGNATURES = {
     "wdg_upsample2x_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upconv_col_supported": (i32, [i32]),
     "wdg_upconv_col": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, c_fp]),
-    "wdg_upconv_gather": (i32, [c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, f32, c_fp]),
+    "wdg_upconv_gather": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, f32, c_fp]),
     "wdg_patch_gather": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_patch_scatter": (i32, [c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
