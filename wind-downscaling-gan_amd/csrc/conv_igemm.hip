@@ -595,6 +595,7 @@ extern "C" int wdg_device_cus(void) {
 }
 
 static int g_tile160 = 1;
+static int g_tile80 = 2;     // 80-column tiles for column counts like 400 (no padding): 2 = 128x80 (75.56 -> 75.29 ms/step), 1 = 256x80 (slower)
 struct TileCfg {
     int BM, BN;
 };
@@ -614,6 +615,7 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
     // 160 columns (the generator's widest decoder layer): one 128 x 160 tile, five column fragments per wave,
     // instead of five 256 x 32 tiles (2.2 instead of 1.3 MFMAs per LDS fragment read)
     if (igemm && g_tile160 && ncols % 160 == 0) return TileCfg{128, 160};
+    if (igemm && g_tile80 && ncols % 80 == 0 && ncols >= 240) return TileCfg{g_tile80 == 2 ? 128 : 256, 80};
     static const TileCfg cand[4] = {{128, 128}, {128, 64}, {256, 32}, {256, 16}};
     int best = 1 << 30;
     for (auto& c : cand) best = std::min(best, wdg_round_up(ncols, c.BN));
@@ -840,6 +842,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         return WDG_OK;
     }
 
+    if (key && !strcmp(key, "tile80")) {
+        g_tile80 = value;
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "tile64")) {   // takes effect for plans created afterwards
         g_tile64 = value;
         return WDG_OK;
@@ -923,6 +929,8 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         else rc = launch_variant<BM_, BN_, WM_, WN_, 2>(grid, block, st, p);                            \
     }
     WDG_IGEMM_CASE(128, 160, 2, 2)
+    WDG_IGEMM_CASE(256, 80, 4, 1)
+    WDG_IGEMM_CASE(128, 80, 4, 1)
     WDG_IGEMM_CASE(128, 128, 2, 2)
     WDG_IGEMM_CASE(128, 64, 2, 2)
     WDG_IGEMM_CASE(64, 64, 2, 2)
