@@ -175,7 +175,7 @@ class TorchOps:
 
     upconv_colfwd = True    # mirrors HipOps.upconv_colfwd: which operand the 16-bit path rounds
 
-    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16"):
+    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16", pool=None):
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
         if self.upconv_colfwd and (g.kh, g.kw, g.stride, g.pad) == (5, 5, 1, 2) and pk.cout % 8 == 0 and pk.cin in (4, 8, 16):
             # column form: the 16-bit GEMM operands are the LOW-RES input and the weights; the bilinear interpolation
@@ -191,12 +191,12 @@ class TorchOps:
         self.upsample2x_fwd(x_low, up)
         self.conv_dgrad_bf16(up, pk, y, g, bias=bias, act=act, affine=affine, slope=slope, fmt=fmt)
 
-    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
+    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2, pool=None):
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
         self.upsample2x_fwd(x_low, up)
         self.conv_dgrad(up, pk, y, g, bias=bias, act=act, slope=slope)
 
-    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g):
+    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g, pool=None):
         """Backward of upconv_fwd as the reference's tape computes it: through the materialised upsampled tensor."""
         n, Hl, Wl, C = x_low.shape
         up = torch.zeros(n, 2 * Hl, 2 * Wl, C, dtype=x_low.dtype)
@@ -275,7 +275,8 @@ class TorchOps:
         saved[:C] = mean
         saved[C:] = inv
         mmean.mul_(momentum).add_(mean * (1 - momentum))
-        mvar.mul_(momentum).add_(var * (1 - momentum))
+        # the fused op's batch_variance (what Keras averages into moving_variance) is Bessel-corrected in TF 2.4
+        mvar.mul_(momentum).add_(var * (count / (count - 1.0) if count > 1 else 1.0) * (1 - momentum))
 
     def bn_finalize_infer(self, gamma, beta, mmean, mvar, eps, ss):
         C = gamma.numel()

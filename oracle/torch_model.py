@@ -95,7 +95,11 @@ def batch_norm(x, w, name, training, new_state):
         var = x.var(dims, unbiased=False)
         if new_state is not None:
             new_state[name + "/moving_mean"] = (w[name + "/moving_mean"] * BN_MOM + mean * (1 - BN_MOM)).detach()
-            new_state[name + "/moving_variance"] = (w[name + "/moving_variance"] * BN_MOM + var * (1 - BN_MOM)).detach()
+            # TF 2.4: 5-D input takes the fused op, whose batch_variance (averaged into moving_variance) is the
+            # Bessel-corrected one; the normalisation below uses the biased variance
+            n = x.numel() // x.shape[-1]
+            new_state[name + "/moving_variance"] = (w[name + "/moving_variance"] * BN_MOM
+                                                    + x.var(dims, unbiased=n > 1) * (1 - BN_MOM)).detach()
     else:
         mean, var = w[name + "/moving_mean"], w[name + "/moving_variance"]
     return (x - mean) / torch.sqrt(var + BN_EPS) * gamma + beta

@@ -183,3 +183,39 @@ def test_tile_plan_golden():
             assert got[k] == v, (case, k, got[k])
     with pytest.raises(RuntimeError):
         tile_plan(300, 90, 24, 0.05)
+
+
+def test_load_weights_is_strict_and_reports(cpu_backend, tmp_path):
+    """A checkpoint that lacks a variable of the model must not leave random weights behind silently (the reference's
+    Keras restore tracks unmatched objects): strict by default, explicit strict=False opt-out, unused keys reported."""
+    from downscaling.engine.tf_bundle import read_bundle, write_bundle
+    from downscaling.gan.models import make_generator
+    S, T = 8, 1
+    g = make_generator(S, 3, 2, 2, T, feature_channels=32)
+    g.save_weights(str(tmp_path / "full"))
+    full = read_bundle(str(tmp_path / "full"))
+    dropped = "layer_with_weights-3/moving_variance"
+    assert dropped in full
+    part = {k: v for k, v in full.items() if k != dropped}
+    part["layer_with_weights-99/layer/kernel"] = np.zeros((1, 1, 4, 4), np.float32)     # a key of some other graph
+    write_bundle(str(tmp_path / "part"), part)
+    g2 = make_generator(S, 3, 2, 2, T, feature_channels=32)
+    before = g2.get_weights_dict()
+    with pytest.raises(KeyError, match="moving_variance"):
+        g2.load_weights(str(tmp_path / "part"))
+    after = g2.get_weights_dict()
+    assert all(np.array_equal(before[k], after[k]) for k in before)                     # nothing was half-restored
+    with pytest.warns(UserWarning) as rec:
+        restored, missing, unused = g2.load_weights(str(tmp_path / "part"), strict=False)
+    assert missing == [dropped] and unused == ["layer_with_weights-99/layer/kernel"] and len(restored) == len(full) - 1
+    assert any("keep their current values" in str(w.message) for w in rec) and any("unused" in str(w.message) for w in rec)
+    restored, missing, unused = g2.load_weights(str(tmp_path / "full"))
+    assert not missing and not unused
+    # a bundle whose header / entries name a second data shard is read shard by shard, a missing shard is named
+    from downscaling.engine import tf_bundle
+    assert tf_bundle.read_num_shards(str(tmp_path / "full") + ".index") == 1
+    assert tf_bundle.read_num_shards(str(ROOT / "tests" / "golden" / "weights-55_generator.index")) == 1
+    with pytest.raises(FileNotFoundError, match="data-00000-of-00001"):
+        import shutil
+        shutil.copy(ROOT / "tests" / "golden" / "weights-55_generator.index", tmp_path / "blobless.index")
+        tf_bundle.read_bundle(str(tmp_path / "blobless"))

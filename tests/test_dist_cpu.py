@@ -46,9 +46,10 @@ def _worker(rank, port, outdir, sync_bn):
     g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
     for step in range(2):
         low, high = _data(rank, step)
-        eng.train_step(low, high, g_opt, d_opt)
+        logs = eng.train_step(low, high, g_opt, d_opt)
     torch.save({"g": {v.name: v.value.clone() for v in gen.params.vars},
-                "d": {v.name: v.value.clone() for v in disc.params.vars}, "seed": eng.noise.seed},
+                "d": {v.name: v.value.clone() for v in disc.params.vars}, "seed": eng.noise.seed,
+                "logs": {k: float(v) for k, v in logs.items() if v is not None}},
                os.path.join(outdir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -88,10 +89,45 @@ def test_two_rank_step_equals_global_batch_reference():
     draws = _GlobalDraws([x["seed"] for x in r])
     for step in range(2):
         lows, highs = zip(*[_data(rank, step) for rank in range(WORLD)])
-        TM.train_step(gw, dw, torch.cat(lows, 0), torch.cat(highs, 0), draws, og, od, n_critic=2)
+        ref_logs = TM.train_step(gw, dw, torch.cat(lows, 0), torch.cat(highs, 0), draws, og, od, n_critic=2)
     for net, w in (("g", gw), ("d", dw)):
         for k in w:
             assert rel_err(r[0][net][k], w[k]) < 1e-7, (net, k)
+    # the logged scalars are those of the GLOBAL batch on every rank (one small all-reduce; ganbase.py:75-81)
+    assert r[0]["logs"] == r[1]["logs"]
+    for k in ("g_loss", "g_disc_loss", "d_loss", "d_gradient_pen", "g_gradient_param", "d_gradient_param"):
+        assert abs(r[0]["logs"][k] - float(ref_logs[k])) < 1e-7 * max(1.0, abs(float(ref_logs[k]))), k
+
+
+def _gan_rank_worker(rank, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    from downscaling.engine import runtime
+    from downscaling.gan.ganbase import GAN
+    from downscaling.gan.models import make_discriminator, make_generator
+    from oracle.torch_backend import TorchOps
+    runtime.set_ops(TorchOps(torch.float64))
+    g, d = make_generator(S, CIN, NZ, CH, T, feature_channels=32), make_discriminator(S, S, CIN, CH, T, feature_channels=8)
+    # the caller forgot rank= (get_network does): GAN must key the seeded stream with its DistSync rank
+    gan = GAN(g, d, FlexibleNoiseGenerator((B_LOCAL, T, S, S, NZ), std=0.1, random_seed=7))
+    assert gan.noise_generator.rank == rank
+    noise = gan.noise_generator(bs=2)
+    torch.save({"noise": noise.clone(), "seed": gan.noise_generator.prng.seed}, os.path.join(outdir, f"noise{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gan_decorrelates_seeded_noise_across_ranks():
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_gan_rank_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+        r = [torch.load(os.path.join(out, f"noise{i}.pt")) for i in range(WORLD)]
+    assert r[0]["seed"] != r[1]["seed"]
+    a, b = r[0]["noise"].flatten(), r[1]["noise"].flatten()
+    assert not torch.equal(a, b)
+    assert abs(float(torch.corrcoef(torch.stack([a, b]))[0, 1])) < 0.2
 
 
 def _predict_worker(rank, port, outdir):

@@ -119,7 +119,11 @@ __global__ void wdg_bn_finalize_train_kernel(const double* stats, double count, 
     saved[c] = (float)mean;
     saved[C + c] = (float)invstd;
     mmean[c] = mmean[c] * momentum + (float)mean * (1.f - momentum);
-    mvar[c] = mvar[c] * momentum + (float)var * (1.f - momentum);
+    // TF 2.4 runs BatchNormalization on 5-D input through the fused op (ndims in (4, 5)), whose batch_variance output —
+    // the value Keras folds into moving_variance — carries Bessel's correction N / (N - 1); the normalisation itself
+    // uses the biased variance above.
+    const double var_unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    mvar[c] = mvar[c] * momentum + (float)var_unbiased * (1.f - momentum);
 }
 
 extern "C" int wdg_bn_finalize_train(const double* stats, double count, const float* gamma, const float* beta,

@@ -21,6 +21,18 @@ class FlexibleNoiseGenerator(object):
             self._prng = PhiloxSource(runtime.get_ops(), self.random_seed, self.rank)
         return self._prng
 
+    def set_rank(self, rank):
+        """Data-parallel rank of this process (GAN passes its DistSync rank): decorrelates the ranks' streams of one
+        `random_seed`.  Re-keys an already created, still unused source; refuses to re-key one that has been drawn from."""
+        rank = int(rank)
+        if rank == self.rank:
+            return
+        if self._prng is not None and self._prng.offset != 0:
+            raise RuntimeError("FlexibleNoiseGenerator.set_rank after noise has been drawn: the stream cannot be re-keyed")
+        self.rank = rank
+        if self._prng is not None and self.random_seed is not None:
+            self._prng = PhiloxSource(self._prng.ops, self.random_seed, rank)
+
     def __call__(self, bs=None, channels=None, std=None):
         bs = self.noise_shape[0] if bs is None else int(bs)
         t = self.noise_shape[1]

@@ -128,6 +128,7 @@ class _PrepBatch:
         native.check(ops.lib.wdg_prep_batch_create(C.byref(self.handle), arr, len(entries)), "prep_batch_create")
         self.scratch = ops.empty(max(int(ops.lib.wdg_prep_batch_scratch_floats(self.handle)), 4))
         self.any_sn = any(u is not None for _, u in entries)
+        self.epoch = 0      # bumped whenever run() rewrote weights / packed layouts (key of captured inference graphs)
 
     def run(self, sn, pack_all):
         flags = (native.PREP_SN if sn and self.any_sn else 0) | (native.PREP_PACK_ALL if pack_all else 0)
@@ -135,6 +136,7 @@ class _PrepBatch:
             return
         native.check(self.ops.lib.wdg_prep_batch_run(self.handle, self.scratch.data_ptr(), flags, self.ops.stream),
                      "prep_batch_run")
+        self.epoch += 1
         for pk, u in self.entries:
             if pack_all or (sn and u is not None):
                 pk._bf16_stale = True
@@ -294,7 +296,7 @@ class HipOps:
         native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
                         y.data_ptr(), int(act), slope, self.stream), "conv_halo_fwd_16")
 
-    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16"):
+    def upconv_fwd_bf16(self, x_low, pk, bias, y, g, act=True, affine=None, slope=0.2, fmt="bf16", pool=None):
         px, ldl, isl = _v4(x_low)
         py, ldy, isy = _v4(y)
         n, H, W, _ = y.shape
@@ -302,7 +304,7 @@ class HipOps:
                 x_low.shape[3] == pk.cout and pk.cout % 8 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
                 pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (affine is None or affine.data_ptr() % 16 == 0):
             # column form with 16-bit GEMM operands: z = x * W (fp32 result), then the fp32 bilinear gather
-            z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin)
+            z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin, pool=pool)
             plan, _, _ = self._plan(z, x_low, 25 * pk.cin, pk.cout, ConvGeom(1, 1, 1, 0))
             fn = self.lib.wdg_conv_dgrad_bf16 if fmt == "bf16" else self.lib.wdg_conv_dgrad_f16
             native.check(fn(plan, x_low.data_ptr(), pk.half(fmt)[1].data_ptr(), 0, 0, z.data_ptr(), 0, slope, 0, self.stream),
@@ -316,7 +318,7 @@ class HipOps:
         native.check(fn(plan, px, ldl, isl, pk.half(fmt)[1].data_ptr(), _ptr(bias), _ptr(affine),
                         py, int(act), slope, self.stream), "upconv_fwd_16")
 
-    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2):
+    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2, pool=None):
         """y = act(convT(bilinear_x2(x_low), W) + bias) without materialising the upsampled tensor.
         pk/g describe the transposed conv as the conv it is the adjoint of (cin = y channels)."""
         px, ldl, isl = _v4(x_low)
@@ -326,7 +328,7 @@ class HipOps:
                 x_low.shape[3] == pk.cout and pk.cout % 4 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
                 pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0):
             # column form: z = x * W on the low-res grid (1x1 GEMM, 25*cin columns), then the bilinear gather
-            z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin)
+            z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin, pool=pool)
             self.conv_dgrad(x_low, pk.as_1x1(), z, ConvGeom(1, 1, 1, 0))
             native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), 0, py, ldy, isy, n, H // 2, W // 2, pk.cin,
                                                     int(act), slope, self.stream), "upconv_gather")
@@ -342,13 +344,18 @@ class HipOps:
         native.check(self.lib.wdg_upconv_fwd(plan, px, ldl, isl, pk.wD.data_ptr(), _ptr(bias), py, int(act), slope,
                                              self.stream), "upconv_fwd")
 
-    def _scratch(self, key, *shape):
-        t = self._scratch_bufs.get(key)
+    def _scratch(self, key, *shape, pool=None):
+        """Scratch tensor of the caller's `pool` (a dict the caller owns).  Networks pass the dict that lives in their
+        resident buffer set, next to the HIP graphs captured on those buffers: a captured graph bakes the scratch address
+        in, so the scratch must live and die with the graphs, and a second live network (other image size / T) must not
+        be able to free it.  Without a pool: the process-wide one (eager callers only)."""
+        pool = self._scratch_bufs if pool is None else pool
+        t = pool.get(key)
         if t is None or tuple(t.shape) != tuple(shape):
-            t = self._scratch_bufs[key] = self.empty(*shape)
+            t = pool[key] = self.empty(*shape)
         return t
 
-    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g):
+    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g, pool=None):
         """Backward of y = convT(bilinear_x2(x_low), W) given dpre = dL/dy (before bias/activation):
         dw += dL/dW, dx_low = dL/dx_low.  pk/g as in upconv_fwd.  5x5 layers with 4/8/16 output channels run in
         column form on the low-res grid (csrc/upconv_col.hip: a quarter of the multiply-adds); anything else
@@ -358,14 +365,14 @@ class HipOps:
         if self.upconv_col and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
                 C == pk.cout and pk.cout % 4 == 0 and lib.wdg_upconv_col_supported(pk.cin) and pk.wD is pk.w:
             pdy, lddy, isdy = _v4(dpre)
-            col = self._scratch("upc_col", n, Hl, Wl, 25 * pk.cin)
+            col = self._scratch("upc_col", n, Hl, Wl, 25 * pk.cin, pool=pool)
             native.check(lib.wdg_upconv_col(pdy, lddy, isdy, col.data_ptr(), n, Hl, Wl, pk.cin, self.stream), "upconv_col")
             pk1, g1 = pk.as_1x1(), ConvGeom(1, 1, 1, 0)
             self.conv_fwd(col, pk1, None, dx_low, g1, act=False)
             self.conv_wgrad(col, x_low, pk1, dw.view(1, 1, 25 * pk.cin, pk.cout), g1, accumulate=True)
             return
-        up = self._scratch("upc_up", n, 2 * Hl, 2 * Wl, C)
-        dup = self._scratch("upc_dup", n, 2 * Hl, 2 * Wl, C)
+        up = self._scratch("upc_up", n, 2 * Hl, 2 * Wl, C, pool=pool)
+        dup = self._scratch("upc_dup", n, 2 * Hl, 2 * Wl, C, pool=pool)
         self.upsample2x_fwd(x_low, up)
         self.conv_wgrad(dpre, up, pk, dw, g, accumulate=True)
         self.conv_fwd(dpre, pk, None, dup, g, act=False)

@@ -138,6 +138,12 @@ class GeneratorNet(_Net):
             )
         return self._grad_bufs
 
+    @staticmethod
+    def _scratch_pool(b):
+        """Operator scratch (the column tensor of the upsample + transposed-conv block) owned by THIS buffer set, like the
+        graphs captured on it: see HipOps._scratch."""
+        return b.setdefault("scratch", {})
+
     # ---- inputs ------------------------------------------------------------------------------------
     def set_image(self, image):
         """image [B,T,S,S,in] -> channels [0:in] of the concatenated input buffer (models.py:28)."""
@@ -170,7 +176,10 @@ class GeneratorNet(_Net):
         self._graphs = graphs
         if not getattr(self.ops, "supports_graphs", False) or getattr(self, "_graphs_disabled", False):
             return self.forward(B, training=False, precision=precision)
-        key = (B, precision, self.params.version)
+        # weights version + prep epoch: a training-mode forward (SN power iteration, no optimizer step) rewrites w and the
+        # packed fp32 layouts in place, but the 16-bit copies / composite kernels are reconverted lazily on the HOST path
+        # only — a graph captured before must not be replayed on them
+        key = (B, precision, self.params.version, self._prep.epoch if self._prep is not None else 0)
         entry = graphs.get(key)
         if entry is None:
             # capture pays off only for repeated calls: the first two forwards of a configuration run eagerly (they also
@@ -189,7 +198,7 @@ class GeneratorNet(_Net):
                 torch.cuda.synchronize()
                 self._graphs_disabled = True
                 return self.forward(B, training=False, precision=precision)
-            for k in [k for k in graphs if isinstance(k, tuple) and k[2] != self.params.version]:
+            for k in [k for k in graphs if isinstance(k, tuple) and k[2:] != key[2:]]:
                 del graphs[k]                                             # graphs of older weights
             seen.clear()
             entry = graphs[key] = (graph, out)
@@ -220,7 +229,7 @@ class GeneratorNet(_Net):
             self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
             self.c7.forward_bf16(b["cat4"], b["cat2"][..., :F // 4], affine=self.bn8.infer_affine(), fmt=f)
             self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
-                                     affine=self.bn10.infer_affine(), fmt=f)
+                                     affine=self.bn10.infer_affine(), fmt=f, pool=self._scratch_pool(b))
             self.ops.conv_halo_fwd_bf16(b["z9"], self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
             return b["out"]
         if precision != "fp32":
@@ -234,7 +243,8 @@ class GeneratorNet(_Net):
         self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), training)
         self.c7.forward(b["cat4"], b["y7"])
         self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), training)
-        self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True)       # :62-64 fused
+        self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True,      # :62-64 fused
+                            pool=self._scratch_pool(b))
         self.bn10.forward(v2(b["y9"]), v2(b["z9"]), training)
         self.c11.forward(b["z9"], b["out"])
         return b["out"]
@@ -252,7 +262,8 @@ class GeneratorNet(_Net):
         self.c11.backward_input(dout, g["dz9"])
         # bn10 + LeakyReLU of c9
         self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad)
-        o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g)   # :60-64 backward
+        o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g,   # :60-64 backward
+                     pool=self._scratch_pool(b))
         # bn8 + c7
         d7 = g["dcat2"][..., :F // 4]
         self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad)

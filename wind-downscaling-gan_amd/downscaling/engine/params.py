@@ -90,15 +90,25 @@ class ParamStore:
         return {v.name: v.value.detach().double().cpu().numpy().astype(np.float32) for v in self.vars}
 
     def set_weights(self, mapping, strict=True):
+        """Copies `mapping[name]` into every variable it names.  Returns (restored, missing, unused): variable names
+        that were set, variables of this network absent from the mapping, and mapping keys that name no variable.
+        strict=True raises KeyError when anything is missing (BEFORE touching any value); shape clashes always raise."""
+        names = {v.name for v in self.vars}
+        missing = [v.name for v in self.vars if v.name not in mapping]
+        unused = [k for k in mapping if k not in names]
+        if strict and missing:
+            raise KeyError(f"{len(missing)} variable(s) not in the checkpoint / mapping: {missing[:6]}"
+                           + (" ..." if len(missing) > 6 else ""))
+        for v in self.vars:
+            if v.name in mapping and tuple(np.asarray(mapping[v.name]).shape) != v.shape:
+                raise ValueError(f"{v.name}: shape {np.asarray(mapping[v.name]).shape} != {v.shape}")
+        restored = []
         for v in self.vars:
             if v.name in mapping:
-                arr = np.asarray(mapping[v.name])
-                if tuple(arr.shape) != v.shape:
-                    raise ValueError(f"{v.name}: shape {arr.shape} != {v.shape}")
-                v.value.copy_(self.ops.from_host(arr).view(v.shape))
-            elif strict:
-                raise KeyError(f"missing variable {v.name}")
+                v.value.copy_(self.ops.from_host(np.asarray(mapping[v.name])).view(v.shape))
+                restored.append(v.name)
         self.version += 1
+        return restored, missing, unused
 
 
 # ---- Keras default initialisers -------------------------------------------------------------------

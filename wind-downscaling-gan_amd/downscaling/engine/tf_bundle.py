@@ -89,20 +89,50 @@ def read_index(index_path):
     return out
 
 
+def read_num_shards(index_path):
+    """BundleHeaderProto.num_shards (field 1) of the entry with the empty key; 1 when absent."""
+    data = open(index_path, "rb").read()
+    footer = data[-48:]
+    i = 0
+    _, i = _varint(footer, i)
+    _, i = _varint(footer, i)
+    ioff, i = _varint(footer, i)
+    isize, i = _varint(footer, i)
+    for _, handle in _block(data, ioff, isize):
+        j = 0
+        boff, j = _varint(handle, j)
+        bsize, j = _varint(handle, j)
+        for key, val in _block(data, boff, bsize):
+            if key == b"":
+                return int(_proto(val).get(1, [1])[0]) or 1
+    return 1
+
+
 def read_bundle(prefix, include_optimizer_slots=False):
-    """{variable name: numpy array} (names stripped of '/.ATTRIBUTES/VARIABLE_VALUE')."""
+    """{variable name: numpy array} (names stripped of '/.ATTRIBUTES/VARIABLE_VALUE').  Every entry is read from the
+    data shard its BundleEntryProto names (`<prefix>.data-<shard_id>-of-<num_shards>`); a missing shard file raises
+    FileNotFoundError naming it."""
     prefix = str(prefix)
     entries = read_index(prefix + ".index")
-    out = {}
-    with open(prefix + ".data-00000-of-00001", "rb") as f:
+    num_shards = read_num_shards(prefix + ".index")
+    out, files = {}, {}
+    try:
         for key, dt, shape, shard, off, size in entries:
             if not key.endswith(_SUFFIX) or dt not in _DTYPES:
                 continue
             if ".OPTIMIZER_SLOT" in key and not include_optimizer_slots:
                 continue
+            if not 0 <= shard < num_shards:
+                raise ValueError(f"{prefix}.index: entry {key!r} names shard {shard} of {num_shards}")
+            f = files.get(shard)
+            if f is None:
+                f = files[shard] = open(f"{prefix}.data-{shard:05d}-of-{num_shards:05d}", "rb")
             f.seek(off)
             arr = np.frombuffer(f.read(size), dtype=_DTYPES[dt]).reshape(shape).copy()   # writable, detached from the buffer
             out[key[:-len(_SUFFIX)]] = arr
+    finally:
+        for f in files.values():
+            f.close()
     return out
 
 

@@ -128,6 +128,25 @@ class GanEngine:
             finish()
             opt.apply_gradients(net.params, grad_scale=scale)
 
+    # keys whose value is a mean over THIS rank's batch shard; the gradient-norm metrics are formed from the all-reduced
+    # gradients and are global already
+    _SHARD_MEANS = ("g_loss", "g_disc_loss", "g_reco_loss", "d_loss", "d_gradient_pen", "_d_loss_train", "_d_real",
+                    "_d_fake", "loss")
+
+    def _reduce_metrics(self, res):
+        """ganbase.py:75-81 logs losses of the WHOLE batch.  Under batch data-parallelism every rank holds the mean over
+        its equal-sized shard, so the global value is the mean over ranks: one small all-reduce of the stacked scalars
+        (SURVEY 8e), after which every rank returns identical logs."""
+        if self.sync is None or self.sync.world_size == 1:
+            return res
+        keys = [k for k in self._SHARD_MEANS if res.get(k) is not None]
+        vec = torch.stack([res[k].reshape(()) for k in keys])
+        self.sync.all_reduce_sum(vec)
+        vec /= self.sync.world_size
+        for i, k in enumerate(keys):
+            res[k] = vec[i]
+        return res
+
     def _grad_param_metric(self, net, scale):
         st = net.params
         self.ops.segment_meansq(st.grads, st.seg_pairs, st.seg_out)
@@ -204,7 +223,7 @@ class GanEngine:
         fake_scores = disc.forward(B, training=False)
         fake_mean = fake_scores.mean()
         self.last_fake_tm = fake
-        return {
+        return self._reduce_metrics({
             "g_loss": -fake_mean,
             "g_disc_loss": gen_disc_loss,
             "g_reco_loss": reco_loss,
@@ -215,7 +234,7 @@ class GanEngine:
             "_d_loss_train": disc_loss,
             "_d_real": real_mean,
             "_d_fake": fake_mean,
-        }
+        })
 
     def _reco_grad(self, reconstruction_loss, low, fake_tm, B, T):
         """User-supplied reconstruction loss (train.py:19-26) evaluated with torch autograd on a leaf
@@ -246,4 +265,4 @@ class GanEngine:
         fake = gen.forward(B, training=False)
         disc.set_high_tm(fake, B)
         fake_mean = disc.forward(B, training=False).mean()
-        return {"loss": fake_mean - real_mean}
+        return self._reduce_metrics({"loss": fake_mean - real_mean})

@@ -38,6 +38,10 @@ class GAN:
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if distributed:
             sync = DistSync()
+            # every rank must draw its OWN generator noise / gradient-penalty eps / instance noise: key the Philox stream
+            # of a seeded generator with the rank (an unseeded one takes a fresh os.urandom seed per process)
+            if hasattr(noise_generator, "set_rank"):
+                noise_generator.set_rank(sync.rank)
         self.engine = GanEngine(generator.net, discriminator.net, noise_generator.prng, noise_generator.std,
                                 n_critic=n_critic, sync=sync, sync_bn=sync_bn)
 

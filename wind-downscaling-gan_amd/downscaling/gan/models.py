@@ -91,7 +91,7 @@ class _Model:
         return self.net.params.get_weights()
 
     def set_weights_dict(self, mapping, strict=True):
-        self.net.params.set_weights(mapping, strict=strict)
+        return self.net.params.set_weights(mapping, strict=strict)
 
     def save_weights(self, filepath, overwrite=True, save_format=None, **kwargs):
         """Keras `Model.save_weights(prefix)` of the reference (ganbase.py:132-135) writes the TF tensor-bundle format
@@ -108,17 +108,32 @@ class _Model:
         from downscaling.engine.tf_bundle import write_bundle
         write_bundle(filepath, self.get_weights_dict())
 
-    def load_weights(self, filepath, *args, **kwargs):
+    def load_weights(self, filepath, *args, strict=True, **kwargs):
+        """Keras `load_weights(prefix)` (ganbase.py:137-140) from `<prefix>.index` + data shards (TF tensor bundle) or
+        `<prefix>.npz`.  strict (default): every variable of this model must be in the checkpoint — a foreign or
+        partly matching checkpoint raises KeyError instead of leaving randomly initialised weights behind; checkpoint
+        keys that name no variable are reported with a warning (the shipped discriminator checkpoint holds
+        `layer_with_weights-11..13` of the shortcut variant, for example).  strict=False restores what matches.
+        Returns (restored, missing, unused) name lists."""
+        import warnings
         filepath = os.fspath(filepath)
         if os.path.exists(filepath + ".npz"):
             with np.load(filepath + ".npz") as z:
-                self.set_weights_dict({k.replace("|", "/"): z[k] for k in z.files})
-            return
-        if os.path.exists(filepath + ".index"):
+                mapping = {k.replace("|", "/"): z[k] for k in z.files}
+        elif os.path.exists(filepath + ".index"):
             from downscaling.engine.tf_bundle import read_bundle
-            self.set_weights_dict(read_bundle(filepath), strict=False)
-            return
-        raise FileNotFoundError(f"no checkpoint at {filepath}(.npz|.index)")
+            mapping = {k: v for k, v in read_bundle(filepath).items() if not k.startswith(("optimizer", "save_counter"))}
+        else:
+            raise FileNotFoundError(f"no checkpoint at {filepath}(.npz|.index)")
+        restored, missing, unused = self.set_weights_dict(mapping, strict=strict)
+        if missing:
+            warnings.warn(f"{self.name}.load_weights({filepath!r}): {len(missing)} variable(s) keep their current values: "
+                          f"{missing[:6]}{' ...' if len(missing) > 6 else ''}")
+        if unused:
+            warnings.warn(f"{self.name}.load_weights({filepath!r}): {len(unused)} checkpoint value(s) unused: "
+                          f"{unused[:6]}{' ...' if len(unused) > 6 else ''}")
+        self.last_load_report = dict(restored=restored, missing=missing, unused=unused)
+        return restored, missing, unused
 
 
 class Generator(_Model):
