@@ -131,9 +131,71 @@ def cpu_baseline(batch=4):
     for _ in range(nsteps):
         TM.train_step(gw, dw, low, high, draws, og, od)
     dt = time.perf_counter() - t0
-    return {"value": nsteps * batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} full GAN train steps (n_critic=3), batch {batch}, {S}x{S}, T={T}, torch-CPU fp32 restatement "
-                      f"(oracle/torch_model.py; TensorFlow is not installable here), {dt:.1f} s"}
+    out = {"value": nsteps * batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"{nsteps} full GAN train steps (n_critic=3), batch {batch}, {S}x{S}, T={T}, torch-CPU fp32 restatement "
+                     f"(oracle/torch_model.py; TensorFlow is not installable here), {dt:.1f} s"}
+    # BASELINE configs[0] (the reference's own CPU-runnable case): generator-only forward of G(128, T=1) on one
+    # 16x16 ERA5 patch (x8 nearest) + 128x128 DEM, batch 1, 3 warm-up + 10 timed iterations
+    gen = GeneratorNet(ops, 128, CIN, NZ, CH, 1, seed=1)
+    gw0 = {v.name: v.value.clone() for v in gen.params.vars}
+    del gen
+    wind = np.repeat(np.repeat(np.random.default_rng(0).standard_normal((1, 1, 16, 16, 2)), 8, axis=2), 8, axis=3)
+    image = torch.from_numpy(np.concatenate([wind, np.random.default_rng(1).standard_normal((1, 1, 128, 128, 1))], -1).astype(np.float32))
+    noise = torch.from_numpy((0.1 * np.random.default_rng(2).standard_normal((1, 1, 128, 128, NZ))).astype(np.float32))
+    with torch.no_grad():
+        for _ in range(3):
+            TM.generator_forward(gw0, image, noise, False)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            TM.generator_forward(gw0, image, noise, False)
+        dt0 = (time.perf_counter() - t0) / 10
+    out["configs0_generator_forward_128"] = {"ms_per_forward": 1e3 * dt0, "samples_per_s": 1.0 / dt0, "cores": cores, "kind": "port",
+                                             "sample": "G(128,3,20,2,T=1) forward, batch 1, 3 warm-up + 10 timed, torch-CPU fp32 restatement"}
+    return out
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (sorted csrc/*.hip, *.h): ties profiles/pmc_traffic.json to the code it measured
+    (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "wind-downscaling-gan_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def generator_leg(generator, gan, dev, batch=64, warm=3, iters=10):
+    """The north star's "generator conv stack at batch 64" figure inside the default bench line: inference-mode forward
+    of G(256,3,20,2,T=1) on 64 synthetic tiles with fresh Philox noise each step (inputs resident in HBM), timed with
+    HIP events over `iters` forwards.  frac_algorithmic prices the reference layer's FLOPs (22.385 GFLOP per sample, SURVEY
+    8d); frac_executed only the multiply-adds the kernels execute — the upsample + 5x5 transposed-conv block runs in column
+    form on the low-resolution grid (2*160*400 FLOP per low-res pixel instead of 2*25*160*16 per output pixel)."""
+    net = generator.net
+    low, _ = synthetic_batch(batch, 77, dev)
+    net.set_image(low)
+
+    def step():
+        gan.noise_generator.prng.normal_into(net.noise_view(batch), 0.1)
+        return net.forward(batch, training=False)
+    for _ in range(warm):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    gf_alg = 22.385e9
+    up_alg, up_exec = 2.0 * 25 * 160 * 16 * S * S, 2.0 * 160 * 400 * (S // 2) * (S // 2)
+    gf_exec = gf_alg - up_alg + up_exec
+    return {"ms": ms, "batch": batch, "samples_per_s": batch / ms * 1e3,
+            "tflops_algorithmic": gf_alg * batch / ms * 1e-9, "frac_algorithmic": gf_alg * batch / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS,
+            "tflops_executed": gf_exec * batch / ms * 1e-9, "frac_executed": gf_exec * batch / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS,
+            "peak_tflops": PEAK_F32_MFMA_TFLOPS, "iters": iters, "warmup": warm,
+            "note": "whole forward incl. noise generation, norms, ConvLSTM cell; target of BASELINE.json: >= 0.50"}
 
 
 def bench_generator_forward(args, generator, gan, low, world, rank, dev):
@@ -185,6 +247,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-generator-leg", action="store_true", help="skip the generator-forward-at-batch-64 leg of the default line")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp16"], default="fp32", help="gen_fwd only: inference precision")
     ap.add_argument("--workload", choices=["train", "gen_fwd"], default="train",
                     help="train: the headline GAN train step (default); gen_fwd: generator-only forward (inference "
@@ -213,8 +276,12 @@ def main():
     backend = os.environ.get("WDG_DIST_BACKEND", "nccl")
     dev_index = int(os.environ.get("WDG_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # WDG_DIST_ALWAYS=1 with --gpus 1: a one-rank RCCL group, so the exchange code path (async all-reduce, deferred Adam,
+    # SyncBN, metric reduce) runs on real collectives on a single-GPU box (functional check, not the headline)
+    dist_on = world > 1 or os.environ.get("WDG_DIST_ALWAYS", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
         else:
@@ -236,7 +303,7 @@ def main():
     generator = make_generator(S, CIN, NZ, CH, T)
     discriminator = make_discriminator(S, S, CIN, CH, T)
     gan = GAN(generator, discriminator, FlexibleNoiseGenerator((B, T, S, S, NZ), std=0.1, random_seed=1234, rank=rank),
-              n_critic=3, distributed=world > 1, sync_bn=not args.no_sync_bn)
+              n_critic=3, distributed=dist_on, sync_bn=not args.no_sync_bn)
     gan.compile(generator_optimizer=train.generator_optimizer(), discriminator_optimizer=train.discriminator_optimizer(),
                 discriminator_loss=train.discriminator_loss)
     low, high = synthetic_batch(B, 10 + rank, dev)
@@ -290,7 +357,7 @@ def main():
                                    f"metrics recompute) on G({S},3,20,2,T={T})+D({S},{S},3,2,T={T})" +
                                    (", configs[1]" if headline else " (not the headline configuration)"),
                        "per_gpu_batch": B, "global_batch": world * B, "image_size": S, "n_timesteps": T,
-                       "parallelism": f"dp{world}" + ("" if args.no_sync_bn or world == 1 else "+syncbn")},
+                       "parallelism": f"dp{world}" + ("" if args.no_sync_bn or not dist_on else "+syncbn")},
             "step_tflops_algorithmic": step_flops * 1e-12 if headline else None,
             "step_frac_of_mfma_f32_peak": step_flops / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12) if headline else None,
             "roofline": {"bound": "mfma", "kernel": dom[0],
@@ -305,14 +372,23 @@ def main():
             "losses": {k: float(v) for k, v in logs.items() if v is not None},
         }
         # HBM traffic of the dominant kernel comes from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes
-        # (counters cannot be read inside this process); the committed summary is attached when it names the
-        # same kernel.
+        # (counters cannot be read inside this process); the committed summary is attached only when it was collected
+        # on THESE kernel sources (hash of csrc/) for the same kernel and the same number of launches per step —
+        # otherwise `traffic` stays null rather than quoting a stale number.
         tj = ROOT / "profiles" / "pmc_traffic.json"
         if tj.exists():
             t = json.loads(tj.read_text())
-            if t.get("kernel") == dom[0]:
+            same = (t.get("kernel") == dom[0] and t.get("csrc_sha256") == csrc_hash()
+                    and t.get("launches_per_step") == dom[1][2] / args.steps)
+            if same:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
+            else:
+                out["roofline"]["traffic_note"] = ("profiles/pmc_traffic.json was collected on other kernel sources / another "
+                                                   "launch mix (kernel %s, %s launches per step) — not quoted" %
+                                                   (t.get("kernel"), t.get("launches_per_step")))
+        if headline and world == 1 and not args.no_generator_leg:
+            out["generator_fwd_b64"] = generator_leg(generator, gan, dev)
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -1,8 +1,11 @@
 """Inference driver with the reference names and defaults
-(/root/reference/src/downscaling/api.py:21-160): constants, get_network, the tiled `predict`
-(tile plan, per-tile latitude flip, normalisation, groups of 16, 2-px crop, mean blend) and the
-xarray-facing `downscale` wrappers.  The array core (`tile_plan`, `predict_array`) is plain numpy so it
-runs where xarray / netCDF4 / rasterio are absent; the generator calls run on the HIP kernels."""
+(/root/reference/src/downscaling/api.py:21-160): constants, get_network, the tiled `predict` (tile plan, per-tile
+latitude flip, normalisation, groups of 16, 2-px crop, mean blend) and the `downscale` wrappers around it.
+
+The reference carries its grids in xarray Datasets and reads netCDF / GeoTIFF through xarray + rasterio, none of which
+exist in the GPU image.  Here the grids are `downscaling.io.GridDataset` objects (labelled numpy arrays; xarray objects
+passed in are converted), the files are read by `downscaling.io` (NetCDF-3 via scipy, .npz, a built-in GeoTIFF reader),
+and the array core (`tile_plan`, `predict_array`) runs on the generator's device from upload to blended result."""
 import math
 import os
 from pathlib import Path
@@ -13,6 +16,7 @@ from downscaling.data.data_generator import FlexibleNoiseGenerator
 from downscaling.gan import train, metrics
 from downscaling.gan.ganbase import GAN
 from downscaling.gan.models import make_generator, make_discriminator
+from downscaling.io import GridDataset
 
 WEIGHTS_PATH = (Path(__file__) / '../weights-55.ckpt').resolve()
 SEQUENCE_LENGTH = 24
@@ -22,77 +26,88 @@ NOISE_CHANNELS = 20
 NOISE_STD = 0.1
 NB_INPUTS = 3
 NB_OUTPUTS = 2
+# api.py:47-48: the high-resolution template has 26 x / 18 x the ERA5 points per latitude / longitude
+UPSAMPLING = {'latitude': 26, 'longitude': 18}
 
 __all__ = ['WEIGHTS_PATH', 'SEQUENCE_LENGTH', 'IMG_SIZE', 'BATCH_SIZE', 'NOISE_CHANNELS', 'NOISE_STD', 'NB_INPUTS',
            'NB_OUTPUTS', 'process_topo', 'process_era5', 'build_high_res_template_from_era5', 'get_network',
            'predict', 'downscale', 'tile_plan', 'predict_array', 'GAN', 'make_generator', 'make_discriminator',
-           'FlexibleNoiseGenerator']
+           'FlexibleNoiseGenerator', 'GridDataset']
 
 
-def _xr():
-    try:
-        import xarray as xr
-        return xr
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("the xarray-facing wrappers need xarray (+ netCDF4 / rasterio); "
-                          "use predict_array() on numpy fields instead") from e
-
-
-def process_topo(raster_topo, high_res_template):
-    xr = _xr()
-    lon_coord, lat_coord = [c for c in high_res_template.coords if c.startswith('lon')][0], [c for c in high_res_template.coords if c.startswith('lat')][0]
-    dem = raster_topo.isel(band=0, drop=True)
-    inputs_topo = xr.DataArray(dem, coords=dem.coords, name='elevation').to_dataset().sel(
-        x=high_res_template.get(lon_coord), y=high_res_template.get(lat_coord), method='nearest').drop(['x', 'y'])
-    return inputs_topo
-
-
-def process_era5(ds_era5, high_res_template):
-    lon_coord, lat_coord = [c for c in high_res_template.coords if c.startswith('lon')][0], [c for c in high_res_template.coords if c.startswith('lat')][0]
-    inputs_surface = ds_era5[['u10', 'v10']].sel(longitude=high_res_template.get(lon_coord), latitude=high_res_template.get(lat_coord), method='nearest').drop(['longitude', 'latitude'])
-    return inputs_surface
+def _axis_name(names, *prefixes):
+    """First name starting with one of the prefixes (the reference finds 'lon_1' / 'lat_1' / 'x' / 'y' this way)."""
+    for n in names:
+        if str(n).startswith(prefixes):
+            return n
+    raise KeyError(f"no coordinate starting with {prefixes} among {list(names)}")
 
 
 def build_high_res_template_from_era5(ds_era5, range_lon=None, range_lat=None):
-    upsampling_lat = 26
-    upsampling_lon = 18
-    if not range_lon:
-        range_lon = (float(ds_era5.longitude.min()), float(ds_era5.longitude.max()))
-    else:
-        ds_era5 = ds_era5.sel(longitude=slice(range_lon[0], range_lon[1]))
-    if not range_lat:
-        range_lat = (float(ds_era5.latitude.min()), float(ds_era5.latitude.max()))
-    else:
-        ds_era5 = ds_era5.sel(latitude=slice(range_lat[1], range_lat[0]))
-    nb_lon = ds_era5.dims['longitude']
-    nb_lat = ds_era5.dims['latitude']
-    new_longitudes = np.linspace(range_lon[0], range_lon[1], upsampling_lon * nb_lon)
-    new_latitudes = np.linspace(range_lat[0], range_lat[1], upsampling_lat * nb_lat)
-    high_res_template = ds_era5.coords.to_dataset().assign_coords({'lon_1': new_longitudes, 'lat_1': new_latitudes}).drop(['longitude', 'latitude'])
-    return high_res_template
+    """api.py:46-62: the target grid.  Per axis: the requested range (or the whole ERA5 extent) is covered by
+    UPSAMPLING[axis] x (number of ERA5 points inside the range) evenly spaced points, end points included; the result
+    keeps the dataset's other coordinates (time) and names the new axes 'lon_1' / 'lat_1'."""
+    ds = GridDataset.from_xarray(ds_era5)
+    axes = {}
+    for axis, rng in (('longitude', range_lon), ('latitude', range_lat)):
+        coord = ds.coords[axis]
+        if rng:
+            lo, hi = float(rng[0]), float(rng[1])
+            # label slice in the coordinate's own direction: longitudes ascend, ERA5 latitudes descend (api.py:53,57)
+            inside = ds.sel_range(axis, lo, hi) if axis == 'longitude' else ds.sel_range(axis, hi, lo)
+            count = len(inside.coords[axis])
+        else:
+            lo, hi, count = float(coord.min()), float(coord.max()), len(coord)
+        axes[axis] = np.linspace(lo, hi, UPSAMPLING[axis] * count)
+    coords = {k: v for k, v in ds.coords.items() if k not in axes}
+    coords.update(lon_1=axes['longitude'], lat_1=axes['latitude'])
+    return GridDataset(coords)
+
+
+def process_era5(ds_era5, high_res_template):
+    """api.py:40-43: the 10 m wind components at the ERA5 grid point nearest to every template point."""
+    ds, tpl = GridDataset.from_xarray(ds_era5), GridDataset.from_xarray(high_res_template)
+    lon, lat = _axis_name(tpl.coords, 'lon'), _axis_name(tpl.coords, 'lat')
+    winds = GridDataset(ds.coords, {v: ds.variables[v] for v in ('u10', 'v10')})
+    return winds.sel_nearest(rename={'longitude': lon, 'latitude': lat}, longitude=tpl.coords[lon], latitude=tpl.coords[lat])
+
+
+def process_topo(raster_topo, high_res_template):
+    """api.py:31-37: band 0 of the DEM raster, as 'elevation', at the raster pixel nearest to every template point."""
+    dem, tpl = GridDataset.from_xarray(raster_topo), GridDataset.from_xarray(high_res_template)
+    lon, lat = _axis_name(tpl.coords, 'lon'), _axis_name(tpl.coords, 'lat')
+    name = next(iter(dem.variables))
+    dims, arr = dem.variables[name]
+    if 'band' in dims:
+        arr = np.take(arr, 0, axis=dims.index('band'))
+        dims = tuple(d for d in dims if d != 'band')
+    band0 = GridDataset({k: dem.coords[k] for k in dims}, {'elevation': (dims, arr)})
+    return band0.sel_nearest(rename={'x': lon, 'y': lat}, x=tpl.coords[lon], y=tpl.coords[lat])
+
+
+# (metric constructors, in the order api.py:77-81 lists them)
+_GENERATOR_METRICS = ('AngularCosineDistance', 'LogSpectralDistance', 'WeightedRMSEForExtremes', 'WindSpeedWeightedRMSE',
+                      'SpatialKS')
 
 
 def get_network(weights_path=WEIGHTS_PATH, allow_random_init=None, random_seed=None):
-    """Builds G(96,3,20,2,T=24) / D and the compiled GAN exactly as api.py:65-86 and loads the checkpoint.
-    The shipped weights-55.ckpt blobs are absent from the reference tree (.MISSING_LARGE_BLOBS); unless
-    `allow_random_init` (or DOWNSCALING_ALLOW_RANDOM_INIT=1) is set a missing checkpoint raises, as the
-    reference's load_weights would."""
+    """The shipped network (api.py:65-86): generator and discriminator on 96 x 96 tiles of 24 time steps, 3 inputs
+    (u10, v10, elevation), 20 noise channels of std 0.1, compiled with the Adam pair of gan/train.py and the five
+    generator metrics, then restored from weights-55.ckpt.
+    The checkpoint blobs are absent from the reference tree (.MISSING_LARGE_BLOBS): a missing checkpoint raises, as the
+    reference's load_weights would, unless `allow_random_init` (or DOWNSCALING_ALLOW_RANDOM_INIT=1) is set."""
     print('Loading network...')
-    generator = make_generator(image_size=IMG_SIZE, in_channels=NB_INPUTS,
-                               noise_channels=NOISE_CHANNELS, out_channels=NB_OUTPUTS,
-                               n_timesteps=SEQUENCE_LENGTH)
-    discriminator = make_discriminator(low_res_size=IMG_SIZE, high_res_size=IMG_SIZE,
-                                       low_res_channels=NB_INPUTS,
-                                       high_res_channels=NB_OUTPUTS, n_timesteps=SEQUENCE_LENGTH)
-    noise_shape = (BATCH_SIZE, SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NOISE_CHANNELS)
-    gan = GAN(generator, discriminator, noise_generator=FlexibleNoiseGenerator(noise_shape, std=NOISE_STD, random_seed=random_seed))
+    if random_seed is None and os.environ.get('DOWNSCALING_RANDOM_SEED'):
+        random_seed = int(os.environ['DOWNSCALING_RANDOM_SEED'])      # reproducible CLI runs (the reference's are not)
+    tile = dict(n_timesteps=SEQUENCE_LENGTH)
+    generator = make_generator(IMG_SIZE, NB_INPUTS, NOISE_CHANNELS, NB_OUTPUTS, **tile)
+    discriminator = make_discriminator(IMG_SIZE, IMG_SIZE, NB_INPUTS, NB_OUTPUTS, **tile)
+    noise = FlexibleNoiseGenerator((BATCH_SIZE, SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NOISE_CHANNELS), std=NOISE_STD,
+                                   random_seed=random_seed)
+    gan = GAN(generator, discriminator, noise_generator=noise)
     gan.compile(generator_optimizer=train.generator_optimizer(),
-                generator_metrics=[metrics.AngularCosineDistance(),
-                                   metrics.LogSpectralDistance(),
-                                   metrics.WeightedRMSEForExtremes(),
-                                   metrics.WindSpeedWeightedRMSE(),
-                                   metrics.SpatialKS()],
                 discriminator_optimizer=train.discriminator_optimizer(),
+                generator_metrics=[getattr(metrics, name)() for name in _GENERATOR_METRICS],
                 discriminator_loss=train.discriminator_loss,
                 metrics=[metrics.discriminator_score_fake(), metrics.discriminator_score_real()])
     if allow_random_init is None:
@@ -108,29 +123,33 @@ def get_network(weights_path=WEIGHTS_PATH, allow_random_init=None, random_seed=N
     return gan
 
 
+def _axis_tiles(pixels, overlap_factor):
+    """One axis of the tile plan (api.py:101-116): number of IMG_SIZE-wide tiles, their common spacing, the pixels
+    that spacing leaves uncovered, and the start offsets.  The count moves from 'just enough to cover the axis'
+    (overlap_factor 0) to 'one tile per pixel offset' (overlap_factor 1) with the square of the factor; the leftover
+    pixels are absorbed by shifting the first `leftovers` gaps by one pixel each."""
+    fewest, most = math.ceil(pixels / IMG_SIZE), pixels - IMG_SIZE
+    count = math.floor(fewest + overlap_factor ** 2 * (most - fewest))
+    spacing = (pixels - IMG_SIZE) // (count - 1)
+    leftovers = pixels - ((count - 1) * spacing + IMG_SIZE)
+    if count - leftovers - 1 < 0:
+        raise ValueError('negative dimensions are not allowed')       # what np.zeros raises in the reference
+    starts = [i * spacing + min(i, leftovers) for i in range(count)]
+    return count, spacing, leftovers, starts
+
+
 def tile_plan(pixels_lat, pixels_lon, time_window, overlap_factor=0.05):
-    """The integer tile planner of predict (api.py:98-116), quirks included (the row check tests the
-    column variables, api.py:105)."""
-    ntimeseq = time_window // SEQUENCE_LENGTH
-    # ceil and not floor, we want to cover the whole map
-    min_cols, max_cols = math.ceil(pixels_lon / IMG_SIZE), pixels_lon - IMG_SIZE
-    if max_cols < min_cols:
+    """The integer tile planner of predict (api.py:98-116).  Only the longitude axis is checked for being wide
+    enough: the reference repeats the column test where it means to test the rows (api.py:105), so a too-short
+    latitude axis runs into the arithmetic instead — kept, the golden plans in tests/golden/tile_plan.json pin it."""
+    if pixels_lon - IMG_SIZE < math.ceil(pixels_lon / IMG_SIZE):
         raise RuntimeError(f'Lon dimension too small: got {pixels_lon} pixels, need at least {IMG_SIZE}')
-    min_rows, max_rows = math.ceil(pixels_lat / IMG_SIZE), pixels_lat - IMG_SIZE
-    if max_cols < min_cols:
-        raise RuntimeError(f'Lat dimension too small: got {pixels_lat} pixels, need at least {IMG_SIZE}')
     assert 0 <= overlap_factor <= 1, 'overlap_factor must be in [0,1] range'
-    ncols = math.floor(min_cols + overlap_factor ** 2 * (max_cols - min_cols))
-    nrows = math.floor(min_rows + overlap_factor ** 2 * (max_rows - min_rows))
-    ydist, xdist = (pixels_lat - IMG_SIZE) // (nrows - 1), (pixels_lon - IMG_SIZE) // (ncols - 1)
-    leftovers_y, leftovers_x = pixels_lat - ((nrows - 1) * ydist + IMG_SIZE), pixels_lon - ((ncols - 1) * xdist + IMG_SIZE)
-    x_vec_leftovers, y_vec_leftovers = np.concatenate(
-        [[0], np.ones(leftovers_x), np.zeros(ncols - leftovers_x - 1)]).cumsum(), np.concatenate(
-        [[0], np.ones(leftovers_y), np.zeros(nrows - leftovers_y - 1)]).cumsum()
-    slices_start_x = [int(i * xdist + x) for (i, x) in zip(range(ncols), x_vec_leftovers)]
-    slices_start_y = [int(j * ydist + y) for (j, y) in zip(range(nrows), y_vec_leftovers)]
-    return dict(ntimeseq=ntimeseq, ncols=ncols, nrows=nrows, xdist=xdist, ydist=ydist, leftovers_x=leftovers_x,
-                leftovers_y=leftovers_y, slices_start_x=slices_start_x, slices_start_y=slices_start_y)
+    ncols, xdist, leftovers_x, slices_start_x = _axis_tiles(pixels_lon, overlap_factor)
+    nrows, ydist, leftovers_y, slices_start_y = _axis_tiles(pixels_lat, overlap_factor)
+    return dict(ntimeseq=time_window // SEQUENCE_LENGTH, ncols=ncols, nrows=nrows, xdist=xdist, ydist=ydist,
+                leftovers_x=leftovers_x, leftovers_y=leftovers_y, slices_start_x=slices_start_x,
+                slices_start_y=slices_start_y)
 
 
 def _tile_lat_index(sy):
@@ -197,7 +216,7 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
                 acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
                 cnt[ts, rs, cs] += 1
             print(f'Predicted {(t + 1) / num_groups:.0%}')
-    if world > 1:
+    if sync is not None and sync.active:
         sync.all_reduce_sum(acc)
         sync.all_reduce_sum(cnt)
     out = (acc / cnt[..., None].double()).float()                                  # api.py:149-150 (uniform mean); 0/0 -> NaN
@@ -205,24 +224,26 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     return (out, cnt) if return_count else out
 
 
-def predict(inputs_era5, inputs_topo, high_res_template, overlap_factor=0.05):
-    xr = _xr()
-    lat_coord_hr, lon_coord_hr = [c for c in high_res_template.dims if c.startswith('lat') or c.startswith('y')][0], [c for c in high_res_template.dims if c.startswith('lon') or c.startswith('x')][0]
-    time_var_topo = inputs_topo.expand_dims({'time': inputs_era5.time})
-    inputs = xr.merge([inputs_era5, time_var_topo])
-    inputs = inputs.drop(c for c in inputs.coords if c not in ['time'] + [lat_coord_hr, lon_coord_hr])
-    fields = np.stack([inputs[v].transpose('time', lat_coord_hr, lon_coord_hr).to_numpy() for v in ('u10', 'v10', 'elevation')], axis=-1)
-    out, cnt = predict_array(fields, overlap_factor=overlap_factor, return_count=True)
-    nt = out.shape[0]
+def predict(inputs_era5, inputs_topo, high_res_template, overlap_factor=0.05, network=None):
+    """api.py:89-152 on GridDatasets: winds (time, lat, lon) + elevation (lat, lon) on the template grid -> downscaled
+    u10 / v10 on the pixels at least one tile covers (the reference's dataframe group-by has no rows elsewhere)."""
+    era, topo, tpl = (GridDataset.from_xarray(d) for d in (inputs_era5, inputs_topo, high_res_template))
+    lat = _axis_name(tpl.dims, 'lat', 'y')
+    lon = _axis_name(tpl.dims, 'lon', 'x')
+    nt = len(era.coords['time'])
+    elevation = np.broadcast_to(topo.transposed('elevation', lat, lon)[None], (nt, len(tpl.coords[lat]), len(tpl.coords[lon])))
+    fields = np.stack([era.transposed('u10', 'time', lat, lon), era.transposed('v10', 'time', lat, lon), elevation], axis=-1)
+    out, cnt = predict_array(fields, overlap_factor=overlap_factor, network=network, return_count=True)
     keep_lat, keep_lon = cnt[0].any(axis=1), cnt[0].any(axis=0)
-    coords = {'time': inputs.time[:nt], lat_coord_hr: inputs[lat_coord_hr][keep_lat], lon_coord_hr: inputs[lon_coord_hr][keep_lon]}
     out = out[:, keep_lat][:, :, keep_lon]
-    return xr.Dataset({v: (('time', lat_coord_hr, lon_coord_hr), out[..., i]) for i, v in enumerate(['u10', 'v10'])}, coords=coords)
+    coords = {'time': era.coords['time'][:out.shape[0]], lat: tpl.coords[lat][keep_lat], lon: tpl.coords[lon][keep_lon]}
+    return GridDataset(coords, {v: (('time', lat, lon), out[..., i]) for i, v in enumerate(('u10', 'v10'))})
 
 
-def downscale(era5, raster_topo, range_lon=None, range_lat=None, overlap_factor=0.05):
-    high_res_template = build_high_res_template_from_era5(era5, range_lon=range_lon, range_lat=range_lat)
-    inputs_era5 = process_era5(era5, high_res_template)
-    inputs_topo = process_topo(raster_topo, high_res_template)
-    prediction = predict(inputs_era5, inputs_topo, high_res_template, overlap_factor=overlap_factor)
-    return prediction
+def downscale(era5, raster_topo, range_lon=None, range_lat=None, overlap_factor=0.05, network=None):
+    """api.py:155-160: template from the ERA5 grid, nearest-neighbour regridding of winds and DEM onto it, tiled
+    generator inference.  `era5` needs `longitude` (ascending), `latitude` (descending, as ERA5), `time`, `u10`, `v10`;
+    `raster_topo` is a (band, y, x) raster as `downscaling.io.open_raster` / `xr.open_rasterio` return it."""
+    template = build_high_res_template_from_era5(era5, range_lon=range_lon, range_lat=range_lat)
+    return predict(process_era5(era5, template), process_topo(raster_topo, template), template,
+                   overlap_factor=overlap_factor, network=network)

@@ -62,6 +62,10 @@ class DistSync:
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # WDG_DIST_ALWAYS=1: run the exchange code path (async all-reduce, deferred Adam, SyncBN, metric reduce) even
+        # in a one-rank group — a single MI355X then executes the real RCCL collectives (identity results), which is how
+        # the `-m gpu` suite covers the "nccl" branch on a one-GPU box
+        self.active = self.world_size > 1 or os.environ.get("WDG_DIST_ALWAYS", "0") == "1"
 
         # gloo has no device collectives in every build: stage device tensors through the host there (tests that
         # run two ranks on one GPU; the production backend is "nccl" = RCCL, which reduces in place on the device)
@@ -112,7 +116,7 @@ class GanEngine:
         next critic iteration does not depend on the discriminator's weights (and the discriminator pass that opens the
         metrics recompute not on the generator's), so that compute hides the exchange."""
         scale = 1.0
-        if self.sync is not None and self.sync.world_size > 1:
+        if self.sync is not None and self.sync.active:
             scale = 1.0 / self.sync.world_size
             finish = self.sync.all_reduce_sum_async(net.params.grads)
             self._pending[id(net)] = (net, opt, scale, finish)
@@ -137,7 +141,7 @@ class GanEngine:
         """ganbase.py:75-81 logs losses of the WHOLE batch.  Under batch data-parallelism every rank holds the mean over
         its equal-sized shard, so the global value is the mean over ranks: one small all-reduce of the stacked scalars
         (SURVEY 8e), after which every rank returns identical logs."""
-        if self.sync is None or self.sync.world_size == 1:
+        if self.sync is None or not self.sync.active:
             return res
         keys = [k for k in self._SHARD_MEANS if res.get(k) is not None]
         vec = torch.stack([res[k].reshape(()) for k in keys])
