@@ -390,6 +390,30 @@ int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out,
                        wdg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Generator evaluation metrics (gan/metrics.py; compiled into the GAN by api.py:77-81 and updated by
+ * every train step, ganbase.py:71).  real / fake: dense [B][T][H][W][2] wind fields.
+ *
+ * wdg_metrics_pointwise: one pass, out6[b][0..5] (fp64) = per-sample sums of
+ *   0 tau*((u^-beta u)^2+(v^-beta v)^2)   wind_speed_weighted_rmse  metrics.py:32-45  (sqrt(sum/THW))
+ *   1 (|w|-|w^|)^2                        wind_speed_rmse           metrics.py:79-88
+ *   2 acos(clip(cos,-1,1))/pi             angular_cosine_distance   metrics.py:94-101
+ *   3 0.5*(1-cos)                         opposite_cosine_similarity metrics.py:103-105
+ *   4 u^2+v^2, 5 u^2(u-u^)^2+v^2(v-v^)^2  extreme_weighted_rmse     metrics.py:66-73   (sqrt(sum5_b / sum_b sum4_b))
+ * NaN terms count as zero where the reference masks them (tf.where(is_nan)). */
+int wdg_metrics_pointwise(const float* real, const float* fake, int64_t pixels_per_sample, int B, double* out6,
+                          wdg_stream stream);
+/* log_spectral_distance (metrics.py:121-137): out[b] = sum over the bins of the two rfft2d spectra (interleaved
+ * complex64, [B][bins_per_sample]) of (10*log10((|R|^2+eps)/(|F|^2+eps)))^2; lsd = sqrt(out/bins). */
+int wdg_lsd_reduce(const float* spec_real, const float* spec_fake, int64_t bins_per_sample, int B, float eps,
+                   double* out, wdg_stream stream);
+/* spatially_convolved_ks_stat (metrics.py:155-187): out[(H-patch+1)*(W-patch+1)] (fp64) = mean over (time x channel)
+ * and batch of max_k |ECDF_real(p_k) - ECDF_fake(p_k)| on every stride-1 patch, p = points100 (the 100 evaluation
+ * points of ks_stat_on_patch, ascending).  scratch: wdg_spatial_ks_scratch_bytes bytes.  patch <= 48. */
+size_t wdg_spatial_ks_scratch_bytes(int B, int T, int H, int W, int C);
+int wdg_spatial_ks(const float* real, const float* fake, int B, int T, int H, int W, int C, int patch,
+                   const float* points100, void* scratch, double* out, wdg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * FlexibleNoiseGenerator: N(0, std^2) from Philox4x32-10 + Box-Muller.   data_generator.py:319-335
  * Element e of the (dense, row-major) logical tensor [P][C] uses counter (offset + e/4), lane e%4.
  * out[p*ldo + c] = (add ? add[p*lda + c] : 0) + std * z       (instance noise: ganbase.py:40,42)

@@ -24,6 +24,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 from dataclasses import dataclass
 
 import numpy as np
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -234,6 +236,46 @@ class TorchOps:
             def join(self):
                 pass
         return _Inline()
+
+    # ---- evaluation metrics: restatement of /root/reference/src/downscaling/gan/metrics.py (the formulas, line by line) --
+    def metrics_pointwise(self, real, fake):
+        """[B, 6] per-sample sums (layout of wdg_metrics_pointwise): metrics.py:32-45, 79-88, 94-105, 66-73."""
+        u, v, uh, vh = real[..., 0], real[..., 1], fake[..., 0], fake[..., 1]
+        est, rea = torch.sqrt(uh ** 2 + vh ** 2), torch.sqrt(u ** 2 + v ** 2)
+        beta = (4 + rea) / (4 + est)                                                   # :39-41 epsilon = 4, t = 0.425
+        tau = torch.where(est >= rea, torch.full_like(u, 0.425), torch.full_like(u, 1 - 0.425))
+        wsw = torch.nan_to_num(tau * ((uh - beta * u) ** 2 + (vh - beta * v) ** 2), nan=0.0, posinf=float("inf"), neginf=-float("inf"))
+        wsr = torch.nan_to_num((rea - est) ** 2, nan=0.0, posinf=float("inf"), neginf=-float("inf"))
+        nrm = lambda x: x * torch.rsqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-12))   # noqa: E731 keras l2_normalize
+        cos = (nrm(real) * nrm(fake)).sum(-1)
+        acd = torch.acos(torch.clamp(cos, -1, 1)) / math.pi
+        ocs = 0.5 * (1 - cos)
+        sq = real ** 2
+        ext = torch.nan_to_num(sq * (real - fake) ** 2, nan=0.0, posinf=float("inf"), neginf=-float("inf"))
+        red = lambda x: x.double().flatten(1).sum(1)                                    # noqa: E731
+        return torch.stack([red(wsw), red(wsr), red(acd), red(ocs), red(sq), red(ext)], 1)
+
+    def lsd_sums(self, real, fake, eps):
+        """metrics.py:121-137: tf.signal.rfft2d acts on the last two axes of the (B,T,H,W,C) tensor as written."""
+        pr = torch.fft.rfft2(real).abs() ** 2 + eps
+        pf = torch.fft.rfft2(fake).abs() ** 2 + eps
+        ratio = torch.where(pf == 0, torch.zeros_like(pr), pr / pf)
+        res = (10 * (torch.log(ratio) / math.log(10.0))) ** 2
+        return res.double().flatten(1).sum(1), res[0].numel()
+
+    def spatial_ks(self, real, fake, patch, points):
+        """metrics.py:155-180: per (time, channel) image, stride-1 VALID patches, sup over `points` of |ECDF difference|."""
+        pts = torch.as_tensor(points, dtype=real.dtype)
+        stats = []
+        for t in range(real.shape[1]):
+            for c in range(real.shape[-1]):
+                p1 = real[:, t, ..., c].unfold(1, patch, 1).unfold(2, patch, 1).flatten(-2)
+                p2 = fake[:, t, ..., c].unfold(1, patch, 1).unfold(2, patch, 1).flatten(-2)
+                ks = torch.zeros(p1.shape[:-1], dtype=torch.float64)
+                for p in pts:
+                    ks = torch.maximum(ks, ((p1 <= p).double().mean(-1) - (p2 <= p).double().mean(-1)).abs())
+                stats.append(ks)
+        return torch.stack(stats).mean(dim=(0, 1))
 
     def make_prep_batch(self, entries):
         """Restatement of HipOps.make_prep_batch: layer by layer (the batching is a launch-count optimisation)."""

@@ -11,6 +11,11 @@ only: /root/reference does not exist on the GPU box).
                         (`_BatchGenerator.transform_sequence` :271-290, `NaiveDecoder` :338-360,
                         `WindSpeedDecoder` / `WindComponentDecoder` :363-417) imported with TensorFlow, xarray,
                         parse stubbed by MagicMock and run on seeded inputs
+  metrics.json          the numpy variants of /root/reference/src/downscaling/gan/metrics.py
+                        (`tanh_wind_speed_weighted_rmse_from_xarray` :48-60, `cosine_similarity_from_xarray` :108-113,
+                        `log_spectral_distance_from_xarray` :143-152, `rmse_from_xarray` :181-187) imported with
+                        TensorFlow / tfa / tfp stubbed and run on seeded wind fields; they share their formulas with
+                        the TF metrics (:32-45, 94-101, 121-137) the package implements
 """
 import ast
 import json
@@ -118,6 +123,41 @@ def reference_data_pipeline():
     (HERE / "data_pipeline.json").write_text(json.dumps(out))
 
 
+def reference_metrics():
+    """Import the reference's gan/metrics.py with TensorFlow & co. stubbed and run its numpy-only members."""
+    import importlib.util
+    import types
+    from unittest.mock import MagicMock
+    for m in ("tensorflow", "tensorflow_addons", "tensorflow_probability", "tensorflow.keras", "tensorflow.keras.losses"):
+        sys.modules[m] = MagicMock()
+    sys.modules["tensorflow"].keras.backend.epsilon = lambda: 1e-7
+    sys.modules["xarray"] = types.SimpleNamespace(where=np.where)
+    spec = importlib.util.spec_from_file_location("ref_metrics", REF / "gan" / "metrics.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class Fields:                      # the slice of an xarray Dataset those functions touch
+        def __init__(self, **arrays):
+            self.__dict__.update(arrays)
+
+        def __getitem__(self, names):
+            arrays = [self.__dict__[n] for n in names]
+            return types.SimpleNamespace(to_array=lambda: np.stack(arrays))
+    rng = np.random.default_rng(2024)
+    T, H, W = 3, 12, 10
+    real = rng.standard_normal((T, H, W, 2)) * 4
+    fake = real + rng.standard_normal((T, H, W, 2)) * 1.5
+    r = Fields(U_10M=real[..., 0], V_10M=real[..., 1])
+    f = Fields(u10=fake[..., 0], v10=fake[..., 1])
+    out = dict(real=real.tolist(), fake=fake.tolist(),
+               tanh_ws_weighted_rmse=np.asarray(mod.tanh_wind_speed_weighted_rmse_from_xarray(r, f)).tolist(),
+               cosine_similarity=np.asarray(mod.cosine_similarity_from_xarray(r, f)).tolist(),
+               rmse=np.asarray(mod.rmse_from_xarray(real[None], fake[None])).tolist())
+    out["log_spectral_distance"] = np.asarray(mod.log_spectral_distance_from_xarray(r, f)).tolist()
+    (HERE / "metrics.json").write_text(json.dumps(out))
+
+
 if __name__ == "__main__":
     main()
     reference_data_pipeline()
+    reference_metrics()

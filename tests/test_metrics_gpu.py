@@ -1,0 +1,103 @@
+"""csrc/metrics.hip (the fused evaluation-metric reductions, reference gan/metrics.py:32-187) against the oracle
+restatement (oracle/torch_backend.py, fp64) on the same inputs, through the package's metric functions; and
+GAN.train_step with the five metrics of get_network compiled in (api.py:77-81, ganbase.py:71) on the device."""
+import numpy as np
+import pytest
+import torch
+
+from downscaling.engine import runtime
+from downscaling.gan import metrics as M
+from oracle.torch_backend import TorchOps
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(seed, B, T, S):
+    rng = np.random.default_rng(seed)
+    real = (rng.standard_normal((B, T, S, S, 2)) * 4).astype(np.float32)
+    fake = (real + rng.standard_normal((B, T, S, S, 2)) * 2).astype(np.float32)
+    return real, fake
+
+
+def _both(fn, real, fake, hip_ops, **kw):
+    runtime.set_ops(hip_ops)
+    got = fn(torch.from_numpy(real), torch.from_numpy(fake), **kw)
+    assert got.is_cuda
+    runtime.set_ops(TorchOps(torch.float64))
+    try:
+        want = fn(torch.from_numpy(real).double(), torch.from_numpy(fake).double(), **kw)
+    finally:
+        runtime.set_ops(hip_ops)
+    return got.double().cpu().numpy(), want.numpy()
+
+
+@pytest.mark.parametrize("B,T,S", [(3, 2, 20), (2, 1, 96), (5, 3, 33)])
+def test_pointwise_and_spectral_metrics(hip_ops, B, T, S):
+    real, fake = _fields(B * 100 + S, B, T, S)
+    for fn, tol in ((M.wind_speed_weighted_rmse, 2e-6), (M.wind_speed_rmse, 2e-6), (M.angular_cosine_distance, 1e-5),
+                    (M.opposite_cosine_similarity, 2e-6), (M.extreme_weighted_rmse, 2e-6), (M.log_spectral_distance, 2e-5)):
+        got, want = _both(fn, real, fake, hip_ops)
+        assert got.shape == (B,)
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol * 1e-2, err_msg=fn.__name__)
+    # NaN handling: masked terms (tf.where(is_nan)), NaN-poisoned weight sum -> 0
+    bad = real.copy()
+    bad[0, 0, 1, 2, 0] = np.nan
+    for fn in (M.wind_speed_weighted_rmse, M.wind_speed_rmse, M.extreme_weighted_rmse):
+        got, want = _both(fn, bad, fake, hip_ops)
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9, err_msg=fn.__name__)
+    # zero vectors: keras' l2_normalize clamp keeps the cosine finite
+    z = real.copy()
+    z[:, :, :3] = 0.0
+    got, want = _both(M.angular_cosine_distance, z, fake, hip_ops)
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,S,patch", [(2, 1, 20, None), (2, 2, 96, None), (1, 1, 40, 7), (3, 1, 17, 17)])
+def test_spatial_ks(hip_ops, B, T, S, patch):
+    real, fake = _fields(7 + S, B, T, S)
+    real[0, 0, 2, 3, 1] = 31.0            # beyond the last evaluation point
+    fake[0, 0, 5, 5, 0] = -30.0           # exactly the first one
+    fake[-1, -1, 4, 1, 1] = np.nan
+    got, want = _both(M.spatially_convolved_ks_stat, real, fake, hip_ops, patch_size=patch)
+    p = patch or S // 10
+    assert got.shape == (S - p + 1, S - p + 1)
+    # the statistic is a ratio of small integers: exact up to the fp64 mean
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    same, _ = _both(M.spatially_convolved_ks_stat, real, real.copy(), hip_ops, patch_size=patch)
+    assert float(np.abs(same).max()) == 0.0
+
+
+def test_train_step_with_compiled_metrics(hip_ops):
+    """GAN.compile(generator_metrics=[...the five of api.py:77-81...]) -> train_step returns g_<name> for each; values
+    equal the oracle metrics of (high_res, last generated batch)."""
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    from downscaling.gan import train
+    from downscaling.gan.ganbase import GAN
+    from downscaling.gan.models import make_discriminator, make_generator
+    runtime.set_ops(hip_ops)
+    B, T, S = 2, 2, 32
+    g, d = make_generator(S, 3, 4, 2, T, feature_channels=32), make_discriminator(S, S, 3, 2, T, feature_channels=8)
+    gan = GAN(g, d, FlexibleNoiseGenerator((B, T, S, S, 4), std=0.1, random_seed=3), n_critic=1)
+    mets = [M.AngularCosineDistance(), M.LogSpectralDistance(), M.WeightedRMSEForExtremes(), M.WindSpeedWeightedRMSE(), M.SpatialKS()]
+    gan.compile(train.generator_optimizer(), train.discriminator_optimizer(), generator_metrics=mets,
+                discriminator_loss=train.discriminator_loss,
+                metrics=[M.discriminator_score_fake(), M.discriminator_score_real()])
+    rng = np.random.default_rng(0)
+    low = rng.standard_normal((B, T, S, S, 3)).astype(np.float32)
+    high = (rng.standard_normal((B, T, S, S, 2)) * 3).astype(np.float32)
+    logs = gan.train_step((low, high))
+    assert {"g_acd", "g_lsd", "g_extreme_rmse", "g_ws_weighted_rmse", "g_spatial_ks", "d_fake", "d_real"} <= set(logs)
+    fake = torch.empty(B, T, S, S, 2, device=hip_ops.device)
+    g.net.from_time_major(gan.engine.last_fake_tm, fake)
+    fake = fake.cpu().numpy()
+    runtime.set_ops(TorchOps(torch.float64))
+    try:
+        th, tf_ = torch.from_numpy(high).double(), torch.from_numpy(fake).double()
+        want = {"g_acd": M.angular_cosine_distance(th, tf_).mean(), "g_lsd": M.log_spectral_distance(th, tf_).mean(),
+                "g_extreme_rmse": M.extreme_weighted_rmse(th, tf_).mean(), "g_ws_weighted_rmse": M.wind_speed_weighted_rmse(th, tf_).mean(),
+                "g_spatial_ks": M.spatially_convolved_ks_stat(th, tf_).mean()}
+    finally:
+        runtime.set_ops(hip_ops)
+    for k, v in want.items():
+        assert abs(float(logs[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), (k, float(logs[k]), float(v))

@@ -628,6 +628,39 @@ class HipOps:
         native.check(self.lib.wdg_segment_meansq(flat.data_ptr(), offsets.data_ptr(), out.numel(), out.data_ptr(),
                                                  self.stream), "segment_meansq")
 
+    # ---- evaluation metrics (csrc/metrics.hip) --------------------------------------------------------
+    def metrics_pointwise(self, real, fake):
+        """[B, 6] fp64 per-sample sums of the pointwise metrics (see wdg_metrics_pointwise) for dense [B,T,H,W,2] winds."""
+        assert real.shape == fake.shape and real.shape[-1] == 2 and real.is_contiguous() and fake.is_contiguous()
+        B = real.shape[0]
+        out = torch.empty(B, 6, dtype=torch.float64, device=self.device)
+        native.check(self.lib.wdg_metrics_pointwise(real.data_ptr(), fake.data_ptr(), real[0].numel() // 2, B, out.data_ptr(),
+                                                    self.stream), "metrics_pointwise")
+        return out
+
+    def lsd_sums(self, real, fake, eps):
+        """([B] fp64 sums of (10 log10 power ratio)^2, bins per sample).  The 2-D real FFT is rocFFT's (through
+        torch.fft) over the LAST TWO axes of the 5-D tensor, as tf.signal.rfft2d is applied in metrics.py:123-126."""
+        B = real.shape[0]
+        sr = torch.view_as_real(torch.fft.rfft2(real)).contiguous()
+        sf = torch.view_as_real(torch.fft.rfft2(fake)).contiguous()
+        n = sr[0].numel() // 2
+        out = torch.empty(B, dtype=torch.float64, device=self.device)
+        native.check(self.lib.wdg_lsd_reduce(sr.data_ptr(), sf.data_ptr(), n, B, eps, out.data_ptr(), self.stream), "lsd_reduce")
+        return out, n
+
+    def spatial_ks(self, real, fake, patch, points):
+        """[H-patch+1, W-patch+1] fp64 image of the mean KS statistic (wdg_spatial_ks); points: 100 ascending floats."""
+        assert real.shape == fake.shape and real.is_contiguous() and fake.is_contiguous()
+        B, T, H, W, Cc = real.shape
+        pts = torch.as_tensor(points, dtype=torch.float32).to(self.device)
+        assert pts.numel() == 100
+        scratch = torch.empty(int(self.lib.wdg_spatial_ks_scratch_bytes(B, T, H, W, Cc)), dtype=torch.uint8, device=self.device)
+        out = torch.empty(H - patch + 1, W - patch + 1, dtype=torch.float64, device=self.device)
+        native.check(self.lib.wdg_spatial_ks(real.data_ptr(), fake.data_ptr(), B, T, H, W, Cc, patch, pts.data_ptr(),
+                                             scratch.data_ptr(), out.data_ptr(), self.stream), "spatial_ks")
+        return out
+
     def philox_normal(self, out, seed, offset, std, add=None):
         po, ldo = _v2(out)
         pa, lda = _v2(add) if add is not None else (0, 0)

@@ -109,6 +109,10 @@ SIGNATURES = {
     "wdg_lerp_batch": (i32, [c_fp, i32, c_fp, i32, c_fp, c_fp, i32, i64, i64, i32, i32, c_fp]),
     "wdg_sumsq_batch_ch": (i32, [c_fp, i32, i64, i32, i32, i32, c_fp, c_fp]),
     "wdg_segment_meansq": (i32, [c_fp, c_fp, i32, c_fp, c_fp]),
+    "wdg_metrics_pointwise": (i32, [c_fp, c_fp, i64, i32, c_fp, c_fp]),
+    "wdg_lsd_reduce": (i32, [c_fp, c_fp, i64, i32, f32, c_fp, c_fp]),
+    "wdg_spatial_ks_scratch_bytes": (szt, [i32, i32, i32, i32, i32]),
+    "wdg_spatial_ks": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     "wdg_philox_normal": (i32, [c_fp, i32, c_fp, i32, i64, i32, u64, u64, f32, c_fp]),
     "wdg_philox_uniform": (i32, [c_fp, i64, u64, u64, c_fp]),
     "wdg_adam_tf": (i32, [c_fp, c_fp, c_fp, c_fp, i64, f32, f32, f32, f32, f32, c_fp]),

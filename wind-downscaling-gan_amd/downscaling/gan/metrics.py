@@ -1,7 +1,9 @@
 """Metrics of the reference (/root/reference/src/downscaling/gan/metrics.py:8-187): running means of the
 discriminator scores, the wind-speed-weighted RMSE that can serve as the generator's content
 (reconstruction-slot) loss, and the evaluation metrics `get_network` wires in (angular cosine distance,
-log-spectral distance, extreme-weighted RMSE, wind-speed RMSE, spatial KS)."""
+log-spectral distance, extreme-weighted RMSE, wind-speed RMSE, spatial KS) — computed by the fused HIP reductions
+of csrc/metrics.hip through the operator backend (no torch arithmetic on the product path, except the
+differentiable form the reconstruction-loss slot needs)."""
 import math
 
 import torch
@@ -45,19 +47,111 @@ class discriminator_score_fake(Mean):
         return super().update_state(fake_output, sample_weight)
 
 
-def wind_speed_weighted_rmse(real_output, fake_output):
-    # Only for cases where we output both wind speed components
+# ---- the metric functions of gan/metrics.py:32-187 on the operator backend -------------------------------------------
+# Every function takes (real_output, fake_output) of shape (B, T, H, W, 2) and returns the reference's per-sample vector
+# (or the patch-position image for the spatial KS).  The arithmetic is the HIP kernels of csrc/metrics.hip: one fused
+# pass yields the sums of all pointwise metrics, so a train step with the five compiled metrics reads the two fields
+# once for them; the pass result is cached per (real, fake) pair for the sibling metrics evaluated right after.
+import numpy as np
+
+from downscaling.engine import runtime
+
+KS_POINTS = np.linspace(-30., 30., 100)          # metrics.py:156
+_cache = {}
+
+
+def _dev_pair(real_output, fake_output):
+    from downscaling.gan.models import _to_dev
+    ops = runtime.get_ops()
+    return ops, _to_dev(real_output, ops), _to_dev(fake_output, ops)
+
+
+def _pointwise(real_output, fake_output):
+    """(sums [B, 6], elements per sample) of the fused pointwise pass; cached while both tensors are unchanged."""
+    key = None
+    if torch.is_tensor(real_output) and torch.is_tensor(fake_output):     # (in-place edits bump torch's version counter)
+        key = tuple((id(t), t._version, t.data_ptr()) for t in (real_output, fake_output))
+        hit = _cache.get("pointwise")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    ops, r, f = _dev_pair(real_output, fake_output)
+    if r.shape[-1] != 2:
+        raise ValueError("the wind metrics need the two wind components on the last axis")
+    res = (ops.metrics_pointwise(r, f), r[0].numel() // 2, r.dtype)
+    if key is not None:
+        _cache["pointwise"] = (key, res)
+    return res
+
+
+def _ws_weighted_rmse_autograd(real_output, fake_output):
+    """Differentiable form for the reconstruction-loss slot (ganbase.py:57-61 takes its gradient w.r.t. the generated
+    winds): the same formula in torch tensor ops."""
     u, v = real_output[..., 0], real_output[..., 1]
     u_hat, v_hat = fake_output[..., 0], fake_output[..., 1]
-    estimated_wind_speed = torch.sqrt(u_hat ** 2 + v_hat ** 2)
-    realized_wind_speed = torch.sqrt(u ** 2 + v ** 2)
-    epsilon = 4  # See Jerome Dujardin thesis
-    t = 0.425  # See Jerome Dujardin thesis
-    beta = (epsilon + realized_wind_speed) / (epsilon + estimated_wind_speed)
-    tau = torch.where(estimated_wind_speed >= realized_wind_speed, torch.full_like(u, t), torch.full_like(u, 1 - t))
+    est, rea = torch.sqrt(u_hat ** 2 + v_hat ** 2), torch.sqrt(u ** 2 + v ** 2)
+    beta = (4 + rea) / (4 + est)
+    tau = torch.where(est >= rea, torch.full_like(u, 0.425), torch.full_like(u, 1 - 0.425))
     result = tau * ((u_hat - beta * u) ** 2 + (v_hat - beta * v) ** 2)
     result = torch.where(torch.isnan(result), torch.zeros_like(result), result)
     return torch.sqrt(torch.mean(result, dim=(1, 2, 3)))
+
+
+def wind_speed_weighted_rmse(real_output, fake_output):
+    """metrics.py:32-45 (epsilon = 4, t = 0.425: J. Dujardin's thesis)."""
+    if torch.is_tensor(fake_output) and fake_output.requires_grad:
+        return _ws_weighted_rmse_autograd(torch.as_tensor(real_output, dtype=fake_output.dtype, device=fake_output.device), fake_output)
+    sums, n, dt = _pointwise(real_output, fake_output)
+    return torch.sqrt(sums[:, 0] / n).to(dt)
+
+
+def wind_speed_rmse(real_output, fake_output):
+    """metrics.py:79-88."""
+    sums, n, dt = _pointwise(real_output, fake_output)
+    return torch.sqrt(sums[:, 1] / n).to(dt)
+
+
+def angular_cosine_distance(real_output, fake_output):
+    """metrics.py:94-101."""
+    sums, n, dt = _pointwise(real_output, fake_output)
+    return (sums[:, 2] / n).to(dt)
+
+
+def opposite_cosine_similarity(real_output, fake_output):
+    """metrics.py:103-105."""
+    sums, n, dt = _pointwise(real_output, fake_output)
+    return (sums[:, 3] / n).to(dt)
+
+
+def extreme_weighted_rmse(real_output, fake_output):
+    """metrics.py:66-73: squared errors weighted by real^2 / sum(real^2) over the WHOLE batch (divide_no_nan)."""
+    sums, n, dt = _pointwise(real_output, fake_output)
+    total = sums[:, 4].sum()
+    ok = torch.isfinite(total) & (total != 0)
+    return torch.where(ok, torch.sqrt(sums[:, 5] / torch.where(ok, total, torch.ones_like(total))), torch.zeros_like(sums[:, 5])).to(dt)
+
+
+def log_spectral_distance(real_output, fake_output):
+    """metrics.py:121-137.  The reference applies tf.signal.rfft2d to the (B, T, H, W, C) tensor itself, i.e. over its
+    last two axes (W, C); the transposes it wraps around the absolute value cancel.  Reproduced as written."""
+    ops, r, f = _dev_pair(real_output, fake_output)
+    sums, n = ops.lsd_sums(r, f, 1e-7)                       # tf.keras.backend.epsilon()
+    lsd = torch.sqrt(sums / n)
+    return torch.where(torch.isnan(lsd), torch.zeros_like(lsd), lsd).to(r.dtype)
+
+
+def spatially_convolved_ks_stat(real_output, fake_output, patch_size=None):
+    """metrics.py:164-187 (patch = image size // 10, stride 1): image of the mean KS statistic per patch position."""
+    ops, r, f = _dev_pair(real_output, fake_output)
+    patch_size = patch_size or f.shape[2] // 10
+    return ops.spatial_ks(r, f, int(patch_size), KS_POINTS).to(r.dtype)
+
+
+def rmse_from_xarray(real_output, fake_output):
+    """metrics.py:181-187 (numpy, evaluation scripts)."""
+    real_output, fake_output = np.asarray(real_output), np.asarray(fake_output)
+    u, v = real_output[..., 0], real_output[..., 1]
+    u_hat, v_hat = fake_output[..., 0], fake_output[..., 1]
+    return np.sqrt(np.mean((u - u_hat) ** 2 + (v - v_hat) ** 2, axis=(1, 2, 3)))
 
 
 class WindSpeedWeightedRMSE(Mean):
@@ -66,87 +160,6 @@ class WindSpeedWeightedRMSE(Mean):
 
     def update_state(self, y_true, y_pred, sample_weight=None):
         return super().update_state(wind_speed_weighted_rmse(y_true, y_pred), sample_weight)
-
-
-# ---- the remaining evaluation metrics of the reference (gan/metrics.py:66-187), torch tensor ops ----------
-# They are outside the timed GAN update: evaluation of (real, generated) winds, wired into
-# `get_network` (api.py:77-81).  Plain torch reductions / FFT on whatever device the tensors live on.
-def _l2_normalize(x, dim=-1, eps=1e-12):
-    return x * torch.rsqrt(torch.clamp((x * x).sum(dim, keepdim=True), min=eps))
-
-
-def cosine_similarity(y_true, y_pred, axis=-1):
-    """tf.keras.losses.cosine_similarity: the NEGATIVE cosine similarity."""
-    return -(_l2_normalize(y_true, axis) * _l2_normalize(y_pred, axis)).sum(axis)
-
-
-def _divide_no_nan(a, b):
-    return torch.where(b == 0, torch.zeros_like(a), a / torch.where(b == 0, torch.ones_like(b), b))
-
-
-def extreme_weighted_rmse(real_output, fake_output):
-    sq = real_output ** 2
-    # Weights proportional to extremeness of winds
-    weights = _divide_no_nan(sq, sq.sum())
-    result = weights * (real_output - fake_output) ** 2
-    result = torch.where(torch.isnan(result), torch.zeros_like(result), result)
-    return torch.sqrt(result.sum(dim=(1, 2, 3, 4)))
-
-
-def wind_speed_rmse(real_output, fake_output):
-    # Only for cases where we output both wind speed components
-    u, v = real_output[..., 0], real_output[..., 1]
-    u_hat, v_hat = fake_output[..., 0], fake_output[..., 1]
-    estimated_wind_speed = torch.sqrt(u_hat ** 2 + v_hat ** 2)
-    realized_wind_speed = torch.sqrt(u ** 2 + v ** 2)
-    result = (realized_wind_speed - estimated_wind_speed) ** 2
-    result = torch.where(torch.isnan(result), torch.zeros_like(result), result)
-    return torch.sqrt(result.mean(dim=(1, 2, 3)))
-
-
-def angular_cosine_distance(real_output, fake_output):
-    cos_sim = -cosine_similarity(real_output, fake_output)
-    bounded_cos_sim = torch.clamp(cos_sim, -1, 1)
-    acd = torch.acos(bounded_cos_sim) / math.pi
-    return acd.mean(dim=(1, 2, 3))
-
-
-def opposite_cosine_similarity(real_output, fake_output):
-    cos_sim = .5 * (1 + cosine_similarity(real_output, fake_output))
-    return cos_sim.mean(dim=(1, 2, 3))
-
-
-def log_spectral_distance(real_output, fake_output):
-    epsilon = 1e-7  # tf.keras.backend.epsilon()
-
-    def power(x):   # rfft2d over (H, W) of (B, T, H, W, C)
-        return (torch.fft.rfft2(x.permute(0, 1, 4, 2, 3)).abs() ** 2).permute(0, 1, 3, 4, 2)
-    ratio = _divide_no_nan(power(real_output) + epsilon, power(fake_output) + epsilon)
-    result = (10 * torch.log10(ratio)) ** 2
-    lsd = torch.sqrt(result.mean(dim=(1, 2, 3, 4)))
-    return torch.where(torch.isnan(lsd), torch.zeros_like(lsd), lsd)
-
-
-def ks_stat_on_patch(patch1, patch2):
-    """patches [..., n_samples]; sup over 100 points in [-30, 30] of |ECDF1 - ECDF2| (tfp Empirical.cdf)."""
-    points = torch.linspace(-30., 30., 100, dtype=patch1.dtype, device=patch1.device)
-    ks = torch.zeros(patch1.shape[:-1], dtype=patch1.dtype, device=patch1.device)
-    for p in points:
-        c1 = (patch1 <= p).to(patch1.dtype).mean(-1)
-        c2 = (patch2 <= p).to(patch1.dtype).mean(-1)
-        ks = torch.maximum(ks, (c1 - c2).abs())
-    return ks
-
-
-def spatially_convolved_ks_stat(real_output, fake_output, patch_size=None):
-    patch_size = patch_size or fake_output.shape[2] // 10
-    stats = []
-    for time in range(fake_output.shape[1]):
-        for ch in range(fake_output.shape[-1]):
-            p1 = real_output[:, time, ..., ch].unfold(1, patch_size, 1).unfold(2, patch_size, 1).flatten(-2)
-            p2 = fake_output[:, time, ..., ch].unfold(1, patch_size, 1).unfold(2, patch_size, 1).flatten(-2)
-            stats.append(ks_stat_on_patch(p1, p2))
-    return torch.stack(stats).mean(dim=(0, 1))
 
 
 class MeanMetricWrapper(Mean):
