@@ -170,7 +170,16 @@ def test_torch_generator_matches_numpy_generator():
 
 
 def test_wind_speed_weighted_rmse_matches_numpy():
+    from downscaling.engine import runtime
     from downscaling.gan.metrics import wind_speed_weighted_rmse
+    from oracle.torch_backend import TorchOps
     rng = np.random.default_rng(3)
     a, b = rng.standard_normal((3, 2, 5, 5, 2)) * 5, rng.standard_normal((3, 2, 5, 5, 2)) * 5
-    np.testing.assert_allclose(wind_speed_weighted_rmse(_t(a), _t(b)).numpy(), N.wind_speed_weighted_rmse(a, b), rtol=1e-12)
+    runtime.set_ops(TorchOps(torch.float64))         # the package's metric functions run on the operator backend
+    try:
+        np.testing.assert_allclose(wind_speed_weighted_rmse(_t(a), _t(b)).numpy(), N.wind_speed_weighted_rmse(a, b), rtol=1e-12)
+        # the differentiable form of the reconstruction-loss slot is the same formula
+        np.testing.assert_allclose(wind_speed_weighted_rmse(_t(a), _t(b).requires_grad_(True)).detach().numpy(),
+                                   N.wind_speed_weighted_rmse(a, b), rtol=1e-12)
+    finally:
+        runtime.set_ops(None)
