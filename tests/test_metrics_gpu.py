@@ -63,7 +63,7 @@ def test_spatial_ks(hip_ops, B, T, S, patch):
     p = patch or S // 10
     assert got.shape == (S - p + 1, S - p + 1)
     # the statistic is a ratio of small integers: exact up to the fp64 mean
-    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-7)      # integer counts, fp64 mean; returned in the input dtype (fp32)
     same, _ = _both(M.spatially_convolved_ks_stat, real, real.copy(), hip_ops, patch_size=patch)
     assert float(np.abs(same).max()) == 0.0
 
