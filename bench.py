@@ -57,21 +57,27 @@ class ConvTimer:
 
         orig_fwd, orig_dgrad, orig_wgrad = ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad
 
-        def timed(name, fl, fn, *a, **k):
+        def timed(name, fl, fn, *a, layer=None, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(*a, **k)
             e1.record()
-            timer.records.append((name, fl, e0, e1))
+            timer.records.append((name, fl, e0, e1, layer))
+
+        def geom(which, x, y, pk, g):
+            return f"{which:5s} {g.kh}x{g.kw}s{g.stride} {pk.cin:3d}->{pk.cout:3d} in {tuple(x.shape[:3])} out {tuple(y.shape[:3])}"
 
         def conv_fwd(x, pk, bias, y, g, **k):
-            timed(ops.conv_kernel_label("fwd", x, y, pk, g), flops(x, y, pk, g), orig_fwd, x, pk, bias, y, g, **k)
+            timed(ops.conv_kernel_label("fwd", x, y, pk, g), flops(x, y, pk, g), orig_fwd, x, pk, bias, y, g,
+                  layer=geom("fwd", x, y, pk, g), **k)
 
         def conv_dgrad(dy, pk, dx, g, **k):
-            timed(ops.conv_kernel_label("dgrad", dx, dy, pk, g), flops(dx, dy, pk, g), orig_dgrad, dy, pk, dx, g, **k)
+            timed(ops.conv_kernel_label("dgrad", dx, dy, pk, g), flops(dx, dy, pk, g), orig_dgrad, dy, pk, dx, g,
+                  layer=geom("dgrad", dx, dy, pk, g), **k)
 
         def conv_wgrad(x, dy, pk, dw, g, **k):
-            timed(ops.conv_kernel_label("wgrad", x, dy, pk, g), flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g, **k)
+            timed(ops.conv_kernel_label("wgrad", x, dy, pk, g), flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g,
+                  layer=geom("wgrad", x, dy, pk, g), **k)
 
         orig_up = ops.upconv_fwd
 
@@ -80,7 +86,7 @@ class ConvTimer:
             # (csrc/upconv4.hip) executes 16/25 of these MACs
             n, Ho, Wo = y.shape[0], y.shape[1], y.shape[2]
             timed("wdg_upconv4_kernel (fused upsample + 5x5 transposed conv; executes 0.64 of the algorithmic MACs)",
-                  2.0 * n * Ho * Wo * pk.cin * g.kh * g.kw * pk.cout, orig_up, x_low, pk, bias, y, g, **k)
+                  2.0 * n * Ho * Wo * pk.cin * g.kh * g.kw * pk.cout, orig_up, x_low, pk, bias, y, g, layer="upconv", **k)
 
         ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = conv_fwd, conv_dgrad, conv_wgrad
         if not getattr(ops, "upconv_colfwd", False):
@@ -90,12 +96,23 @@ class ConvTimer:
 
     def summary(self):
         agg = {}
-        for name, fl, e0, e1 in self.records:
+        for name, fl, e0, e1, _ in self.records:
             a = agg.setdefault(name, [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
         return agg
+
+    def per_layer(self, steps):
+        """{layer geometry: (kernel, calls per step, ms per call, TFLOP/s)} — `bench.py --per-layer` (stderr table)."""
+        agg = {}
+        for name, fl, e0, e1, layer in self.records:
+            a = agg.setdefault((layer, name), [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        rows = [(k[0], k[1], v[2] / steps, 1e3 * v[1] / v[2], v[0] / v[1] * 1e-12, 1e3 * v[1] / steps) for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r[5])
 
 
 def cpu_baseline(batch=4):
@@ -247,6 +264,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print a per-layer table of the timed conv launches to stderr")
     ap.add_argument("--no-generator-leg", action="store_true", help="skip the generator-forward-at-batch-64 leg of the default line")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp16"], default="fp32", help="gen_fwd only: inference precision")
     ap.add_argument("--workload", choices=["train", "gen_fwd"], default="train",
@@ -336,6 +354,9 @@ def main():
         gf, df = 22.385e9, 2.994e9
         step_flops = (7 * gf + 28 * df) * B
         agg = timer.summary()
+        if args.per_layer:
+            for layer, kern, calls, ms, tf, tot in timer.per_layer(args.steps):
+                print(f"{tot:7.3f} ms/step  {calls:4.0f} x {ms:7.3f} ms  {tf:6.1f} TF/s  {kern:28s} {layer}", file=sys.stderr)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         conv_time = sum(a[1] for a in agg.values())
         conv_flops = sum(a[0] for a in agg.values())

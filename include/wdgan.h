@@ -101,6 +101,22 @@ int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, 
                    float* dx, int act, float slope, int accumulate,
                    void* ws, size_t ws_bytes, wdg_stream stream);
 
+/* The same two launches as PRODUCERS OF A BatchNormalization INPUT (models.py:33-34, 39-40, 49-50, 55-56: conv ->
+ * bias -> LeakyReLU -> BatchNormalization), with the norm's first pass folded into the epilogue:
+ *   stats  != NULL (training):  y = act(conv + bias), and the replica slabs stats[stats_rep][2][C] (fp64, zeroed by the
+ *           caller, C = output channels) receive sum_p y and sum_p y^2 per channel — no separate read of y for
+ *           wdg_bn_stats; finish with wdg_bn_finalize_train(stats, stats_rep, ...) and wdg_bn_apply;
+ *   affine != NULL (inference): y = act(conv + bias) * affine[c] + affine[C + c], affine = the [scale | shift] of
+ *           wdg_bn_finalize_infer — neither wdg_bn_stats nor wdg_bn_apply runs.
+ * Exactly one of the two.  Launches that cannot carry the hook (split-K second stage, halo-tile kernel) run the
+ * standalone pass behind the convolution, so the results do not depend on the route. */
+int wdg_conv_fwd_bn(const wdg_conv_plan* plan, const float* x, const float* wF, const float* bias, float* y, int act,
+                    float slope, double* stats, int stats_rep, const float* affine, void* ws, size_t ws_bytes,
+                    wdg_stream stream);
+int wdg_conv_dgrad_bn(const wdg_conv_plan* plan, const float* dy, const float* wD, const float* bias, float* dx, int act,
+                      float slope, double* stats, int stats_rep, const float* affine, void* ws, size_t ws_bytes,
+                      wdg_stream stream);
+
 /* Fused UpSampling2D(2,'bilinear') + Conv2DTranspose forward: y = act(convT(upsample2x(x_low), wD) + bias).
  * `plan` is the transposed conv's plan on the UPSAMPLED grid (conv-output side 2H x 2W, stride 1, k <= 5,
  * Cin <= 64); x_low is the H x W tensor with pixel stride ld_low.  The upsampled tensor is never
@@ -213,9 +229,14 @@ int wdg_prep_batch_destroy(wdg_prep_batch* b);
 int wdg_bn_stats(const float* x, int64_t P, int C, int ldx, double* stats, wdg_stream stream);
 /* training: mean/var from stats over `count` pixels -> scale/shift, saved mean/invstd, moving
  * stats update (moving = momentum*moving + (1-momentum)*batch).  scale_shift: [2*C]; saved: [2*C]. */
-int wdg_bn_finalize_train(const double* stats, double count, const float* gamma, const float* beta,
+/* `stats` = `replicas` slabs [2][C] (summed here): wdg_bn_stats fills slab 0, the fused producers below spread
+ * their atomics over all of them. */
+int wdg_bn_finalize_train(const double* stats, int replicas, double count, const float* gamma, const float* beta,
                           float* moving_mean, float* moving_var, float momentum, float eps,
                           float* scale_shift, float* saved_mean_invstd, int C, wdg_stream stream);
+/* stats[0] = sum over the replica slabs (in place): collapse before a data-parallel all-reduce of the statistics, then
+ * finalize with replicas = 1. */
+int wdg_bn_collapse(double* stats, int replicas, int C, wdg_stream stream);
 /* inference: scale/shift from the moving statistics. */
 int wdg_bn_finalize_infer(const float* gamma, const float* beta, const float* moving_mean,
                           const float* moving_var, float eps, float* scale_shift, int C,
@@ -339,7 +360,8 @@ int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, float* col, 
  * y = affine(act(bias + gather(z))): the adjoint of wdg_upconv_col with the clamped-bilinear coefficients,
  * y [n, 2Hl, 2Wl, >= C]; affine = optional [2*C] scale | shift (fused inference BatchNorm). */
 int wdg_upconv_gather(const float* z, const float* bias, const float* affine, float* y, int ldy,
-                      int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope, wdg_stream stream);
+                      int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope,
+                      double* stats, int stats_rep, wdg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Flatten + Dense(1) per timestep + GlobalAveragePooling1D over T.             models.py:137-140

@@ -131,16 +131,29 @@ class TorchOps:
     def _oihw(pk):
         return pk.w.permute(3, 2, 0, 1)
 
-    def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2):
+    @staticmethod
+    def _bn_hook(out, bn_stats, bn_affine):
+        """BatchNormalization hooks of the conv launches (wdg_conv_fwd_bn): statistics of the activated output, or the
+        inference-mode scale / shift."""
+        C = out.shape[-1]
+        if bn_stats is not None:
+            bn_stats[0, :C] += out.sum((0, 1, 2)).to(bn_stats.dtype)
+            bn_stats[0, C:] += (out * out).sum((0, 1, 2)).to(bn_stats.dtype)
+        if bn_affine is not None:
+            out = out * bn_affine[:C] + bn_affine[C:]
+        return out
+
+    def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
         xin = x[..., :pk.cin].permute(0, 3, 1, 2)
         out = F.conv2d(xin, self._oihw(pk), bias, stride=g.stride, padding=g.pad).permute(0, 2, 3, 1)
         if act:
             out = _lrelu(out, slope)
+        out = self._bn_hook(out, bn_stats, bn_affine)
         if accumulate:
             out = out + y[..., :pk.cout]
         y[..., :pk.cout] = out
 
-    def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2):
+    def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
         H, W = dx.shape[1], dx.shape[2]
         Ho, Wo = dy.shape[1], dy.shape[2]
         oph = H - ((Ho - 1) * g.stride - 2 * g.pad + g.kh)
@@ -149,6 +162,7 @@ class TorchOps:
                                  padding=g.pad, output_padding=(oph, opw)).permute(0, 2, 3, 1)
         if act:
             out = _lrelu(out, slope)
+        out = self._bn_hook(out, bn_stats, bn_affine)
         if accumulate:
             out = out + dx[..., :pk.cin]
         dx[..., :pk.cin] = out
@@ -193,10 +207,10 @@ class TorchOps:
         self.upsample2x_fwd(x_low, up)
         self.conv_dgrad_bf16(up, pk, y, g, bias=bias, act=act, affine=affine, slope=slope, fmt=fmt)
 
-    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2, pool=None):
+    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2, pool=None, bn_stats=None, bn_affine=None):
         up = torch.zeros(x_low.shape[0], 2 * x_low.shape[1], 2 * x_low.shape[2], x_low.shape[3], dtype=x_low.dtype)
         self.upsample2x_fwd(x_low, up)
-        self.conv_dgrad(up, pk, y, g, bias=bias, act=act, slope=slope)
+        self.conv_dgrad(up, pk, y, g, bias=bias, act=act, slope=slope, bn_stats=bn_stats, bn_affine=bn_affine)
 
     def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g, pool=None):
         """Backward of upconv_fwd as the reference's tape computes it: through the materialised upsampled tensor."""
@@ -309,6 +323,7 @@ class TorchOps:
 
     def bn_finalize_train(self, stats, count, gamma, beta, mmean, mvar, momentum, eps, ss, saved):
         C = gamma.numel()
+        stats = stats.sum(0)                                  # [R, 2C] replica slabs of the fused producers
         mean = stats[:C] / count
         var = torch.clamp(stats[C:] / count - mean * mean, min=0)
         inv = 1.0 / torch.sqrt(var + eps)
@@ -319,6 +334,9 @@ class TorchOps:
         mmean.mul_(momentum).add_(mean * (1 - momentum))
         # the fused op's batch_variance (what Keras averages into moving_variance) is Bessel-corrected in TF 2.4
         mvar.mul_(momentum).add_(var * (count / (count - 1.0) if count > 1 else 1.0) * (1 - momentum))
+
+    def bn_collapse(self, stats):
+        stats[0] = stats.sum(0)
 
     def bn_finalize_infer(self, gamma, beta, mmean, mvar, eps, ss):
         C = gamma.numel()

@@ -390,10 +390,10 @@ def test_batchnorm(C, P, hip_ops, ref_ops):
     res = {}
     for name, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev))):
         yy, dzz, ga, be = cv(y), cv(dz), cv(gamma), cv(beta)
-        stats = ops.zeros(2 * C, dtype=torch.float64)
+        stats = ops.zeros(3, 2 * C, dtype=torch.float64)     # replica slabs: the standalone pass fills slab 0
         mm, mv = cv(torch.zeros(C, dtype=torch.float64)), cv(torch.ones(C, dtype=torch.float64))
         ss, saved = ops.empty(2 * C), ops.empty(2 * C)
-        ops.bn_stats(yy, stats)
+        ops.bn_stats(yy, stats[0])
         ops.bn_finalize_train(stats, P, ga, be, mm, mv, 0.99, 1e-3, ss, saved)
         z = ops.empty(P, C)
         ops.bn_apply(yy, ss, z)
@@ -410,6 +410,91 @@ def test_batchnorm(C, P, hip_ops, ref_ops):
     assert rel_err(res["ref"]["z"], zz) < 1e-12
     for k in res["ref"]:
         assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+
+
+BN_HOOK_CASES = [
+    # name, n, H, W, cin, cout, k, s, p, direction
+    ("g0_8x8s2_cin23", 3, 64, 64, 23, 128, 8, 2, 3, "fwd"),          # 128x128 tile
+    ("g2_4x4s2", 3, 32, 32, 128, 128, 4, 2, 1, "fwd"),
+    ("g5_3x3_128to64", 3, 48, 40, 128, 64, 3, 1, 1, "fwd"),          # 128x64 tile / 64x64
+    ("g7_convT2x2", 2, 32, 32, 32, 192, 2, 2, 0, "dgrad"),           # four dgrad phases, 256x32 tile
+    ("splitk_small_m", 8, 8, 8, 256, 512, 7, 3, 1, "fwd"),           # split-K route: standalone pass behind the conv
+    ("halo_route", 4, 128, 128, 16, 16, 3, 1, 1, "fwd"),             # halo-tile kernel route
+    ("ragged_cout", 2, 20, 24, 16, 40, 3, 1, 1, "fwd"),
+]
+
+
+@pytest.mark.parametrize("case", BN_HOOK_CASES, ids=[c[0] for c in BN_HOOK_CASES])
+def test_conv_batchnorm_hooks(case, hip_ops, ref_ops):
+    """wdg_conv_fwd_bn / wdg_conv_dgrad_bn: the BatchNormalization that follows a conv (models.py:33-34 ff.) folded into
+    the launch — training: per-channel sum / sum of squares of the activated output land in the replica slabs;
+    inference: the [scale | shift] affine is applied by the epilogue.  Same results on every route."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    name, n, H, W, cin, cout, k, s_, p_, direction = case
+    gen = torch.Generator().manual_seed(17)
+    dev = hip_ops.device
+    Ho, Wo = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+    w = torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) / np.sqrt(k * k * cin)
+    cinp, coutp = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    if direction == "fwd":
+        src = torch.zeros(n, H, W, cinp, dtype=torch.float64)
+        src[..., :cin] = torch.randn(n, H, W, cin, generator=gen, dtype=torch.float64)
+        C, oshape = cout, (n, Ho, Wo, coutp)
+    else:
+        src = torch.zeros(n, Ho, Wo, coutp, dtype=torch.float64)
+        src[..., :cout] = torch.randn(n, Ho, Wo, cout, generator=gen, dtype=torch.float64)
+        C, oshape = cin, (n, H, W, cinp)
+    bias = torch.randn(C, generator=gen, dtype=torch.float64) * 0.3
+    aff = torch.cat([torch.rand(C, generator=gen, dtype=torch.float64) + 0.5, torch.randn(C, generator=gen, dtype=torch.float64)])
+    res = {}
+    for tag, ops, cv, G in (("ref", ref_ops, lambda t: t.clone(), RG), ("hip", hip_ops, lambda t: t.float().to(dev).contiguous(), ConvGeom)):
+        pk = ops.pack_weights(cv(w))
+        g = G(k, k, s_, p_)
+        call = (lambda out, **kw: ops.conv_fwd(cv(src), pk, cv(bias), out, g, act=True, slope=0.2, **kw)) if direction == "fwd" else \
+               (lambda out, **kw: ops.conv_dgrad(cv(src), pk, out, g, bias=cv(bias), act=True, slope=0.2, **kw))
+        plain, y1, y2 = ops.zeros(*oshape), ops.zeros(*oshape), ops.zeros(*oshape)
+        call(plain)
+        stats = ops.zeros(5, 2 * C, dtype=torch.float64)
+        call(y1, bn_stats=stats)
+        call(y2, bn_affine=cv(aff))
+        res[tag] = dict(plain=plain, y1=y1, stats=stats.sum(0), y2=y2)
+    r, h = res["ref"], res["hip"]
+    assert torch.equal(h["y1"], h["plain"])                              # the statistics hook does not touch the output
+    assert rel_err(h["plain"], r["plain"]) < TOL
+    assert rel_err(h["stats"][:C], r["stats"][:C]) < TOL and rel_err(h["stats"][C:], r["stats"][C:]) < TOL
+    # oracle consistency: statistics are those of the written tensor
+    assert rel_err(r["stats"][:C], r["plain"][..., :C].sum((0, 1, 2))) < 1e-12
+    assert rel_err(h["y2"], r["y2"]) < TOL
+    assert rel_err(r["y2"][..., :C], r["plain"][..., :C] * aff[:C] + aff[C:]) < 1e-12
+    assert float(h["y2"][..., C:].abs().max() if oshape[3] > C else 0.0) == 0.0          # pad channels stay zero
+
+
+def test_upconv_batchnorm_hooks(hip_ops, ref_ops):
+    """The fused upsample + 5x5 transposed-conv block (models.py:62-64) as a BatchNormalization producer: statistics /
+    inference affine in the column-form gather kernel."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    gen = torch.Generator().manual_seed(23)
+    dev = hip_ops.device
+    x = torch.randn(3, 36, 44, 160, generator=gen, dtype=torch.float64)
+    w = torch.randn(5, 5, 16, 160, generator=gen, dtype=torch.float64) * 0.03
+    b = torch.randn(16, generator=gen, dtype=torch.float64) * 0.2
+    aff = torch.cat([torch.rand(16, generator=gen, dtype=torch.float64) + 0.5, torch.randn(16, generator=gen, dtype=torch.float64)])
+    out = {}
+    for tag, ops, cv, G in (("ref", ref_ops, lambda t: t.clone(), RG), ("hip", hip_ops, lambda t: t.float().to(dev).contiguous(), ConvGeom)):
+        pk, g = ops.pack_weights(cv(w)), G(5, 5, 1, 2)
+        y0, y1, y2 = ops.zeros(3, 72, 88, 16), ops.zeros(3, 72, 88, 16), ops.zeros(3, 72, 88, 16)
+        stats = ops.zeros(4, 32, dtype=torch.float64)
+        ops.upconv_fwd(cv(x), pk, cv(b), y0, g, act=True)
+        ops.upconv_fwd(cv(x), pk, cv(b), y1, g, act=True, bn_stats=stats)
+        ops.upconv_fwd(cv(x), pk, cv(b), y2, g, act=True, bn_affine=cv(aff))
+        out[tag] = dict(y0=y0, y1=y1, y2=y2, stats=stats.sum(0))
+    r, h = out["ref"], out["hip"]
+    assert torch.equal(h["y0"], h["y1"])
+    for k_ in ("y0", "y2"):
+        assert rel_err(h[k_], r[k_]) < TOL, k_
+    assert rel_err(h["stats"][:16], r["stats"][:16]) < TOL and rel_err(h["stats"][16:], r["stats"][16:]) < TOL
 
 
 @pytest.mark.parametrize("C,P", [(16, 5000), (32, 1234), (64, 999), (128, 500), (256, 130), (512, 77)])

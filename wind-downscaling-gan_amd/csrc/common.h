@@ -71,6 +71,27 @@ __device__ __forceinline__ double wdg_wave_sum_d(double v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane of the row: four v_add_f32 with DPP
+// operands (quad swaps, half-row mirror, row mirror) instead of four ds_bpermute round trips
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define WDG_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
+__device__ __forceinline__ float wdg_row16_sum(float v) {
+    v = WDG_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
+    v = WDG_DPP_ADD(v, 0x4E);    // quad_perm [2,3,0,1]
+    v = WDG_DPP_ADD(v, 0x141);   // row_half_mirror
+    v = WDG_DPP_ADD(v, 0x140);   // row_mirror
+    return v;
+}
+// wave sum through the row sums: four scalar reads of the row results
+__device__ __forceinline__ float wdg_wave_sum_fast(float v) {
+    v = wdg_row16_sum(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+#endif
+
 // ---- buffer (SRD) loads: 32-bit byte offsets relative to a wave-uniform base, hardware range check.
 // The descriptor spans 2 GiB; an offset of WDG_SRD_OOB is out of range and the load returns zeros
 // (cdna_hip_programming.md T8/T20: build the descriptor only from kernel arguments / blockIdx values).

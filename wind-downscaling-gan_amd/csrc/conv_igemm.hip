@@ -39,6 +39,15 @@ struct WdgIgemm {
     int splitk, k4_per_split;
     int Mmax, nphase;
     int xcd_swizzle;   // remap blockIdx.x so that each XCD (blocks b, b+8, ...) walks a contiguous range of tiles
+    int phase_in_x;    // > 0: blockIdx.x = tile * nphase + phase (the phases of one output tile run back to back on ONE XCD and
+                       // share its L2 copy of the input rows); 0: phase = blockIdx.z
+    // fused BatchNorm hooks of the epilogue (EPI template flag): per-channel sum / sum of squares of the written values
+    // into one of `stats_rep` replica slabs [2][stats_C] (fp64 atomics; replicas spread the contention), or the
+    // inference-mode normalisation  v * affine[n] + affine[Ncols_pad + n]  after the activation
+    double* stats;
+    int stats_C, stats_rep;
+    const float* affine;
+    int affine_ld;
     WdgPhase ph[9];
 };
 
@@ -50,7 +59,9 @@ __device__ __forceinline__ int wdg_xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int BM, int BN, int WGM, int WGN, int PIPE>
+// EPI: 0 plain epilogue, 1 = + BatchNorm batch statistics of the output (training-mode producer), 2 = + inference-mode
+// BatchNorm affine.  Separate instantiations: the plain kernels keep their register allocation.
+template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0>
 __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;
@@ -70,9 +81,14 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     const int kg = t & 7;
     const int lrow = t >> 3;  // 0..31
 
-    const WdgPhase ph = p.ph[blockIdx.z];
+    int bid = p.xcd_swizzle ? wdg_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int phase_id = blockIdx.z;
+    if (p.phase_in_x) {
+        phase_id = bid % p.phase_in_x;
+        bid /= p.phase_in_x;
+    }
+    const WdgPhase ph = p.ph[phase_id];
     const int tiles_m = (p.Mmax + BM - 1) / BM;
-    const int bid = p.xcd_swizzle ? wdg_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tm = bid % tiles_m;
     const int tn = bid / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -88,7 +104,7 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     // ---- buffer descriptors (wave-uniform: kernel arguments and blockIdx only).  Every operand load is a
     // buffer_load_dwordx4 whose byte offset is pushed out of range for padding / out-of-image / tail lanes,
     // so the hardware range check returns the zeros and the load sequence has no branches.
-    const int img0 = m0 / PaPb;
+    const int img0 = (int)wdg_fastdiv_do((unsigned)m0, ph.div_papb);
     const wdg_srd srdA = wdg_make_srd(p.A + (long long)img0 * p.imgStrideA);
     const wdg_srd srdB = wdg_make_srd(p.B);
 
@@ -99,9 +115,9 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     for (int i = 0; i < A_LOADS; ++i) {
         const int m = m0 + lrow + 32 * i;
         if (m < Mph) {
-            const int img = m / PaPb;
+            const int img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
             const int rem = m - img * PaPb;
-            const int pa = rem / ph.Pb;
+            const int pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
             const int pb = rem - pa * ph.Pb;
             const int ih0 = pa * p.a_mul + ph.a_off_h;
             const int iw0 = pb * p.a_mul + ph.a_off_w;
@@ -265,21 +281,28 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     // ---- epilogue: one pixel per (row tile a), four consecutive output channels per (column tile b)
     const int q4 = 4 * (lane >> 4);
     const int NcP = (p.Ncols + 3) & ~3;
+    float st1[EPI == 1 ? NT : 1][4], st2[EPI == 1 ? NT : 1][4];
+    if constexpr (EPI == 1) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st1[b][r] = st2[b][r] = 0.f;
+    }
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
         if (m >= Mph) continue;
         if (p.splitk > 1) {
-            float* dst = p.partial + (((long long)blockIdx.z * p.splitk + blockIdx.y) * p.Mmax + m) * NcP;
+            float* dst = p.partial + (((long long)phase_id * p.splitk + blockIdx.y) * p.Mmax + m) * NcP;
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
                 if (n < NcP) *reinterpret_cast<f32x4*>(dst + n) = acc[a][b];
             }
         } else {
-            const int img = m / PaPb;
+            const int img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
             const int rem = m - img * PaPb;
-            const int pa = rem / ph.Pb;
+            const int pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
             const int pb = rem - pa * ph.Pb;
             const int oh = pa * p.o_mul + ph.o_off_h;
             const int ow = pb * p.o_mul + ph.o_off_w;
@@ -297,8 +320,60 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
                 }
+                if constexpr (EPI == 1) {
+                    // (pad channels Ncols..NcP-1 carry zeros: zero weights, no bias)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st1[b][r] += v[r];
+                        st2[b][r] = fmaf(v[r], v[r], st2[b][r]);
+                    }
+                }
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.Ncols) v[r] = fmaf(v[r], p.affine[n + r], p.affine[p.affine_ld + n + r]);
+                }
                 if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst + n);
                 *reinterpret_cast<f32x4*>(dst + n) = v;   // channels Ncols .. round4(Ncols)-1 receive zeros (padding)
+            }
+        }
+    }
+    if constexpr (EPI == 1) {
+        // per-channel partial sums of this block -> one replica slab.  Lanes that share lane >> 4 hold the same four
+        // channels of 16 different pixels: butterfly over lane & 15, then the WGM row-waves meet in LDS (the K loop has
+        // ended behind a barrier, its stages are free), one fp64 atomic pair per channel and block.
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                st1[b][r] = wdg_row16_sum(st1[b][r]);
+                st2[b][r] = wdg_row16_sum(st2[b][r]);
+            }
+        float* red = reinterpret_cast<float*>(lds_all);          // [WGM][BN][2]
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = wn * (BN / WGN) + b * 16 + q4 + r;
+                    red[(wm * BN + col) * 2 + 0] = st1[b][r];
+                    red[(wm * BN + col) * 2 + 1] = st2[b][r];
+                }
+        }
+        __syncthreads();
+        double* slab = p.stats + (size_t)((blockIdx.x + blockIdx.z) % (unsigned)p.stats_rep) * 2 * p.stats_C;
+        for (int c = t; c < BN; c += 256) {
+            const int n = n0 + c;
+            if (n < p.Ncols) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) {
+                    s1 += red[(w * BN + c) * 2 + 0];
+                    s2 += red[(w * BN + c) * 2 + 1];
+                }
+                atomicAdd(slab + n, (double)s1);
+                atomicAdd(slab + p.stats_C + n, (double)s2);
             }
         }
     }
@@ -739,6 +814,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
                 ++cnt;
             }
             ph.K4 = cnt;
+            wdg_phase_finish(ph);
             pl->K4_dgrad_max = std::max(pl->K4_dgrad_max, cnt);
             pl->ph_dgrad.push_back(ph);
         }
@@ -821,6 +897,7 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
 static int g_xcd_swizzle = 1;
+static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
 extern "C" int wdg_set_tuning(const char* key, int value) {
@@ -870,6 +947,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_wgrad_thin_enable(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "phase_major")) {
+        g_phase_major = value != 0;
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "xcd_swizzle")) {
         g_xcd_swizzle = value != 0;
         return WDG_OK;
@@ -878,23 +959,24 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     return WDG_ERR_ARG;
 }
 
-template <int BM, int BN, int WGM, int WGN, int PIPE>
+template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
     constexpr size_t lds = (size_t)((PIPE == 0 || PIPE == 3) ? 1 : 2) * 8 * (BM + BN) * sizeof(f32x4);
+    static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 48 * 1024)
-            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE>),
+            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI>), grid, block, lds, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
 
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, bool* bn_fused = nullptr) {
     TileCfg tc = pick_tile(p.Ncols, true, p.Mmax);
     const int tiles_m = (p.Mmax + tc.BM - 1) / tc.BM;
     const int tiles_n = (p.Ncols + tc.BN - 1) / tc.BN;
@@ -918,12 +1000,23 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         p.partial = nullptr;
     }
     dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
+    p.phase_in_x = 0;
+    if (nphase > 1 && g_phase_major) {
+        grid = dim3(tiles_m * tiles_n * nphase, split, 1);
+        p.phase_in_x = nphase;
+    }
     p.xcd_swizzle = g_xcd_swizzle && grid.x >= 16;
     const int pipe = g_igemm_pipe;
     int rc = WDG_OK;
+    // fused BatchNorm hooks: only without split-K (the reduce kernel owns the epilogue then; callers fall back to the
+    // standalone passes — see conv_fused_bn) and only on the default pipeline
+    const int epi = (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : 0;
+    if (bn_fused) *bn_fused = epi != 0;
 #define WDG_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                              \
     if (tc.BM == BM_ && tc.BN == BN_) {                                                                 \
-        if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);                  \
+        if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);                \
+        else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \
+        else if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);             \
         else if (pipe == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 1>(grid, block, st, p);             \
         else if (pipe == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3>(grid, block, st, p);             \
         else rc = launch_variant<BM_, BN_, WM_, WN_, 2>(grid, block, st, p);                            \
@@ -948,15 +1041,43 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     return WDG_OK;
 }
 
-extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias,
-                            float* y, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
+// BatchNorm hooks shared by the forward / data-gradient entry points.  `stats` (training-mode producer): the replica
+// slabs [stats_rep][2][stats_C] (fp64) receive the per-channel sum and sum of squares of the written output; `affine`
+// (inference mode): y = act(conv + bias) * affine[c] + affine[affine_ld + c].  When the launch cannot carry the hook in
+// its epilogue (split-K second stage, halo-tile kernel) the standalone pass runs behind it, so the result is the same.
+struct WdgBnHook {
+    double* stats;
+    int stats_C, stats_rep;
+    const float* affine;
+    int affine_ld;
+};
+
+static int bn_hook_fallback(const WdgBnHook& h, float* y, int ldy, int64_t img_stride, int n_img, int Ho, int Wo, int C,
                             wdg_stream stream) {
+    if (img_stride != (int64_t)Ho * Wo * ldy) {
+        wdg_set_error("conv + BatchNorm hook: the unfused path needs contiguous output images");
+        return WDG_ERR_ARG;
+    }
+    const int64_t P = (int64_t)n_img * Ho * Wo;
+    if (h.stats) return wdg_bn_stats(y, P, C, ldy, h.stats, stream);
+    if (h.affine_ld != C) {
+        wdg_set_error("conv + BatchNorm hook: affine must be [scale | shift] with stride C on the unfused path");
+        return WDG_ERR_ARG;
+    }
+    return wdg_bn_apply(y, ldy, h.affine, y, ldy, P, C, stream);
+}
+
+static int conv_fwd_impl(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y, int act,
+                         float slope, int accumulate, const WdgBnHook* hook, void* ws, size_t ws_bytes, wdg_stream stream) {
     WDG_CHECK_ARG(pl && x && wF && y, "null argument");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0 && ((uintptr_t)y & 15) == 0, "x / wF / y must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
-    if (pl->halo_auto_fwd && pl->halo_fwd_nt)
-        return wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, accumulate,
-                               (hipStream_t)stream);
+    if (pl->halo_auto_fwd && pl->halo_fwd_nt) {
+        const int rc = wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, accumulate,
+                                       (hipStream_t)stream);
+        if (rc != WDG_OK || !hook) return rc;
+        return bn_hook_fallback(*hook, y, g.ldy, g.img_stride_y, g.n_img, g.Ho, g.Wo, g.Cout, stream);
+    }
     WdgIgemm p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
@@ -967,22 +1088,29 @@ extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float
     p.a_mul = g.stride; p.o_mul = 1;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
     p.Mmax = g.n_img * g.Ho * g.Wo;
+    if (hook) { p.stats = hook->stats; p.stats_C = hook->stats_C; p.stats_rep = hook->stats_rep; p.affine = hook->affine; p.affine_ld = hook->affine_ld; }
     WdgPhase ph;
     ph.Pa = g.Ho; ph.Pb = g.Wo; ph.a_off_h = -g.pad_h; ph.a_off_w = -g.pad_w;
     ph.o_off_h = 0; ph.o_off_w = 0; ph.K4 = pl->K4_fwd; ph.tab_off = 0;
+    wdg_phase_finish(ph);
     p.ph[0] = ph;
-    return launch_igemm(p, 1, pl->K4_fwd, pl->fwd_split, ws, ws_bytes, (hipStream_t)stream);
+    bool fused = false;
+    const int rc = launch_igemm(p, 1, pl->K4_fwd, pl->fwd_split, ws, ws_bytes, (hipStream_t)stream, &fused);
+    if (rc != WDG_OK || !hook || fused) return rc;
+    return bn_hook_fallback(*hook, y, g.ldy, g.img_stride_y, g.n_img, g.Ho, g.Wo, g.Cout, stream);
 }
 
-extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const float* wD, const float* bias,
-                              float* dx, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
-                              wdg_stream stream) {
+static int conv_dgrad_impl(const wdg_conv_plan* pl, const float* dy, const float* wD, const float* bias, float* dx, int act,
+                           float slope, int accumulate, const WdgBnHook* hook, void* ws, size_t ws_bytes, wdg_stream stream) {
     WDG_CHECK_ARG(pl && dy && wD && dx, "null argument");
     WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0 && ((uintptr_t)dx & 15) == 0, "dy / wD / dx must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
-    if (pl->halo_auto_dgrad && pl->halo_dgrad_nt)
-        return wdg_halo_launch(pl, true, dy, g.ldy, g.img_stride_y, 0, wD, bias, dx, act, slope, accumulate,
-                               (hipStream_t)stream);
+    if (pl->halo_auto_dgrad && pl->halo_dgrad_nt) {
+        const int rc = wdg_halo_launch(pl, true, dy, g.ldy, g.img_stride_y, 0, wD, bias, dx, act, slope, accumulate,
+                                       (hipStream_t)stream);
+        if (rc != WDG_OK || !hook) return rc;
+        return bn_hook_fallback(*hook, dx, g.ldx, g.img_stride_x, g.n_img, g.H, g.W, g.Cin, stream);
+    }
     WdgIgemm p;
     memset(&p, 0, sizeof(p));
     p.A = dy; p.B = wD; p.Out = dx; p.bias = bias; p.ktab = pl->d_tab_dgrad;
@@ -992,6 +1120,7 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
     p.Ncols = g.Cin; p.ldB = pl->Cout_p;
     p.a_mul = 1; p.o_mul = g.stride;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
+    if (hook) { p.stats = hook->stats; p.stats_C = hook->stats_C; p.stats_rep = hook->stats_rep; p.affine = hook->affine; p.affine_ld = hook->affine_ld; }
     int Mmax = 0;
     const int np = (int)pl->ph_dgrad.size();
     for (int i = 0; i < np; ++i) {
@@ -999,7 +1128,49 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
         Mmax = std::max(Mmax, g.n_img * p.ph[i].Pa * p.ph[i].Pb);
     }
     p.Mmax = Mmax;
-    return launch_igemm(p, np, pl->K4_dgrad_max, pl->dgrad_split, ws, ws_bytes, (hipStream_t)stream);
+    bool fused = false;
+    const int rc = launch_igemm(p, np, pl->K4_dgrad_max, pl->dgrad_split, ws, ws_bytes, (hipStream_t)stream, &fused);
+    if (rc != WDG_OK || !hook || fused) return rc;
+    return bn_hook_fallback(*hook, dx, g.ldx, g.img_stride_x, g.n_img, g.H, g.W, g.Cin, stream);
+}
+
+extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias,
+                            float* y, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
+                            wdg_stream stream) {
+    return conv_fwd_impl(pl, x, wF, bias, y, act, slope, accumulate, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const float* wD, const float* bias,
+                              float* dx, int act, float slope, int accumulate, void* ws, size_t ws_bytes,
+                              wdg_stream stream) {
+    return conv_dgrad_impl(pl, dy, wD, bias, dx, act, slope, accumulate, nullptr, ws, ws_bytes, stream);
+}
+
+static int bn_hook_make(WdgBnHook& h, double* stats, int stats_rep, const float* affine, int C) {
+    WDG_CHECK_ARG((stats != nullptr) != (affine != nullptr), "exactly one of stats / affine");
+    WDG_CHECK_ARG(!stats || stats_rep >= 1, "stats_rep must be >= 1");
+    h.stats = stats; h.stats_C = C; h.stats_rep = stats ? stats_rep : 0; h.affine = affine; h.affine_ld = C;
+    return WDG_OK;
+}
+
+extern "C" int wdg_conv_fwd_bn(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y,
+                               int act, float slope, double* stats, int stats_rep, const float* affine, void* ws,
+                               size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl, "null plan");
+    WdgBnHook h;
+    const int rc = bn_hook_make(h, stats, stats_rep, affine, pl->g.Cout);
+    if (rc != WDG_OK) return rc;
+    return conv_fwd_impl(pl, x, wF, bias, y, act, slope, 0, &h, ws, ws_bytes, stream);
+}
+
+extern "C" int wdg_conv_dgrad_bn(const wdg_conv_plan* pl, const float* dy, const float* wD, const float* bias, float* dx,
+                                 int act, float slope, double* stats, int stats_rep, const float* affine, void* ws,
+                                 size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl, "null plan");
+    WdgBnHook h;
+    const int rc = bn_hook_make(h, stats, stats_rep, affine, pl->g.Cin);
+    if (rc != WDG_OK) return rc;
+    return conv_dgrad_impl(pl, dy, wD, bias, dx, act, slope, 0, &h, ws, ws_bytes, stream);
 }
 
 int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out, int accumulate, wdg_stream stream);

@@ -9,7 +9,12 @@ struct WdgPhase {
     int o_off_h, o_off_w;  // Out coord = pa * o_mul + o_off
     int K4;                // k4 groups (padded to a multiple of 8 with invalid entries)
     int tab_off;           // first table entry of this phase
+    wdg_fastdiv div_papb, div_pb;   // row index -> (image, pa, pb) by multiply-high (wdg_phase_finish fills them)
 };
+static inline void wdg_phase_finish(WdgPhase& ph) {
+    ph.div_papb = wdg_fastdiv_make((unsigned)(ph.Pa * ph.Pb > 0 ? ph.Pa * ph.Pb : 1));
+    ph.div_pb = wdg_fastdiv_make((unsigned)(ph.Pb > 0 ? ph.Pb : 1));
+}
 
 struct wdg_conv_plan {
     wdg_conv_geom g;

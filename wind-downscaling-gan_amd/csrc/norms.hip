@@ -104,13 +104,23 @@ extern "C" int wdg_bn_stats(const float* x, int64_t P, int C, int ldx, double* s
     return WDG_OK;
 }
 
-__global__ void wdg_bn_finalize_train_kernel(const double* stats, double count, const float* gamma,
-                                             const float* beta, float* mmean, float* mvar, float momentum,
-                                             float eps, float* ss, float* saved, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: the lanes stride over the replica slabs [replicas][2][C] the producers spread their atomics
+// over (fixed order per lane, then a wave butterfly), lane 0 finalises
+__global__ void __launch_bounds__(256) wdg_bn_finalize_train_kernel(const double* stats, int replicas, double count, const float* gamma,
+                                                                    const float* beta, float* mmean, float* mvar, float momentum,
+                                                                    float eps, float* ss, float* saved, int C) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    const double mean = stats[c] / count;
-    double var = stats[C + c] / count - mean * mean;
+    double s1 = 0, s2 = 0;
+    for (int r = lane; r < replicas; r += 64) {
+        s1 += stats[(size_t)r * 2 * C + c];
+        s2 += stats[(size_t)r * 2 * C + C + c];
+    }
+    s1 = wdg_wave_sum_d(s1);
+    s2 = wdg_wave_sum_d(s2);
+    if (lane) return;
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const float scale = (float)((double)gamma[c] * invstd);
@@ -126,14 +136,31 @@ __global__ void wdg_bn_finalize_train_kernel(const double* stats, double count, 
     mvar[c] = mvar[c] * momentum + (float)var_unbiased * (1.f - momentum);
 }
 
-extern "C" int wdg_bn_finalize_train(const double* stats, double count, const float* gamma, const float* beta,
+extern "C" int wdg_bn_finalize_train(const double* stats, int replicas, double count, const float* gamma, const float* beta,
                                      float* moving_mean, float* moving_var, float momentum, float eps,
                                      float* scale_shift, float* saved_mean_invstd, int C, wdg_stream stream) {
-    WDG_CHECK_ARG(stats && gamma && beta && moving_mean && moving_var && scale_shift && saved_mean_invstd,
+    WDG_CHECK_ARG(stats && gamma && beta && moving_mean && moving_var && scale_shift && saved_mean_invstd && replicas >= 1,
                   "null argument");
-    hipLaunchKernelGGL(wdg_bn_finalize_train_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                       stats, count, gamma, beta, moving_mean, moving_var, momentum, eps, scale_shift,
+    hipLaunchKernelGGL(wdg_bn_finalize_train_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       stats, replicas, count, gamma, beta, moving_mean, moving_var, momentum, eps, scale_shift,
                        saved_mean_invstd, C);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// stats[0][:] = sum_r stats[r][:] (in place): the data-parallel exchange of the batch statistics then moves 2*C values
+__global__ void __launch_bounds__(256) wdg_bn_collapse_kernel(double* stats, int replicas, int C2) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C2) return;
+    double s = 0;
+    for (int r = lane; r < replicas; r += 64) s += stats[(size_t)r * C2 + c];
+    s = wdg_wave_sum_d(s);
+    if (lane == 0) stats[c] = s;
+}
+
+extern "C" int wdg_bn_collapse(double* stats, int replicas, int C, wdg_stream stream) {
+    WDG_CHECK_ARG(stats && replicas >= 1 && C > 0, "bad argument");
+    hipLaunchKernelGGL(wdg_bn_collapse_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, stats, replicas, 2 * C);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -116,7 +116,8 @@ extern "C" int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, f
 template <int CQ>
 __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                                 const float* __restrict__ affine, float* __restrict__ y,
-                                                                int ldy, long long isy, int Hl, int Wl, int act, float slope) {
+                                                                int ldy, long long isy, int Hl, int Wl, int act, float slope,
+                                                                double* stats, int stats_rep) {
     constexpr int ZW = TS + 4;                       // low-res window edge (12)
     constexpr int PX = 5 * CQ;                       // float4 per window pixel and tap row
     __shared__ f32x4 Z[ZW * ZW * PX];
@@ -194,26 +195,54 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __r
         }
         __syncthreads();
     }
-    if (qy < 2 * Hl && qx < 2 * Wl) {
-        float* dst = y + n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+    const bool inside = qy < 2 * Hl && qx < 2 * Wl;
+    float* dst = y + n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
 #pragma unroll
-        for (int o4 = 0; o4 < CQ; ++o4) {
-            f32x4 v = acc[o4];
-            if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
-            if (act) {
+    for (int o4 = 0; o4 < CQ; ++o4) {
+        f32x4 v = acc[o4];
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
+        if (act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
+            for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
+        }
+        if (affine)     // fused inference BatchNorm: scale | shift per channel after the activation
+            v = v * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * CQ + 4 * o4);
+        if (inside) *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
+        acc[o4] = inside ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (stats) {
+        // training-mode BatchNorm producer: per-channel sum / sum of squares of this block's 256 pixels -> one replica
+        // slab [2][4*CQ] (wave butterflies, the four waves meet in LDS, one fp64 atomic pair per channel and block)
+        float* red = reinterpret_cast<float*>(Hs);       // the tap loop has ended behind a barrier
+#pragma unroll
+        for (int o4 = 0; o4 < CQ; ++o4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = wdg_wave_sum_fast(acc[o4][r]), s2 = wdg_wave_sum_fast(acc[o4][r] * acc[o4][r]);
+                if ((t & 63) == 0) {
+                    red[((t >> 6) * 4 * CQ + 4 * o4 + r) * 2 + 0] = s1;
+                    red[((t >> 6) * 4 * CQ + 4 * o4 + r) * 2 + 1] = s2;
+                }
             }
-            if (affine)     // fused inference BatchNorm: scale | shift per channel after the activation
-                v = v * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * CQ + 4 * o4);
-            *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
+        __syncthreads();
+        if (t < 4 * CQ) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s1 += red[(w * 4 * CQ + t) * 2 + 0];
+                s2 += red[(w * 4 * CQ + t) * 2 + 1];
+            }
+            double* slab = stats + (size_t)((blockIdx.x + blockIdx.y) % stats_rep) * 2 * (4 * CQ);
+            atomicAdd(slab + t, (double)s1);
+            atomicAdd(slab + 4 * CQ + t, (double)s2);
         }
     }
 }
 
 extern "C" int wdg_upconv_gather(const float* z, const float* bias, const float* affine, float* y, int ldy,
                                  int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope,
-                                 wdg_stream stream) {
+                                 double* stats, int stats_rep, wdg_stream stream) {
+    WDG_CHECK_ARG(!stats || (stats_rep >= 1 && !affine), "stats: replicas >= 1, not together with affine");
     WDG_CHECK_ARG(z && y && n_img > 0 && n_img < 65536 && Hl > 0 && Wl > 0 && ldy % 4 == 0, "bad argument");
     WDG_CHECK_ARG(wdg_upconv_col_supported(C), "channel count must be 4, 8 or 16");
     WDG_CHECK_ARG(((uintptr_t)z & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)affine & 15) == 0, "z / y / bias / affine must be 16-byte aligned");
@@ -221,11 +250,11 @@ extern "C" int wdg_upconv_gather(const float* z, const float* bias, const float*
     dim3 grid(tiles, n_img), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (C == 16)
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep);
     else if (C == 8)
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep);
     else
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -260,18 +260,34 @@ class HipOps:
         return "wdg_wgrad_halo_kernel" if info[6] == 0 else "wdg_wgrad_kernel<%d>" % info[6]
 
     # ---- convolution family -----------------------------------------------------------------
-    def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2):
-        """y = act(conv(x, W) + bias) (+ y);  x:(N,H,W,>=Cin) y:(N,Ho,Wo,>=Cout)."""
+    def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
+        """y = act(conv(x, W) + bias) (+ y);  x:(N,H,W,>=Cin) y:(N,Ho,Wo,>=Cout).
+        bn_stats [R, 2*Cout] fp64 (zeroed by the caller): the launch also accumulates the per-channel sum / sum of squares
+        of y there (the first pass of a training-mode BatchNormalization on y); bn_affine [2*Cout]: y is additionally
+        scaled / shifted per channel (inference-mode BatchNormalization) — see wdg_conv_fwd_bn."""
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
+        if bn_stats is not None or bn_affine is not None:
+            assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * pk.cout))
+            native.check(self.lib.wdg_conv_fwd_bn(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), int(act), slope,
+                                                  _ptr(bn_stats), bn_stats.shape[0] if bn_stats is not None else 0,
+                                                  _ptr(bn_affine), ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_bn")
+            return
         native.check(self.lib.wdg_conv_fwd(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(),
                                            int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                            self.stream), "conv_fwd")
 
-    def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2):
-        """dx = act(conv_transpose(dy, W) + bias) (+ dx);  the geometry is that of the forward conv."""
+    def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
+        """dx = act(conv_transpose(dy, W) + bias) (+ dx);  the geometry is that of the forward conv.  bn_stats / bn_affine
+        as in conv_fwd, over the Cin channels this launch writes."""
         plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
+        if bn_stats is not None or bn_affine is not None:
+            assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * pk.cin))
+            native.check(self.lib.wdg_conv_dgrad_bn(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(), int(act), slope,
+                                                    _ptr(bn_stats), bn_stats.shape[0] if bn_stats is not None else 0,
+                                                    _ptr(bn_affine), ws.data_ptr(), ws.numel(), self.stream), "conv_dgrad_bn")
+            return
         native.check(self.lib.wdg_conv_dgrad(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(),
                                              int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                              self.stream), "conv_dgrad")
@@ -310,7 +326,7 @@ class HipOps:
             native.check(fn(plan, x_low.data_ptr(), pk.half(fmt)[1].data_ptr(), 0, 0, z.data_ptr(), 0, slope, 0, self.stream),
                          "conv_dgrad_16")
             native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), _ptr(affine), py, ldy, isy, n, H // 2, W // 2,
-                                                    pk.cin, int(act), slope, self.stream), "upconv_gather")
+                                                    pk.cin, int(act), slope, 0, 0, self.stream), "upconv_gather")
             return
         cp = (pk.cout + 3) // 4 * 4
         plan, _, _ = self._plan_dims(n, H, W, pk.cin, ldy, isy, H, W, pk.cout, cp, H * W * cp, g)
@@ -318,9 +334,23 @@ class HipOps:
         native.check(fn(plan, px, ldl, isl, pk.half(fmt)[1].data_ptr(), _ptr(bias), _ptr(affine),
                         py, int(act), slope, self.stream), "upconv_fwd_16")
 
-    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2, pool=None):
+    def upconv_fwd(self, x_low, pk, bias, y, g, act=True, slope=0.2, pool=None, bn_stats=None, bn_affine=None):
         """y = act(convT(bilinear_x2(x_low), W) + bias) without materialising the upsampled tensor.
-        pk/g describe the transposed conv as the conv it is the adjoint of (cin = y channels)."""
+        pk/g describe the transposed conv as the conv it is the adjoint of (cin = y channels).
+        bn_stats / bn_affine: BatchNormalization hooks as in conv_fwd (fused in the column-form gather kernel; the other
+        routes run the standalone pass behind the convolution)."""
+        if bn_stats is not None or bn_affine is not None:
+            col = self.upconv_colfwd and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
+                x_low.shape[3] == pk.cout and pk.cout % 4 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
+                pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (bn_affine is None or bn_affine.data_ptr() % 16 == 0)
+            if not col:
+                self.upconv_fwd(x_low, pk, bias, y, g, act=act, slope=slope, pool=pool)
+                y2 = y.view(-1, y.shape[-1])[:, :pk.cin]
+                if bn_stats is not None:
+                    self.bn_stats(y2, bn_stats[0])
+                else:
+                    self.bn_apply(y2, bn_affine, y2)
+                return
         px, ldl, isl = _v4(x_low)
         py, ldy, isy = _v4(y)
         n, H, W, _ = y.shape
@@ -330,8 +360,9 @@ class HipOps:
             # column form: z = x * W on the low-res grid (1x1 GEMM, 25*cin columns), then the bilinear gather
             z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin, pool=pool)
             self.conv_dgrad(x_low, pk.as_1x1(), z, ConvGeom(1, 1, 1, 0))
-            native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), 0, py, ldy, isy, n, H // 2, W // 2, pk.cin,
-                                                    int(act), slope, self.stream), "upconv_gather")
+            native.check(self.lib.wdg_upconv_gather(z.data_ptr(), _ptr(bias), _ptr(bn_affine), py, ldy, isy, n, H // 2, W // 2, pk.cin,
+                                                    int(act), slope, _ptr(bn_stats), bn_stats.shape[0] if bn_stats is not None else 0,
+                                                    self.stream), "upconv_gather")
             return
         if self.upconv4 and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
                 self.lib.wdg_upconv4_supported(pk.cin, pk.cout, H // 2, W // 2):
@@ -411,9 +442,15 @@ class HipOps:
         native.check(self.lib.wdg_bn_stats(px, x.shape[0], x.shape[1], ld, stats.data_ptr(), self.stream), "bn_stats")
 
     def bn_finalize_train(self, stats, count, gamma, beta, mmean, mvar, momentum, eps, ss, saved):
-        native.check(self.lib.wdg_bn_finalize_train(stats.data_ptr(), float(count), gamma.data_ptr(), beta.data_ptr(),
+        """stats: [R, 2C] fp64 replica slabs (summed by the kernel)."""
+        assert stats.dim() == 2 and stats.is_contiguous()
+        native.check(self.lib.wdg_bn_finalize_train(stats.data_ptr(), stats.shape[0], float(count), gamma.data_ptr(), beta.data_ptr(),
                                                     mmean.data_ptr(), mvar.data_ptr(), momentum, eps, ss.data_ptr(),
                                                     saved.data_ptr(), gamma.numel(), self.stream), "bn_finalize_train")
+
+    def bn_collapse(self, stats):
+        """stats[0] = stats.sum(0) in place ([R, 2C] fp64)."""
+        native.check(self.lib.wdg_bn_collapse(stats.data_ptr(), stats.shape[0], stats.shape[1] // 2, self.stream), "bn_collapse")
 
     def bn_finalize_infer(self, gamma, beta, mmean, mvar, eps, ss):
         native.check(self.lib.wdg_bn_finalize_infer(gamma.data_ptr(), beta.data_ptr(), mmean.data_ptr(),

@@ -44,11 +44,14 @@ class Conv:
         """(packed weights, sn_u or None) for the network's batched SN / repack stage (_Net._prepare)."""
         return [(self.pk, self.u.value.view(-1) if self.sn else None)]
 
-    def forward(self, x, y):
+    def forward(self, x, y, bn_stats=None, bn_affine=None):
+        """bn_stats / bn_affine: the BatchNormalization that follows the layer, folded into the launch (training: batch
+        statistics of y accumulated by the epilogue; inference: y normalised in the epilogue) — HipOps.conv_fwd."""
+        hooks = {} if bn_stats is None and bn_affine is None else dict(bn_stats=bn_stats, bn_affine=bn_affine)
         if self.transposed:
-            self.ops.conv_dgrad(x, self.pk, y, self.g, bias=self.b.value, act=self.act, slope=LRELU)
+            self.ops.conv_dgrad(x, self.pk, y, self.g, bias=self.b.value, act=self.act, slope=LRELU, **hooks)
         else:
-            self.ops.conv_fwd(x, self.pk, self.b.value, y, self.g, act=self.act, slope=LRELU)
+            self.ops.conv_fwd(x, self.pk, self.b.value, y, self.g, act=self.act, slope=LRELU, **hooks)
 
     def forward_bf16(self, x, y, affine=None, fmt="bf16"):
         """Inference precision (bf16 or fp16 operands, fp32 accumulate); `affine` = fused inference BatchNorm."""
@@ -96,6 +99,8 @@ class Dense:
 
 
 class BatchNorm:
+    REPLICAS = 512
+
     def __init__(self, net, name, C):
         self.net, self.ops, self.C = net, net.ops, C
         st = net.params
@@ -107,25 +112,36 @@ class BatchNorm:
     def build(self):
         import torch
         o, C = self.ops, self.C
-        self.stats = o.zeros(2 * C, dtype=torch.float64)
+        # [replica][sum | sum of squares]: the conv epilogues that produce this layer's input spread their fp64 atomics over
+        # the replicas; wdg_bn_stats (standalone pass) uses replica 0; bn_finalize_train sums them
+        self.stats = o.zeros(self.REPLICAS, 2 * C, dtype=torch.float64)
         self.red = o.zeros(2 * C, dtype=torch.float64)
         self.red_local = o.zeros(2 * C, dtype=torch.float64)
         self.ss = o.empty(2 * C)
         self.saved = o.empty(2 * C)
         self.count = 1.0
 
-    def forward(self, y, z, training):
+    def begin_stats(self):
+        """Zeroed statistics slabs for the producing conv launch (pass them as its bn_stats; then forward(..., have_stats=True))."""
+        self.stats.zero_()
+        return self.stats
+
+    def forward(self, y, z, training, have_stats=False):
         o = self.ops
         if training:
-            self.stats.zero_()
-            o.bn_stats(y, self.stats)
+            if not have_stats:
+                self.stats.zero_()
+                o.bn_stats(y, self.stats[0])
             count = float(y.shape[0])
             sync = self.net.sync
+            stats = self.stats
             if sync is not None:  # SyncBN: the batch statistics couple the *global* batch
-                sync.all_reduce_sum(self.stats)
+                o.bn_collapse(stats)          # the exchange moves 2*C values, not the replica slabs
+                stats = stats[:1]
+                sync.all_reduce_sum(stats)
                 count *= sync.world_size
             self.count = count
-            o.bn_finalize_train(self.stats, count, self.gamma.value, self.beta.value, self.mmean.value,
+            o.bn_finalize_train(stats, count, self.gamma.value, self.beta.value, self.mmean.value,
                                 self.mvar.value, BN_MOMENTUM, BN_EPS, self.ss, self.saved)
         else:
             o.bn_finalize_infer(self.gamma.value, self.beta.value, self.mmean.value, self.mvar.value, BN_EPS, self.ss)

@@ -43,6 +43,8 @@ SIGNATURES = {
     "wdg_conv_plan_info": (i32, [C.c_void_p, C.POINTER(i32)]),
     "wdg_conv_fwd": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp, szt, c_fp]),
     "wdg_conv_dgrad": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, i32, c_fp, szt, c_fp]),
+    "wdg_conv_fwd_bn": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp, i32, c_fp, c_fp, szt, c_fp]),
+    "wdg_conv_dgrad_bn": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp, i32, c_fp, c_fp, szt, c_fp]),
     "wdg_upconv_fwd": (i32, [C.c_void_p, c_fp, i32, i64, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     "wdg_upconv4_weight_floats": (szt, [i32, i32]),
     "wdg_upconv4_supported": (i32, [i32, i32, i32, i32]),
@@ -68,7 +70,8 @@ SIGNATURES = {
     "wdg_prep_batch_run": (i32, [C.c_void_p, c_fp, i32, c_fp]),
     "wdg_prep_batch_destroy": (i32, [C.c_void_p]),
     "wdg_bn_stats": (i32, [c_fp, i64, i32, i32, c_fp, c_fp]),
-    "wdg_bn_finalize_train": (i32, [c_fp, f64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, c_fp, i32, c_fp]),
+    "wdg_bn_finalize_train": (i32, [c_fp, i32, f64, c_fp, c_fp, c_fp, c_fp, f32, f32, c_fp, c_fp, i32, c_fp]),
+    "wdg_bn_collapse": (i32, [c_fp, i32, i32, c_fp]),
     "wdg_bn_finalize_infer": (i32, [c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, c_fp]),
     "wdg_bn_apply": (i32, [c_fp, i32, c_fp, c_fp, i32, i64, i32, c_fp]),
     "wdg_bn_bwd_reduce": (i32, [c_fp, i32, c_fp, i32, c_fp, i64, i32, c_fp, c_fp]),
@@ -98,7 +101,7 @@ SIGNATURES = {
     "wdg_upsample2x_bwd": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_upconv_col_supported": (i32, [i32]),
     "wdg_upconv_col": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, c_fp]),
-    "wdg_upconv_gather": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, f32, c_fp]),
+    "wdg_upconv_gather": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, f32, c_fp, i32, c_fp]),
     "wdg_patch_gather": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_patch_scatter": (i32, [c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

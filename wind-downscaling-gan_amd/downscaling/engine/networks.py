@@ -234,18 +234,32 @@ class GeneratorNet(_Net):
             return b["out"]
         if precision != "fp32":
             raise ValueError(f"unknown precision {precision!r}")
-        self.c0.forward(b["x0"], b["y0"])
-        self.bn1.forward(v2(b["y0"]), v2(res2), training)
-        self.c2.forward(res2, b["y2"])
-        self.bn3.forward(v2(b["y2"]), v2(res4), training)
+        if not training:
+            # inference: every BatchNormalization is a per-channel affine of moving statistics, applied by the epilogue of
+            # the launch that produces its input (no pre-norm tensor, no normalisation pass)
+            self.c0.forward(b["x0"], res2, bn_affine=self.bn1.infer_affine())
+            self.c2.forward(res2, res4, bn_affine=self.bn3.infer_affine())
+            self.lstm.forward(res4, b["h"], B, T)
+            self.c5.forward(b["h"], b["cat4"][..., :F // 2], bn_affine=self.bn6.infer_affine())
+            self.c7.forward(b["cat4"], b["cat2"][..., :F // 4], bn_affine=self.bn8.infer_affine())
+            self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
+                                pool=self._scratch_pool(b), bn_affine=self.bn10.infer_affine())
+            self.c11.forward(b["z9"], b["out"])
+            return b["out"]
+        # training: batch statistics come out of the producing launch's epilogue (BatchNorm.begin_stats), the
+        # normalisation itself is one pass (bn_apply) once they are complete
+        self.c0.forward(b["x0"], b["y0"], bn_stats=self.bn1.begin_stats())
+        self.bn1.forward(v2(b["y0"]), v2(res2), True, have_stats=True)
+        self.c2.forward(res2, b["y2"], bn_stats=self.bn3.begin_stats())
+        self.bn3.forward(v2(b["y2"]), v2(res4), True, have_stats=True)
         self.lstm.forward(res4, b["h"], B, T)
-        self.c5.forward(b["h"], b["y5"])
-        self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), training)
-        self.c7.forward(b["cat4"], b["y7"])
-        self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), training)
+        self.c5.forward(b["h"], b["y5"], bn_stats=self.bn6.begin_stats())
+        self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), True, have_stats=True)
+        self.c7.forward(b["cat4"], b["y7"], bn_stats=self.bn8.begin_stats())
+        self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), True, have_stats=True)
         self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True,      # :62-64 fused
-                            pool=self._scratch_pool(b))
-        self.bn10.forward(v2(b["y9"]), v2(b["z9"]), training)
+                            pool=self._scratch_pool(b), bn_stats=self.bn10.begin_stats())
+        self.bn10.forward(v2(b["y9"]), v2(b["z9"]), True, have_stats=True)
         self.c11.forward(b["z9"], b["out"])
         return b["out"]
 
