@@ -282,9 +282,11 @@ def _grads(loss, w, keys):
     return {k: (g if g is not None else torch.zeros_like(w[k])) for k, g in zip(keys, gs)}
 
 
-def train_step(gw, dw, low, high, draws, g_opt, d_opt, n_critic=3, gamma=100.0):
+def train_step(gw, dw, low, high, draws, g_opt, d_opt, n_critic=3, gamma=100.0, d_loss_fn=None):
     """GAN.train_step, ganbase.py:21-94.  `draws` supplies the random tensors in call order:
-    draws.noise() [B,T,S,S,nz], draws.eps() [B], draws.inst() [B,T,S,S,ch].  Mutates gw/dw in place."""
+    draws.noise() [B,T,S,S,nz], draws.eps() [B], draws.inst() [B,T,S,S,ch].  Mutates gw/dw in place.
+    d_loss_fn(real_output [B,1], fake_output [B,1]) -> scalar: the discriminator's compiled loss
+    (ganbase.py:44-45; default the Wasserstein form of train.py:11-12)."""
     S = high.shape[2]
     gk, dk = trainable_keys(gw), trainable_keys(dw)
     for k in gk:
@@ -310,14 +312,30 @@ def train_step(gw, dw, low, high, draws, g_opt, d_opt, n_critic=3, gamma=100.0):
         gradient_reg = gamma * ((gnorm - 1) ** 2).mean()                               # :37
         hr = high + draws.inst()                                                       # :40
         apply_sn(dw, d_sn, True)
-        real_s = discriminator_forward(dw, low, hr)                                    # :41
-        g_real = _grads(-real_s.mean(), dw, dk)     # weights as they were for this call (TF reads the
-        fhr = fake + draws.inst()                   # variable value at forward time)          :42
-        apply_sn(dw, d_sn, True)
-        fake_s = discriminator_forward(dw, low, fhr)                                   # :43
-        g_fake = _grads(fake_s.mean(), dw, dk)
-        disc_loss = (fake_s.mean() - real_s.mean()).detach() + gradient_reg.detach()   # :44-45
-        d_grads = {k: g_real[k] + g_fake[k] for k in dk}                               # :46
+        if d_loss_fn is None:
+            real_s = discriminator_forward(dw, low, hr)                                # :41
+            g_real = _grads(-real_s.mean(), dw, dk)     # weights as they were for this call (TF reads the
+            fhr = fake + draws.inst()                   # variable value at forward time)          :42
+            apply_sn(dw, d_sn, True)
+            fake_s = discriminator_forward(dw, low, fhr)                               # :43
+            g_fake = _grads(fake_s.mean(), dw, dk)
+            disc_loss = (fake_s.mean() - real_s.mean()).detach() + gradient_reg.detach()   # :44-45
+            d_grads = {k: g_real[k] + g_fake[k] for k in dk}                           # :46
+        else:
+            # a loss that couples the two outputs: the real pass keeps the variable values it read (a copy: the fake
+            # pass' SN update overwrites them in place), the tape sums both passes' partial derivatives per variable
+            w_real = {k: (v.detach().clone().requires_grad_(True) if k in dk else v.detach().clone()) for k, v in dw.items()}
+            real_s = discriminator_forward(w_real, low, hr)                            # :41
+            fhr = fake + draws.inst()                                                  # :42
+            apply_sn(dw, d_sn, True)
+            fake_s = discriminator_forward(dw, low, fhr)                               # :43
+            loss = d_loss_fn(real_s, fake_s)                                           # :44 compiled_loss(real, fake)
+            both = torch.autograd.grad(loss, [w_real[k] for k in dk] + [dw[k] for k in dk], allow_unused=True)
+            zero = lambda g, k: g if g is not None else torch.zeros_like(dw[k])   # noqa: E731
+            g_real = {k: zero(g, k) for k, g in zip(dk, both[:len(dk)])}
+            g_fake = {k: zero(g, k) for k, g in zip(dk, both[len(dk):])}
+            disc_loss = loss.detach() + gradient_reg.detach()
+            d_grads = {k: g_real[k] + g_fake[k] for k in dk}
         d_opt.step(dw, d_grads)                                                        # :47
     noise = draws.noise()                                                              # :51
     apply_sn(gw, g_sn, True)

@@ -121,6 +121,38 @@ def test_train_step(hip_ops, S, T):
                 assert rel_err(got[k], w[k]) < TOL, (step, k)
 
 
+def _relativistic(real_output, fake_output):
+    return (torch.relu(1.0 - (real_output - fake_output.mean())).mean() + torch.relu(1.0 + (fake_output - real_output.mean())).mean())
+
+
+@pytest.mark.parametrize("S,T", [(32, 2), (20, 1)])
+def test_train_step_custom_discriminator_loss(hip_ops, S, T):
+    """compile(discriminator_loss=<callable coupling real and generated scores>) (ganbase.py:44-45): the coupled critic
+    path (real pass on the discriminator's twin) on the HIP kernels against the autograd restatement."""
+    from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
+    from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
+    B, cin, nz, ch = 2, 3, 4, 2
+    dev = hip_ops.device
+    gen = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=32, seed=5)
+    disc = DiscriminatorNet(hip_ops, S, S, cin, ch, T, feature_channels=8, seed=6)
+    gw, dw = randomize(gen, 21), randomize(disc, 22)
+    eng = GanEngine(gen, disc, PhiloxSource(hip_ops, seed=99), noise_std=0.1, n_critic=2)
+    g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
+    og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
+    draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
+    for step in range(2):
+        low, _, high = _inputs(B, T, S, cin, nz, ch, seed=50 + step)
+        res = eng.train_step(low.float().to(dev), high.float().to(dev), g_opt, d_opt, d_loss_fn=_relativistic)
+        ref = TM.train_step(gw, dw, low, high, draws, og, od, n_critic=2, d_loss_fn=_relativistic)
+        for k in ("g_loss", "d_loss", "d_gradient_pen", "d_gradient_param", "_d_loss_train"):
+            a, b = float(res[k]), float(ref[k])
+            assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (step, k, a, b)
+        for net, w in ((gen, gw), (disc, dw)):
+            got = weights64(net)
+            for k in w:
+                assert rel_err(got[k], w[k]) < TOL, (step, k)
+
+
 @pytest.mark.parametrize("S,T,latent", [(96, 2, 96), (40, 1, 8)])
 def test_encoder_feature_extractor(hip_ops, S, T, latent):
     """The reconstruction-loss feature extractor (autoencoder/autoencoder.py:23-36) on the HIP kernels: forward and

@@ -357,6 +357,10 @@ class DiscriminatorNet(_Net):
     def __init__(self, ops, low_res_size, high_res_size, low_res_channels, high_res_channels, n_timesteps,
                  feature_channels=16, seed=1, sync=None, shortcut_variant=False):
         super().__init__(ops, sync)
+        self._ctor = dict(low_res_size=low_res_size, high_res_size=high_res_size, low_res_channels=low_res_channels,
+                          high_res_channels=high_res_channels, n_timesteps=n_timesteps, feature_channels=feature_channels,
+                          seed=seed, shortcut_variant=shortcut_variant)
+        self._twin = None
         if low_res_size != high_res_size:               # models.py:89-91
             raise NotImplementedError("The discriminator assumes that the low res and high res images have the "
                                       "same size.Perhaps you should upsample your low res image first?")
@@ -443,6 +447,14 @@ class DiscriminatorNet(_Net):
                      sc_z=o.empty(N, t, t, sc["cout"]), sc_dz=o.empty(N, t, t, sc["cout"]))
         self._bufs = {B: b}
         return b
+
+    def twin(self):
+        """A second network of the same graph with its OWN variables and activations, for train steps whose
+        discriminator loss couples the real and the generated scores (GanEngine._critic_coupled): it holds the real pass
+        — the variable values that pass read and its activations — while this network runs the generated pass."""
+        if self._twin is None:
+            self._twin = DiscriminatorNet(self.ops, **self._ctor)
+        return self._twin
 
     def set_low(self, low):
         """low [B,T,S,S,cl] -> channels [0:cl] of the mix buffer (constant over a train step)."""

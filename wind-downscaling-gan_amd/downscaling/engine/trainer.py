@@ -156,8 +156,45 @@ class GanEngine:
         self.ops.segment_meansq(st.grads, st.seg_pairs, st.seg_out)
         return st.seg_out.mean() * (scale * scale)
 
-    def train_step(self, low, high, g_opt, d_opt, sample_weight=None, reconstruction_loss=None):
-        """One GAN.train_step (ganbase.py:21-94).  low [B,T,S,S,cl], high [B,T,S,S,ch] device tensors."""
+    def _critic_coupled(self, d_loss_fn, B, real, fake, noisy, sw_mean, low):
+        """Real + generated pass of one critic iteration for an arbitrary compiled loss d_loss_fn(real_output,
+        fake_output) (ganbase.py:41-46).  The built-in Wasserstein loss is separable, so its real pass is differentiated
+        before the generated pass runs; a general loss needs both score vectors first.  The real pass therefore runs on
+        the discriminator's twin (same variable values: copied, then the same deterministic SN update), which keeps that
+        pass' weights and activations while this network takes the SN update of the generated pass; the loss is
+        differentiated w.r.t. the two score vectors by torch autograd (2 x B numbers) and each pass is back-propagated
+        with its own scores' gradient.  Returns (loss value, real mean, fake mean)."""
+        disc, ops, noise = self.disc, self.ops, self.noise
+        ch = disc.ch
+        twin = disc.twin()
+        twin.params.flat.copy_(disc.params.flat)
+        twin.params.state.copy_(disc.params.state)
+        twin.params.version += 1
+        twin.params.zero_grad()
+        twin.set_low(low)
+        noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(real[..., :ch]))        # :40
+        twin.set_high_tm(noisy, B)
+        real_scores = twin.forward(B, training=True).clone()                                  # :41  (SN update on the copy)
+        disc._prepare(True)                                                                   # ... and the same one here
+        # (the twin reads `noisy` in place until its backward has run: the generated pass gets its own buffer)
+        noisy2 = self._buf("noisy2", *noisy.shape)
+        noise.normal_into(v2(noisy2[..., :ch]), self.noise_std, add=v2(fake[..., :ch]))       # :42
+        disc.set_high_tm(noisy2, B)
+        fake_scores = disc.forward(B, training=True).clone()                                  # :43
+        r = real_scores.detach().clone().requires_grad_(True)
+        f = fake_scores.detach().clone().requires_grad_(True)
+        loss = d_loss_fn(r.view(B, 1), f.view(B, 1)) * sw_mean                                # :44 compiled_loss
+        gr, gf = torch.autograd.grad(loss, (r, f), allow_unused=True)
+        gr = torch.zeros_like(r) if gr is None else gr
+        gf = torch.zeros_like(f) if gf is None else gf
+        twin.backward(B, gr.contiguous(), need_wgrad=True, need_input_grad=False)
+        disc.backward(B, gf.contiguous(), need_wgrad=True, need_input_grad=False)
+        disc.params.grads.add_(twin.params.grads)
+        return loss.detach(), real_scores.mean(), fake_scores.mean()
+
+    def train_step(self, low, high, g_opt, d_opt, sample_weight=None, reconstruction_loss=None, d_loss_fn=None):
+        """One GAN.train_step (ganbase.py:21-94).  low [B,T,S,S,cl], high [B,T,S,S,ch] device tensors.
+        d_loss_fn: the discriminator's compiled loss when it is not the built-in Wasserstein form (None = built-in)."""
         gen, disc, ops, noise = self.gen, self.disc, self.ops, self.noise
         B, T = low.shape[0], low.shape[1]
         S, ch = gen.S, disc.ch
@@ -187,6 +224,11 @@ class GanEngine:
             gnorm = torch.sqrt(gsq[:, :ch])
             gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()               # :37  (a constant w.r.t. D's weights)
             disc.params.zero_grad()
+            if d_loss_fn is not None:
+                loss_value, real_mean, fake_mean = self._critic_coupled(d_loss_fn, B, real, fake, noisy, sw_mean, low)
+                disc_loss = loss_value + gradient_reg                             # :44-45 (regularization_losses)
+                dscale = self._reduce_and_step(disc, d_opt)                       # :46-47
+                continue
             noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(real[..., :ch]))   # :40
             disc.set_high_tm(noisy, B)
             real_mean = disc.forward(B, training=True).mean()                     # :41

@@ -62,9 +62,10 @@ class GAN:
                 **kwargs):
         self.compiled_metrics = _Metrics(metrics)
         self._compiled = True
-        if discriminator_loss not in (None, _train.discriminator_loss, _train.discriminator_adversarial_loss):
-            raise NotImplementedError("the fused critic step implements the reference Wasserstein loss "
-                                      "(train.discriminator_loss) only")
+        # any callable loss(real_output, fake_output) -> scalar (ganbase.py:44-45 goes through compiled_loss); the reference's
+        # own Wasserstein form takes the step's built-in path, anything else the coupled path (GanEngine._critic_coupled)
+        builtin = (None, _train.discriminator_loss, _train.discriminator_adversarial_loss)
+        self._d_loss_fn = None if discriminator_loss in builtin else discriminator_loss
         self.generator.compile(generator_optimizer, generator_loss, metrics=generator_metrics)
         self.discriminator.compile(discriminator_optimizer, discriminator_loss or _train.discriminator_loss)
 
@@ -74,7 +75,8 @@ class GAN:
         ops = self.generator.ops
         low_res, high_res = _to_dev(low_res, ops), _to_dev(high_res, ops)
         res = self.engine.train_step(low_res, high_res, self.generator.optimizer, self.discriminator.optimizer,
-                                     sample_weight=sample_weight, reconstruction_loss=self.reconstruction_loss)
+                                     sample_weight=sample_weight, reconstruction_loss=self.reconstruction_loss,
+                                     d_loss_fn=getattr(self, "_d_loss_fn", None))
         return_metrics = {k: res[k] for k in ('g_loss', 'g_disc_loss', 'g_reco_loss', 'd_loss', 'd_gradient_pen',
                                               'g_gradient_param', 'd_gradient_param')}
         if self.generator.metrics or self.metrics:
