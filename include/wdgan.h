@@ -104,7 +104,7 @@ int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, 
 /* The same two launches as PRODUCERS OF A BatchNormalization INPUT (models.py:33-34, 39-40, 49-50, 55-56: conv ->
  * bias -> LeakyReLU -> BatchNormalization), with the norm's first pass folded into the epilogue:
  *   stats  != NULL (training):  y = act(conv + bias), and the replica slabs stats[stats_rep][2][C] (fp64, zeroed by the
- *           caller, C = output channels) receive sum_p y and sum_p y^2 per channel — no separate read of y for
+ *           caller, C = output channels rounded up to a multiple of 4) receive sum_p y and sum_p y^2 per channel — no separate read of y for
  *           wdg_bn_stats; finish with wdg_bn_finalize_train(stats, stats_rep, ...) and wdg_bn_apply;
  *   affine != NULL (inference): y = act(conv + bias) * affine[c] + affine[C + c], affine = the [scale | shift] of
  *           wdg_bn_finalize_infer — neither wdg_bn_stats nor wdg_bn_apply runs.

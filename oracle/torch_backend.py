@@ -136,11 +136,13 @@ class TorchOps:
         """BatchNormalization hooks of the conv launches (wdg_conv_fwd_bn): statistics of the activated output, or the
         inference-mode scale / shift."""
         C = out.shape[-1]
-        if bn_stats is not None:
+        if bn_stats is not None:                      # slabs [2][round4(C)]
+            Cp = bn_stats.shape[1] // 2
             bn_stats[0, :C] += out.sum((0, 1, 2)).to(bn_stats.dtype)
-            bn_stats[0, C:] += (out * out).sum((0, 1, 2)).to(bn_stats.dtype)
-        if bn_affine is not None:
-            out = out * bn_affine[:C] + bn_affine[C:]
+            bn_stats[0, Cp:Cp + C] += (out * out).sum((0, 1, 2)).to(bn_stats.dtype)
+        if bn_affine is not None:                     # [scale | shift], round4(C) entries each
+            Cp = bn_affine.shape[0] // 2
+            out = out * bn_affine[:C] + bn_affine[Cp:Cp + C]
         return out
 
     def conv_fwd(self, x, pk, bias, y, g, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):

@@ -63,6 +63,10 @@ def test_reference_signatures_and_errors(cpu_backend):
         models.make_generator(18, 3, 2, 2, 1, feature_channels=32)      # image_size % 4 (models.py:19)
     with pytest.raises(AssertionError):
         models.make_generator(16, 3, 2, 2, 1, feature_channels=36)      # feature_channels % 8 (models.py:20)
+    for fc in (16, 48, 80, 128):                                        # multiples of 16 build (the reference: of 8)
+        assert models.make_generator(16, 3, 2, 2, 1, feature_channels=fc).net.F == fc
+    with pytest.raises(NotImplementedError, match="% 16"):
+        models.make_generator(16, 3, 2, 2, 1, feature_channels=24)      # 8 mod 16: stated limitation of this build
     with pytest.raises(NotImplementedError):
         models.make_discriminator(16, 32, 3, 2, 1)                      # models.py:89-91
     o = train.generator_optimizer(), train.discriminator_optimizer()

@@ -30,9 +30,12 @@ def _inputs(B, T, S, cin, nz, ch, seed=0):
     return low, noise, high
 
 
-@pytest.mark.parametrize("S,T,training", [(12, 2, True), (12, 2, False), (20, 1, True), (16, 3, True)])
-def test_generator_forward_backward(ops, S, T, training):
-    B, cin, nz, ch, F = 2, 3, 2, 2, 32
+@pytest.mark.parametrize("S,T,training,F", [(12, 2, True, 32), (12, 2, False, 32), (20, 1, True, 32), (16, 3, True, 32),
+                                            (12, 2, True, 16), (16, 1, True, 48), (12, 1, False, 80)])
+def test_generator_forward_backward(ops, S, T, training, F):
+    """F = 16 / 48 / 80: feature_channels that are multiples of 16 but not of 32 (models.py:20 asserts % 8) — the last
+    decoder stage then has feature_channels / 8 = 2 / 6 / 10 channels and runs at the zero-padded width."""
+    B, cin, nz, ch = 2, 3, 2, 2
     net = GeneratorNet(ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
     w = randomize(net, 11)
     low, noise, _ = _inputs(B, T, S, cin, nz, ch)
@@ -66,6 +69,9 @@ def test_generator_forward_backward(ops, S, T, training):
     g = grads64(net)
     for k in keys:
         assert rel_err(g[k], gref[k]) < 1e-8, k
+    # the 4-element alignment slots behind the variables (read as zero pad channels) stay zero
+    pads = float(net.params.grads.abs().sum()) - sum(float(v.grad.abs().sum()) for v in net.params.trainable)
+    assert abs(pads) < 1e-9 * max(1.0, float(net.params.grads.abs().sum()))
 
 
 @pytest.mark.parametrize("S,T,Fd,variant", [(12, 2, 8, False), (20, 1, 8, False), (32, 2, 8, False), (24, 1, 8, False),

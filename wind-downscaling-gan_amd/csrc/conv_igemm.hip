@@ -1059,12 +1059,9 @@ static int bn_hook_fallback(const WdgBnHook& h, float* y, int ldy, int64_t img_s
         return WDG_ERR_ARG;
     }
     const int64_t P = (int64_t)n_img * Ho * Wo;
-    if (h.stats) return wdg_bn_stats(y, P, C, ldy, h.stats, stream);
-    if (h.affine_ld != C) {
-        wdg_set_error("conv + BatchNorm hook: affine must be [scale | shift] with stride C on the unfused path");
-        return WDG_ERR_ARG;
-    }
-    return wdg_bn_apply(y, ldy, h.affine, y, ldy, P, C, stream);
+    const int Cp = wdg_round_up(C, 4);      // (pad channels of y are zero: their statistics are zero, their affine is applied to zeros)
+    if (h.stats) return wdg_bn_stats(y, P, Cp, ldy, h.stats, stream);
+    return wdg_bn_apply(y, ldy, h.affine, y, ldy, P, Cp, stream);
 }
 
 static int conv_fwd_impl(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y, int act,
@@ -1149,7 +1146,8 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
 static int bn_hook_make(WdgBnHook& h, double* stats, int stats_rep, const float* affine, int C) {
     WDG_CHECK_ARG((stats != nullptr) != (affine != nullptr), "exactly one of stats / affine");
     WDG_CHECK_ARG(!stats || stats_rep >= 1, "stats_rep must be >= 1");
-    h.stats = stats; h.stats_C = C; h.stats_rep = stats ? stats_rep : 0; h.affine = affine; h.affine_ld = C;
+    const int Cp = wdg_round_up(C, 4);      // per-channel vectors of the hooks are laid out at the padded channel count
+    h.stats = stats; h.stats_C = Cp; h.stats_rep = stats ? stats_rep : 0; h.affine = affine; h.affine_ld = Cp;
     return WDG_OK;
 }
 

@@ -268,7 +268,7 @@ class HipOps:
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         if bn_stats is not None or bn_affine is not None:
-            assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * pk.cout))
+            assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * ((pk.cout + 3) // 4 * 4)))
             native.check(self.lib.wdg_conv_fwd_bn(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), int(act), slope,
                                                   _ptr(bn_stats), bn_stats.shape[0] if bn_stats is not None else 0,
                                                   _ptr(bn_affine), ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_bn")
@@ -283,7 +283,7 @@ class HipOps:
         plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         if bn_stats is not None or bn_affine is not None:
-            assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * pk.cin))
+            assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * ((pk.cin + 3) // 4 * 4)))
             native.check(self.lib.wdg_conv_dgrad_bn(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(), int(act), slope,
                                                     _ptr(bn_stats), bn_stats.shape[0] if bn_stats is not None else 0,
                                                     _ptr(bn_affine), ws.data_ptr(), ws.numel(), self.stream), "conv_dgrad_bn")

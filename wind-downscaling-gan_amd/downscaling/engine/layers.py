@@ -99,10 +99,14 @@ class Dense:
 
 
 class BatchNorm:
+    """keras BatchNormalization over the channel axis.  A channel count that is not a multiple of 4 (feature_channels / 8
+    for feature_channels % 32 != 0) runs at the padded width: activations carry zero pad channels, and the per-channel
+    vectors are read through the 4-element alignment slots of the flat parameter buffers (zeros beyond C: scale 0,
+    shift 0, so the pad channels stay zero and their gradient slots receive zeros)."""
     REPLICAS = 512
 
     def __init__(self, net, name, C):
-        self.net, self.ops, self.C = net, net.ops, C
+        self.net, self.ops, self.C, self.Cp = net, net.ops, C, round4(C)
         st = net.params
         self.gamma = st.add(f"{name}/gamma", (C,), P.ones_init)
         self.beta = st.add(f"{name}/beta", (C,), P.zeros_init)
@@ -111,7 +115,7 @@ class BatchNorm:
 
     def build(self):
         import torch
-        o, C = self.ops, self.C
+        o, C = self.ops, self.Cp
         # [replica][sum | sum of squares]: the conv epilogues that produce this layer's input spread their fp64 atomics over
         # the replicas; wdg_bn_stats (standalone pass) uses replica 0; bn_finalize_train sums them
         self.stats = o.zeros(self.REPLICAS, 2 * C, dtype=torch.float64)
@@ -120,6 +124,8 @@ class BatchNorm:
         self.ss = o.empty(2 * C)
         self.saved = o.empty(2 * C)
         self.count = 1.0
+        if self.Cp != self.C:
+            self.mvar.value_pad[self.C:] = 0.0     # (alignment slots: keep the pad channels' variance at 0, not the init 1)
 
     def begin_stats(self):
         """Zeroed statistics slabs for the producing conv launch (pass them as its bn_stats; then forward(..., have_stats=True))."""
@@ -141,15 +147,15 @@ class BatchNorm:
                 sync.all_reduce_sum(stats)
                 count *= sync.world_size
             self.count = count
-            o.bn_finalize_train(stats, count, self.gamma.value, self.beta.value, self.mmean.value,
-                                self.mvar.value, BN_MOMENTUM, BN_EPS, self.ss, self.saved)
+            o.bn_finalize_train(stats, count, self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad,
+                                self.mvar.value_pad, BN_MOMENTUM, BN_EPS, self.ss, self.saved)
         else:
-            o.bn_finalize_infer(self.gamma.value, self.beta.value, self.mmean.value, self.mvar.value, BN_EPS, self.ss)
+            o.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS, self.ss)
         o.bn_apply(y, self.ss, z)
 
     def infer_affine(self):
         """[scale | shift] of the inference-mode normalisation (moving statistics), for epilogue fusion."""
-        self.ops.bn_finalize_infer(self.gamma.value, self.beta.value, self.mmean.value, self.mvar.value, BN_EPS, self.ss)
+        self.ops.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS, self.ss)
         return self.ss
 
     def backward(self, dz, y, dpre, dbias, act_slope=LRELU):
@@ -163,8 +169,8 @@ class BatchNorm:
             self.red_local.copy_(self.red)
             red_param = self.red_local
             sync.all_reduce_sum(self.red)
-        o.bn_bwd_apply(dz, y, self.saved, self.gamma.value, self.red, red_param, self.count, act_slope, dpre,
-                       self.gamma.grad, self.beta.grad, dbias)
+        o.bn_bwd_apply(dz, y, self.saved, self.gamma.value_pad, self.red, red_param, self.count, act_slope, dpre,
+                       self.gamma.grad_pad, self.beta.grad_pad, dbias)
 
 
 class LayerNorm:

@@ -84,8 +84,11 @@ class GeneratorNet(_Net):
         if F / 8 < out_channels:
             # models.py:66-68: that branch skips the upsampling and fails its own shape assertion
             raise AssertionError("feature_channels / 8 must be >= out_channels (reference else-branch is dead)")
-        if F % 32 != 0 or IF % 4 != 0:
-            raise NotImplementedError("this build needs feature_channels % 32 == 0 (16-byte aligned channel slices)")
+        if F % 16 != 0 or IF % 4 != 0:
+            # feature_channels / 4 is the width of the first segment of the [conv-transpose path | res_2] concatenation
+            # (models.py:60): the skip tensor behind it is addressed in place and needs a 16-byte aligned start
+            raise NotImplementedError("this build needs feature_channels % 16 == 0 (the reference asserts % 8, models.py:20): "
+                                      "the zero-copy channel concatenations need 16-byte aligned segment starts")
         self.S, self.F, self.IF, self.T = S, F, IF, n_timesteps
         self.cin, self.in_channels, self.noise_channels, self.out_channels = cin, in_channels, noise_channels, out_channels
         L = "layer_with_weights-"
@@ -118,8 +121,8 @@ class GeneratorNet(_Net):
             h=o.zeros(N, S4, S4, F),
             y5=o.empty(N, S4, S4, F // 2),
             y7=o.empty(N, S2, S2, F // 4),
-            y9=o.empty(N, S, S, F // 8),
-            z9=o.empty(N, S, S, F // 8),
+            y9=o.zeros(N, S, S, round4(F // 8)),       # (F / 8 not a multiple of 4: zero pad channels)
+            z9=o.zeros(N, S, S, round4(F // 8)),
             out=o.zeros(N, S, S, round4(self.out_channels)),
         )
         self._bufs = {B: b}      # one resident batch size at a time
@@ -131,7 +134,7 @@ class GeneratorNet(_Net):
             o, S, F, IF, T = self.ops, self.S, self.F, self.IF, self.T
             N, S2, S4 = T * B, S // 2, S // 4
             self._grad_bufs = dict(
-                dz9=o.empty(N, S, S, F // 8),
+                dz9=o.zeros(N, S, S, round4(F // 8)),
                 dcat2=o.empty(N, S2, S2, F // 4 + IF),
                 dcat4=o.empty(N, S4, S4, F // 2 + F),
                 dh=o.zeros(N, S4, S4, F),
@@ -275,29 +278,29 @@ class GeneratorNet(_Net):
         self.c11.backward_weights(b["z9"], dout)
         self.c11.backward_input(dout, g["dz9"])
         # bn10 + LeakyReLU of c9
-        self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad)
+        self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad_pad)
         o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g,   # :60-64 backward
                      pool=self._scratch_pool(b))
         # bn8 + c7
         d7 = g["dcat2"][..., :F // 4]
-        self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad)
+        self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad_pad)
         self.c7.backward_weights(b["cat4"], d7)
         self.c7.backward_input(d7, g["dcat4"])
         # bn6 + c5
         d5 = g["dcat4"][..., :F // 2]
-        self.bn6.backward(v2(d5), v2(b["y5"]), v2(d5), self.c5.b.grad)
+        self.bn6.backward(v2(d5), v2(b["y5"]), v2(d5), self.c5.b.grad_pad)
         self.c5.backward_weights(b["h"], d5)
         self.c5.backward_input(d5, g["dh"])
         # ConvLSTM; its input gradient adds to the skip gradient already in dcat4[..., F/2:]
         dres4 = g["dcat4"][..., F // 2:]
         self.lstm.backward(res4, b["h"], g["dh"], dres4, B, T, need_wgrad=True, accumulate_dx=True)
         # bn3 + c2
-        self.bn3.backward(v2(dres4), v2(b["y2"]), v2(dres4), self.c2.b.grad)
+        self.bn3.backward(v2(dres4), v2(b["y2"]), v2(dres4), self.c2.b.grad_pad)
         self.c2.backward_weights(res2, dres4)
         dres2 = g["dcat2"][..., F // 4:]
         self.c2.backward_input(dres4, dres2, accumulate=True)
         # bn1 + c0
-        self.bn1.backward(v2(dres2), v2(b["y0"]), v2(dres2), self.c0.b.grad)
+        self.bn1.backward(v2(dres2), v2(b["y0"]), v2(dres2), self.c0.b.grad_pad)
         self.c0.backward_weights(b["x0"], dres2)
 
 

@@ -13,7 +13,7 @@ import torch
 
 
 class Var:
-    __slots__ = ("name", "shape", "trainable", "init", "offset", "size", "value", "grad")
+    __slots__ = ("name", "shape", "trainable", "init", "offset", "size", "value", "grad", "value_pad", "grad_pad")
 
     def __init__(self, name, shape, trainable, init):
         self.name, self.shape, self.trainable, self.init = name, tuple(shape), trainable, init
@@ -21,6 +21,7 @@ class Var:
         self.offset = -1
         self.value = None
         self.grad = None
+        self.value_pad = self.grad_pad = None    # flat views up to the 4-element alignment slot (zeros beyond `size`)
 
 
 class ParamStore:
@@ -61,8 +62,11 @@ class ParamStore:
         for v in train:
             v.value = self.flat[v.offset:v.offset + v.size].view(v.shape)
             v.grad = self.grads[v.offset:v.offset + v.size].view(v.shape)
+            v.value_pad = self.flat[v.offset:v.offset + (v.size + 3) // 4 * 4]
+            v.grad_pad = self.grads[v.offset:v.offset + (v.size + 3) // 4 * 4]
         for v in other:
             v.value = self.state[v.offset:v.offset + v.size].view(v.shape)
+            v.value_pad = self.state[v.offset:v.offset + (v.size + 3) // 4 * 4]
         self.trainable = train
         self.non_trainable = other
         # segment table for the g/d_gradient_param metric (mean over variables of mean(g^2))
