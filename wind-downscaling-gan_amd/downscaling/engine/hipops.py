@@ -345,7 +345,7 @@ class HipOps:
                 pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (bn_affine is None or bn_affine.data_ptr() % 16 == 0)
             if not col:
                 self.upconv_fwd(x_low, pk, bias, y, g, act=act, slope=slope, pool=pool)
-                y2 = y.view(-1, y.shape[-1])[:, :pk.cin]
+                y2 = y.view(-1, y.shape[-1])[:, :(pk.cin + 3) // 4 * 4]      # (zero pad channels included: the norm's padded width)
                 if bn_stats is not None:
                     self.bn_stats(y2, bn_stats[0])
                 else:
