@@ -117,6 +117,18 @@ int wdg_conv_dgrad_bn(const wdg_conv_plan* plan, const float* dy, const float* w
                       float slope, double* stats, int stats_rep, const float* affine, void* ws, size_t ws_bytes,
                       wdg_stream stream);
 
+/* conv -> bias -> LeakyReLU -> LayerNormalization in one call (the discriminator's blocks, models.py:113-116, 122-125,
+ * 134-136; the shortcut branch, tf_utils.py:29-31; the encoder, autoencoder.py:27-30):
+ *   y = act(conv(x) + bias)            (kept: the backward pass needs the pre-norm activation)
+ *   z = (y - mean) * rstd * gamma + beta   over the channel axis, eps inside the square root
+ *   mean_rstd[2 * pixel] = (mean, rstd)    (optional)
+ * z has the layout of y (same ld / image stride).  The normalisation runs in whichever epilogue owns complete output rows
+ * (the implicit-GEMM tile when it spans all channels, the split-K second stage otherwise); every other route runs
+ * wdg_ln_fwd behind the convolution.  Same results on every route. */
+int wdg_conv_fwd_ln(const wdg_conv_plan* plan, const float* x, const float* wF, const float* bias, float* y, float* z,
+                    const float* gamma, const float* beta, float eps, float* mean_rstd, int act, float slope,
+                    void* ws, size_t ws_bytes, wdg_stream stream);
+
 /* Fused UpSampling2D(2,'bilinear') + Conv2DTranspose forward: y = act(convT(upsample2x(x_low), wD) + bias).
  * `plan` is the transposed conv's plan on the UPSAMPLED grid (conv-output side 2H x 2W, stride 1, k <= 5,
  * Cin <= 64); x_low is the H x W tensor with pixel stride ld_low.  The upsampled tensor is never

@@ -155,6 +155,11 @@ class TorchOps:
             out = out + y[..., :pk.cout]
         y[..., :pk.cout] = out
 
+    def conv_fwd_ln(self, x, pk, bias, y, z, g, gamma, beta, eps, mean_rstd, act=True, slope=0.2):
+        """conv -> bias -> LeakyReLU -> LayerNormalization (wdg_conv_fwd_ln): the two reference layers, one after the other."""
+        self.conv_fwd(x, pk, bias, y, g, act=act, slope=slope)
+        self.ln_fwd(y.view(-1, y.shape[-1])[:, :pk.cout], gamma, beta, eps, z.view(-1, z.shape[-1])[:, :pk.cout], mean_rstd)
+
     def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
         H, W = dx.shape[1], dx.shape[2]
         Ho, Wo = dy.shape[1], dy.shape[2]

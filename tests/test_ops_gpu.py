@@ -470,6 +470,50 @@ def test_conv_batchnorm_hooks(case, hip_ops, ref_ops):
     assert float(h["y2"][..., C:].abs().max() if oshape[3] > C else 0.0) == 0.0          # pad channels stay zero
 
 
+LN_CASES = [
+    # name, n, H, W, cin, cout, k, s, p
+    ("d_block1_epilogue", 3, 96, 96, 32, 64, 7, 3, 1),          # 128x64 tile spans all 64 channels: norm in the igemm epilogue
+    ("d_block2_two_tiles", 3, 30, 30, 64, 128, 7, 3, 1),         # 64-wide tiles, 128 channels: standalone pass behind the conv
+    ("d_block3_splitk", 8, 27, 27, 128, 256, 7, 3, 1),           # split-K: norm in the second stage
+    ("d_block4_splitk", 8, 8, 8, 256, 512, 7, 3, 1),
+    ("tail_3x3s2", 4, 3, 3, 256, 512, 3, 2, 0),
+    ("encoder_5x5s3", 3, 40, 40, 4, 8, 5, 3, 1),
+    ("cout128_one_tile", 2, 64, 64, 128, 128, 3, 1, 1),          # 128x128 tile, epilogue
+]
+
+
+@pytest.mark.parametrize("case", LN_CASES, ids=[c[0] for c in LN_CASES])
+def test_conv_layernorm_fused(case, hip_ops, ref_ops):
+    """wdg_conv_fwd_ln: conv -> bias -> LeakyReLU -> LayerNormalization (models.py:113-116 ff.) with the norm in the
+    epilogue that owns complete rows; y, z and (mean, rstd) against the two reference layers applied one after the other."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    name, n, H, W, cin, cout, k, s_, p_ = case
+    gen = torch.Generator().manual_seed(31)
+    dev = hip_ops.device
+    Ho, Wo = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+    x = torch.randn(n, H, W, cin, generator=gen, dtype=torch.float64)
+    w = torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) / np.sqrt(k * k * cin)
+    bias = torch.randn(cout, generator=gen, dtype=torch.float64) * 0.3
+    gamma = torch.rand(cout, generator=gen, dtype=torch.float64) + 0.5
+    beta = torch.randn(cout, generator=gen, dtype=torch.float64)
+    res = {}
+    for tag, ops, cv, G in (("ref", ref_ops, lambda t: t.clone(), RG), ("hip", hip_ops, lambda t: t.float().to(dev).contiguous(), ConvGeom)):
+        pk, g = ops.pack_weights(cv(w)), G(k, k, s_, p_)
+        y, z = ops.zeros(n, Ho, Wo, cout), ops.zeros(n, Ho, Wo, cout)
+        mr = ops.empty(n * Ho * Wo, 2)
+        ops.conv_fwd_ln(cv(x), pk, cv(bias), y, z, g, cv(gamma), cv(beta), 1e-3, mr, act=True, slope=0.2)
+        y2 = ops.zeros(n, Ho, Wo, cout)
+        ops.conv_fwd(cv(x), pk, cv(bias), y2, g, act=True, slope=0.2)
+        res[tag] = dict(y=y, z=z, mr=mr, y2=y2)
+    r, h = res["ref"], res["hip"]
+    assert rel_err(h["y"], r["y"]) < TOL and rel_err(h["y"], h["y2"]) < 1e-6
+    assert rel_err(h["z"], r["z"]) < TOL
+    assert rel_err(h["mr"][:, 0], r["mr"][:, 0]) < TOL and rel_err(h["mr"][:, 1], r["mr"][:, 1]) < TOL
+    zz = torch.nn.functional.layer_norm(r["y"], (cout,), gamma, beta, 1e-3)
+    assert rel_err(r["z"], zz) < 1e-12
+
+
 def test_upconv_batchnorm_hooks(hip_ops, ref_ops):
     """The fused upsample + 5x5 transposed-conv block (models.py:62-64) as a BatchNormalization producer: statistics /
     inference affine in the column-form gather kernel."""

@@ -48,6 +48,13 @@ struct WdgIgemm {
     int stats_C, stats_rep;
     const float* affine;
     int affine_ld;
+    // fused LayerNormalization of the output rows (EPI 3; the split-K second stage has its own form): y = act(conv + bias)
+    // goes to Out, z = (y - mean) * rstd * gamma + beta to Out2 (same view), (mean, rstd) per pixel to mean_rstd
+    float* Out2;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float* mean_rstd;
+    float ln_eps;
     WdgPhase ph[9];
 };
 
@@ -281,6 +288,94 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     // ---- epilogue: one pixel per (row tile a), four consecutive output channels per (column tile b)
     const int q4 = 4 * (lane >> 4);
     const int NcP = (p.Ncols + 3) & ~3;
+    if constexpr (EPI == 3) {
+        // conv -> bias -> LeakyReLU -> LayerNormalization over the channels, the block owning complete rows (tiles_n == 1,
+        // no split-K: checked by the host).  A row's channels sit in 4 * WGN lanes (the four lane >> 4 groups of WGN
+        // waves): its two reductions (sum, centred sum of squares) go through LDS, the K loop's stage being free.
+        float* red = reinterpret_cast<float*>(lds_all);                    // [BM][4 * WGN]
+        constexpr int RW = 4 * WGN;
+        const int rsub = wn * 4 + (lane >> 4);
+        float mean[MT], rstd[MT];
+        const float invC = 1.f / (float)p.Ncols;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+                f32x4 v = acc[a][b];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (p.bias) v[r] += n + r < p.Ncols ? p.bias[n + r] : 0.f;
+                    if (p.act) v[r] = wdg_lrelu(v[r], p.slope);
+                    s_ += n + r < p.Ncols ? v[r] : 0.f;
+                }
+                acc[a][b] = v;
+            }
+            red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + rsub] = s_;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) s_ += red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + k];
+            mean[a] = s_ * invC;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            float q_ = 0.f;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[a][b][r] - mean[a];
+                    q_ += n + r < p.Ncols ? d * d : 0.f;
+                }
+            }
+            red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + rsub] = q_;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            float q_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) q_ += red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + k];
+            rstd[a] = 1.f / sqrtf(q_ * invC + p.ln_eps);
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
+            if (m >= Mph) continue;
+            const int img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
+            const int rem = m - img * PaPb;
+            const int pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
+            const int pb = rem - pa * ph.Pb;
+            const int oh = pa * p.o_mul + ph.o_off_h;
+            const int ow = pb * p.o_mul + ph.o_off_w;
+            const long long off = (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+                if (n >= NcP) continue;
+                const f32x4 v = acc[a][b];
+                f32x4 z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    z[r] = n + r < p.Ncols ? (v[r] - mean[a]) * rstd[a] * p.ln_gamma[n + r] + p.ln_beta[n + r] : 0.f;
+                *reinterpret_cast<f32x4*>(p.Out + off + n) = v;
+                *reinterpret_cast<f32x4*>(p.Out2 + off + n) = z;
+            }
+            if (p.mean_rstd && rsub == 0) {
+                // (forward launches only: one phase, so m is the output pixel index)
+                p.mean_rstd[2 * (long long)m] = mean[a];
+                p.mean_rstd[2 * (long long)m + 1] = rstd[a];
+            }
+        }
+        return;
+    }
     float st1[EPI == 1 ? NT : 1][4], st2[EPI == 1 ? NT : 1][4];
     if constexpr (EPI == 1) {
 #pragma unroll
@@ -404,6 +499,67 @@ __global__ void __launch_bounds__(256) wdg_igemm_reduce_kernel(const WdgIgemm p)
         if (p.act) v = wdg_lrelu(v, p.slope);
         if (p.accumulate) v += *dst;
         *dst = v;
+    }
+}
+
+// split-K second stage of a forward conv that feeds a LayerNormalization: one wave per output pixel sums the slabs of
+// its row (16-byte loads, lanes along the channels), applies bias + LeakyReLU, normalises the row with two wave
+// reductions and writes y, z and (mean, rstd) — the separate wdg_ln_fwd launch and its re-read of y disappear.
+// Ncols % 4 == 0, Ncols <= 1024, one phase.
+__global__ void __launch_bounds__(256) wdg_igemm_reduce_ln_kernel(const WdgIgemm p) {
+    const WdgPhase ph = p.ph[0];
+    const int PaPb = ph.Pa * ph.Pb;
+    const int Mph = p.n_img * PaPb;
+    const int lane = threadIdx.x & 63;
+    const int c4n = p.Ncols >> 2;
+    const float invC = 1.f / (float)p.Ncols;
+    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < Mph; m += gridDim.x * 4) {
+        f32x4 v[4];
+        float s_ = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = lane + 64 * j;
+            v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < c4n) {
+                const float* src = p.partial + (long long)m * p.Ncols + 4 * c4;
+                for (int sp = 0; sp < p.splitk; ++sp) v[j] += *reinterpret_cast<const f32x4*>(src + (long long)sp * p.Mmax * p.Ncols);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (p.bias) v[j][r] += p.bias[4 * c4 + r];
+                    if (p.act) v[j][r] = wdg_lrelu(v[j][r], p.slope);
+                    s_ += v[j][r];
+                }
+            }
+        }
+        const float mean = wdg_wave_sum(s_) * invC;
+        float q_ = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < c4n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q_ += (v[j][r] - mean) * (v[j][r] - mean);
+        const float rstd = 1.f / sqrtf(wdg_wave_sum(q_) * invC + p.ln_eps);
+        const int img = m / PaPb;
+        const int rem = m - img * PaPb;
+        const int pa = rem / ph.Pb;
+        const int pb = rem - pa * ph.Pb;
+        const long long off = (long long)img * p.imgStrideO + ((long long)(pa * p.o_mul + ph.o_off_h) * p.Wo + pb * p.o_mul + ph.o_off_w) * p.ldO;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 < c4n) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * c4), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * c4);
+                f32x4 z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = (v[j][r] - mean) * rstd * g[r] + bt[r];
+                *reinterpret_cast<f32x4*>(p.Out + off + 4 * c4) = v[j];
+                *reinterpret_cast<f32x4*>(p.Out2 + off + 4 * c4) = z;
+            }
+        }
+        if (p.mean_rstd && lane == 0) {
+            p.mean_rstd[2 * (long long)m] = mean;
+            p.mean_rstd[2 * (long long)m + 1] = rstd;
+        }
     }
 }
 
@@ -963,6 +1119,7 @@ template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
     constexpr size_t lds = (size_t)((PIPE == 0 || PIPE == 3) ? 1 : 2) * 8 * (BM + BN) * sizeof(f32x4);
     static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
+    static_assert(EPI != 3 || lds >= (size_t)BM * 4 * WGN * sizeof(float), "LayerNorm scratch fits the K-loop stage");
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 48 * 1024)
@@ -1010,12 +1167,14 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     int rc = WDG_OK;
     // fused BatchNorm hooks: only without split-K (the reduce kernel owns the epilogue then; callers fall back to the
     // standalone passes — see conv_fused_bn) and only on the default pipeline
-    const int epi = (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : 0;
+    const bool ln_ok = p.ln_gamma && split == 1 && tiles_n == 1 && nphase == 1 && (p.Ncols & 3) == 0;
+    const int epi = (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
     if (bn_fused) *bn_fused = epi != 0;
 #define WDG_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                              \
     if (tc.BM == BM_ && tc.BN == BN_) {                                                                 \
         if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);                \
         else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \
+        else if (epi == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);           \
         else if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);             \
         else if (pipe == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 1>(grid, block, st, p);             \
         else if (pipe == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3>(grid, block, st, p);             \
@@ -1033,6 +1192,14 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     if (rc != WDG_OK) return rc;
     WDG_LAUNCH_CHECK();
     if (split > 1) {
+        if (p.ln_gamma && nphase == 1 && (p.Ncols & 3) == 0 && p.Ncols <= 1024 && !p.accumulate) {
+            // (the slabs of a 4-aligned column count are dense: NcP == Ncols)
+            const int blocks = (int)std::min<long long>(((long long)p.Mmax + 3) / 4, 8192);
+            hipLaunchKernelGGL(wdg_igemm_reduce_ln_kernel, dim3(blocks), block, 0, st, p);
+            WDG_LAUNCH_CHECK();
+            if (bn_fused) *bn_fused = true;
+            return WDG_OK;
+        }
         long long total = (long long)p.Mmax * p.Ncols;
         int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(wdg_igemm_reduce_kernel, dim3(blocks, 1, nphase), block, 0, st, p);
@@ -1129,6 +1296,50 @@ static int conv_dgrad_impl(const wdg_conv_plan* pl, const float* dy, const float
     const int rc = launch_igemm(p, np, pl->K4_dgrad_max, pl->dgrad_split, ws, ws_bytes, (hipStream_t)stream, &fused);
     if (rc != WDG_OK || !hook || fused) return rc;
     return bn_hook_fallback(*hook, dx, g.ldx, g.img_stride_x, g.n_img, g.H, g.W, g.Cin, stream);
+}
+
+// conv -> bias -> LeakyReLU -> LayerNormalization (models.py:113-116, 122-125, 134-136; tf_utils.py:29-31) in one call:
+// y = act(conv(x) + bias), z = LN(y; gamma, beta, eps) over the channels, mean_rstd[pixel] = (mean, 1/sqrt(var + eps)) for
+// the backward pass.  The normalisation runs in the epilogue that owns complete rows — the implicit-GEMM epilogue when one
+// tile spans all output channels, the split-K second stage otherwise — and as the standalone wdg_ln_fwd pass behind the
+// convolution on every other route; results do not depend on the route.
+extern "C" int wdg_conv_fwd_ln(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y, float* z,
+                               const float* gamma, const float* beta, float eps, float* mean_rstd, int act, float slope,
+                               void* ws, size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && wF && y && z && gamma && beta, "null argument");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
+                  ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0, "x / wF / y / z / gamma / beta must be 16-byte aligned");
+    const wdg_conv_geom& g = pl->g;
+    const int64_t P = (int64_t)g.n_img * g.Ho * g.Wo;
+    bool fused = false;
+    if (!(pl->halo_auto_fwd && pl->halo_fwd_nt) && g.Cout % 4 == 0) {
+        WdgIgemm p;
+        memset(&p, 0, sizeof(p));
+        p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
+        p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
+        p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
+        p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
+        p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p;
+        p.a_mul = g.stride; p.o_mul = 1;
+        p.act = act; p.slope = slope; p.accumulate = 0;
+        p.Mmax = g.n_img * g.Ho * g.Wo;
+        p.Out2 = z; p.ln_gamma = gamma; p.ln_beta = beta; p.ln_eps = eps; p.mean_rstd = mean_rstd;
+        WdgPhase ph;
+        ph.Pa = g.Ho; ph.Pb = g.Wo; ph.a_off_h = -g.pad_h; ph.a_off_w = -g.pad_w;
+        ph.o_off_h = 0; ph.o_off_w = 0; ph.K4 = pl->K4_fwd; ph.tab_off = 0;
+        wdg_phase_finish(ph);
+        p.ph[0] = ph;
+        const int rc = launch_igemm(p, 1, pl->K4_fwd, pl->fwd_split, ws, ws_bytes, (hipStream_t)stream, &fused);
+        if (rc != WDG_OK || fused) return rc;
+    } else {
+        const int rc = conv_fwd_impl(pl, x, wF, bias, y, act, slope, 0, nullptr, ws, ws_bytes, stream);
+        if (rc != WDG_OK) return rc;
+    }
+    if (g.img_stride_y != (int64_t)g.Ho * g.Wo * g.ldy) {
+        wdg_set_error("wdg_conv_fwd_ln: the unfused path needs contiguous output images");
+        return WDG_ERR_ARG;
+    }
+    return wdg_ln_fwd(y, g.ldy, gamma, beta, eps, z, g.ldy, mean_rstd, P, g.Cout, stream);
 }
 
 extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias,

@@ -277,6 +277,16 @@ class HipOps:
                                            int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                            self.stream), "conv_fwd")
 
+    def conv_fwd_ln(self, x, pk, bias, y, z, g, gamma, beta, eps, mean_rstd, act=True, slope=0.2):
+        """y = act(conv(x, W) + bias); z = LayerNorm(y) over the channels; mean_rstd [P, 2] — wdg_conv_fwd_ln (the norm runs in
+        the epilogue that owns complete rows, or as the standalone pass behind the conv)."""
+        plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
+        ws = self._workspace(wsb)
+        assert z.shape == y.shape and z.stride() == y.stride()
+        native.check(self.lib.wdg_conv_fwd_ln(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), z.data_ptr(),
+                                              gamma.data_ptr(), beta.data_ptr(), eps, _ptr(mean_rstd), int(act), slope,
+                                              ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_ln")
+
     def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
         """dx = act(conv_transpose(dy, W) + bias) (+ dx);  the geometry is that of the forward conv.  bn_stats / bn_affine
         as in conv_fwd, over the Cin channels this launch writes."""

@@ -53,6 +53,14 @@ class Conv:
         else:
             self.ops.conv_fwd(x, self.pk, self.b.value, y, self.g, act=self.act, slope=LRELU, **hooks)
 
+    def forward_ln(self, x, y, z, ln):
+        """conv -> bias -> LeakyReLU -> LayerNormalization `ln` in one operator call (the norm rides in the conv's epilogue
+        where one owns complete rows): y keeps the pre-norm activation for the backward pass, z the normalised output."""
+        assert not self.transposed and self.act
+        ln.ensure_stats(y.shape[0] * y.shape[1] * y.shape[2])
+        self.ops.conv_fwd_ln(x, self.pk, self.b.value, y, z, self.g, ln.gamma.value, ln.beta.value, LN_EPS, ln.mean_rstd,
+                             act=True, slope=LRELU)
+
     def forward_bf16(self, x, y, affine=None, fmt="bf16"):
         """Inference precision (bf16 or fp16 operands, fp32 accumulate); `affine` = fused inference BatchNorm."""
         if self.transposed:

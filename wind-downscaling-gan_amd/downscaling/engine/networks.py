@@ -498,8 +498,7 @@ class DiscriminatorNet(_Net):
             self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
         x = b["cat"]
         for i, (conv, ln, osz, co) in enumerate(self.blocks):
-            conv.forward(x, b["ys"][i])
-            ln.forward(v2(b["ys"][i]), v2(b["zs"][i]))
+            conv.forward_ln(x, b["ys"][i], b["zs"][i], ln)                            # :113-116 / 122-125 / 134-136
             if self.shortcut is not None and i == self.shortcut["block"]:
                 self._shortcut_fwd(b, x, b["zs"][i])
             x = b["zs"][i]
@@ -663,8 +662,7 @@ class EncoderNet(_Net):
         self.to_time_major(x, b["x0"])
         h = b["x0"]
         for i, (conv, ln, osz, co) in enumerate(self.blocks):
-            conv.forward(h, b["ys"][i])
-            ln.forward(v2(b["ys"][i]), v2(b["zs"][i]))
+            conv.forward_ln(h, b["ys"][i], b["zs"][i], ln)
             h = b["zs"][i]
         h = h.view(N, 1, 1, self.flat) if self.blocks else h.reshape(N, 1, 1, -1)
         for j, d in enumerate(self.dense):
