@@ -521,6 +521,53 @@ class HipOps:
         native.check(self.lib.wdg_lstm_bwd(pg, ldg, pcp, ldcp, pc, ldc, pdh, lddh, pdci, lddci, pdg, lddg, pdcp,
                                            lddcp, gates.shape[0], F, self.stream), "lstm_bwd")
 
+    # ---- ConvLSTM over a whole sequence in one persistent launch (csrc/convlstm_seq.hip) ---------------
+    def convlstm_seq_supported(self, cin, F, h=None):
+        """(cin, F) has a sequence kernel, it is switched on, and (when given) the h buffer meets its line-alignment rule.
+        OFF by default: measured on MI355X (profiles/r02h_kernel_stats_T24_seq.csv) the persistent kernels are correct but
+        SLOWER than the per-timestep launches at the shipped shape (96 x 96 x 8 tiles, T = 24): 4.2 vs ~1.4 ms per pass
+        for the 5 -> 16 layer — the per-tile hand-off (sequential polls of 8 neighbour counters + an agent-scope release
+        that writes the L2 back) costs ~30 us per tile and step, and with 2.25 tiles per workgroup the scalar-fed fp32
+        FMAs are no faster than the MFMA halo kernel they replace.  WDG_CONVLSTM_SEQ=1 enables them (parity tests do)."""
+        if os.environ.get("WDG_CONVLSTM_SEQ", "0") != "1" or not self.lib.wdg_convlstm_seq_supported(cin, F):
+            return False
+        if h is not None:
+            n, H, W, ld = h.shape[0], h.shape[1], h.shape[2], h.stride(2)
+            if (W * ld) % 32 or h.data_ptr() % 128 or (W * 4 * F) % 32 or h.stride(0) % 32:
+                return False
+        return True
+
+    def convlstm_seq_scratch(self, B, H, W, F):
+        return torch.zeros(int(self.lib.wdg_convlstm_seq_scratch_bytes(B, H, W, F)), dtype=torch.uint8, device=self.device)
+
+    def convlstm_seq_fwd(self, x, wx, wh, bias, h, gates, c, B, T, cin, F, scratch):
+        """x [T*B,H,W,>=cin] time-major -> h [T*B,H,W,>=F], c [T*B,H,W,F], gates [T*B,H,W,4F] (None: not stored)."""
+        px, ldx, isx = _v4(x)
+        ph, ldh, ish = _v4(h)
+        _, H, W, _ = h.shape
+        assert c.is_contiguous() and (gates is None or gates.is_contiguous())
+        native.check(self.lib.wdg_convlstm_seq_fwd(px, ldx, isx, wx.data_ptr(), wh.data_ptr(), bias.data_ptr(), ph, ldh, ish,
+                                                   _ptr(gates), c.data_ptr(), B, T, H, W, cin, F, scratch.data_ptr(),
+                                                   scratch.numel(), self.stream), "convlstm_seq_fwd")
+        if os.environ.get("WDG_SEQ_CHECK", "0") == "1":
+            self.convlstm_seq_check(scratch, B, H, W)
+
+    def convlstm_seq_bwd(self, gates, c, wh, dh, dgates, B, T, cin, F, scratch):
+        """dgates [T*B,H,W,4F] from the incoming gradient dh of every h_t (dh is not modified)."""
+        pdh, lddh, isdh = _v4(dh)
+        _, H, W, _ = dh.shape
+        assert gates.is_contiguous() and c.is_contiguous() and dgates.is_contiguous()
+        native.check(self.lib.wdg_convlstm_seq_bwd(gates.data_ptr(), c.data_ptr(), wh.data_ptr(), pdh, lddh, isdh,
+                                                   dgates.data_ptr(), B, T, H, W, cin, F, scratch.data_ptr(), scratch.numel(),
+                                                   self.stream), "convlstm_seq_bwd")
+        if os.environ.get("WDG_SEQ_CHECK", "0") == "1":
+            self.convlstm_seq_check(scratch, B, H, W)
+
+    def convlstm_seq_check(self, scratch, B, H, W):
+        rc = int(self.lib.wdg_convlstm_seq_check(scratch.data_ptr(), B, H, W, self.stream))
+        if rc != 0:
+            raise native.NativeError("persistent ConvLSTM kernel: a bounded inter-workgroup wait timed out (results invalid)")
+
     def convlstm1_supported(self, cin, F):
         return bool(self.lib.wdg_convlstm1_supported(cin, F))
 

@@ -240,6 +240,10 @@ class ConvLSTM:
             self._pk_i = None
             self._shape = (N, H, W)
 
+    def _seq(self, T, h):
+        """Sequence length > 1 + few channels: the whole recurrence in one persistent launch (convlstm_seq.hip)."""
+        return T > 1 and self.ops.convlstm_seq_supported(self.cin, self.F, h)
+
     def _fused1(self, T):
         """Single timestep + few channels: the fused, gate-recomputing kernels (convlstm1.hip)."""
         return T == 1 and self.ops.convlstm1_supported(self.cin, self.F)
@@ -253,6 +257,12 @@ class ConvLSTM:
             o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
             return
         self._buffers(N, H, W)
+        if not bf16 and self._seq(T, h):
+            if getattr(self, "_seq_scratch", None) is None or self._seq_key != (B, H, W):
+                self._seq_scratch, self._seq_key = o.convlstm_seq_scratch(B, H, W, F), (B, H, W)
+            o.convlstm_seq_fwd(x, self.wx.value, self.wh.value, self.b.value, h, self.gates, self.c, B, T, self.cin, F,
+                               self._seq_scratch)
+            return
         conv = (lambda *a, **k: o.conv_fwd_bf16(*a, fmt=fmt, **k)) if bf16 else o.conv_fwd
         if T == 1 and not bf16:
             # h_0 = c_0 = 0: the forget gate is never read at t = 0 -> skip its quarter of the input convolution
@@ -287,8 +297,11 @@ class ConvLSTM:
         if self.dgates is None:
             self.dgates = o.empty(N, H, W, 4 * F)
             self.dc = [o.empty(B, H, W, F), o.empty(B, H, W, F)]
+        seq = self._seq(T, h) and getattr(self, "_seq_scratch", None) is not None
+        if seq:
+            o.convlstm_seq_bwd(self.gates, self.c, self.wh.value, dh, self.dgates, B, T, self.cin, F, self._seq_scratch)
         dc_in = None
-        for t in range(T - 1, -1, -1):
+        for t in range(T - 1, -1, -1) if not seq else ():
             sl = slice(t * B, (t + 1) * B)
             pv = slice((t - 1) * B, t * B)
             dc_out = self.dc[t & 1] if t > 0 else None

@@ -482,7 +482,10 @@ class DiscriminatorNet(_Net):
         b = self.buffers(B)
         o, Fd, T = self.ops, self.Fd, self.T
         self._prepare(training)
-        if T > 1 and self.overlap_branches:
+        # (the persistent sequence kernels size their grids to be fully resident: never two of them side by side)
+        overlap = T > 1 and self.overlap_branches and not self.lstm_b._seq(T, b["hb"])
+        self._overlap_now = overlap
+        if overlap:
             # the two input branches are independent chains of small per-timestep launches: run the high-res-only one
             # on a side stream under the other (at T = 1 every kernel fills the chip and the overlap gains nothing)
             with o.fork() as side:
@@ -589,7 +592,7 @@ class DiscriminatorNet(_Net):
             self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad)
             self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
 
-        if T > 1 and self.overlap_branches:
+        if getattr(self, "_overlap_now", False):
             with o.fork() as side:
                 branch_a()
             branch_b()
