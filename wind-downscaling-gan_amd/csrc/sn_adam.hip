@@ -86,6 +86,74 @@ __device__ __forceinline__ void wdg_sn_colpart_block(int blk, const float* __res
     }
 }
 
+// ---- SN steps 1 + 2 fused (batched path): one block per 64-row chunk computes vraw for its rows AND the chunk's
+// contribution to v W — the second product is linear in v, so it is formed from the UNNORMALISED vraw and scaled by
+// 1 / |vraw| in the finish stage.  W is streamed from HBM once per power iteration instead of twice (the chunk, 64 x cols
+// floats, is re-read from L1 / L2), and one launch + its dependency bubble disappears.
+__device__ __forceinline__ void wdg_sn_chunk_block(int blk, const float* __restrict__ w, const float* __restrict__ u,
+                                                   int rows, int cols, float* vraw, float* part1, float* part2) {
+    __shared__ float vs[64];
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blk * 64;
+    float sq = 0.f;
+    for (int i = 0; i < 16; ++i) {                       // each wave owns 16 of the chunk's rows
+        const int r = r0 + wave * 16 + i;
+        float s_ = 0.f;
+        if (r < rows)
+            for (int c = lane; c < cols; c += 64) s_ += u[c] * w[(size_t)r * cols + c];
+        s_ = wdg_wave_sum(s_);
+        if (lane == 0) {
+            vs[wave * 16 + i] = r < rows ? s_ : 0.f;
+            if (r < rows) vraw[r] = s_;
+            sq += r < rows ? s_ * s_ : 0.f;
+        }
+    }
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) part1[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+    const int nr = min(64, rows - r0);
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float s_ = 0.f;
+        for (int r = 0; r < nr; ++r) s_ += vs[r] * w[(size_t)(r0 + r) * cols + c];
+        part2[(size_t)blk * cols + c] = s_;
+    }
+}
+
+// finish for the fused form: part2 holds UNNORMALISED chunk sums; s = 1 / max(|vraw|, eps) is applied here
+__device__ __forceinline__ void wdg_sn_finish_unnorm_block(const float* __restrict__ part1, int nparts, const float* __restrict__ part2,
+                                                           int nchunks, int cols, float* u, float* inv_sigma) {
+    __shared__ float red[1024];
+    __shared__ float s_norm2, s_vscale;
+    if (threadIdx.x == 0) {
+        float n2 = 0.f;
+        for (int i = 0; i < nparts; ++i) n2 += part1[i];   // fixed order
+        s_vscale = 1.f / sqrtf(fmaxf(n2, 1e-12f));         // tf.math.l2_normalize of v
+    }
+    __syncthreads();
+    const float vscale = s_vscale;
+    float local = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 1024) {
+        float s_ = 0.f;
+        for (int k = 0; k < nchunks; ++k) s_ += part2[(size_t)k * cols + c];
+        s_ *= vscale;
+        u[c] = s_;  // u_raw, normalised below
+        local += s_ * s_;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s_norm2 = red[0];
+    __syncthreads();
+    const float n2 = s_norm2;
+    const float sc = 1.f / sqrtf(fmaxf(n2, 1e-12f));
+    for (int c = threadIdx.x; c < cols; c += 1024) u[c] = u[c] * sc;
+    if (threadIdx.x == 0) inv_sigma[0] = 1.f / (n2 * sc);
+}
+
 // ---- SN step 3 (one block of 1024): u_raw, its norm, sigma; writes u and 1/sigma ------------------
 __device__ __forceinline__ void wdg_sn_finish_block(const float* __restrict__ part2, int nchunks, int cols, float* u,
                                                     float* inv_sigma) {
@@ -130,6 +198,15 @@ __global__ void __launch_bounds__(1024) wdg_sn_finish_kernel(const float* __rest
     wdg_sn_finish_block(part2, nchunks, cols, u, inv_sigma);
 }
 
+__global__ void __launch_bounds__(256) wdg_sn_chunk_kernel(const float* __restrict__ w, const float* __restrict__ u, int rows,
+                                                           int cols, float* vraw, float* part1, float* part2) {
+    wdg_sn_chunk_block(blockIdx.x, w, u, rows, cols, vraw, part1, part2);
+}
+__global__ void __launch_bounds__(1024) wdg_sn_finish2_kernel(const float* __restrict__ part1, const float* __restrict__ part2,
+                                                              int nchunks, int cols, float* u, float* inv_sigma) {
+    wdg_sn_finish_unnorm_block(part1, nchunks, part2, nchunks, cols, u, inv_sigma);
+}
+
 __global__ void __launch_bounds__(256) wdg_scale_inplace_kernel(float* w, int64_t n, const float* __restrict__ s) {
     const float k = s[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) w[i] *= k;
@@ -148,12 +225,10 @@ extern "C" int wdg_sn_power_iter(float* w, float* u, int rows, int cols, float* 
     float* part1 = vraw + rows;
     float* part2 = part1 + nb1;
     float* inv_sigma = part2 + (size_t)nchunks * cols;
-    hipLaunchKernelGGL(wdg_sn_rowdot_kernel, dim3(nb1), dim3(256), 0, st, w, u, rows, cols, vraw, part1);
+    // (same arithmetic as the batched path: u W^T and the chunk sums of v W from one pass, v's norm applied in the finish)
+    hipLaunchKernelGGL(wdg_sn_chunk_kernel, dim3(nchunks), dim3(256), 0, st, w, u, rows, cols, vraw, part1, part2);
     WDG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wdg_sn_colpart_kernel, dim3(nchunks), dim3(256), 0, st, w, vraw, part1, nb1, rows, cols,
-                       part2);
-    WDG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wdg_sn_finish_kernel, dim3(1), dim3(1024), 0, st, part2, nchunks, cols, u, inv_sigma);
+    hipLaunchKernelGGL(wdg_sn_finish2_kernel, dim3(1), dim3(1024), 0, st, part1, part2, nchunks, cols, u, inv_sigma);
     WDG_LAUNCH_CHECK();
     const int64_t n = (int64_t)rows * cols;
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096));
@@ -201,6 +276,19 @@ __device__ __forceinline__ int wdg_prep_find(const WdgPrepLayer* L, int n, int b
     return l;
 }
 
+__global__ void __launch_bounds__(256) wdg_prep_chunk_kernel(const WdgPrepLayer* __restrict__ L, int n, float* scratch) {
+    const int l = wdg_prep_find(L, n, blockIdx.x, 2);
+    const WdgPrepLayer q = L[l];
+    float* vraw = scratch + q.s_off;
+    float* part1 = vraw + q.rows;            // [nchunks] here (the slot is sized for nb1 >= nchunks entries)
+    wdg_sn_chunk_block(blockIdx.x - q.b2, q.w, q.u, q.rows, q.cols, vraw, part1, part1 + q.nb1);
+}
+__global__ void __launch_bounds__(1024) wdg_prep_finish2_kernel(const WdgPrepLayer* __restrict__ L, float* scratch) {
+    const WdgPrepLayer q = L[blockIdx.x];
+    float* part1 = scratch + q.s_off + q.rows;
+    float* part2 = part1 + q.nb1;
+    wdg_sn_finish_unnorm_block(part1, q.nchunks, part2, q.nchunks, q.cols, q.u, part2 + (size_t)q.nchunks * q.cols);
+}
 __global__ void __launch_bounds__(256) wdg_prep_rowdot_kernel(const WdgPrepLayer* __restrict__ L, int n, float* scratch) {
     const int l = wdg_prep_find(L, n, blockIdx.x, 1);
     const WdgPrepLayer q = L[l];
@@ -317,10 +405,13 @@ extern "C" int wdg_prep_batch_run(const wdg_prep_batch* b, float* scratch, int f
     hipStream_t st = (hipStream_t)stream;
     const bool sn = (flags & WDG_PREP_SN) && b->n_sn > 0;
     if (sn) {
+        // [u W^T per row chunk + the chunk's share of v W, one pass over W] -> [norms, u, 1/sigma] -> [w / sigma] -> [repack]
         WDG_CHECK_ARG(scratch, "scratch required");
-        hipLaunchKernelGGL(wdg_prep_rowdot_kernel, dim3(b->g1), dim3(256), 0, st, b->d, b->n_sn, scratch);
-        hipLaunchKernelGGL(wdg_prep_colpart_kernel, dim3(b->g2), dim3(256), 0, st, b->d, b->n_sn, scratch);
-        hipLaunchKernelGGL(wdg_prep_finish_kernel, dim3(b->n_sn), dim3(1024), 0, st, b->d, scratch);
+        hipLaunchKernelGGL(wdg_prep_chunk_kernel, dim3(b->g2), dim3(256), 0, st, b->d, b->n_sn, scratch);
+        hipLaunchKernelGGL(wdg_prep_finish2_kernel, dim3(b->n_sn), dim3(1024), 0, st, b->d, scratch);
+        WDG_LAUNCH_CHECK();
+    }
+    if (sn) {
         hipLaunchKernelGGL(wdg_prep_scale_kernel, dim3(b->g4), dim3(256), 0, st, b->d, b->n_sn, scratch);
         WDG_LAUNCH_CHECK();
     }
