@@ -66,6 +66,26 @@ __device__ __forceinline__ int wdg_xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// row index of a phase -> (image, pa, pb): linear order, or 2-D row tiles (WdgPhase::t2_w)
+template <int BM>
+__device__ __forceinline__ void wdg_row_to_pixel(const WdgPhase& ph, int PaPb, int m, int& img, int& pa, int& pb) {
+    if (ph.t2_w) {
+        const int tile = m / BM, ml = m - tile * BM;
+        img = (int)wdg_fastdiv_do((unsigned)tile, ph.div_t2_img);
+        const int tr = tile - img * (int)(PaPb / BM);
+        const int ty = (int)wdg_fastdiv_do((unsigned)tr, ph.div_t2_w);
+        const int tx = tr - ty * ph.t2_tiles_w;
+        const int t2h = BM >> ph.t2_wshift;
+        pa = ty * t2h + (ml >> ph.t2_wshift);
+        pb = tx * ph.t2_w + (ml & (ph.t2_w - 1));
+    } else {
+        img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
+        const int rem = m - img * PaPb;
+        pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
+        pb = rem - pa * ph.Pb;
+    }
+}
+
 // EPI: 0 plain epilogue, 1 = + BatchNorm batch statistics of the output (training-mode producer), 2 = + inference-mode
 // BatchNorm affine.  Separate instantiations: the plain kernels keep their register allocation.
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0>
@@ -111,7 +131,7 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     // ---- buffer descriptors (wave-uniform: kernel arguments and blockIdx only).  Every operand load is a
     // buffer_load_dwordx4 whose byte offset is pushed out of range for padding / out-of-image / tail lanes,
     // so the hardware range check returns the zeros and the load sequence has no branches.
-    const int img0 = (int)wdg_fastdiv_do((unsigned)m0, ph.div_papb);
+    const int img0 = (int)wdg_fastdiv_do((unsigned)m0, ph.div_papb);   // (2-D tiles: PaPb is a multiple of BM, so the tile's image is the same)
     const wdg_srd srdA = wdg_make_srd(p.A + (long long)img0 * p.imgStrideA);
     const wdg_srd srdB = wdg_make_srd(p.B);
 
@@ -122,10 +142,8 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     for (int i = 0; i < A_LOADS; ++i) {
         const int m = m0 + lrow + 32 * i;
         if (m < Mph) {
-            const int img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
-            const int rem = m - img * PaPb;
-            const int pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
-            const int pb = rem - pa * ph.Pb;
+            int img, pa, pb;
+            wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const int ih0 = pa * p.a_mul + ph.a_off_h;
             const int iw0 = pb * p.a_mul + ph.a_off_w;
             a_ih0[i] = ih0;
@@ -349,10 +367,8 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
             if (m >= Mph) continue;
-            const int img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
-            const int rem = m - img * PaPb;
-            const int pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
-            const int pb = rem - pa * ph.Pb;
+            int img, pa, pb;
+            wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const int oh = pa * p.o_mul + ph.o_off_h;
             const int ow = pb * p.o_mul + ph.o_off_w;
             const long long off = (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
@@ -369,9 +385,10 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
                 *reinterpret_cast<f32x4*>(p.Out2 + off + n) = z;
             }
             if (p.mean_rstd && rsub == 0) {
-                // (forward launches only: one phase, so m is the output pixel index)
-                p.mean_rstd[2 * (long long)m] = mean[a];
-                p.mean_rstd[2 * (long long)m + 1] = rstd[a];
+                // (forward launches only: one phase, so the output pixel index is img * PaPb + pa * Pb + pb)
+                const long long pixi = (long long)img * PaPb + pa * ph.Pb + pb;
+                p.mean_rstd[2 * pixi] = mean[a];
+                p.mean_rstd[2 * pixi + 1] = rstd[a];
             }
         }
         return;
@@ -395,10 +412,8 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
                 if (n < NcP) *reinterpret_cast<f32x4*>(dst + n) = acc[a][b];
             }
         } else {
-            const int img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
-            const int rem = m - img * PaPb;
-            const int pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
-            const int pb = rem - pa * ph.Pb;
+            int img, pa, pb;
+            wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const int oh = pa * p.o_mul + ph.o_off_h;
             const int ow = pb * p.o_mul + ph.o_off_w;
             float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
@@ -1053,6 +1068,7 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
 static int g_xcd_swizzle = 1;
+static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase::t2_w)
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
@@ -1101,6 +1117,14 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "wgrad_thin")) {
         wdg_wgrad_thin_enable(value);
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "tile2d")) {
+        g_tile2d = value != 0;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "convlstm1_mfma")) {
+        wdg_convlstm1_set_mfma(value);
         return WDG_OK;
     }
     if (key && !strcmp(key, "phase_major")) {
@@ -1155,6 +1179,13 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         p.partial = (float*)ws;
     } else {
         p.partial = nullptr;
+    }
+    if (g_tile2d && split == 1) {
+        // rows of a tile = a 2-D patch of output pixels (8 x 16 for 128 rows, 8 x 8 for 64, 16 x 16 for 256) where the
+        // phase's pixel grid divides evenly: a 128-row tile of the 8x8 stride-2 layer then touches 22 x 38 input pixels
+        // instead of 8 x 262.  (Split-K launches keep the linear order: their second stage maps rows linearly.)
+        const int t2w = tc.BM == 64 ? 8 : 16;
+        for (int i = 0; i < nphase; ++i) wdg_phase_tile2d(p.ph[i], tc.BM, t2w);
     }
     dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
     p.phase_in_x = 0;

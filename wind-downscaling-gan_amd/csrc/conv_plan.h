@@ -10,10 +10,27 @@ struct WdgPhase {
     int K4;                // k4 groups (padded to a multiple of 8 with invalid entries)
     int tab_off;           // first table entry of this phase
     wdg_fastdiv div_papb, div_pb;   // row index -> (image, pa, pb) by multiply-high (wdg_phase_finish fills them)
+    // 2-D row tiles (t2_w > 0): the BM rows of a tile are a (BM / t2_w) x t2_w patch of output pixels instead of BM consecutive
+    // pixels of one output row — fewer distinct input rows per tile, so neighbouring taps hit L1 / L2 instead of the fabric
+    int t2_w, t2_wshift, t2_tiles_w;
+    wdg_fastdiv div_t2_img, div_t2_w;   // tile index -> (image, tile row, tile column)
 };
 static inline void wdg_phase_finish(WdgPhase& ph) {
     ph.div_papb = wdg_fastdiv_make((unsigned)(ph.Pa * ph.Pb > 0 ? ph.Pa * ph.Pb : 1));
     ph.div_pb = wdg_fastdiv_make((unsigned)(ph.Pb > 0 ? ph.Pb : 1));
+    ph.t2_w = ph.t2_wshift = ph.t2_tiles_w = 0;
+    ph.div_t2_img = ph.div_t2_w = wdg_fastdiv_make(1u);
+}
+// enable 2-D row tiles of bm rows (bm, t2w powers of two) when the phase's pixel grid divides evenly
+static inline bool wdg_phase_tile2d(WdgPhase& ph, int bm, int t2w) {
+    const int t2h = bm / t2w;
+    if (t2w <= 0 || t2h <= 0 || t2w * t2h != bm || ph.Pa % t2h || ph.Pb % t2w) return false;
+    int sh = 0;
+    while ((1 << sh) < t2w) ++sh;
+    ph.t2_w = t2w; ph.t2_wshift = sh; ph.t2_tiles_w = ph.Pb / t2w;
+    ph.div_t2_img = wdg_fastdiv_make((unsigned)((ph.Pa / t2h) * (ph.Pb / t2w)));
+    ph.div_t2_w = wdg_fastdiv_make((unsigned)(ph.Pb / t2w));
+    return true;
 }
 
 struct wdg_conv_plan {
@@ -50,6 +67,9 @@ void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
                     hipStream_t st);
+
+// convlstm1.hip
+void wdg_convlstm1_set_mfma(int v);
 
 // wgrad_halo.hip
 int wdg_wgrad_halo_eligible(const wdg_conv_plan* pl);

@@ -178,9 +178,15 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
 // (grid-stride over tiles, accumulators stay in registers); each block leaves one partial that a second kernel sums
 // in block order.  This replaces writing the dense 4F-channel dgates tensor (537 MB at the headline shape) and
 // reading it back in a separate weight-gradient kernel.
-template <int CIN, int F, bool WG>
+// MF = true (F = 16 only): the gate recompute of stage 2 runs on the MATRIX pipe — rows = halo pixels (16 per tile), columns
+// = the 3F = 48 live gate columns, k = the 9 * CIN = 45 (padded 48) flattened (tap, channel) pairs, weights resident in LDS
+// for the life of the persistent block — and the cell backward runs on the transposed accumulators (a lane holds gates
+// i, c~, o of four features of one pixel).  The vector pipe keeps the cell math and the input-gradient stage; with three
+// workgroups per CU in different stages the two pipes overlap (MI355X_MICROARCH.md: MFMA and VALU issue are separate).
+template <int CIN, int F, bool WG, bool MF = false>
 __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, const float* __restrict__ Wx,
                                                                 const float* __restrict__ bias) {
+    static_assert(!MF || F == 16, "the MFMA gate stage is written for 16 features");
     constexpr int FH = F >= 2 ? F / 2 : 1;
     constexpr int C4 = (CIN + 3) / 4;
     constexpr int XH = CL_TH + 4, XW = CL_TW + 4;    // x halo (two 3x3 stages)
@@ -193,6 +199,8 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     __shared__ __attribute__((aligned(16))) float dgs[GH * GW * G3];
     __shared__ float dxp[128 * CIN];
     __shared__ float red_extra[(WG && !RED_IN_DGS) ? 4 * WN : 1];
+    constexpr int KP = (9 * CIN + 3) / 4 * 4;        // flattened (tap, channel) rows padded to the MFMA k granule
+    __shared__ float wl[MF ? KP * 3 * F : 1];        // [k][gate column i | c~ | o]: row stride 48 = 16 mod 32 words: the two 16-lane k groups of a b32 read hit disjoint banks
 
     const int t = threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(t >> 7);
@@ -219,6 +227,26 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
         }
     }
 
+    int xoff[MF ? KP / 4 : 1];
+    if constexpr (MF) {
+        for (int idx = t; idx < KP * 3 * F; idx += 256) {
+            const int k = idx / (3 * F), n = idx - k * (3 * F);
+            const int g = n / F, f = n - g * F;
+            wl[idx] = k < 9 * CIN ? Wx[k * 4 * F + (g == 0 ? 0 : g + 1) * F + f] : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KP / 4; ++ks) {
+            const int k = 4 * ks + lq;
+            int off = 0;                                   // padding rows: any valid address (their weights are zero)
+            if (k < 9 * CIN) {
+                const int tap = k / CIN, c = k - tap * CIN;
+                const int th = tap / 3, tw = tap - 3 * th;
+                off = (((c >> 2) * (XH * XW) + th * XW + tw) << 2) + (c & 3);
+            }
+            xoff[ks] = off;
+        }
+        __syncthreads();
+    }
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int b = tile;
@@ -242,6 +270,47 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
         xs[c4 * (XH * XW) + pix] = v;   // channel-group planes: a wave's 16-byte reads of consecutive pixels are contiguous
     }
     __syncthreads();
+    if constexpr (MF) {
+        // 2'. gates of the (GH x GW) halo pixels on the matrix pipe, 16 pixels per tile, wave w takes tiles w, w + 4, ...
+        const float* xsf2 = reinterpret_cast<const float*>(xs);
+        constexpr int NMT = (GH * GW + 15) / 16;
+        for (int mt = wv; mt < NMT; mt += 4) {
+            const int hp_ = mt * 16 + li;
+            const bool hp_ok = hp_ < GH * GW;
+            const int hy = hp_ok ? hp_ / GW : 0, hx = hp_ok ? hp_ - hy * GW : 0;
+            const int pix0 = (hy * XW + hx) << 2;
+            f32x4 ga[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ga[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KP / 4; ++ks) {
+                const float xv = xsf2[pix0 + xoff[ks]];
+                const float* wr = &wl[(4 * ks + lq) * 3 * F + li];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g * F], xv, ga[g], 0, 0, 0);
+            }
+            // accumulator reg r of lane (li, lq): gate g of feature 4*lq + r of halo pixel li
+            const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            const bool inside = hp_ok && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            f32x4 dh4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (inside) dh4 = *reinterpret_cast<const f32x4*>(DHimg + ((long long)gy * p.W + gx) * p.lddh + 4 * lq);
+            if (hp_ok) {
+                float* d = &dgs[hp_ * G3 + 4 * lq];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 4 * lq + r;
+                    const float xi = ga[0][r] + bias[f], xc = ga[1][r] + bias[2 * F + f], xo = ga[2][r] + bias[3 * F + f];
+                    const float si = cl_hsig(xi), tc_ = cl_tanh(xc), so = cl_hsig(xo);
+                    const float th = cl_tanh(si * tc_);
+                    const float dh = dh4[r];
+                    const float dc = dh * so * (1.f - th * th);
+                    d[r] = inside ? dc * tc_ * cl_hsig_grad(xi) : 0.f;
+                    d[F + r] = inside ? dc * si * (1.f - tc_ * tc_) : 0.f;
+                    d[2 * F + r] = inside ? dh * th * cl_hsig_grad(xo) : 0.f;
+                }
+            }
+        }
+    } else
     // 2. dgates on the (GH x GW) halo: work item = (halo pixel, half); halves are wave-uniform
     for (int base = 0; base < GH * GW; base += 128) {
         const int hp_ = base + (t & 127);
@@ -418,6 +487,15 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_wgrad_reduce_kernel(const f
 }
 
 // ---- host -------------------------------------------------------------------------------------------------
+static int g_cl1_mfma = 0;     // wdg_set_tuning("convlstm1_mfma", 0/1): gate recompute of the 5 -> 16 backward on the matrix pipe
+void wdg_convlstm1_set_mfma(int v) { g_cl1_mfma = v != 0; }
+static int cl1_cus() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        return prop.multiProcessorCount;
+    return 256;
+}
 extern "C" int wdg_convlstm1_supported(int cin, int F) { return (cin == 2 && F == 2) || (cin == 5 && F == 16); }
 
 extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
@@ -463,8 +541,13 @@ static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* w
         dim3 grid((unsigned)ntiles);
         if (cin == 2)
             hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2, false>), grid, block, 0, st, p, wx, bias);
-        else
+        else if (dgates || !g_cl1_mfma)
             hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false>), grid, block, 0, st, p, wx, bias);
+        else {
+            // persistent like the weight-gradient form: the LDS-resident weights are loaded once per workgroup
+            dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 2));   // 61 KB of LDS: two resident workgroups per CU
+            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false, true>), pgrid, block, 0, st, p, wx, bias);
+        }
         WDG_LAUNCH_CHECK();
         return WDG_OK;
     }
@@ -473,7 +556,7 @@ static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* w
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    const int nb = (int)std::min<long long>(ntiles, (long long)cus * 3);
+    const int nb = (int)std::min<long long>(ntiles, (long long)cus * ((cin == 5 && g_cl1_mfma) ? 2 : 3));
     const int rows = 9 * cin + 1, cols = 3 * F;
     const size_t slab = (size_t)((rows + 15) / 16 * 16) * ((cols + 15) / 16 * 16);
     if (ws_bytes < (size_t)nb * slab * sizeof(float)) {
@@ -486,7 +569,10 @@ static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* w
         hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2, true>), grid, block, 0, st, p, wx, bias);
         hipLaunchKernelGGL((wdg_convlstm1_wgrad_reduce_kernel<2, 2>), rgrid, block, 0, st, p.dWpart, nb, dw, dbias);
     } else {
-        hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, true>), grid, block, 0, st, p, wx, bias);
+        if (g_cl1_mfma)
+            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, true, true>), grid, block, 0, st, p, wx, bias);
+        else
+            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, true>), grid, block, 0, st, p, wx, bias);
         hipLaunchKernelGGL((wdg_convlstm1_wgrad_reduce_kernel<5, 16>), rgrid, block, 0, st, p.dWpart, nb, dw, dbias);
     }
     WDG_LAUNCH_CHECK();
