@@ -50,6 +50,11 @@ CONV_CASES = [
     ("halo_5x5_8to16", 4, 128, 128, 8, 16, 5, 1, 2),
     ("halo_3x3_12to24", 4, 128, 132, 12, 24, 3, 1, 1),
     ("n160_tile32", 2, 24, 24, 16, 160, 5, 1, 2),
+    # 65,536 .. 131,071 output pixels: fewer than two 8-row halo tiles per CU -> 4-row tiles (the per-timestep recurrent
+    # convolutions of the discriminator's ConvLSTMs at the shipped shape: 8 tiles of 96 x 96)
+    ("halo_th4_16to64", 8, 96, 96, 16, 64, 3, 1, 1),
+    ("halo_th4_2to8", 8, 96, 96, 2, 8, 3, 1, 1),
+    ("halo_th4_ragged", 9, 90, 100, 16, 64, 3, 1, 1),
     # thin 3x3 weight-gradient kernel: ragged tile edges, every built row-tile count, 32 output channels
     ("thin_3to32", 3, 150, 150, 3, 32, 3, 1, 1),
     ("thin_4to8", 3, 150, 151, 4, 8, 3, 1, 1),

@@ -41,7 +41,9 @@ struct WdgHalo {
 // WG = 1: the weight fragments are read straight from global memory (they are a few hundred KB, L1/L2
 // resident, and each lane needs exactly one float4 per tap and column tile), which frees the LDS weight
 // stage (25.6 of 52 KB for the 5x5 layer) and lets more blocks share a CU.
-template <int NT, int WG>
+// TH = 8 (default) or 4 output rows per tile: a launch with fewer than two 8-row tiles per CU (the per-timestep recurrent
+// convolutions at n_timesteps > 1: 288 tiles on 256 CUs) halves its tiles to double the number of workgroups.
+template <int NT, int WG, int TH = HALO_TH>
 __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, const float* __restrict__ Bw) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem[];
     f32x4* lds_a = smem;                 // [4][npix]
@@ -56,15 +58,16 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
     bid /= p.tiles_w;
     const int ty = bid % p.tiles_h;
     const int img = bid / p.tiles_h;
-    const int oy0 = ty * HALO_TH, ox0 = tx * HALO_TW;
+    constexpr int RPW = TH / 4, NA = 2 * RPW;   // output rows per wave, 16-pixel row tiles per wave
+    const int oy0 = ty * TH, ox0 = tx * HALO_TW;
     const int hy0 = oy0 + p.dh_min, hx0 = ox0 + p.dw_min;
     const int npr = p.halo_h * p.halo_w;
     const float* Aimg = p.A + (long long)img * p.imgStrideA;
     const int ly0 = (hy0 >> 1) - 1, lx0 = (hx0 >> 1) - 1;   // low-res origin of the staging tile
 
-    f32x4 acc[4][NT];
+    f32x4 acc[NA][NT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -142,10 +145,10 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
             for (int tap = 0; tap < p.ntaps; ++tap) {
                 const int4 e = p.taps[tap];
                 const int rowoff = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
-                f32x4 af[4], bf[NT];
+                f32x4 af[NA], bf[NT];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int row = 2 * wave + (a >> 1), col = (a & 1) * 16 + li;
+                for (int a = 0; a < NA; ++a) {
+                    const int row = RPW * wave + (a >> 1), col = (a & 1) * 16 + li;
                     af[a] = kvalid ? lds_a[lg * p.npix + row * p.halo_w + col + rowoff] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < NA; ++a)
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);   // transposed tile
@@ -176,10 +179,10 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                 const int kg = ent - tap * kgs;
                 const int4 e = p.taps[tap];
                 const int rowoff = (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);
-                f32x4 af[4], bf[NT];
+                f32x4 af[NA], bf[NT];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int row = 2 * wave + (a >> 1), col = (a & 1) * 16 + li;
+                for (int a = 0; a < NA; ++a) {
+                    const int row = RPW * wave + (a >> 1), col = (a & 1) * 16 + li;
                     af[a] = kvalid ? lds_a[kg * p.npix + row * p.halo_w + col + rowoff] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < NA; ++a)
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);   // transposed tile
@@ -207,8 +210,8 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
     // output channel b*16 + 4*lg + r of pixel column li: one 16-byte store per lane and tile
     const int NcP = (p.Ncols + 3) & ~3;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int oy = oy0 + 2 * wave + (a >> 1);
+    for (int a = 0; a < NA; ++a) {
+        const int oy = oy0 + RPW * wave + (a >> 1);
         const int ox = ox0 + (a & 1) * 16 + li;
         if (oy >= p.Ho || ox >= p.Wo) continue;
         float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO;
@@ -361,13 +364,15 @@ static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols
 static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
 void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
 static int g_halo_persistent = 1;   // wdg_set_tuning("halo_persistent", 0/1)
+static int g_halo_th4 = 1;          // wdg_set_tuning("halo_th4", 0/1): 4-row tiles for launches with fewer than two tiles per CU
+void wdg_halo_set_th4(int v) { g_halo_th4 = v != 0; }
 static int g_halo_max_cin = 64;     // reduction channels above which conv_fwd / conv_dgrad do not take the halo kernel (0 = no limit)
 void wdg_halo_set_max_cin(int v) { g_halo_max_cin = v; }
 static int g_halo1_bpc = 4;         // resident workgroups per CU of the persistent kernel (126 registers -> 4 waves per SIMD; measured 2: 122, 3: 113, 4: 111, 5: 127 us)
 void wdg_halo_set_persistent(int v) { g_halo_persistent = v != 0; if (v > 1) g_halo1_bpc = v; }
 
-static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 0) {
-    const int hh = HALO_TH + kh - 1, hw = HALO_TW + kw - 1;
+static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 0, int th = HALO_TH) {
+    const int hh = th + kh - 1, hw = HALO_TW + kw - 1;
     const int npix = wdg_round_up(hh * hw, 16);
     const int lr = upsample ? (hh / 2 + 3) * (hw / 2 + 3) * 4 : 0;
     return (size_t)(4 * npix + (wg ? 0 : kh * kw * 4 * nt * 16) + lr) * sizeof(f32x4);
@@ -453,15 +458,20 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
         wdg_set_error("halo: plan is not eligible for the halo-tile kernel");
         return WDG_ERR_ARG;
     }
-    p.halo_h = HALO_TH + g.kh - 1; p.halo_w = HALO_TW + g.kw - 1;
+    // small launches (fewer than two 8-row tiles per CU) use 4-row tiles: twice the workgroups (not the upsampling form,
+    // whose low-resolution staging tile is sized for 8 rows, nor the persistent 3x3 kernel below)
+    const bool persistent1 = g_halo_persistent && !upsample && nt == 1 && p.C4 == 4 && pl->taps == 9 && g.kh == 3;
+    const long long tiles8 = (long long)g.n_img * ((p.Ho + HALO_TH - 1) / HALO_TH) * ((p.Wo + HALO_TW - 1) / HALO_TW);
+    const int th = (g_halo_th4 && !upsample && !persistent1 && tiles8 < 2LL * pl->cus) ? 4 : HALO_TH;
+    p.halo_h = th + g.kh - 1; p.halo_w = HALO_TW + g.kw - 1;
     p.npix = wdg_round_up(p.halo_h * p.halo_w, 16);
-    p.tiles_h = (p.Ho + HALO_TH - 1) / HALO_TH;
+    p.tiles_h = (p.Ho + th - 1) / th;
     p.tiles_w = (p.Wo + HALO_TW - 1) / HALO_TW;
     const int wg = upsample ? 1 : g_halo_wg;   // the low-res staging tile takes the LDS of the weight stage
     p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
-    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg, upsample);
+    const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg, upsample, th);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
-    if (g_halo_persistent && !upsample && nt == 1 && p.C4 == 4 && pl->taps == 9 && g.kh == 3) {
+    if (persistent1) {
         // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
         const size_t lds1 = ((size_t)4 * p.npix + 9 * 64) * sizeof(f32x4);
         const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * g_halo1_bpc);
@@ -471,7 +481,9 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     }
 #define WDG_HALO_CASE(NT_)                                                                             \
     if (nt == NT_) {                                                                                   \
-        if (wg) hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 1>), grid, block, lds, st, p, Bw);       \
+        if (th == 4 && wg) hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 1, 4>), grid, block, lds, st, p, Bw);   \
+        else if (th == 4) hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 0, 4>), grid, block, lds, st, p, Bw);    \
+        else if (wg) hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 1>), grid, block, lds, st, p, Bw);  \
         else hipLaunchKernelGGL((wdg_conv_halo_kernel<NT_, 0>), grid, block, lds, st, p, Bw);          \
     }
     WDG_HALO_CASE(1)

@@ -1119,6 +1119,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_wgrad_thin_enable(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "halo_th4")) {
+        wdg_halo_set_th4(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "tile2d")) {
         g_tile2d = value != 0;
         return WDG_OK;

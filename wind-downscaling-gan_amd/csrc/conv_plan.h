@@ -62,6 +62,7 @@ int wdg_halo_plan_init(wdg_conv_plan* pl);
 void wdg_halo_plan_free(wdg_conv_plan* pl);
 void wdg_halo_set_wg(int v);
 void wdg_halo_set_persistent(int v);
+void wdg_halo_set_th4(int v);
 void wdg_halo_set_max_cin(int v);
 void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
