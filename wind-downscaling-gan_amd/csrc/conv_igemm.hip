@@ -39,6 +39,8 @@ struct WdgIgemm {
     int splitk, k4_per_split;
     int Mmax, nphase;
     int xcd_swizzle;   // remap blockIdx.x so that each XCD (blocks b, b+8, ...) walks a contiguous range of tiles
+    int n_fastest;     // 1: consecutive blocks walk the column tiles of ONE row tile (they share the A rows in L2; the whole B
+                       // operand is small enough to stay resident); 0: consecutive blocks walk row tiles (share the B tile)
     int phase_in_x;    // > 0: blockIdx.x = tile * nphase + phase (the phases of one output tile run back to back on ONE XCD and
                        // share its L2 copy of the input rows); 0: phase = blockIdx.z
     // fused BatchNorm hooks of the epilogue (EPI template flag): per-channel sum / sum of squares of the written values
@@ -116,8 +118,15 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     }
     const WdgPhase ph = p.ph[phase_id];
     const int tiles_m = (p.Mmax + BM - 1) / BM;
-    const int tm = bid % tiles_m;
-    const int tn = bid / tiles_m;
+    int tm, tn;
+    if (p.n_fastest) {
+        const int tiles_n = (p.Ncols + BN - 1) / BN;
+        tn = bid % tiles_n;
+        tm = bid / tiles_n;
+    } else {
+        tm = bid % tiles_m;
+        tn = bid / tiles_m;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int PaPb = ph.Pa * ph.Pb;
     const int Mph = p.n_img * PaPb;
@@ -1068,6 +1077,8 @@ extern "C" int wdg_conv_plan_info(const wdg_conv_plan* pl, int32_t* info) {
 // tuning knob (wdg_set_tuning): 0 = single LDS stage / two barriers, 1 = double-buffered LDS / one barrier,
 // 2 = 1 + fragment prefetch
 static int g_xcd_swizzle = 1;
+static int g_n_fastest = 1;
+static long long g_n_fastest_bytes = 2 << 20;
 static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase::t2_w)
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
@@ -1117,6 +1128,11 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "wgrad_thin")) {
         wdg_wgrad_thin_enable(value);
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "n_fastest")) {
+        g_n_fastest = value != 0;
+        if (value > 1) g_n_fastest_bytes = (long long)value << 10;   // value > 1: B-operand limit in KiB
         return WDG_OK;
     }
     if (key && !strcmp(key, "halo_th4")) {
@@ -1192,6 +1208,10 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         for (int i = 0; i < nphase; ++i) wdg_phase_tile2d(p.ph[i], tc.BM, t2w);
     }
     dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
+    // several column tiles over a small B operand (the 400-column GEMM of the column-form upsample-conv: 5 tiles, 256 KB of
+    // weights): walk the column tiles of a row tile back to back, so its A rows are fetched from the fabric once, not once
+    // per column tile
+    p.n_fastest = g_n_fastest && tiles_n > 1 && (long long)p.Ncols * K4max * 16 <= g_n_fastest_bytes;
     p.phase_in_x = 0;
     if (nphase > 1 && g_phase_major) {
         grid = dim3(tiles_m * tiles_n * nphase, split, 1);
