@@ -79,6 +79,14 @@ class ConvTimer:
             timed(ops.conv_kernel_label("wgrad", x, dy, pk, g), flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g,
                   layer=geom("wgrad", x, dy, pk, g), **k)
 
+        orig_fwd_ln = ops.conv_fwd_ln
+
+        def conv_fwd_ln(x, pk, bias, y, z, g, *a, **k):
+            # conv -> LeakyReLU -> LayerNorm in one call: the convolution's FLOPs, timed with its fused norm
+            timed(ops.conv_kernel_label("fwd", x, y, pk, g), flops(x, y, pk, g), orig_fwd_ln, x, pk, bias, y, z, g, *a,
+                  layer=geom("fwd+LN", x, y, pk, g), **k)
+
+        ops.conv_fwd_ln = conv_fwd_ln
         orig_up = ops.upconv_fwd
 
         def upconv_fwd(x_low, pk, bias, y, g, **k):
