@@ -881,7 +881,11 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
         if (wdg_round_up(ncols, c.BN) * 100 <= best * 113) return c;
     return cand[3];
 }
-static int pick_wgrad_bn(int ncols) { return pick_tile(ncols, false).BN; }
+static int g_wgrad_bn160 = 32;   // wdg_set_tuning("wgrad_bn160", 32 | 64 | 128): column tile of 160-column weight gradients
+static int pick_wgrad_bn(int ncols) {
+    if (ncols == 160 && g_wgrad_bn160 != 32) return g_wgrad_bn160;
+    return pick_tile(ncols, false).BN;
+}
 // wdg_set_tuning("force_{fwd,dgrad,wgrad}_split", n): n > 0 overrides the split chosen at plan creation (sweeps)
 static int g_force_split[3] = {0, 0, 0};
 // resident workgroups per CU (512 unified VGPRs per lane and SIMD: 244 -> 2 waves, 156 -> 3, ...)
@@ -1128,6 +1132,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "wgrad_thin")) {
         wdg_wgrad_thin_enable(value);
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "wgrad_bn160")) {
+        g_wgrad_bn160 = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "n_fastest")) {
