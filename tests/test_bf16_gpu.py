@@ -17,6 +17,13 @@ CASES = [
     ("c5_128to64", 2, 16, 16, 128, 64, 3, 1, 1),
     ("convT2x2_as_conv", 2, 16, 16, 32, 192, 2, 2, 0),
     ("odd_sizes", 3, 21, 19, 40, 72, 3, 1, 1),
+    # conv_patch_h16.hip (input patch in LDS): 1 x 16 fragments (map width % 16) and 4 x 4 fragments (map width % 24)
+    ("patchA_c0_96", 2, 96, 96, 23, 128, 8, 2, 3),
+    ("patchA_c40_cout72", 2, 16, 32, 40, 72, 3, 1, 1),
+    ("patchA_5x5_cout32", 1, 16, 16, 24, 32, 5, 1, 2),
+    ("patchB_gates_24", 3, 24, 24, 128, 512, 3, 1, 1),
+    ("patchB_c5_24", 2, 24, 24, 128, 64, 3, 1, 1),
+    ("patchB_4x4s2_c16", 2, 48, 48, 16, 72, 4, 2, 1),
 ]
 
 

@@ -8,19 +8,10 @@
 // rounded to bf16 (4 LDS reads per output slot instead of 8 global loads).  Weight fragments are read straight
 // from global memory (bf16 copy of the packed weights, L1/L2 resident).
 #include "conv_plan.h"
+#include "h16.h"
 #include <algorithm>
 
 // operand format FMT: 0 = bf16, 1 = IEEE fp16 (same kernels, see conv_igemm_bf16.hip)
-template <int FMT> struct WdgH16;
-template <> struct WdgH16<0> { typedef __bf16 T; };
-template <> struct WdgH16<1> { typedef _Float16 T; };
-template <int FMT> using wdg_h16 = typename WdgH16<FMT>::T;
-template <int FMT> using wdg_h16x8 = wdg_h16<FMT> __attribute__((ext_vector_type(8)));
-template <int FMT>
-__device__ __forceinline__ f32x4 wdg_mfma16(const wdg_h16x8<FMT>& a, const wdg_h16x8<FMT>& b, const f32x4& c) {
-    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
 constexpr int HB_TH = 8, HB_TW = 32;
 
 struct WdgHaloBf16 {

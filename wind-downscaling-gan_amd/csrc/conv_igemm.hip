@@ -1147,6 +1147,11 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_halo_set_th4(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "patch_h16")) {
+        wdg_patch_h16_set(value != 0);
+        if (value > 1) wdg_patch_h16_set_budget(value);   // value > 1: LDS bytes of a patch chunk in KiB
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "tile2d")) {
         g_tile2d = value != 0;
         return WDG_OK;

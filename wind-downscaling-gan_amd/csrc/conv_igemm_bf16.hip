@@ -12,21 +12,12 @@
 //   * the kernel is L2-bandwidth bound, not MFMA bound, so the epilogue can also apply the inference-mode
 //     BatchNorm (per-channel scale/shift after the LeakyReLU) instead of a separate pass.
 #include "conv_plan.h"
+#include "h16.h"
 #include <algorithm>
 
 // Two 16-bit operand formats share every kernel of this file (template parameter FMT): 0 = bf16
 // (v_mfma_f32_16x16x32_bf16), 1 = IEEE fp16 (v_mfma_f32_16x16x32_f16, BASELINE.json configs[4]).  Both round to
 // nearest even from the fp32 activations while staging and accumulate in fp32.
-template <int FMT> struct WdgH16;
-template <> struct WdgH16<0> { typedef __bf16 T; };
-template <> struct WdgH16<1> { typedef _Float16 T; };
-template <int FMT> using wdg_h16 = typename WdgH16<FMT>::T;
-template <int FMT> using wdg_h16x8 = wdg_h16<FMT> __attribute__((ext_vector_type(8)));
-template <int FMT>
-__device__ __forceinline__ f32x4 wdg_mfma16(const wdg_h16x8<FMT>& a, const wdg_h16x8<FMT>& b, const f32x4& c) {
-    if constexpr (FMT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
 
 struct WdgIgemmBf16 {
     const float* A;
@@ -264,6 +255,9 @@ static int conv_fwd_h16(const wdg_conv_plan* pl, const float* x, const void* wF1
     WDG_CHECK_ARG(pl->Cin_p % 8 == 0, "bf16 path needs the padded input channel count to be a multiple of 8");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF16 & 15) == 0, "alignment");
     const wdg_conv_geom& g = pl->g;
+    // input patch resident in LDS (conv_patch_h16.hip) when the output map divides into its tiles
+    const int prc = wdg_patch_h16_launch(pl, x, wF16, bias, affine, y, act, slope, accumulate, fmt, (hipStream_t)stream);
+    if (prc != 1) return prc;
     WdgIgemmBf16 p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.B = wF16; p.Out = y; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_fwd;
