@@ -1147,6 +1147,14 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_halo_set_th4(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "patch_nloop")) {
+        wdg_patch_h16_set_nloop(value);
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "patch_dbg")) {
+        wdg_patch_h16_set_dbg(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "patch_h16")) {
         wdg_patch_h16_set(value != 0);
         if (value > 1) wdg_patch_h16_set_budget(value);   // value > 1: LDS bytes of a patch chunk in KiB

@@ -256,7 +256,7 @@ static int conv_fwd_h16(const wdg_conv_plan* pl, const float* x, const void* wF1
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF16 & 15) == 0, "alignment");
     const wdg_conv_geom& g = pl->g;
     // input patch resident in LDS (conv_patch_h16.hip) when the output map divides into its tiles
-    const int prc = wdg_patch_h16_launch(pl, x, wF16, bias, affine, y, act, slope, accumulate, fmt, (hipStream_t)stream);
+    const int prc = wdg_patch_h16_launch(pl, 0, x, wF16, bias, affine, y, act, slope, accumulate, fmt, (hipStream_t)stream);
     if (prc != 1) return prc;
     WdgIgemmBf16 p;
     memset(&p, 0, sizeof(p));
@@ -293,6 +293,10 @@ static int conv_dgrad_h16(const wdg_conv_plan* pl, const float* dy, const void* 
     WDG_CHECK_ARG(pl->Cout_p % 8 == 0, "bf16 path needs the padded channel count of dy to be a multiple of 8");
     WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD16 & 15) == 0, "alignment");
     const wdg_conv_geom& g = pl->g;
+    // 1 x 1 transposed conv (the column GEMM of the column-form upsample layer): a plain GEMM whose result is the larger
+    // side -> the patch kernel's full-line stores (conv_patch_h16.hip)
+    const int prc = wdg_patch_h16_launch(pl, 1, dy, wD16, bias, affine, dx, act, slope, accumulate, fmt, (hipStream_t)stream);
+    if (prc != 1) return prc;
     WdgIgemmBf16 p;
     memset(&p, 0, sizeof(p));
     p.A = dy; p.B = wD16; p.Out = dx; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_dgrad;

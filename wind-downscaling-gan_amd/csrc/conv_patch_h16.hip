@@ -41,13 +41,25 @@ struct WdgPatchH16 {
     int fw_shift, tfx;         // fragment width 1 << fw_shift (16 or 4), fragments per fragment-row of the tile
     int TH, TW, PH, PW, PWs, pitch;   // tile, patch, columns per parity plane, slots per channel-group plane
     int CK8, nchunk, kcn;      // channel groups per chunk, chunks, K-steps per tap and chunk
-    int tiles_x, tiles_y, tiles_n;
+    int tiles_x, tiles_y, tiles_n, ntn_blk;   // tiles_n counts workgroups along the channels, each doing ntn_blk channel tiles
     wdg_fastdiv div_tn, div_tx, div_ty, div_ck, div_pw;
 };
 
 // MT fragments of 16 pixels per wave (2 waves along the pixels), NT 16-channel tiles per wave (2 waves along the channels)
-template <int FMT, int MT, int NT>
-__global__ void __launch_bounds__(256) wdg_conv_patch_h16_kernel(const WdgPatchH16 p) {
+// compile-time experiment knobs (tools/build_variants.sh)
+#ifndef WDG_PATCH_LB2
+#define WDG_PATCH_LB2 1
+#endif
+#ifndef WDG_PATCH_HG
+#define WDG_PATCH_HG ((MT * NT <= 16) ? 2 : 1)
+#endif
+#if WDG_PATCH_LB2
+#define WDG_PATCH_BOUNDS __launch_bounds__(256, 2)
+#else
+#define WDG_PATCH_BOUNDS __launch_bounds__(256)
+#endif
+template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0>
+__global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) {
     typedef wdg_h16x8<FMT> h16x8;
     constexpr int BN = 2 * NT * 16;
     constexpr int B_LOADS = 8 * BN / 256;          // 16-byte weight slots per thread and stage (2 K-steps)
@@ -75,7 +87,6 @@ __global__ void __launch_bounds__(256) wdg_conv_patch_h16_kernel(const WdgPatchH
     const int ty = r2 - img * p.tiles_y;
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
     const int iy0 = oy0 * s - p.pad_h, ix0 = ox0 * s - p.pad_w;
-    const int n0 = tn * BN;
 
     const wdg_srd srdA = wdg_make_srd(p.A + (long long)img * p.imgStrideA);
     const wdg_srd srdB = wdg_make_srd(p.B);
@@ -93,6 +104,18 @@ __global__ void __launch_bounds__(256) wdg_conv_patch_h16_kernel(const WdgPatchH
         opix[a] = (oy0 + oyl) * p.Wo + ox0 + oxl;
     }
 
+    const int nks = p.kh * p.kw * p.kcn;            // K-steps per chunk
+    const int nstage = (nks + 1) >> 1;
+    const int npatch = p.CK8 * p.PH * p.PW;
+    const int dummy_slot = p.CK8 * p.pitch;         // one spare slot behind the patch takes the stores of the tail threads
+    const int bj = t & 7, bh = bj >> 2, bq = bj & 3;
+    float* outImg = p.Out + (long long)img * p.imgStrideO;
+
+    // ---- channel tiles of this workgroup: one, or (ntn_blk > 1: a patch that holds every channel, shallow reductions) several
+    // against the same resident patch
+    // (NLOOP is a template parameter: the single-tile kernels keep their register allocation)
+    for (int tni = 0; tni < (NLOOP ? p.ntn_blk : 1); ++tni) {
+    const int n0 = NLOOP ? tni * BN : tn * BN;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -102,7 +125,6 @@ __global__ void __launch_bounds__(256) wdg_conv_patch_h16_kernel(const WdgPatchH
     // ---- this thread's weight slots of a stage: j = (K-step of the stage, channel group q), column n
     int b_row[B_LOADS];        // element offset of row n, or -1
     int b_slot[B_LOADS];       // LDS slot inside a stage
-    const int bj = t & 7, bh = bj >> 2, bq = bj & 3;
 #pragma unroll
     for (int r = 0; r < B_LOADS; ++r) {
         const int n = (t >> 3) + 32 * r;
@@ -110,126 +132,181 @@ __global__ void __launch_bounds__(256) wdg_conv_patch_h16_kernel(const WdgPatchH
         b_slot[r] = bj * BN + (n ^ bj);
     }
 
-    const int nks = p.kh * p.kw * p.kcn;            // K-steps per chunk
-    const int nstage = (nks + 1) >> 1;
-    const int npatch = p.CK8 * p.PH * p.PW;
-
     for (int ck = 0; ck < p.nchunk; ++ck) {
-        __syncthreads();                             // every wave is done with the previous chunk's patch and weight stages
-        // ---- patch chunk: global fp32 -> 16-bit -> LDS, 4 slots per thread in flight
-        for (int base = 0; base < npatch; base += 4 * 256) {
-            f32x4 v[4][2];
-            int slot[4];
+        __syncthreads();                             // every wave is done with the previous chunk's patch, weight stages and epilogue tiles
+        // ---- patch chunk: global fp32 -> 16-bit -> LDS, PU slots (2 x 16-byte loads each) per thread in flight
+        constexpr int PU = 8;
+        for (int base = (!NLOOP || tni == 0) ? 0 : npatch; base < npatch; base += PU * 256) {
+            f32x4 v[PU][2];
+            int slot[PU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PU; ++u) {
                 const int idx = base + u * 256 + t;
                 const int pix = (int)wdg_fastdiv_do((unsigned)idx, p.div_ck);
                 const int c = idx - pix * p.CK8;
                 const int y = (int)wdg_fastdiv_do((unsigned)pix, p.div_pw);
                 const int x = pix - y * p.PW;
                 const int gy = iy0 + y, gx = ix0 + x;
-                const bool ok = idx < npatch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const bool ok = idx < npatch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && !(DBG & 2);
                 const unsigned off = ok ? (unsigned)((gy * p.W + gx) * p.ldA + (ck * p.CK8 + c) * 8) << 2 : WDG_SRD_OOB;
                 v[u][0] = wdg_buffer_load_f32x4(srdA, off);
                 v[u][1] = wdg_buffer_load_f32x4(srdA, ok ? off + 16u : WDG_SRD_OOB);
-                slot[u] = idx < npatch ? c * p.pitch + (((y << p.sshift) + (x & (s - 1))) * p.PWs) + (x >> p.sshift) : -1;
+                slot[u] = idx < npatch ? c * p.pitch + (((y << p.sshift) + (x & (s - 1))) * p.PWs) + (x >> p.sshift) : dummy_slot;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (slot[u] >= 0) ldsP[slot[u]] = wdg_pack_h16<FMT>(v[u][0], v[u][1]);
+            for (int u = 0; u < PU; ++u) ldsP[slot[u]] = wdg_pack_h16<FMT>(v[u][0], v[u][1]);
         }
 
-        // ---- weight stages: (tap, kc) counters of the stage being FETCHED (f*) and of the stage being COMPUTED (c*)
+        // ---- weight stages.  Stage st+2 is fetched into registers while stage st is computed from LDS and stage st+1
+        // (fetched one iteration earlier) is written to the other LDS buffer behind the MFMAs: one barrier per stage, two
+        // stages of load latency budget.  (tap, kc) counters: f* of the stage being fetched, c* of the one being computed.
         int f_kc = 0, f_kx = 0, f_ky = 0;
         int c_kc = 0, c_kx = 0, c_ky = 0;
-        u32x4 rb[B_LOADS];
+        u32x4 rb[2][B_LOADS];
         auto advance = [&](int& kc, int& kx, int& ky) {
             if (++kc == p.kcn) {
                 kc = 0;
                 if (++kx == p.kw) { kx = 0; ++ky; }
             }
         };
-        auto fetch_stage = [&]() {
+        auto fetch_stage = [&](u32x4 (&r_)[B_LOADS]) {
             // the two K-steps of the stage; this thread serves K-step bh, channel group bq
-            int kc0 = f_kc, kx0 = f_kx, ky0 = f_ky;
+            const int kc0 = f_kc, kx0 = f_kx, ky0 = f_ky;
             advance(f_kc, f_kx, f_ky);
-            int kc1 = f_kc, kx1 = f_kx, ky1 = f_ky;
+            const int kc1 = f_kc, kx1 = f_kx, ky1 = f_ky;
             advance(f_kc, f_kx, f_ky);
             const int kc = bh ? kc1 : kc0, kx = bh ? kx1 : kx0, ky = bh ? ky1 : ky0;
             const int g8 = kc * 4 + bq;              // channel group inside the chunk
-            const bool kok = ky < p.kh && g8 < p.CK8;
+            const bool kok = ky < p.kh && g8 < p.CK8 && !(DBG & 1);
             const int koff = (ky * p.kw + kx) * p.Cin_p + (ck * p.CK8 + g8) * 8;
 #pragma unroll
             for (int r = 0; r < B_LOADS; ++r)
-                rb[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB, (kok && b_row[r] >= 0) ? (int)((unsigned)(b_row[r] + koff) << 1) : (int)WDG_SRD_OOB, 0, 0);
+                r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB, (kok && b_row[r] >= 0) ? (int)((unsigned)(b_row[r] + koff) << 1) : (int)WDG_SRD_OOB, 0, 0);
         };
-        fetch_stage();
-        for (int st = 0; st < nstage; ++st) {
-            h16x8* sB = ldsB + (st & 1) * 8 * BN;
+        auto store_stage = [&](const u32x4 (&r_)[B_LOADS], int buf) {
+            h16x8* sB = ldsB + buf * 8 * BN;
 #pragma unroll
-            for (int r = 0; r < B_LOADS; ++r) sB[b_slot[r]] = __builtin_bit_cast(h16x8, rb[r]);
-            __syncthreads();
-            if (st + 1 < nstage) fetch_stage();
+            for (int r = 0; r < B_LOADS; ++r) sB[b_slot[r]] = __builtin_bit_cast(h16x8, r_[r]);
+        };
+        // the slot offset of a K-step's tap and channel group for this lane (K-steps past the end: offset 0, their weights are zero;
+        // lanes whose channel group is past the chunk read group 0 for the same reason)
+        auto tap_offset = [&]() {
+            const int g8 = c_kc * 4 + lq;
+            const int o = (((c_ky << p.sshift) + (c_kx & (s - 1))) * p.PWs) + (c_kx >> p.sshift) + (g8 < p.CK8 ? g8 : 0) * p.pitch;
+            const int r = c_ky < p.kh ? o : 0;
+            advance(c_kc, c_kx, c_ky);
+            return r;
+        };
+        auto compute_stage = [&](int buf) {
+            const h16x8* sB = ldsB + buf * 8 * BN;
+            const int off0 = tap_offset(), off1 = tap_offset();
+            // both K-steps' fragments are requested before the first MFMA where the registers allow it (the 6 x 4 tile: one at a time)
+            constexpr int HG = WDG_PATCH_HG;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (c_ky < p.kh) {                   // (an odd K-step count leaves the last stage half empty)
-                    const int g8 = c_kc * 4 + lq;
-                    // lanes whose channel group is past the chunk read group 0 (finite data); their weights are zero
-                    const int tapoff = (((c_ky << p.sshift) + (c_kx & (s - 1))) * p.PWs) + (c_kx >> p.sshift) + (g8 < p.CK8 ? g8 : 0) * p.pitch;
-                    const int pl = h * 4 + lq;
-                    h16x8 af[MT], bf[NT];
+            for (int h0 = 0; h0 < 2; h0 += HG) {
+                h16x8 af[HG][MT], bf[HG][NT];
+                if constexpr (!(DBG & 8)) {
 #pragma unroll
-                    for (int b = 0; b < NT; ++b) bf[b] = sB[pl * BN + ((wn * (BN / 2) + b * 16 + li) ^ pl)];
+                    for (int hh = 0; hh < HG; ++hh) {
+                        const int h = h0 + hh;
+                        const int pl = h * 4 + lq;
 #pragma unroll
-                    for (int a = 0; a < MT; ++a) af[a] = ldsP[fbase[a] + tapoff];
+                        for (int b = 0; b < NT; ++b) bf[hh][b] = sB[pl * BN + ((wn * (BN / 2) + b * 16 + li) ^ pl)];
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) af[hh][a] = ldsP[fbase[a] + (h ? off1 : off0)];
+                    }
+                } else {
+#pragma unroll
+                    for (int hh = 0; hh < HG; ++hh) {
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) bf[hh][b] = __builtin_bit_cast(h16x8, (u32x4){(unsigned)off0, (unsigned)b, (unsigned)hh, 1u});
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) af[hh][a] = __builtin_bit_cast(h16x8, (u32x4){(unsigned)off1, (unsigned)a, (unsigned)hh, 2u});
+                    }
+                }
+                if constexpr (!(DBG & 4)) {
+#pragma unroll
+                    for (int hh = 0; hh < HG; ++hh)
+#pragma unroll
+                        for (int a = 0; a < MT; ++a)
+#pragma unroll
+                            for (int b = 0; b < NT; ++b)
+                                acc[a][b] = wdg_mfma16<FMT>(bf[hh][b], af[hh][a], acc[a][b]);
+                } else {
 #pragma unroll
                     for (int a = 0; a < MT; ++a)
 #pragma unroll
                         for (int b = 0; b < NT; ++b)
-                            acc[a][b] = wdg_mfma16<FMT>(bf[b], af[a], acc[a][b]);
+                            acc[a][b][0] += (float)bf[0][b][0] + (float)af[HG - 1][a][1];
                 }
-                advance(c_kc, c_kx, c_ky);
+            }
+        };
+        fetch_stage(rb[0]);
+        if (nstage > 1) fetch_stage(rb[1]);
+        store_stage(rb[0], 0);
+        __syncthreads();
+        const bool bar = !(DBG & 32);
+        for (int st = 0; st < nstage; st += 2) {
+            if (st + 2 < nstage) fetch_stage(rb[0]);
+            compute_stage(0);
+            if (st + 1 < nstage) store_stage(rb[1], 1);
+            if (bar) __syncthreads();
+            if (st + 1 < nstage) {
+                if (st + 3 < nstage) fetch_stage(rb[1]);
+                compute_stage(1);
+                if (st + 2 < nstage) store_stage(rb[0], 0);
+                if (bar) __syncthreads();
             }
         }
     }
 
-    // ---- epilogue: lane (li, lq) holds channels 4*lq .. 4*lq+3 of pixel li of every fragment
-    float* outImg = p.Out + (long long)img * p.imgStrideO;
+    // ---- epilogue.  Lane (li, lq) holds channels 4*lq .. 4*lq+3 of pixel li of every fragment and stores them directly,
+    // 16 bytes per lane.  (A transpose through LDS to whole-pixel stores was measured SLOWER: 654 vs 487 us on the 400-column
+    // GEMM, profiles/r02n_perf_patch_epilogue.txt.)
+    const int nw0 = n0 + wn * (BN / 2);
+    {
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int n = n0 + wn * (BN / 2) + b * 16 + 4 * lq;
-        if (n >= p.Ncols) continue;
-        const bool full = n + 3 < p.Ncols;
-        f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = bias4;
+        for (int b = 0; b < NT; ++b) {
+            const int n = nw0 + b * 16 + 4 * lq;
+            if (n >= p.Ncols || (DBG & 16)) continue;
+            const bool full = n + 3 < p.Ncols;
+            f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = bias4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < p.Ncols) {
-                if (p.bias) bias4[r] = p.bias[n + r];
-                if (p.affine) { sc4[r] = p.affine[n + r]; sh4[r] = p.affine[p.Ncols + n + r]; }
-            }
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.Ncols) {
+                    if (p.bias) bias4[r] = p.bias[n + r];
+                    if (p.affine) { sc4[r] = p.affine[n + r]; sh4[r] = p.affine[p.Ncols + n + r]; }
+                }
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            float* dst = outImg + (long long)opix[a] * p.ldO + n;
-            f32x4 v = acc[a][b] + bias4;
-            if (p.act) {
+            for (int a = 0; a < MT; ++a) {
+                float* dst = outImg + (long long)opix[a] * p.ldO + n;
+                f32x4 v = acc[a][b] + bias4;
+                if (p.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
-            }
-            if (p.affine) v = v * sc4 + sh4;
-            if (full) {
-                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                *reinterpret_cast<f32x4*>(dst) = v;
-            } else {
+                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
+                }
+                if (p.affine) v = v * sc4 + sh4;
+                if (full) {
+                    if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.Ncols) dst[r] = p.accumulate ? dst[r] + v[r] : v[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.Ncols) dst[r] = p.accumulate ? dst[r] + v[r] : v[r];
+                }
             }
         }
     }
+    }   // channel tiles
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 static int g_patch_h16 = 1;
+static int g_patch_dbg = 0;   // timing experiments (builds with -DWDG_PATCH_EXPERIMENTS): template DBG bit 0 no weight fetch, 1 no patch
+                              // loads, 2 no MFMA, 3 no fragment reads, 4 no output stores, 5 no stage barriers
+void wdg_patch_h16_set_dbg(int v) { g_patch_dbg = v; }
+static int g_patch_nloop = 1;            // a workgroup walks all channel tiles of its pixel tile when the patch holds every channel
+void wdg_patch_h16_set_nloop(int v) { g_patch_nloop = v; }
 static int g_patch_budget = 44 * 1024;     // LDS bytes of a patch chunk: with the 32 KiB of weight stages two workgroups share a CU
 void wdg_patch_h16_set(int v) { g_patch_h16 = v; }
 void wdg_patch_h16_set_budget(int kib) { g_patch_budget = kib * 1024; }
@@ -238,17 +315,36 @@ struct WdgPatchCfg {
     int fw_shift, tfx, TH, TW, MT;
 };
 
+// what the kernel needs of a convolution: the forward conv of a plan, or the 1 x 1 transposed conv (= the column GEMM of the
+// column-form upsample + transposed-conv layer, upconv_col.hip) whose operand is dy and whose result is dx
+struct WdgPatchView {
+    int n_img, H, W, ldA, Ho, Wo, ldO;
+    long long imgStrideA, imgStrideO;
+    int K_p, Ncols;            // padded reduction channels per tap, output channels
+    int kh, kw, stride, pad_h, pad_w, cus;
+};
+static WdgPatchView patch_view(const wdg_conv_plan* pl, bool transposed1x1) {
+    const wdg_conv_geom& g = pl->g;
+    WdgPatchView v;
+    if (!transposed1x1)
+        v = {g.n_img, g.H, g.W, g.ldx, g.Ho, g.Wo, g.ldy, g.img_stride_x, g.img_stride_y, pl->Cin_p, g.Cout,
+             g.kh, g.kw, g.stride, g.pad_h, g.pad_w, pl->cus};
+    else
+        v = {g.n_img, g.Ho, g.Wo, g.ldy, g.H, g.W, g.ldx, g.img_stride_y, g.img_stride_x, pl->Cout_p, g.Cin,
+             1, 1, 1, 0, 0, pl->cus};
+    return v;
+}
+
 // tile shape for the output map, or false
-static bool patch_shape(const wdg_conv_geom& g, WdgPatchCfg& c) {
+static bool patch_shape(const WdgPatchView& g, WdgPatchCfg& c) {
     if (g.Ho % 8) return false;
     if (g.Wo % 16 == 0) { c = {4, 1, 8, 16, 4}; return true; }       // 8 fragments of 1 x 16
     if (g.Wo % 24 == 0) { c = {2, 6, 8, 24, 6}; return true; }       // 12 fragments of 4 x 4
     return false;
 }
 
-static bool patch_plan(const wdg_conv_plan* pl, WdgPatchH16& p) {
-    const wdg_conv_geom& g = pl->g;
-    if (!g_patch_h16 || (g.stride != 1 && g.stride != 2) || pl->Cin_p % 8 || g.Cout < 32 || g.ldy % 4) return false;
+static bool patch_plan(const WdgPatchView& g, WdgPatchH16& p) {
+    if (!g_patch_h16 || (g.stride != 1 && g.stride != 2) || g.K_p % 8 || g.Ncols < 32 || g.ldO % 4) return false;
     WdgPatchCfg c;
     if (!patch_shape(g, c)) return false;
     const int s = g.stride;
@@ -261,7 +357,7 @@ static bool patch_plan(const wdg_conv_plan* pl, WdgPatchH16& p) {
         while (((s * s * PWs) & 15) != 4 && ((s * s * PWs) & 15) != 12) ++PWs;    // rows of a 4 x 4 fragment on disjoint banks
     p.PWs = PWs;
     p.pitch = wdg_round_up(p.PH * s * PWs, 16);
-    const int C8 = pl->Cin_p / 8;
+    const int C8 = g.K_p / 8;
     int CK8 = 0;
     if ((long long)C8 * p.pitch * 16 <= g_patch_budget) CK8 = C8;
     else
@@ -276,42 +372,46 @@ static bool patch_plan(const wdg_conv_plan* pl, WdgPatchH16& p) {
 int wdg_patch_h16_eligible(const wdg_conv_plan* pl) {
     WdgPatchH16 p;
     memset(&p, 0, sizeof(p));
-    return patch_plan(pl, p) ? 1 : 0;
+    return patch_plan(patch_view(pl, false), p) ? 1 : 0;
 }
 
-template <int FMT, int MT, int NT>
+template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0>
 static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_t st) {
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_conv_patch_h16_kernel<FMT, MT, NT>),
+        WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_conv_patch_h16_kernel<FMT, MT, NT, NLOOP, DBG>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL((wdg_conv_patch_h16_kernel<FMT, MT, NT>), dim3(blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((wdg_conv_patch_h16_kernel<FMT, MT, NT, NLOOP, DBG>), dim3(blocks), dim3(256), lds, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
 
-// returns WDG_OK after launching, or 1 when the geometry is not eligible (caller falls back to the gather kernel)
-int wdg_patch_h16_launch(const wdg_conv_plan* pl, const float* x, const void* w16, const float* bias, const float* affine,
-                         float* y, int act, float slope, int accumulate, int fmt, hipStream_t st) {
+// returns WDG_OK after launching, or 1 when the geometry is not eligible (caller falls back to the gather kernel).
+// transposed1x1: x is dy, y is dx and w16 the data-gradient packing [Cin][Cout_p] of a 1 x 1, stride-1 plan.
+int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
+                         const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st) {
+    if (transposed1x1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
+    const WdgPatchView g = patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;
     memset(&p, 0, sizeof(p));
-    if (!patch_plan(pl, p)) return 1;
-    const wdg_conv_geom& g = pl->g;
+    if (!patch_plan(g, p)) return 1;
     p.A = x; p.B = w16; p.Out = y; p.bias = bias; p.affine = affine;
-    p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
-    p.H = g.H; p.W = g.W; p.ldA = g.ldx; p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
-    p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p; p.Cin_p = pl->Cin_p;
+    p.imgStrideA = g.imgStrideA; p.imgStrideO = g.imgStrideO;
+    p.H = g.H; p.W = g.W; p.ldA = g.ldA; p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldO;
+    p.Ncols = g.Ncols; p.ldB = g.kh * g.kw * g.K_p; p.Cin_p = g.K_p;
     p.kh = g.kh; p.kw = g.kw; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
-    if ((long long)g.H * g.W * g.ldx * 4 >= (1LL << 31) || (long long)g.Cout * p.ldB * 2 >= (1LL << 31)) return 1;
+    if ((long long)g.H * g.W * g.ldA * 4 >= (1LL << 31) || (long long)g.Ncols * p.ldB * 2 >= (1LL << 31)) return 1;
     const int MT = p.tfx == 1 ? 4 : 6;
     // 64-channel tiles when the map is small (the per-timestep recurrent convolution) or the layer is narrow
     const long long tiles_px = (long long)g.n_img * p.tiles_x * p.tiles_y;
-    const bool narrow = g.Cout <= 64 || tiles_px * ((g.Cout + 127) / 128) < (long long)pl->cus * 3 / 2;
+    const bool narrow = g.Ncols <= 64 || tiles_px * ((g.Ncols + 127) / 128) < (long long)g.cus * 3 / 2;
     const int BN = narrow ? 64 : 128;
-    p.tiles_n = (g.Cout + BN - 1) / BN;
+    p.tiles_n = (g.Ncols + BN - 1) / BN;
+    p.ntn_blk = 1;
+    if (g_patch_nloop && p.nchunk == 1 && p.tiles_n > 1 && tiles_px >= 4LL * g.cus) { p.ntn_blk = p.tiles_n; p.tiles_n = 1; }
     p.div_tn = wdg_fastdiv_make((unsigned)p.tiles_n);
     p.div_tx = wdg_fastdiv_make((unsigned)p.tiles_x);
     p.div_ty = wdg_fastdiv_make((unsigned)p.tiles_y);
@@ -319,8 +419,17 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, const float* x, const void* w1
     p.div_pw = wdg_fastdiv_make((unsigned)p.PW);
     const long long blocks = tiles_px * p.tiles_n;
     if (blocks <= 0 || blocks >= (1LL << 31)) return 1;
-    const size_t lds = (size_t)2 * 8 * BN * 16 + (size_t)p.CK8 * p.pitch * 16;
-#define WDG_PATCH_CASE(F, M, N) if (fmt == F && MT == M && BN == 32 * N) return patch_launch<F, M, N>(p, (int)blocks, lds, st)
+    const size_t lds = (size_t)2 * 8 * BN * 16 + ((size_t)p.CK8 * p.pitch + 1) * 16;   // weight stages + patch
+#ifdef WDG_PATCH_EXPERIMENTS
+    // timing experiments (wrong results by design): bf16, 1 x 16 fragments, 128 channels per tile only
+#define WDG_PATCH_DBG_CASE(D) if (g_patch_dbg == D && fmt == 0 && MT == 4 && BN == 128) return patch_launch<0, 4, 4, false, D>(p, (int)blocks, lds, st)
+    WDG_PATCH_DBG_CASE(1); WDG_PATCH_DBG_CASE(2); WDG_PATCH_DBG_CASE(4); WDG_PATCH_DBG_CASE(8); WDG_PATCH_DBG_CASE(12);
+    WDG_PATCH_DBG_CASE(16); WDG_PATCH_DBG_CASE(32); WDG_PATCH_DBG_CASE(3); WDG_PATCH_DBG_CASE(15);
+#undef WDG_PATCH_DBG_CASE
+#endif
+#define WDG_PATCH_CASE(F, M, N)                                                                        \
+    if (fmt == F && MT == M && BN == 32 * N)                                                           \
+        return p.ntn_blk > 1 ? patch_launch<F, M, N, true>(p, (int)blocks, lds, st) : patch_launch<F, M, N, false>(p, (int)blocks, lds, st)
     WDG_PATCH_CASE(0, 4, 4); WDG_PATCH_CASE(0, 4, 2); WDG_PATCH_CASE(0, 6, 4); WDG_PATCH_CASE(0, 6, 2);
     WDG_PATCH_CASE(1, 4, 4); WDG_PATCH_CASE(1, 4, 2); WDG_PATCH_CASE(1, 6, 4); WDG_PATCH_CASE(1, 6, 2);
 #undef WDG_PATCH_CASE

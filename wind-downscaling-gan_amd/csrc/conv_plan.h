@@ -72,9 +72,11 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
 // conv_patch_h16.hip
 void wdg_patch_h16_set(int v);
 void wdg_patch_h16_set_budget(int kib);
+void wdg_patch_h16_set_dbg(int v);
+void wdg_patch_h16_set_nloop(int v);
 int wdg_patch_h16_eligible(const wdg_conv_plan* pl);
-int wdg_patch_h16_launch(const wdg_conv_plan* pl, const float* x, const void* w16, const float* bias, const float* affine,
-                         float* y, int act, float slope, int accumulate, int fmt, hipStream_t st);
+int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
+                         const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st);
 
 // convlstm1.hip
 void wdg_convlstm1_set_mfma(int v);
