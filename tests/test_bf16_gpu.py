@@ -24,6 +24,7 @@ CASES = [
     ("patchB_gates_24", 3, 24, 24, 128, 512, 3, 1, 1),
     ("patchB_c5_24", 2, 24, 24, 128, 64, 3, 1, 1),
     ("patchB_4x4s2_c16", 2, 48, 48, 16, 72, 4, 2, 1),
+    ("patchC_c2_48", 2, 48, 48, 128, 128, 4, 2, 1),          # 4 x 24 tiles: the 8-row patch of 128 channels does not fit
     # 1 x 1: the transposed direction is the column GEMM of the column-form upsample layer (400 columns), through the patch kernel
     ("col_gemm_1x1", 2, 16, 32, 400, 160, 1, 1, 0),
     ("col_gemm_1x1_24", 2, 24, 24, 100, 64, 1, 1, 0),

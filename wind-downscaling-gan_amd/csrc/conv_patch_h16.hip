@@ -38,6 +38,7 @@ struct WdgPatchH16 {
     int pad_h, pad_w;
     int act, accumulate;
     float slope;
+    int mt;                    // fragments per wave (host side: picks the instantiation)
     int fw_shift, tfx;         // fragment width 1 << fw_shift (16 or 4), fragments per fragment-row of the tile
     int TH, TW, PH, PW, PWs, pitch;   // tile, patch, columns per parity plane, slots per channel-group plane
     int CK8, nchunk, kcn;      // channel groups per chunk, chunks, K-steps per tap and chunk
@@ -335,38 +336,42 @@ static WdgPatchView patch_view(const wdg_conv_plan* pl, bool transposed1x1) {
     return v;
 }
 
-// tile shape for the output map, or false
-static bool patch_shape(const WdgPatchView& g, WdgPatchCfg& c) {
-    if (g.Ho % 8) return false;
-    if (g.Wo % 16 == 0) { c = {4, 1, 8, 16, 4}; return true; }       // 8 fragments of 1 x 16
-    if (g.Wo % 24 == 0) { c = {2, 6, 8, 24, 6}; return true; }       // 12 fragments of 4 x 4
-    return false;
+// candidate tile shapes for the output map (most pixels per tile first); returns their number
+static int patch_shapes(const WdgPatchView& g, WdgPatchCfg* c) {
+    int n = 0;
+    if (g.Ho % 8 == 0 && g.Wo % 16 == 0) c[n++] = {4, 1, 8, 16, 4};      // 8 fragments of 1 x 16
+    if (g.Ho % 8 == 0 && g.Wo % 24 == 0) c[n++] = {2, 6, 8, 24, 6};      // 12 fragments of 4 x 4
+    if (g.Ho % 4 == 0 && g.Wo % 24 == 0) c[n++] = {2, 6, 4, 24, 3};      // 6 fragments of 4 x 4 (strided layers with many channels: smaller patch)
+    return n;
 }
 
 static bool patch_plan(const WdgPatchView& g, WdgPatchH16& p) {
     if (!g_patch_h16 || (g.stride != 1 && g.stride != 2) || g.K_p % 8 || g.Ncols < 32 || g.ldO % 4) return false;
-    WdgPatchCfg c;
-    if (!patch_shape(g, c)) return false;
+    WdgPatchCfg cand[3];
+    const int ncand = patch_shapes(g, cand);
     const int s = g.stride;
-    p.sshift = s == 2 ? 1 : 0;
-    p.fw_shift = c.fw_shift; p.tfx = c.tfx; p.TH = c.TH; p.TW = c.TW;
-    p.PH = (c.TH - 1) * s + g.kh;
-    p.PW = (c.TW - 1) * s + g.kw;
-    int PWs = (p.PW + s - 1) / s;
-    if (c.fw_shift == 2)
-        while (((s * s * PWs) & 15) != 4 && ((s * s * PWs) & 15) != 12) ++PWs;    // rows of a 4 x 4 fragment on disjoint banks
-    p.PWs = PWs;
-    p.pitch = wdg_round_up(p.PH * s * PWs, 16);
     const int C8 = g.K_p / 8;
-    int CK8 = 0;
-    if ((long long)C8 * p.pitch * 16 <= g_patch_budget) CK8 = C8;
-    else
-        for (int k = 4; k < C8; k += 4)
-            if (C8 % k == 0 && (long long)k * p.pitch * 16 <= g_patch_budget) CK8 = k;
-    if (!CK8) return false;
-    p.CK8 = CK8; p.nchunk = C8 / CK8; p.kcn = (CK8 + 3) / 4;
-    p.tiles_x = g.Wo / c.TW; p.tiles_y = g.Ho / c.TH;
-    return true;
+    for (int ci = 0; ci < ncand; ++ci) {
+        const WdgPatchCfg& c = cand[ci];
+        const int PH = (c.TH - 1) * s + g.kh, PW = (c.TW - 1) * s + g.kw;
+        int PWs = (PW + s - 1) / s;
+        if (c.fw_shift == 2)
+            while (((s * s * PWs) & 15) != 4 && ((s * s * PWs) & 15) != 12) ++PWs;    // rows of a 4 x 4 fragment on disjoint banks
+        const int pitch = wdg_round_up(PH * s * PWs, 16);
+        int CK8 = 0;
+        if ((long long)C8 * pitch * 16 <= g_patch_budget) CK8 = C8;
+        else
+            for (int k = 4; k < C8; k += 4)
+                if (C8 % k == 0 && (long long)k * pitch * 16 <= g_patch_budget) CK8 = k;
+        if (!CK8) continue;
+        p.sshift = s == 2 ? 1 : 0;
+        p.fw_shift = c.fw_shift; p.tfx = c.tfx; p.TH = c.TH; p.TW = c.TW; p.mt = c.MT;
+        p.PH = PH; p.PW = PW; p.PWs = PWs; p.pitch = pitch;
+        p.CK8 = CK8; p.nchunk = C8 / CK8; p.kcn = (CK8 + 3) / 4;
+        p.tiles_x = g.Wo / c.TW; p.tiles_y = g.Ho / c.TH;
+        return true;
+    }
+    return false;
 }
 
 int wdg_patch_h16_eligible(const wdg_conv_plan* pl) {
@@ -404,7 +409,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     p.kh = g.kh; p.kw = g.kw; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
     if ((long long)g.H * g.W * g.ldA * 4 >= (1LL << 31) || (long long)g.Ncols * p.ldB * 2 >= (1LL << 31)) return 1;
-    const int MT = p.tfx == 1 ? 4 : 6;
+    const int MT = p.mt;
     // 64-channel tiles when the map is small (the per-timestep recurrent convolution) or the layer is narrow
     const long long tiles_px = (long long)g.n_img * p.tiles_x * p.tiles_y;
     const bool narrow = g.Ncols <= 64 || tiles_px * ((g.Ncols + 127) / 128) < (long long)g.cus * 3 / 2;
@@ -430,8 +435,8 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
 #define WDG_PATCH_CASE(F, M, N)                                                                        \
     if (fmt == F && MT == M && BN == 32 * N)                                                           \
         return p.ntn_blk > 1 ? patch_launch<F, M, N, true>(p, (int)blocks, lds, st) : patch_launch<F, M, N, false>(p, (int)blocks, lds, st)
-    WDG_PATCH_CASE(0, 4, 4); WDG_PATCH_CASE(0, 4, 2); WDG_PATCH_CASE(0, 6, 4); WDG_PATCH_CASE(0, 6, 2);
-    WDG_PATCH_CASE(1, 4, 4); WDG_PATCH_CASE(1, 4, 2); WDG_PATCH_CASE(1, 6, 4); WDG_PATCH_CASE(1, 6, 2);
+    WDG_PATCH_CASE(0, 4, 4); WDG_PATCH_CASE(0, 4, 2); WDG_PATCH_CASE(0, 6, 4); WDG_PATCH_CASE(0, 6, 2); WDG_PATCH_CASE(0, 3, 4); WDG_PATCH_CASE(0, 3, 2);
+    WDG_PATCH_CASE(1, 4, 4); WDG_PATCH_CASE(1, 4, 2); WDG_PATCH_CASE(1, 6, 4); WDG_PATCH_CASE(1, 6, 2); WDG_PATCH_CASE(1, 3, 4); WDG_PATCH_CASE(1, 3, 2);
 #undef WDG_PATCH_CASE
     return 1;
 }

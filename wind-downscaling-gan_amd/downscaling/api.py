@@ -159,7 +159,7 @@ def _tile_lat_index(sy):
     return np.arange(IMG_SIZE, 0, -1)
 
 
-def predict_array(fields, overlap_factor=0.05, network=None, return_count=False, sync=None):
+def predict_array(fields, overlap_factor=0.05, network=None, return_count=False, sync=None, timings=None):
     """Array core of predict (api.py:96-151).  fields: (time, lat, lon, 3) float array with channels
     [u10, v10, elevation in metres].  Returns (ntimeseq*24, lat, lon, 2) with NaN where no tile
     contributes (the reference's dataframe simply has no such rows).
@@ -172,14 +172,28 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
 
     `sync` (engine.trainer.DistSync, one process per GPU): tiles are independent, so the groups of 16 are dealt
     round-robin to the ranks and the per-rank sum / count grids are all-reduced once at the end — no exchange
-    inside the model (SURVEY §8 e).  Every rank returns the full blended field."""
+    inside the model (SURVEY §8 e).  Every rank returns the full blended field.
+
+    `timings` (dict): filled with the seconds of each phase (upload, tiles + normalisation, generator + blend, mean +
+    download), each closed by a device synchronisation — measurement runs only."""
+    import time
     import torch
+
+    def lap(name):
+        if timings is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - lap.t0
+            lap.t0 = now
+    lap.t0 = time.perf_counter()
     network = network or get_network()
     gen = network.generator
     ops = gen.ops
     dev, dt = getattr(ops, "device", "cpu"), ops.dtype
     f = torch.as_tensor(np.asarray(fields, dtype=np.float32)).to(dev)
     f[..., 2] = f[..., 2] / 1e3                                                    # api.py:96
+    lap('upload')
     time_window, pixels_lat, pixels_lon = f.shape[:3]
     plan = tile_plan(pixels_lat, pixels_lon, time_window, overlap_factor)
     keys = [(sx, sy, k) for sx in plan['slices_start_x'] for sy in plan['slices_start_y'] for k in range(plan['ntimeseq'])]
@@ -203,24 +217,40 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     cnt = torch.zeros(nt, pixels_lat, pixels_lon, dtype=torch.int32, device=dev)
     group_size = BATCH_SIZE * 2
     num_groups = math.ceil(tensors.shape[0] / group_size)
+    lap('tiles_and_normalisation')
     rank, world = (sync.rank, sync.world_size) if sync is not None else (0, 1)
-    with torch.no_grad():
+    cnt_host = np.zeros((nt, pixels_lat, pixels_lon), dtype=np.int32)              # the same integer bookkeeping on the host: the
+    with torch.no_grad():                                                          # count grid is never downloaded
         for t in range(rank, num_groups, world):
             tensor = tensors[t * group_size:(t + 1) * group_size, ...]
-            noise = network.noise_generator(bs=tensor.shape[0], channels=NOISE_CHANNELS)
+            n_real = tensor.shape[0]
+            noise = network.noise_generator(bs=n_real, channels=NOISE_CHANNELS)
+            if n_real < group_size and num_groups > 1:
+                # a short last group runs at the resident batch size (zero tiles behind the real ones, their outputs unused):
+                # inference treats every tile independently, and the generator keeps its buffers, plans and graph
+                pad = group_size - n_real
+                tensor = torch.cat([tensor, tensor.new_zeros((pad,) + tuple(tensor.shape[1:]))], dim=0)
+                noise = torch.cat([noise, noise.new_zeros((pad,) + tuple(noise.shape[1:]))], dim=0)
             pred = gen([tensor, noise])                                            # stays on the device (api.py:137)
+            lap('generator')
             for j, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):
                 r = _tile_lat_index(sy)[2:-2]                                      # api.py:148: descending, contiguous
                 ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
                 rs, cs = slice(int(r[-1]), int(r[0]) + 1), slice(sx + 2, sx + IMG_SIZE - 2)
                 acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
                 cnt[ts, rs, cs] += 1
+            lap('blend')
             print(f'Predicted {(t + 1) / num_groups:.0%}')
+    for (sx, sy, k) in keys:                                                       # every rank: the global count
+        r = _tile_lat_index(sy)[2:-2]
+        cnt_host[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH, int(r[-1]):int(r[0]) + 1, sx + 2:sx + IMG_SIZE - 2] += 1
     if sync is not None and sync.active:
         sync.all_reduce_sum(acc)
         sync.all_reduce_sum(cnt)
     out = (acc / cnt[..., None].double()).float()                                  # api.py:149-150 (uniform mean); 0/0 -> NaN
-    out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+    lap('mean')
+    out, cnt = out.cpu().numpy(), cnt_host
+    lap('download')
     return (out, cnt) if return_count else out
 
 
