@@ -136,7 +136,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     for (int ck = 0; ck < p.nchunk; ++ck) {
         __syncthreads();                             // every wave is done with the previous chunk's patch, weight stages and epilogue tiles
         // ---- patch chunk: global fp32 -> 16-bit -> LDS, PU slots (2 x 16-byte loads each) per thread in flight
-        constexpr int PU = 8;
+        constexpr int PU = (MT * NT >= 24) ? 8 : 10;   // (the 6 x 4 tile has no registers to spare)
         for (int base = (!NLOOP || tni == 0) ? 0 : npatch; base < npatch; base += PU * 256) {
             f32x4 v[PU][2];
             int slot[PU];

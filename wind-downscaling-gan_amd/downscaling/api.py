@@ -185,6 +185,7 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
                 torch.cuda.synchronize()
             now = time.perf_counter()
             timings[name] = timings.get(name, 0.0) + now - lap.t0
+            timings.setdefault('laps', []).append((name, round(now - lap.t0, 5)))
             lap.t0 = now
     lap.t0 = time.perf_counter()
     network = network or get_network()
@@ -219,12 +220,12 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     num_groups = math.ceil(tensors.shape[0] / group_size)
     lap('tiles_and_normalisation')
     rank, world = (sync.rank, sync.world_size) if sync is not None else (0, 1)
-    cnt_host = np.zeros((nt, pixels_lat, pixels_lon), dtype=np.int32)              # the same integer bookkeeping on the host: the
-    with torch.no_grad():                                                          # count grid is never downloaded
+    with torch.no_grad():
         for t in range(rank, num_groups, world):
             tensor = tensors[t * group_size:(t + 1) * group_size, ...]
             n_real = tensor.shape[0]
             noise = network.noise_generator(bs=n_real, channels=NOISE_CHANNELS)
+            lap('noise')
             if n_real < group_size and num_groups > 1:
                 # a short last group runs at the resident batch size (zero tiles behind the real ones, their outputs unused):
                 # inference treats every tile independently, and the generator keeps its buffers, plans and graph
@@ -241,15 +242,17 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
                 cnt[ts, rs, cs] += 1
             lap('blend')
             print(f'Predicted {(t + 1) / num_groups:.0%}')
-    for (sx, sy, k) in keys:                                                       # every rank: the global count
+    cnt2d = np.zeros((plan['ntimeseq'], pixels_lat, pixels_lon), dtype=np.int32)   # every rank: the global count (one map per sequence)
+    for (sx, sy, k) in keys:
         r = _tile_lat_index(sy)[2:-2]
-        cnt_host[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH, int(r[-1]):int(r[0]) + 1, sx + 2:sx + IMG_SIZE - 2] += 1
+        cnt2d[k, int(r[-1]):int(r[0]) + 1, sx + 2:sx + IMG_SIZE - 2] += 1
+    cnt_host = np.broadcast_to(cnt2d[:, None], (plan['ntimeseq'], SEQUENCE_LENGTH, pixels_lat, pixels_lon)).reshape(nt, pixels_lat, pixels_lon)
     if sync is not None and sync.active:
         sync.all_reduce_sum(acc)
         sync.all_reduce_sum(cnt)
     out = (acc / cnt[..., None].double()).float()                                  # api.py:149-150 (uniform mean); 0/0 -> NaN
     lap('mean')
-    out, cnt = out.cpu().numpy(), cnt_host
+    out, cnt = out.cpu().numpy(), cnt_host                                         # (the same integer bookkeeping: the count grid is not downloaded)
     lap('download')
     return (out, cnt) if return_count else out
 
