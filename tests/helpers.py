@@ -11,23 +11,23 @@ def randomize(net, seed, scale=1.0):
     for v in net.params.vars:
         n = v.name
         if n.endswith("gamma"):
-            a = rng.uniform(0.5, 1.5, v.shape)
+            a = rng.uniform(0.5, 1.5, v.tf_shape)
         elif n.endswith("moving_variance"):
-            a = rng.uniform(0.5, 2.0, v.shape)
+            a = rng.uniform(0.5, 2.0, v.tf_shape)
         elif n.endswith("beta") or n.endswith("bias") or n.endswith("moving_mean"):
-            a = rng.normal(0, 0.3, v.shape)
+            a = rng.normal(0, 0.3, v.tf_shape)
         elif n.endswith("sn_u"):
-            a = rng.normal(0, 0.02, v.shape)
+            a = rng.normal(0, 0.02, v.tf_shape)
         else:
-            fan_in = int(np.prod(v.shape[:-1]))
-            a = rng.normal(0, scale / np.sqrt(fan_in), v.shape)
+            fan_in = int(np.prod(v.tf_shape[:-1]))
+            a = rng.normal(0, scale / np.sqrt(fan_in), v.tf_shape)
         vals[n] = a
     net.params.set_weights(vals)
     return {k: torch.tensor(a, dtype=torch.float64) for k, a in vals.items()}
 
 
 def weights64(net):
-    return {v.name: v.value.detach().double().cpu().clone() for v in net.params.vars}
+    return {v.name: net.params.squeeze(v, v.value).detach().double().cpu().clone() for v in net.params.vars}   # TF shapes
 
 
 def rel_err(a, b):
@@ -37,7 +37,7 @@ def rel_err(a, b):
 
 
 def grads64(net):
-    return {v.name: v.grad.detach().double().cpu().clone() for v in net.params.trainable}
+    return {v.name: net.params.squeeze(v, v.grad).detach().double().cpu().clone() for v in net.params.trainable}
 
 
 class Draws:

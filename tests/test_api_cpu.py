@@ -63,10 +63,10 @@ def test_reference_signatures_and_errors(cpu_backend):
         models.make_generator(18, 3, 2, 2, 1, feature_channels=32)      # image_size % 4 (models.py:19)
     with pytest.raises(AssertionError):
         models.make_generator(16, 3, 2, 2, 1, feature_channels=36)      # feature_channels % 8 (models.py:20)
-    for fc in (16, 48, 80, 128):                                        # multiples of 16 build (the reference: of 8)
-        assert models.make_generator(16, 3, 2, 2, 1, feature_channels=fc).net.F == fc
-    with pytest.raises(NotImplementedError, match="% 16"):
-        models.make_generator(16, 3, 2, 2, 1, feature_channels=24)      # 8 mod 16: stated limitation of this build
+    for fc in (16, 24, 40, 48, 80, 128):                                # every multiple of 8 the reference can build (models.py:20;
+        assert models.make_generator(16, 3, 2, 2, 1, feature_channels=fc).net.F == fc   # 8 fails models.py:66-68 there too)
+    with pytest.raises(AssertionError):
+        models.make_generator(16, 3, 2, 2, 1, feature_channels=8)       # feature_channels / 8 < out_channels: the reference's dead branch
     with pytest.raises(NotImplementedError):
         models.make_discriminator(16, 32, 3, 2, 1)                      # models.py:89-91
     o = train.generator_optimizer(), train.discriminator_optimizer()
@@ -223,3 +223,28 @@ def test_load_weights_is_strict_and_reports(cpu_backend, tmp_path):
         import shutil
         shutil.copy(ROOT / "tests" / "golden" / "weights-55_generator.index", tmp_path / "blobless.index")
         tf_bundle.read_bundle(str(tmp_path / "blobless"))
+
+
+def test_gapped_kernel_round_trips_in_tf_shape(cpu_backend, tmp_path):
+    """feature_channels % 16 == 8: the kernel of the layer behind the [conv-transpose path | res_2] concatenation is stored
+    with zero alignment rows (params.Var.gap); checkpoints, get/set and the parameter count see the TF shape
+    (models.py:60-64: Conv2DTranspose kernel (5, 5, F/8, F/4 + initial filters))."""
+    from downscaling.engine.tf_bundle import read_bundle
+    from downscaling.gan.models import make_generator
+    S, T, F = 8, 1, 24
+    g = make_generator(S, 3, 2, 2, T, feature_channels=F)
+    key = "layer_with_weights-9/layer/kernel"
+    v = g.net.params.by_name(key)
+    assert v.tf_shape == (5, 5, F // 8, F // 4 + F) and v.shape == (5, 5, F // 8, 8 + F) and v.gap == (3, 6, 2)
+    w = g.get_weights_dict()
+    assert w[key].shape == v.tf_shape and np.abs(w[key]).min() > 0          # glorot draw of the TF shape, no zero rows
+    g.save_weights(str(tmp_path / "gap"))
+    assert read_bundle(str(tmp_path / "gap"))[key].shape == v.tf_shape
+    g2 = make_generator(S, 3, 2, 2, T, feature_channels=F)
+    g2.net.params.set_weights({k: a * 0 + 7.0 for k, a in w.items()})
+    g2.load_weights(str(tmp_path / "gap"))
+    w2 = g2.get_weights_dict()
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    assert float(g2.net.params.by_name(key).value[..., 6:8].abs().max()) == 0.0   # the alignment rows are zero again
+    lim = np.sqrt(6.0 / (25 * (F // 8) + 25 * (F // 4 + F)))                 # Keras glorot_uniform limit of the TF shape
+    assert np.abs(w[key]).max() <= lim

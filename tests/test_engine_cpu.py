@@ -31,12 +31,16 @@ def _inputs(B, T, S, cin, nz, ch, seed=0):
 
 
 @pytest.mark.parametrize("S,T,training,F", [(12, 2, True, 32), (12, 2, False, 32), (20, 1, True, 32), (16, 3, True, 32),
-                                            (12, 2, True, 16), (16, 1, True, 48), (12, 1, False, 80)])
+                                            (12, 2, True, 16), (16, 1, True, 48), (12, 1, False, 80),
+                                            (12, 2, True, 24), (16, 1, True, 40), (12, 1, False, 56)])
 def test_generator_forward_backward(ops, S, T, training, F):
     """F = 16 / 48 / 80: feature_channels that are multiples of 16 but not of 32 (models.py:20 asserts % 8) — the last
-    decoder stage then has feature_channels / 8 = 2 / 6 / 10 channels and runs at the zero-padded width."""
+    decoder stage then has feature_channels / 8 = 2 / 6 / 10 channels and runs at the zero-padded width.
+    F = 24 / 40 / 56 (8 mod 16): the [conv-transpose path | res_2] concatenation carries zero alignment channels behind its
+    feature_channels / 4 = 6 / 10 / 14 wide first segment and the kernel reading it matching zero rows (params.Var.gap)."""
     B, cin, nz, ch = 2, 3, 2, 2
     net = GeneratorNet(ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
+    assert (net.c9.w.gap is not None) == (F % 16 == 8)
     w = randomize(net, 11)
     low, noise, _ = _inputs(B, T, S, cin, nz, ch)
     net.set_image(low)
@@ -72,6 +76,10 @@ def test_generator_forward_backward(ops, S, T, training, F):
     # the 4-element alignment slots behind the variables (read as zero pad channels) stay zero
     pads = float(net.params.grads.abs().sum()) - sum(float(v.grad.abs().sum()) for v in net.params.trainable)
     assert abs(pads) < 1e-9 * max(1.0, float(net.params.grads.abs().sum()))
+    if net.c9.w.gap is not None:              # the zero rows of the gapped kernel: zero value, zero gradient
+        _, pos, width = net.c9.w.gap
+        assert float(net.c9.w.value[..., pos:pos + width].abs().max()) == 0.0
+        assert float(net.c9.w.grad[..., pos:pos + width].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("S,T,Fd,variant", [(12, 2, 8, False), (20, 1, 8, False), (32, 2, 8, False), (24, 1, 8, False),

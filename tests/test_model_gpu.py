@@ -24,10 +24,12 @@ def _inputs(B, T, S, cin, nz, ch, seed=0):
 
 
 @pytest.mark.parametrize("S,T,F,nz,training", [(32, 2, 128, 20, True), (32, 2, 128, 20, False), (48, 1, 32, 2, True), (20, 3, 64, 5, True),
-                                               (32, 1, 16, 4, True), (24, 2, 48, 4, True), (32, 1, 80, 4, False)])
+                                               (32, 1, 16, 4, True), (24, 2, 48, 4, True), (32, 1, 80, 4, False),
+                                               (32, 1, 24, 4, True), (24, 2, 40, 4, True), (32, 1, 56, 4, False)])
 def test_generator(hip_ops, S, T, F, nz, training):
     """F = 16 / 48 / 80: feature_channels % 16 == 0 but not % 32 (feature_channels / 8 = 2 / 6 / 10 channels in the last
-    decoder stage, run at the zero-padded width)."""
+    decoder stage, run at the zero-padded width); F = 24 / 40 / 56: 8 mod 16 (zero alignment channels inside the
+    [conv-transpose path | res_2] concatenation, params.Var.gap)."""
     from downscaling.engine.networks import GeneratorNet
     B, cin, ch = 2, 3, 2
     dev = hip_ops.device

@@ -24,11 +24,21 @@ class Conv:
     inputs; forward runs the data-gradient kernel, input-gradient runs the forward kernel.
     """
 
-    def __init__(self, net, name, k, cin, cout, stride, pad, *, transposed=False, sn=False, act=True, prefix="layer"):
+    def __init__(self, net, name, k, cin, cout, stride, pad, *, transposed=False, sn=False, act=True, prefix="layer",
+                 cout_gap=None):
+        """cout_gap = (pos, width): the `cout` side of the kernel (for a transposed layer: the channels of the tensor it
+        reads) carries `width` zero alignment channels at `pos`; `cout` counts the real channels (params.Var.gap)."""
         self.net, self.ops, self.name = net, net.ops, name
         self.g = ConvGeom(k, k, stride, pad)
         self.cin, self.cout, self.transposed, self.sn, self.act = cin, cout, transposed, sn, act
         store = net.params
+        if cout_gap is not None:
+            assert not sn and transposed, "the gap is on the reduction side of a plain transposed layer only"
+            self.w = store.add(f"{name}/{prefix}/kernel", (k, k, cin, cout), P.conv_glorot, gap=(3, cout_gap[0], cout_gap[1]))
+            self.b = store.add(f"{name}/{prefix}/bias", (cin,), P.zeros_init)
+            self.u, self.pk = None, None
+            self.cout = cout + cout_gap[1]
+            return
         # TF checkpoint keys (weights-55.ckpt/*.index): TimeDistributed -> "layer", SN wrapper -> "w"/"sn_u"
         wname = f"{name}/{prefix}/w" if sn else f"{name}/{prefix}/kernel"
         bname = f"{name}/{prefix}/layer/bias" if sn else f"{name}/{prefix}/bias"

@@ -84,11 +84,11 @@ class GeneratorNet(_Net):
         if F / 8 < out_channels:
             # models.py:66-68: that branch skips the upsampling and fails its own shape assertion
             raise AssertionError("feature_channels / 8 must be >= out_channels (reference else-branch is dead)")
-        if F % 16 != 0 or IF % 4 != 0:
-            # feature_channels / 4 is the width of the first segment of the [conv-transpose path | res_2] concatenation
-            # (models.py:60): the skip tensor behind it is addressed in place and needs a 16-byte aligned start
-            raise NotImplementedError("this build needs feature_channels % 16 == 0 (the reference asserts % 8, models.py:20): "
-                                      "the zero-copy channel concatenations need 16-byte aligned segment starts")
+        # feature_channels / 4 is the width of the first segment of the [conv-transpose path | res_2] concatenation
+        # (models.py:60); the skip tensor behind it is addressed in place and needs a 16-byte aligned start, so for
+        # feature_channels % 16 == 8 the segment is followed by zero alignment channels and the kernel of the layer that
+        # reads the concatenation carries matching zero rows (params.Var.gap) — every % 8 width of the reference builds
+        self.F4p = round4(F // 4)
         self.S, self.F, self.IF, self.T = S, F, IF, n_timesteps
         self.cin, self.in_channels, self.noise_channels, self.out_channels = cin, in_channels, noise_channels, out_channels
         L = "layer_with_weights-"
@@ -101,7 +101,8 @@ class GeneratorNet(_Net):
         self.bn6 = self._add(BatchNorm(self, L + "6", F // 2))                        # :50
         self.c7 = self._add(Conv(self, L + "7", 2, F // 4, F // 2 + F, 2, 0, transposed=True, sn=True))  # :54-55
         self.bn8 = self._add(BatchNorm(self, L + "8", F // 4))                        # :56
-        self.c9 = self._add(Conv(self, L + "9", 5, F // 8, F // 4 + IF, 1, 2, transposed=True))          # :60-64
+        self.c9 = self._add(Conv(self, L + "9", 5, F // 8, F // 4 + IF, 1, 2, transposed=True,            # :60-64
+                                 cout_gap=(F // 4, self.F4p - F // 4) if self.F4p != F // 4 else None))
         self.bn10 = self._add(BatchNorm(self, L + "10", F // 8))                      # :69
         self.c11 = self._add(Conv(self, L + "11", 3, F // 8, out_channels, 1, 1, act=False))            # :70-71
         self._finalize(seed)
@@ -115,12 +116,12 @@ class GeneratorNet(_Net):
         b = dict(
             x0=o.zeros(N, S, S, round4(self.cin)),
             y0=o.empty(N, S2, S2, IF),
-            cat2=o.empty(N, S2, S2, F // 4 + IF),      # [c7 path | res_2]
+            cat2=o.zeros(N, S2, S2, self.F4p + IF),    # [c7 path (+ zero alignment channels) | res_2]
             y2=o.empty(N, S4, S4, F),
             cat4=o.empty(N, S4, S4, F // 2 + F),       # [c5 path | res_4]
             h=o.zeros(N, S4, S4, F),
             y5=o.empty(N, S4, S4, F // 2),
-            y7=o.empty(N, S2, S2, F // 4),
+            y7=o.zeros(N, S2, S2, self.F4p),
             y9=o.zeros(N, S, S, round4(F // 8)),       # (F / 8 not a multiple of 4: zero pad channels)
             z9=o.zeros(N, S, S, round4(F // 8)),
             out=o.zeros(N, S, S, round4(self.out_channels)),
@@ -135,7 +136,7 @@ class GeneratorNet(_Net):
             N, S2, S4 = T * B, S // 2, S // 4
             self._grad_bufs = dict(
                 dz9=o.zeros(N, S, S, round4(F // 8)),
-                dcat2=o.empty(N, S2, S2, F // 4 + IF),
+                dcat2=o.zeros(N, S2, S2, self.F4p + IF),
                 dcat4=o.empty(N, S4, S4, F // 2 + F),
                 dh=o.zeros(N, S4, S4, F),
             )
@@ -220,7 +221,7 @@ class GeneratorNet(_Net):
         b = self.buffers(B)
         F, IF, T = self.F, self.IF, self.T
         self._prepare(training)
-        res2 = b["cat2"][..., F // 4:]
+        res2 = b["cat2"][..., self.F4p:]
         res4 = b["cat4"][..., F // 2:]
         if precision in ("bf16", "fp16"):
             if training:
@@ -230,7 +231,7 @@ class GeneratorNet(_Net):
             self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine(), fmt=f)
             self.lstm.forward(res4, b["h"], B, T, bf16=True, fmt=f)
             self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
-            self.c7.forward_bf16(b["cat4"], b["cat2"][..., :F // 4], affine=self.bn8.infer_affine(), fmt=f)
+            self.c7.forward_bf16(b["cat4"], b["cat2"][..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
             self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
                                      affine=self.bn10.infer_affine(), fmt=f, pool=self._scratch_pool(b))
             self.ops.conv_halo_fwd_bf16(b["z9"], self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
@@ -244,7 +245,7 @@ class GeneratorNet(_Net):
             self.c2.forward(res2, res4, bn_affine=self.bn3.infer_affine())
             self.lstm.forward(res4, b["h"], B, T)
             self.c5.forward(b["h"], b["cat4"][..., :F // 2], bn_affine=self.bn6.infer_affine())
-            self.c7.forward(b["cat4"], b["cat2"][..., :F // 4], bn_affine=self.bn8.infer_affine())
+            self.c7.forward(b["cat4"], b["cat2"][..., :self.F4p], bn_affine=self.bn8.infer_affine())
             self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
                                 pool=self._scratch_pool(b), bn_affine=self.bn10.infer_affine())
             self.c11.forward(b["z9"], b["out"])
@@ -259,7 +260,7 @@ class GeneratorNet(_Net):
         self.c5.forward(b["h"], b["y5"], bn_stats=self.bn6.begin_stats())
         self.bn6.forward(v2(b["y5"]), v2(b["cat4"][..., :F // 2]), True, have_stats=True)
         self.c7.forward(b["cat4"], b["y7"], bn_stats=self.bn8.begin_stats())
-        self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :F // 4]), True, have_stats=True)
+        self.bn8.forward(v2(b["y7"]), v2(b["cat2"][..., :self.F4p]), True, have_stats=True)
         self.ops.upconv_fwd(b["cat2"], self.c9.pk, self.c9.b.value, b["y9"], self.c9.g, act=True,      # :62-64 fused
                             pool=self._scratch_pool(b), bn_stats=self.bn10.begin_stats())
         self.bn10.forward(v2(b["y9"]), v2(b["z9"]), True, have_stats=True)
@@ -272,7 +273,7 @@ class GeneratorNet(_Net):
         Accumulates into params.grads (generator inputs need no gradient)."""
         b, g = self.buffers(B), self.grad_buffers(B)
         o, F, IF, T = self.ops, self.F, self.IF, self.T
-        res2, res4 = b["cat2"][..., F // 4:], b["cat4"][..., F // 2:]
+        res2, res4 = b["cat2"][..., self.F4p:], b["cat4"][..., F // 2:]
         # c11 (linear)
         o.colsum(v2(dout[..., :self.out_channels]), self.c11.b.grad, accumulate=True)
         self.c11.backward_weights(b["z9"], dout)
@@ -282,7 +283,7 @@ class GeneratorNet(_Net):
         o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g,   # :60-64 backward
                      pool=self._scratch_pool(b))
         # bn8 + c7
-        d7 = g["dcat2"][..., :F // 4]
+        d7 = g["dcat2"][..., :self.F4p]
         self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad_pad)
         self.c7.backward_weights(b["cat4"], d7)
         self.c7.backward_input(d7, g["dcat4"])
@@ -297,7 +298,7 @@ class GeneratorNet(_Net):
         # bn3 + c2
         self.bn3.backward(v2(dres4), v2(b["y2"]), v2(dres4), self.c2.b.grad_pad)
         self.c2.backward_weights(res2, dres4)
-        dres2 = g["dcat2"][..., F // 4:]
+        dres2 = g["dcat2"][..., self.F4p:]
         self.c2.backward_input(dres4, dres2, accumulate=True)
         # bn1 + c0
         self.bn1.backward(v2(dres2), v2(b["y0"]), v2(dres2), self.c0.b.grad_pad)

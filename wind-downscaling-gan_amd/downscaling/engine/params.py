@@ -13,11 +13,23 @@ import torch
 
 
 class Var:
-    __slots__ = ("name", "shape", "trainable", "init", "offset", "size", "value", "grad", "value_pad", "grad_pad")
+    """One TF variable.  `tf_shape` is its checkpoint shape; `shape` is the stored shape, which differs only for a variable
+    with a `gap = (axis, pos, width)`: `width` extra entries at index `pos` along `axis` that are zero and stay zero (their
+    gradient is a product with an all-zero alignment channel, and Adam maps a zero gradient on a zero slot to a zero
+    update).  Used for the kernel of a layer that reads a channel concatenation whose second segment starts at a padded,
+    16-byte aligned channel (GeneratorNet: feature_channels % 16 == 8)."""
+    __slots__ = ("name", "shape", "tf_shape", "gap", "trainable", "init", "offset", "size", "tf_size", "value", "grad",
+                 "value_pad", "grad_pad")
 
-    def __init__(self, name, shape, trainable, init):
-        self.name, self.shape, self.trainable, self.init = name, tuple(shape), trainable, init
-        self.size = int(np.prod(shape))
+    def __init__(self, name, shape, trainable, init, gap=None):
+        self.name, self.tf_shape, self.trainable, self.init = name, tuple(shape), trainable, init
+        self.gap = gap
+        st = list(shape)
+        if gap is not None:
+            st[gap[0]] += gap[2]
+        self.shape = tuple(st)
+        self.tf_size = int(np.prod(shape))
+        self.size = int(np.prod(self.shape))
         self.offset = -1
         self.value = None
         self.grad = None
@@ -31,10 +43,28 @@ class ParamStore:
         self.version = 0  # bumped whenever values change outside SN (optimizer step, load, set)
         self.flat = self.grads = self.state = None
 
-    def add(self, name, shape, init, trainable=True):
-        v = Var(name, shape, trainable, init)
+    def add(self, name, shape, init, trainable=True, gap=None):
+        v = Var(name, shape, trainable, init, gap)
         self.vars.append(v)
         return v
+
+    @staticmethod
+    def expand(v, a):
+        """TF-shaped numpy array -> stored shape (zeros in the gap)."""
+        a = np.asarray(a)
+        if v.gap is None:
+            return a
+        axis, pos, width = v.gap
+        z = np.zeros(a.shape[:axis] + (width,) + a.shape[axis + 1:], dtype=a.dtype)
+        return np.concatenate([np.take(a, range(pos), axis=axis), z, np.take(a, range(pos, a.shape[axis]), axis=axis)], axis=axis)
+
+    @staticmethod
+    def squeeze(v, t):
+        """stored-shape tensor (value or gradient) -> TF shape."""
+        if v.gap is None:
+            return t
+        axis, pos, width = v.gap
+        return torch.cat([t.narrow(axis, 0, pos), t.narrow(axis, pos + width, t.shape[axis] - pos - width)], dim=axis)
 
     def finalize(self, rng):
         """Allocate the flat buffers and initialise every variable (Keras default initialisers)."""
@@ -48,7 +78,7 @@ class ParamStore:
         self.n_train = off
         host = np.zeros(off, dtype=np.float64)
         for v in train:
-            host[v.offset:v.offset + v.size] = v.init(v.shape, rng).reshape(-1)
+            host[v.offset:v.offset + v.size] = self.expand(v, v.init(v.tf_shape, rng)).reshape(-1)
         self.flat = self.ops.from_host(host)
         self.grads = self.ops.zeros(off)
         off2 = 0
@@ -57,7 +87,7 @@ class ParamStore:
             off2 += (v.size + 3) // 4 * 4
         host2 = np.zeros(max(off2, 4), dtype=np.float64)
         for v in other:
-            host2[v.offset:v.offset + v.size] = v.init(v.shape, rng).reshape(-1)
+            host2[v.offset:v.offset + v.size] = self.expand(v, v.init(v.tf_shape, rng)).reshape(-1)
         self.state = self.ops.from_host(host2)
         for v in train:
             v.value = self.flat[v.offset:v.offset + v.size].view(v.shape)
@@ -75,12 +105,15 @@ class ParamStore:
             pairs += [v.offset, v.offset + v.size]
         self.seg_pairs = torch.tensor(pairs, dtype=torch.int64).to(self.flat.device)
         self.seg_out = self.ops.empty(len(train))
+        # mean(g^2) is over the TF shape: a gapped variable's stored mean is rescaled (1.0 everywhere else)
+        self.seg_scale = self.ops.from_host(np.array([v.size / v.tf_size for v in train], dtype=np.float64)) if any(
+            v.gap is not None for v in train) else None
 
     def zero_grad(self):
         self.grads.zero_()
 
     def num_trainable(self):
-        return sum(v.size for v in self.trainable)
+        return sum(v.tf_size for v in self.trainable)
 
     def by_name(self, name):
         for v in self.vars:
@@ -91,7 +124,7 @@ class ParamStore:
     # ---- host <-> device ------------------------------------------------------------------------
     def get_weights(self):
         """{name: numpy array} of every variable (trainable and not), TF shapes."""
-        return {v.name: v.value.detach().double().cpu().numpy().astype(np.float32) for v in self.vars}
+        return {v.name: self.squeeze(v, v.value).detach().double().cpu().numpy().astype(np.float32) for v in self.vars}
 
     def set_weights(self, mapping, strict=True):
         """Copies `mapping[name]` into every variable it names.  Returns (restored, missing, unused): variable names
@@ -104,12 +137,12 @@ class ParamStore:
             raise KeyError(f"{len(missing)} variable(s) not in the checkpoint / mapping: {missing[:6]}"
                            + (" ..." if len(missing) > 6 else ""))
         for v in self.vars:
-            if v.name in mapping and tuple(np.asarray(mapping[v.name]).shape) != v.shape:
-                raise ValueError(f"{v.name}: shape {np.asarray(mapping[v.name]).shape} != {v.shape}")
+            if v.name in mapping and tuple(np.asarray(mapping[v.name]).shape) != v.tf_shape:
+                raise ValueError(f"{v.name}: shape {np.asarray(mapping[v.name]).shape} != {v.tf_shape}")
         restored = []
         for v in self.vars:
             if v.name in mapping:
-                v.value.copy_(self.ops.from_host(np.asarray(mapping[v.name])).view(v.shape))
+                v.value.copy_(self.ops.from_host(self.expand(v, np.asarray(mapping[v.name]))).view(v.shape))
                 restored.append(v.name)
         self.version += 1
         return restored, missing, unused

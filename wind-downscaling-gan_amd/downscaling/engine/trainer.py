@@ -154,7 +154,8 @@ class GanEngine:
     def _grad_param_metric(self, net, scale):
         st = net.params
         self.ops.segment_meansq(st.grads, st.seg_pairs, st.seg_out)
-        return st.seg_out.mean() * (scale * scale)
+        per_var = st.seg_out if st.seg_scale is None else st.seg_out * st.seg_scale.to(st.seg_out.dtype)
+        return per_var.mean() * (scale * scale)
 
     def _critic_coupled(self, d_loss_fn, B, real, fake, noisy, sw_mean, low):
         """Real + generated pass of one critic iteration for an arbitrary compiled loss d_loss_fn(real_output,
