@@ -101,6 +101,15 @@ int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, 
                    float* dx, int act, float slope, int accumulate,
                    void* ws, size_t ws_bytes, wdg_stream stream);
 
+/* Experimental fp32-from-bf16-slices mode of the implicit-GEMM kernels (wdg_set_tuning("igemm_pipe", 4)): every fp32 operand
+ * is the exact sum of three bf16 slices and six slice products on v_mfma_f32_16x16x32_bf16 reproduce the fp32 product to
+ * 2^-24 relative.  wdg_split_bf16x3 writes the three slices of n floats as [3][n] bf16 (dst3: 3*n*2 + 16 bytes);
+ * wdg_split_register tells the conv entry points that `w32` (a packed weight buffer passed as wF / wD) has the up-to-date
+ * slice copy `w3` (NULL: forget it) — unregistered weights are sliced inside the kernel.  No reference counterpart (TF
+ * computes these convolutions in fp32: gan/models.py:33-70). */
+int wdg_split_bf16x3(const float* src, void* dst3, int64_t n, wdg_stream stream);
+int wdg_split_register(const float* w32, const void* w3, int64_t n);
+
 /* The same two launches as PRODUCERS OF A BatchNormalization INPUT (models.py:33-34, 39-40, 49-50, 55-56: conv ->
  * bias -> LeakyReLU -> BatchNormalization), with the norm's first pass folded into the epilogue:
  *   stats  != NULL (training):  y = act(conv + bias), and the replica slabs stats[stats_rep][2][C] (fp64, zeroed by the

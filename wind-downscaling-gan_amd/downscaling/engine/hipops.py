@@ -47,6 +47,8 @@ class PackedWeights:
         self._half = {}
         self._hver = 0
         self._bf16_stale = True
+        self._split = {}                 # "wF" / "wD" -> three-slice bf16 copy (HipOps.split_mode), refreshed lazily
+        self._split_stale = {"wF": True, "wD": True}
         self._up4 = None
         self.refresh()
 
@@ -66,6 +68,28 @@ class PackedWeights:
 
     def bf16(self):
         return self.half("bf16")
+
+    def split3(self, which):
+        """Keeps the three-bf16-slice copy of wF / wD (wdg_split_bf16x3) current and registered with the library
+        (wdg_split_register) — HipOps.split_mode only; derived views (as_1x1, column_slice) are sliced inside the kernel."""
+        owner = getattr(self, "_split_owner", None)
+        if owner is not None:            # as_1x1: the same two buffers as its parent
+            return owner.split3(which)
+        src = self.wF if which == "wF" else self.wD
+        lib = self.ops.lib
+        if not hasattr(self, "_split"):
+            # a derived view (column_slice): no copy of its own — and no stale entry of a freed buffer at the same address
+            native.check(lib.wdg_split_register(src.data_ptr(), None, 0), "split_register")
+            return
+        buf = self._split.get(which)
+        if buf is None:
+            buf = torch.zeros(3 * src.numel() + 8, dtype=torch.bfloat16, device=src.device)
+            self._split[which] = buf
+        # (re)registered at every use: the library's map is keyed by address, and addresses are recycled by the allocator
+        native.check(lib.wdg_split_register(src.data_ptr(), buf.data_ptr(), src.numel()), "split_register")
+        if self._split_stale[which]:
+            native.check(lib.wdg_split_bf16x3(src.data_ptr(), buf.data_ptr(), src.numel(), self.ops.stream), "split_bf16x3")
+            self._split_stale[which] = False
 
     def half(self, fmt="bf16"):
         """(wF16, wD16): 16-bit copies (fmt "bf16" or "fp16") of the packed layouts for the inference-precision
@@ -95,6 +119,7 @@ class PackedWeights:
         sub.ops, sub.taps, sub.cin, sub.cout = self.ops, 1, self.taps * self.cin, self.cout
         sub.w = self.w.view(1, 1, self.taps * self.cin, self.cout)
         sub.wF, sub.wD = self.wF, sub.w
+        sub._split_owner = self
         return sub
 
     def column_slice(self, n0, n1):
@@ -107,8 +132,13 @@ class PackedWeights:
         sub._parent, sub._range = self, (n0 * ld, n1 * ld)
         return sub
 
-    def refresh(self):
+    def mark_stale(self):
         self._bf16_stale = True
+        if hasattr(self, "_split_stale"):
+            self._split_stale["wF"] = self._split_stale["wD"] = True
+
+    def refresh(self):
+        self.mark_stale()
         self._up4_stale = True
         lib = self.ops.lib
         native.check(lib.wdg_weight_pack(self.w.data_ptr(), self.wF.data_ptr(),
@@ -139,7 +169,7 @@ class _PrepBatch:
         self.epoch += 1
         for pk, u in self.entries:
             if pack_all or (sn and u is not None):
-                pk._bf16_stale = True
+                pk.mark_stale()
                 pk._up4_stale = True
 
     def __del__(self):
@@ -186,6 +216,11 @@ class HipOps:
         self._plans = {}
         self._ws = None
         self._sn_scratch = None
+        # fp32 implicit-GEMM products from three bf16 slices per operand (conv_igemm.hip PIPE 4; measurement mode, off by default):
+        # WDG_SPLIT=1 or set_split_mode(True) BEFORE the first convolution is planned
+        self.split_mode = False
+        if os.environ.get("WDG_SPLIT", "0") == "1":
+            self.set_split_mode(True)
         self.upconv4 = True   # fused upsample + 5x5 transposed conv through the composite-kernel path
         self.upconv_col = True   # its backward in column form on the low-res grid
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
@@ -223,6 +258,10 @@ class HipOps:
         `join()` on the returned object makes the main stream wait for them.  Only worth it for chains of small
         launches (the per-timestep recurrent kernels at T > 1); full-size kernels fill the chip on their own."""
         return _Fork(self)
+
+    def set_split_mode(self, on):
+        self.split_mode = bool(on)
+        native.check(self.lib.wdg_set_tuning(b"igemm_pipe", 4 if on else 3), "set_tuning")
 
     def _plan(self, x, y, cin, cout, g: ConvGeom):
         px, ldx, isx = _v4(x)
@@ -267,6 +306,8 @@ class HipOps:
         scaled / shifted per channel (inference-mode BatchNormalization) — see wdg_conv_fwd_bn."""
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
+        if self.split_mode:
+            pk.split3("wF")
         if bn_stats is not None or bn_affine is not None:
             assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * ((pk.cout + 3) // 4 * 4)))
             native.check(self.lib.wdg_conv_fwd_bn(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), int(act), slope,
@@ -283,6 +324,8 @@ class HipOps:
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
         assert z.shape == y.shape and z.stride() == y.stride()
+        if self.split_mode:
+            pk.split3("wF")
         native.check(self.lib.wdg_conv_fwd_ln(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), z.data_ptr(),
                                               gamma.data_ptr(), beta.data_ptr(), eps, _ptr(mean_rstd), int(act), slope,
                                               ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_ln")
@@ -292,6 +335,8 @@ class HipOps:
         as in conv_fwd, over the Cin channels this launch writes."""
         plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
+        if self.split_mode:
+            pk.split3("wD")
         if bn_stats is not None or bn_affine is not None:
             assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * ((pk.cin + 3) // 4 * 4)))
             native.check(self.lib.wdg_conv_dgrad_bn(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(), int(act), slope,

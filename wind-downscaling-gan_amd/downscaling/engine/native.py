@@ -37,6 +37,8 @@ SIGNATURES = {
     "wdg_device_cus": (i32, []),
     "wdg_crc32c": (C.c_uint32, [C.c_void_p, szt, C.c_uint32]),
     "wdg_set_tuning": (i32, [C.c_char_p, i32]),
+    "wdg_split_bf16x3": (i32, [c_fp, c_fp, i64, c_fp]),
+    "wdg_split_register": (i32, [c_fp, c_fp, i64]),
     "wdg_conv_plan_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom)]),
     "wdg_conv_plan_destroy": (i32, [C.c_void_p]),
     "wdg_conv_ws_bytes": (szt, [C.c_void_p]),
@@ -154,6 +156,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # measurement runs: WDG_TUNE="key=int,key=int" -> wdg_set_tuning before anything is planned (unknown keys raise)
+    for kv in filter(None, os.environ.get("WDG_TUNE", "").split(",")):
+        key, _, val = kv.partition("=")
+        if lib.wdg_set_tuning(key.strip().encode(), int(val)) != 0:
+            raise NativeError(f"WDG_TUNE: {kv!r} rejected by wdg_set_tuning")
     return lib
 
 
