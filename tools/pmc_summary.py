@@ -2,7 +2,7 @@
 """Aggregate rocprofv3 --pmc passes (counter_collection.csv, one counter group per pass) into a per-kernel summary
 and the dominant kernel's HBM traffic per launch for bench.py's `roofline.traffic`.
 
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generator-leg
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generator-leg --no-split-leg
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py ...
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ... -d gpurun_out/pmc_sq ...
     python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq profiles/<tag>_pmc_summary.csv
@@ -99,7 +99,7 @@ def main():
             h.update(f.name.encode())
             h.update(f.read_bytes())
         tj = {"source": f"{out} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 "
-                        f"--no-cpu-baseline --no-generator-leg)",
+                        f"--no-cpu-baseline --no-generator-leg --no-split-leg)",
               "kernel": "wdg_igemm_kernel<128,128>",
               # bench.py quotes the figure only when these two match what it runs (same kernel sources, same launch mix)
               "csrc_sha256": h.hexdigest(), "launches_per_step": float(dom["launches"]),
