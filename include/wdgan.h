@@ -171,6 +171,19 @@ int wdg_upconv_fwd_bf16(const wdg_conv_plan* plan, const float* x_low, int ld_lo
 int wdg_convert_f16(const float* src, void* dst_f16, int64_t n, wdg_stream stream);
 int wdg_conv_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,
                      const float* affine, float* y, int act, float slope, int accumulate, wdg_stream stream);
+
+/* 16-bit ConvLSTM2D inference (gan/models.py:45; TimeDistributed ConvLSTM2D(F, 3, padding='same', return_sequences=True)):
+ * the input part of the gates for all timesteps, written with INTERLEAVED gate columns (column n = gate n & 3 of feature
+ * n >> 2; Keras order i, f, c, o), then one launch per timestep: recurrent 3x3 convolution of h_{t-1} + cell update
+ * (hard_sigmoid / tanh) in the epilogue -> c_t, h_t.  h_prev == c_prev == NULL is t = 0.  fmt: 0 bf16, 1 fp16.
+ * `plan` is the 3x3 plan of the gate convolution (Cout = 4F, dense output); supported() tells whether it runs here
+ * (otherwise: wdg_conv_fwd_bf16 + accumulate + wdg_lstm_fwd). */
+int wdg_convlstm_h16_supported(const wdg_conv_plan* plan, int F);
+int wdg_conv_fwd_h16_gates(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias, float* gates_x,
+                           int F, int fmt, wdg_stream stream);
+int wdg_convlstm_step_h16(const wdg_conv_plan* plan, const float* h_prev, const void* wF16, const float* gates_x,
+                          const float* c_prev, float* c_out, int ldc, float* h_out, int ldh, int F, int fmt,
+                          wdg_stream stream);
 int wdg_conv_dgrad_f16(const wdg_conv_plan* plan, const float* dy, const void* wD16, const float* bias,
                        const float* affine, float* dx, int act, float slope, int accumulate, wdg_stream stream);
 int wdg_conv_halo_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,

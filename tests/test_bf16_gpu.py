@@ -131,3 +131,31 @@ def test_bf16_generator_forward(hip_ops, S, T, F, fmt):
     assert 1e-6 < err < (3e-2 if fmt == "bf16" else 4e-3), err   # a different precision, within the stated tolerance
     with pytest.raises(ValueError):
         net.forward(B, True, precision=fmt)
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+@pytest.mark.parametrize("S,T,F", [(96, 3, 128), (64, 2, 64)])
+def test_convlstm16_fused_step_matches_unfused(hip_ops, S, T, F, fmt):
+    """16-bit ConvLSTM: one launch per timestep (recurrent convolution with the cell update in its epilogue, gate columns
+    interleaved — wdg_convlstm_step_h16) against the three-launch form (accumulating convolution + wdg_lstm_fwd): the same
+    rounding points and the same fp32 cell arithmetic, so the hidden states agree to fp32 accumulation-order noise."""
+    from downscaling.engine.networks import GeneratorNet
+    B, cin, nz, ch = 2, 3, 20, 2
+    dev = hip_ops.device
+    net = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
+    randomize(net, 11)
+    g = torch.Generator().manual_seed(0)
+    net.set_image(torch.randn(B, T, S, S, cin, generator=g).to(dev))
+    net.set_noise((torch.randn(B, T, S, S, nz, generator=g) * 0.1).to(dev))
+    outs = []
+    for fused in (1, 0):
+        assert hip_ops.lib.wdg_set_tuning(b"lstm16_fused", fused) == 0
+        try:
+            out = net.forward(B, False, precision=fmt).clone()
+            outs.append((out, net.buffers(B)["h"].clone()))
+        finally:
+            hip_ops.lib.wdg_set_tuning(b"lstm16_fused", 1)
+    x = net.buffers(B)["cat4"][..., F // 2:]
+    assert hip_ops.convlstm16_supported(x, net.lstm.gates, net.lstm.pkx, net.lstm.g, F), "the fused path must be the one tested"
+    assert rel_err(outs[0][1], outs[1][1]) < 2e-5, "hidden states"
+    assert rel_err(outs[0][0], outs[1][0]) < 2e-4, "generator output (16-bit layers behind the ConvLSTM re-round the tiny difference)"

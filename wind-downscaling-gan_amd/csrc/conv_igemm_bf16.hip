@@ -325,3 +325,38 @@ extern "C" int wdg_conv_dgrad_f16(const wdg_conv_plan* pl, const float* dy, cons
                                   wdg_stream stream) {
     return conv_dgrad_h16(pl, dy, wD16, bias, affine, dx, act, slope, accumulate, 1, stream);
 }
+
+// ---- 16-bit ConvLSTM2D inference (gan/models.py:45): input part of the gates with interleaved columns, then one launch per
+// timestep = recurrent convolution + cell update (conv_patch_h16.hip, LSTM epilogue)
+static int g_lstm16_fused = 1;
+void wdg_h16_set_lstm_fused(int v) { g_lstm16_fused = v; }
+extern "C" int wdg_convlstm_h16_supported(const wdg_conv_plan* pl, int F) {
+    if (!pl || !g_lstm16_fused || F <= 0 || F % 4) return 0;
+    const wdg_conv_geom& g = pl->g;
+    if (g.Cout != 4 * F || g.ldy != 4 * F || g.img_stride_y != (int64_t)g.Ho * g.Wo * 4 * F || g.stride != 1) return 0;
+    return wdg_patch_h16_eligible(pl);
+}
+extern "C" int wdg_conv_fwd_h16_gates(const wdg_conv_plan* pl, const float* x, const void* wF16, const float* bias, float* y,
+                                      int F, int fmt, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && wF16 && y && wdg_convlstm_h16_supported(pl, F), "not supported for this geometry");
+    WdgPatchGates gx;
+    memset(&gx, 0, sizeof(gx));
+    gx.F = F;
+    const int rc = wdg_patch_h16_launch(pl, 0, x, wF16, bias, nullptr, y, 0, 0.f, 0, fmt, (hipStream_t)stream, &gx);
+    WDG_CHECK_ARG(rc != 1, "patch kernel refused the geometry");
+    return rc;
+}
+extern "C" int wdg_convlstm_step_h16(const wdg_conv_plan* pl, const float* h_prev, const void* wF16, const float* gates_x,
+                                     const float* c_prev, float* c_out, int ldc, float* h_out, int ldh, int F, int fmt,
+                                     wdg_stream stream) {
+    WDG_CHECK_ARG(pl && wF16 && gates_x && c_out && h_out && wdg_convlstm_h16_supported(pl, F), "not supported for this geometry");
+    WDG_CHECK_ARG(ldc >= F && ldh >= F && (h_prev != nullptr) == (c_prev != nullptr), "bad argument");
+    WdgPatchGates gx;
+    memset(&gx, 0, sizeof(gx));
+    gx.F = F; gx.gates_x = gates_x; gx.c_prev = c_prev; gx.c_out = c_out; gx.ldc = ldc; gx.h_out = h_out; gx.ldh = ldh;
+    gx.skip_k = h_prev == nullptr;
+    const int rc = wdg_patch_h16_launch(pl, 0, h_prev ? h_prev : gates_x, wF16, nullptr, nullptr, h_out, 0, 0.f, 0, fmt,
+                                        (hipStream_t)stream, &gx);
+    WDG_CHECK_ARG(rc != 1, "patch kernel refused the geometry");
+    return rc;
+}

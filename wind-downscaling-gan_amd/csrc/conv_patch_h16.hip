@@ -38,6 +38,12 @@ struct WdgPatchH16 {
     int pad_h, pad_w;
     int act, accumulate;
     float slope;
+    int gate_F;                // > 0: ConvLSTM gate columns interleaved — column n is gate n & 3 of feature n >> 2, i.e. weight row
+                               // and bias index (n & 3) * gate_F + (n >> 2); a lane's 4 accumulator registers are then i, f, c~, o
+    const float* gates_x;      // LSTM step (template LSTM): input part of the gates, interleaved columns [pixel][4 * gate_F]
+    const float* c_prev;       // previous cell state [pixel][ldc] or NULL (zero)
+    float* c_out;              // new cell state; Out receives h
+    int ldc;
     int mt;                    // fragments per wave (host side: picks the instantiation)
     int fw_shift, tfx;         // fragment width 1 << fw_shift (16 or 4), fragments per fragment-row of the tile
     int TH, TW, PH, PW, PWs, pitch;   // tile, patch, columns per parity plane, slots per channel-group plane
@@ -59,7 +65,7 @@ struct WdgPatchH16 {
 #else
 #define WDG_PATCH_BOUNDS __launch_bounds__(256)
 #endif
-template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0>
+template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, bool LSTM = false>
 __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) {
     typedef wdg_h16x8<FMT> h16x8;
     constexpr int BN = 2 * NT * 16;
@@ -129,7 +135,9 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
 #pragma unroll
     for (int r = 0; r < B_LOADS; ++r) {
         const int n = (t >> 3) + 32 * r;
-        b_row[r] = (n0 + n < p.Ncols) ? (n0 + n) * p.ldB : -1;
+        const int ng = n0 + n;
+        const int wrow = p.gate_F ? (ng & 3) * p.gate_F + (ng >> 2) : ng;
+        b_row[r] = (ng < p.Ncols) ? wrow * p.ldB : -1;
         b_slot[r] = bj * BN + (n ^ bj);
     }
 
@@ -265,7 +273,30 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     // 16 bytes per lane.  (A transpose through LDS to whole-pixel stores was measured SLOWER: 654 vs 487 us on the 400-column
     // GEMM, profiles/r02n_perf_patch_epilogue.txt.)
     const int nw0 = n0 + wn * (BN / 2);
-    {
+    if constexpr (LSTM) {
+        // ConvLSTM2D cell (gan/models.py:45; Keras hard_sigmoid / tanh, gate order i, f, c, o) on the accumulators: register r of
+        // a lane is gate r of feature (n >> 2) of its pixel.  z = recurrent conv + input part; c = f * c_prev + i * tanh(c~);
+        // h = o * tanh(c).  Same arithmetic as wdg_lstm_fwd (pointwise.hip) behind an accumulating convolution.
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = nw0 + b * 16 + 4 * lq;
+            if (n >= p.Ncols) continue;
+            const int f = n >> 2;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
+                const f32x4 z = acc[a][b] + *reinterpret_cast<const f32x4*>(p.gates_x + pix * (4 * p.gate_F) + n);
+                const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
+                const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
+                const float gc = tanhf(z[2]);
+                const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
+                float cn = gi * gc;
+                if (p.c_prev) cn += gf * p.c_prev[pix * p.ldc + f];
+                p.c_out[pix * p.ldc + f] = cn;
+                outImg[(long long)opix[a] * p.ldO + f] = go * tanhf(cn);
+            }
+        }
+    } else {
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const int n = nw0 + b * 16 + 4 * lq;
@@ -275,8 +306,9 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (n + r < p.Ncols) {
-                    if (p.bias) bias4[r] = p.bias[n + r];
-                    if (p.affine) { sc4[r] = p.affine[n + r]; sh4[r] = p.affine[p.Ncols + n + r]; }
+                    const int nb = p.gate_F ? r * p.gate_F + (n >> 2) : n + r;      // (interleaved gate columns: n % 4 == 0)
+                    if (p.bias) bias4[r] = p.bias[nb];
+                    if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[p.Ncols + nb]; }
                 }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
@@ -380,15 +412,15 @@ int wdg_patch_h16_eligible(const wdg_conv_plan* pl) {
     return patch_plan(patch_view(pl, false), p) ? 1 : 0;
 }
 
-template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0>
+template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, bool LSTM = false>
 static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_t st) {
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_conv_patch_h16_kernel<FMT, MT, NT, NLOOP, DBG>),
+        WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_conv_patch_h16_kernel<FMT, MT, NT, NLOOP, DBG, LSTM>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL((wdg_conv_patch_h16_kernel<FMT, MT, NT, NLOOP, DBG>), dim3(blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((wdg_conv_patch_h16_kernel<FMT, MT, NT, NLOOP, DBG, LSTM>), dim3(blocks), dim3(256), lds, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
@@ -396,7 +428,8 @@ static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_
 // returns WDG_OK after launching, or 1 when the geometry is not eligible (caller falls back to the gather kernel).
 // transposed1x1: x is dy, y is dx and w16 the data-gradient packing [Cin][Cout_p] of a 1 x 1, stride-1 plan.
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
-                         const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st) {
+                         const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
+                         const WdgPatchGates* gx) {
     if (transposed1x1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
     const WdgPatchView g = patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;
@@ -408,6 +441,17 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     p.Ncols = g.Ncols; p.ldB = g.kh * g.kw * g.K_p; p.Cin_p = g.K_p;
     p.kh = g.kh; p.kw = g.kw; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
+    const bool lstm = gx && gx->c_out;
+    if (gx) {
+        // ConvLSTM gate columns interleaved (x-part: plain epilogue, columns written interleaved; step: cell update in the epilogue)
+        if (gx->F <= 0 || g.Ncols != 4 * gx->F || transposed1x1) return 1;
+        p.gate_F = gx->F;
+        if (lstm) {
+            p.gates_x = gx->gates_x; p.c_prev = gx->c_prev; p.c_out = gx->c_out; p.ldc = gx->ldc;
+            p.Out = gx->h_out; p.ldO = gx->ldh; p.imgStrideO = (long long)g.Ho * g.Wo * gx->ldh;
+            if (gx->skip_k) p.nchunk = 0;            // t = 0: h_{-1} = 0, the recurrent convolution contributes nothing
+        }
+    }
     if ((long long)g.H * g.W * g.ldA * 4 >= (1LL << 31) || (long long)g.Ncols * p.ldB * 2 >= (1LL << 31)) return 1;
     const int MT = p.mt;
     // 64-channel tiles when the map is small (the per-timestep recurrent convolution) or the layer is narrow
@@ -416,7 +460,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     const int BN = narrow ? 64 : 128;
     p.tiles_n = (g.Ncols + BN - 1) / BN;
     p.ntn_blk = 1;
-    if (g_patch_nloop && p.nchunk == 1 && p.tiles_n > 1 && tiles_px >= 4LL * g.cus) { p.ntn_blk = p.tiles_n; p.tiles_n = 1; }
+    if (g_patch_nloop && !lstm && p.nchunk == 1 && p.tiles_n > 1 && tiles_px >= 4LL * g.cus) { p.ntn_blk = p.tiles_n; p.tiles_n = 1; }
     p.div_tn = wdg_fastdiv_make((unsigned)p.tiles_n);
     p.div_tx = wdg_fastdiv_make((unsigned)p.tiles_x);
     p.div_ty = wdg_fastdiv_make((unsigned)p.tiles_y);
@@ -434,7 +478,8 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
 #endif
 #define WDG_PATCH_CASE(F, M, N)                                                                        \
     if (fmt == F && MT == M && BN == 32 * N)                                                           \
-        return p.ntn_blk > 1 ? patch_launch<F, M, N, true>(p, (int)blocks, lds, st) : patch_launch<F, M, N, false>(p, (int)blocks, lds, st)
+        return lstm ? patch_launch<F, M, N, false, 0, true>(p, (int)blocks, lds, st)                  \
+                    : p.ntn_blk > 1 ? patch_launch<F, M, N, true>(p, (int)blocks, lds, st) : patch_launch<F, M, N, false>(p, (int)blocks, lds, st)
     WDG_PATCH_CASE(0, 4, 4); WDG_PATCH_CASE(0, 4, 2); WDG_PATCH_CASE(0, 6, 4); WDG_PATCH_CASE(0, 6, 2); WDG_PATCH_CASE(0, 3, 4); WDG_PATCH_CASE(0, 3, 2);
     WDG_PATCH_CASE(1, 4, 4); WDG_PATCH_CASE(1, 4, 2); WDG_PATCH_CASE(1, 6, 4); WDG_PATCH_CASE(1, 6, 2); WDG_PATCH_CASE(1, 3, 4); WDG_PATCH_CASE(1, 3, 2);
 #undef WDG_PATCH_CASE

@@ -65,6 +65,7 @@ void wdg_halo_set_persistent(int v);
 void wdg_halo_set_th4(int v);
 void wdg_halo_set_max_cin(int v);
 void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
+void wdg_h16_set_lstm_fused(int v);
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
                     hipStream_t st);
@@ -75,8 +76,21 @@ void wdg_patch_h16_set_budget(int kib);
 void wdg_patch_h16_set_dbg(int v);
 void wdg_patch_h16_set_nloop(int v);
 int wdg_patch_h16_eligible(const wdg_conv_plan* pl);
+// ConvLSTM gate columns: F features, columns interleaved (gate n & 3 of feature n >> 2).  c_out == NULL: plain convolution
+// that writes its columns interleaved (the input part of the gates); else the recurrent step with the cell update in the epilogue.
+struct WdgPatchGates {
+    int F;
+    const float* gates_x;
+    const float* c_prev;
+    float* c_out;
+    int ldc;
+    float* h_out;
+    int ldh;
+    int skip_k;
+};
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
-                         const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st);
+                         const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
+                         const WdgPatchGates* gx = nullptr);
 
 // convlstm1.hip
 void wdg_convlstm1_set_mfma(int v);

@@ -354,6 +354,26 @@ class HipOps:
         native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
                         y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_16")
 
+    def convlstm16_supported(self, x, gates, pk, g, F):
+        """16-bit ConvLSTM with the cell update in the recurrent convolution's epilogue (wdg_convlstm_step_h16)?"""
+        plan, _, _ = self._plan(x, gates, pk.cin, pk.cout, g)
+        return bool(self.lib.wdg_convlstm_h16_supported(plan, F))
+
+    def convlstm16_gates(self, x, pk, bias, gates, g, F, fmt="bf16"):
+        """Input part of the gates for all timesteps, gate columns interleaved (the layout the step kernel reads)."""
+        plan, _, _ = self._plan(x, gates, pk.cin, pk.cout, g)
+        native.check(self.lib.wdg_conv_fwd_h16_gates(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), gates.data_ptr(),
+                                                     F, 0 if fmt == "bf16" else 1, self.stream), "conv_fwd_h16_gates")
+
+    def convlstm16_step(self, h_prev, pk, gates_t, c_prev, c_out, h_out, g, F, fmt="bf16"):
+        """h_t, c_t from h_{t-1}, c_{t-1} (None at t = 0) and the input part of the gates of timestep t."""
+        plan, _, _ = self._plan(h_out if h_prev is None else h_prev, gates_t, pk.cin, pk.cout, g)
+        _, ldc, _ = _v4(c_out)
+        _, ldh, _ = _v4(h_out)
+        native.check(self.lib.wdg_convlstm_step_h16(plan, _ptr(h_prev), pk.half(fmt)[0].data_ptr(), gates_t.data_ptr(), _ptr(c_prev),
+                                                    c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F, 0 if fmt == "bf16" else 1,
+                                                    self.stream), "convlstm_step_h16")
+
     def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
         plan, _, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
         fn = self.lib.wdg_conv_dgrad_bf16 if fmt == "bf16" else self.lib.wdg_conv_dgrad_f16

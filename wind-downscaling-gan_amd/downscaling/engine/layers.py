@@ -273,6 +273,17 @@ class ConvLSTM:
             o.convlstm_seq_fwd(x, self.wx.value, self.wh.value, self.b.value, h, self.gates, self.c, B, T, self.cin, F,
                                self._seq_scratch)
             return
+        if bf16 and T > 1 and hasattr(o, "convlstm16_supported") and \
+                o.convlstm16_supported(x[:B], self.gates[:B], self.pkh, self.g, F) and \
+                o.convlstm16_supported(x, self.gates, self.pkx, self.g, F):
+            # inference precision: the input part of the gates with interleaved gate columns, then ONE launch per timestep
+            # (recurrent convolution with the cell update in its epilogue) — csrc/conv_patch_h16.hip
+            o.convlstm16_gates(x, self.pkx, self.b.value, self.gates, self.g, F, fmt=fmt)
+            for t in range(T):
+                sl, pv = slice(t * B, (t + 1) * B), slice((t - 1) * B, t * B)
+                o.convlstm16_step(h[pv] if t else None, self.pkh, self.gates[sl], self.c[pv] if t else None, self.c[sl], h[sl],
+                                  self.g, F, fmt=fmt)
+            return
         conv = (lambda *a, **k: o.conv_fwd_bf16(*a, fmt=fmt, **k)) if bf16 else o.conv_fwd
         if T == 1 and not bf16:
             # h_0 = c_0 = 0: the forget gate is never read at t = 0 -> skip its quarter of the input convolution
