@@ -172,6 +172,15 @@ int wdg_convert_f16(const float* src, void* dst_f16, int64_t n, wdg_stream strea
 int wdg_conv_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,
                      const float* affine, float* y, int act, float slope, int accumulate, wdg_stream stream);
 
+/* ConvLSTM2D recurrent step in ONE launch, fp32 (gan/models.py:93,101 with n_timesteps > 1; the discriminator's 2- and
+ * 16-feature ConvLSTMs): gates += conv3x3(h_prev, wF) (gates: the input part on entry, the pre-activation sums [i|f|c~|o] the
+ * backward pass reads on exit), then c_out = hsig(f) c_prev + hsig(i) tanh(c~), h_out = hsig(o) tanh(c_out) on the
+ * accumulators.  supported(): the plan's forward runs the halo-tile kernel with F = 16 or F = 2 (otherwise:
+ * wdg_conv_fwd(accumulate) + wdg_lstm_fwd). */
+int wdg_convlstm_step_supported(const wdg_conv_plan* plan, int F);
+int wdg_convlstm_step(const wdg_conv_plan* plan, const float* h_prev, const float* wF, float* gates, const float* c_prev,
+                      float* c_out, int ldc, float* h_out, int ldh, int F, wdg_stream stream);
+
 /* 16-bit ConvLSTM2D inference (gan/models.py:45; TimeDistributed ConvLSTM2D(F, 3, padding='same', return_sequences=True)):
  * the input part of the gates for all timesteps, written with INTERLEAVED gate columns (column n = gate n & 3 of feature
  * n >> 2; Keras order i, f, c, o), then one launch per timestep: recurrent 3x3 convolution of h_{t-1} + cell update

@@ -751,3 +751,32 @@ def test_convlstm_sequence_kernels(cin, F, B, T, H, W, hip_ops, ref_ops, monkeyp
         q = float(torch.quantile(err[:: max(1, err.numel() // 4_000_000)], 0.999)) if err.numel() > 10 else float(err.max())
         assert q < 5 * TOL, (k, q)
         assert float(err.max()) < 0.2, (k, float(err.max()))
+
+
+@pytest.mark.parametrize("F,cinp,n,H,W", [(16, 16, 3, 24, 40), (16, 16, 8, 96, 96), (2, 4, 3, 24, 40), (2, 4, 8, 96, 96), (16, 16, 2, 19, 33)])
+def test_convlstm_recurrent_step_fused(hip_ops, ref_ops, F, cinp, n, H, W):
+    """fp32 ConvLSTM recurrent step in one launch (wdg_convlstm_step: halo-tile convolution with the cell update in its
+    epilogue; the discriminator's 16- and 2-feature ConvLSTMs at n_timesteps > 1, models.py:93,101) against the oracle's
+    accumulating convolution + cell update: pre-activation gates (read by the backward pass), c_t and h_t."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    g, rg = ConvGeom(3, 3, 1, 1), RG(3, 3, 1, 1)
+    gen = torch.Generator().manual_seed(F + H)
+    dev = hip_ops.device
+    h_prev = torch.zeros(n, H, W, cinp, dtype=torch.float64)
+    h_prev[..., :F] = torch.randn(n, H, W, F, generator=gen, dtype=torch.float64)
+    gates = torch.randn(n, H, W, 4 * F, generator=gen, dtype=torch.float64) * 2
+    c_prev = torch.randn(n, H, W, F, generator=gen, dtype=torch.float64)
+    w = torch.randn(3, 3, F, 4 * F, generator=gen, dtype=torch.float64) * 0.3
+    pk_r, pk_g = ref_ops.pack_weights(w), hip_ops.pack_weights(w.float().to(dev).contiguous())
+    g_r, c_r, h_r = gates.clone(), torch.zeros_like(c_prev), torch.zeros_like(h_prev)
+    ref_ops.conv_fwd(h_prev, pk_r, None, g_r, rg, act=False, accumulate=True)
+    ref_ops.lstm_fwd(g_r.view(-1, 4 * F), c_prev.view(-1, F), c_r.view(-1, F), h_r.view(-1, cinp), F)
+    g_g, hp_g, cp_g = gates.float().to(dev), h_prev.float().to(dev), c_prev.float().to(dev)
+    c_g, h_g = torch.zeros(n, H, W, F, device=dev), torch.zeros(n, H, W, cinp, device=dev)
+    assert hip_ops.convlstm_step_supported(hp_g, g_g, pk_g, g, F)
+    hip_ops.convlstm_step(hp_g, pk_g, g_g, cp_g, c_g, h_g, g, F)
+    assert rel_err(g_g, g_r) < TOL, "pre-activation gates"
+    # a hard-sigmoid knot or tanh amplifies nothing here: c and h are smooth in the gates up to the clip points
+    assert rel_err(c_g, c_r) < 5 * TOL and rel_err(h_g[..., :F], h_r[..., :F]) < 5 * TOL
+    assert float(h_g[..., F:].abs().max()) == 0.0 if cinp > F else True

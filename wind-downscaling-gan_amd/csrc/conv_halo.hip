@@ -36,6 +36,13 @@ struct WdgHalo {
     float slope;
     int tiles_h, tiles_w;
     int lr_h, lr_w;   // low-res staging tile (upsample mode): rows/cols of the source covering the halo
+    // ConvLSTM2D recurrent step (lstm_F > 0; models.py:93,101 at n_timesteps > 1): Out holds the input part of the gates
+    // (columns [i | f | c~ | o], lstm_F each) and receives the pre-activation sums the backward pass reads; the cell update
+    // runs on the accumulators and writes c_out / h_out.  lstm_F = 16 (4 column tiles = 4 gates) or 2 (8 columns in one tile).
+    int lstm_F, ldc, ldh;
+    const float* c_prev;
+    float* c_out;
+    float* h_out;
 };
 
 // WG = 1: the weight fragments are read straight from global memory (they are a few hundred KB, L1/L2
@@ -227,6 +234,40 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
             }
             if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst + n);
             *reinterpret_cast<f32x4*>(dst + n) = v;
+            if constexpr (NT == 4 || NT == 1) acc[a][b] = v;     // (the cell update below needs the complete pre-activations)
+        }
+        if constexpr (NT == 4 || NT == 1) {
+            if (p.lstm_F) {
+                // cell update on the accumulators: Keras hard_sigmoid / tanh, c = f * c_prev + i * c~, h = o * tanh(c)
+                // (the same arithmetic as wdg_lstm_fwd, pointwise.hip)
+                auto hs = [](float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); };
+                const long long pix = (long long)img * p.Ho * p.Wo + (long long)oy * p.Wo + ox;
+                if constexpr (NT == 4) {
+                    // 16 features: column tile b is gate b, this lane holds features 4*lg .. 4*lg+3 of its pixel
+                    const f32x4 cp = *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.ldc + 4 * lg);
+                    f32x4 cn, hn;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        cn[r] = hs(acc[a][1][r]) * cp[r] + hs(acc[a][0][r]) * tanhf(acc[a][2][r]);
+                        hn[r] = hs(acc[a][3][r]) * tanhf(cn[r]);
+                    }
+                    *reinterpret_cast<f32x4*>(p.c_out + pix * p.ldc + 4 * lg) = cn;
+                    *reinterpret_cast<f32x4*>(p.h_out + pix * p.ldh + 4 * lg) = hn;
+                } else {
+                    // 2 features: columns (i0 i1 f0 f1) in lane group 0, (c~0 c~1 o0 o1) in lane group 1 of the same pixel
+                    f32x4 other;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) other[r] = __shfl(acc[a][0][r], li + 16, 64);
+                    if (lg == 0) {
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            const float cn = hs(acc[a][0][2 + f]) * p.c_prev[pix * p.ldc + f] + hs(acc[a][0][f]) * tanhf(other[f]);
+                            p.c_out[pix * p.ldc + f] = cn;
+                            p.h_out[pix * p.ldh + f] = hs(other[2 + f]) * tanhf(cn);
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -421,10 +462,13 @@ void wdg_halo_plan_free(wdg_conv_plan* pl) {
 
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
-                    hipStream_t st) {
+                    hipStream_t st, const WdgHaloLstm* cell) {
     const wdg_conv_geom& g = pl->g;
     WdgHalo p;
     memset(&p, 0, sizeof(p));
+    if (cell) {
+        p.lstm_F = cell->F; p.c_prev = cell->c_prev; p.c_out = cell->c_out; p.h_out = cell->h_out; p.ldc = cell->ldc; p.ldh = cell->ldh;
+    }
     p.A = A; p.B = Bw; p.Out = Out; p.bias = bias;
     p.n_img = g.n_img; p.ldA = ldA; p.imgStrideA = imgStrideA;
     p.ntaps = pl->taps;
@@ -460,7 +504,7 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     }
     // small launches (fewer than two 8-row tiles per CU) use 4-row tiles: twice the workgroups (not the upsampling form,
     // whose low-resolution staging tile is sized for 8 rows, nor the persistent 3x3 kernel below)
-    const bool persistent1 = g_halo_persistent && !upsample && nt == 1 && p.C4 == 4 && pl->taps == 9 && g.kh == 3;
+    const bool persistent1 = g_halo_persistent && !upsample && !cell && nt == 1 && p.C4 == 4 && pl->taps == 9 && g.kh == 3;
     const long long tiles8 = (long long)g.n_img * ((p.Ho + HALO_TH - 1) / HALO_TH) * ((p.Wo + HALO_TW - 1) / HALO_TW);
     const int th = (g_halo_th4 && !upsample && !persistent1 && tiles8 < 2LL * pl->cus) ? 4 : HALO_TH;
     p.halo_h = th + g.kh - 1; p.halo_w = HALO_TW + g.kw - 1;
@@ -504,4 +548,23 @@ extern "C" int wdg_upconv_fwd(const wdg_conv_plan* pl, const float* x_low, int l
     WDG_CHECK_ARG(pl->halo_dgrad_nt != 0, "plan not eligible (needs stride 1, k <= 5, Cin <= 64)");
     return wdg_halo_launch(pl, true, x_low, ld_low, img_stride_low, 1, wD, bias, y, act, slope, 0,
                            (hipStream_t)stream);
+}
+
+// ---- ConvLSTM2D recurrent step in one launch (models.py:93,101 at n_timesteps > 1): recurrent 3x3 convolution of h_{t-1}
+// accumulated onto the input part of the gates (left in `gates` as the pre-activations the backward pass reads) + cell update.
+static int g_lstm_step_fused = 1;
+void wdg_halo_set_lstm_fused(int v) { g_lstm_step_fused = v; }
+extern "C" int wdg_convlstm_step_supported(const wdg_conv_plan* pl, int F) {
+    if (!pl || !g_lstm_step_fused) return 0;
+    const wdg_conv_geom& g = pl->g;
+    if (g.Cout != 4 * F || g.stride != 1 || g.ldy != 4 * F || g.img_stride_y != (int64_t)g.Ho * g.Wo * 4 * F) return 0;
+    return (F == 16 && pl->halo_fwd_nt == 4) || (F == 2 && pl->halo_fwd_nt == 1);
+}
+extern "C" int wdg_convlstm_step(const wdg_conv_plan* pl, const float* h_prev, const float* wF, float* gates, const float* c_prev,
+                                 float* c_out, int ldc, float* h_out, int ldh, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && h_prev && wF && gates && c_prev && c_out && h_out && wdg_convlstm_step_supported(pl, F), "not supported for this geometry");
+    WDG_CHECK_ARG(ldc >= F && ldh >= F && (F != 16 || (ldc % 4 == 0 && ldh % 4 == 0 && (((uintptr_t)c_prev | (uintptr_t)c_out | (uintptr_t)h_out) & 15) == 0)),
+                  "bad strides / alignment");
+    WdgHaloLstm cell = {F, ldc, ldh, c_prev, c_out, h_out};
+    return wdg_halo_launch(pl, false, h_prev, pl->g.ldx, pl->g.img_stride_x, 0, wF, nullptr, gates, 0, 0.f, 1, (hipStream_t)stream, &cell);
 }

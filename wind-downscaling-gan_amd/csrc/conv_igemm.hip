@@ -1282,6 +1282,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_halo_set_th4(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "lstm_step_fused")) {
+        wdg_halo_set_lstm_fused(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "lstm16_fused")) {
         wdg_h16_set_lstm_fused(value);
         return WDG_OK;

@@ -66,9 +66,16 @@ void wdg_halo_set_th4(int v);
 void wdg_halo_set_max_cin(int v);
 void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
 void wdg_h16_set_lstm_fused(int v);
+struct WdgHaloLstm {   // ConvLSTM cell update in the epilogue of the recurrent convolution (conv_halo.hip)
+    int F, ldc, ldh;
+    const float* c_prev;
+    float* c_out;
+    float* h_out;
+};
+void wdg_halo_set_lstm_fused(int v);
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
-                    hipStream_t st);
+                    hipStream_t st, const WdgHaloLstm* cell = nullptr);
 
 // conv_patch_h16.hip
 void wdg_patch_h16_set(int v);

@@ -354,6 +354,20 @@ class HipOps:
         native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
                         y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_16")
 
+    def convlstm_step_supported(self, h_prev, gates_t, pk, g, F):
+        """fp32 ConvLSTM recurrent step in one launch (wdg_convlstm_step: halo-tile kernel with the cell update in its epilogue)?"""
+        plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
+        return bool(self.lib.wdg_convlstm_step_supported(plan, F))
+
+    def convlstm_step(self, h_prev, pk, gates_t, c_prev, c_out, h_out, g, F):
+        """gates_t += conv(h_prev); c_out, h_out from the cell update (gates_t keeps the pre-activations for the backward)."""
+        plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
+        _, ldc, _ = _v4(c_out)
+        _, ldh, _ = _v4(h_out)
+        assert _v4(c_prev)[1] == ldc
+        native.check(self.lib.wdg_convlstm_step(plan, h_prev.data_ptr(), pk.wF.data_ptr(), gates_t.data_ptr(), c_prev.data_ptr(),
+                                                c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F, self.stream), "convlstm_step")
+
     def convlstm16_supported(self, x, gates, pk, g, F):
         """16-bit ConvLSTM with the cell update in the recurrent convolution's epilogue (wdg_convlstm_step_h16)?"""
         plan, _, _ = self._plan(x, gates, pk.cin, pk.cout, g)

@@ -295,10 +295,17 @@ class ConvLSTM:
             conv(x, self._pk_co, self.b.value[2 * F:], self.gates[..., 2 * F:], self.g, act=False)
         else:
             conv(x, self.pkx, self.b.value, self.gates, self.g, act=False)
+        # fp32, T > 1: the recurrent convolution with the cell update in its epilogue where the halo-tile kernel runs the layer
+        # (the discriminator's 2- and 16-feature ConvLSTMs): one launch per timestep instead of two
+        step1 = (not bf16) and T > 1 and hasattr(o, "convlstm_step_supported") and \
+            o.convlstm_step_supported(h[:B], self.gates[:B], self.pkh, self.g, F)
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             if t > 0:
                 pv = slice((t - 1) * B, t * B)
+                if step1:
+                    o.convlstm_step(h[pv], self.pkh, self.gates[sl], self.c[pv], self.c[sl], h[sl], self.g, F)
+                    continue
                 conv(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
                 o.lstm_fwd(v2(self.gates[sl]), v2(self.c[pv]), v2(self.c[sl]), v2(h[sl]), F)
             else:

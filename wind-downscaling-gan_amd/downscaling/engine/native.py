@@ -37,6 +37,8 @@ SIGNATURES = {
     "wdg_device_cus": (i32, []),
     "wdg_crc32c": (C.c_uint32, [C.c_void_p, szt, C.c_uint32]),
     "wdg_set_tuning": (i32, [C.c_char_p, i32]),
+    "wdg_convlstm_step_supported": (i32, [c_fp, i32]),
+    "wdg_convlstm_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_h16_supported": (i32, [c_fp, i32]),
     "wdg_conv_fwd_h16_gates": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_step_h16": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
