@@ -180,6 +180,13 @@ int wdg_conv_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16
 int wdg_convlstm_step_supported(const wdg_conv_plan* plan, int F);
 int wdg_convlstm_step(const wdg_conv_plan* plan, const float* h_prev, const float* wF, float* gates, const float* c_prev,
                       float* c_out, int ldc, float* h_out, int ldh, int F, wdg_stream stream);
+/* Backward counterpart (BPTT of the same layers): dh_prev += conv_transpose(dgates_next, wD) completes the gradient of
+ * h_{t-1}; the epilogue then differentiates the cell of timestep t-1 (gates_t, c_prev [NULL at t-1 = 0], c_cur, dc_in ->
+ * dgates_out and, unless NULL, dc_out).  Replaces wdg_conv_dgrad(accumulate) + wdg_lstm_bwd of the next loop iteration. */
+int wdg_convlstm_bwd_step_supported(const wdg_conv_plan* plan, int F);
+int wdg_convlstm_bwd_step(const wdg_conv_plan* plan, const float* dgates_next, const float* wD, float* dh_prev,
+                          const float* gates_t, const float* c_prev, const float* c_cur, const float* dc_in,
+                          float* dgates_out, float* dc_out, int ldc, int F, wdg_stream stream);
 
 /* 16-bit ConvLSTM2D inference (gan/models.py:45; TimeDistributed ConvLSTM2D(F, 3, padding='same', return_sequences=True)):
  * the input part of the gates for all timesteps, written with INTERLEAVED gate columns (column n = gate n & 3 of feature

@@ -780,3 +780,41 @@ def test_convlstm_recurrent_step_fused(hip_ops, ref_ops, F, cinp, n, H, W):
     # a hard-sigmoid knot or tanh amplifies nothing here: c and h are smooth in the gates up to the clip points
     assert rel_err(c_g, c_r) < 5 * TOL and rel_err(h_g[..., :F], h_r[..., :F]) < 5 * TOL
     assert float(h_g[..., F:].abs().max()) == 0.0 if cinp > F else True
+
+
+@pytest.mark.parametrize("F,cinp,n,H,W,first", [(16, 16, 3, 24, 40, False), (16, 16, 8, 96, 96, True), (2, 4, 3, 24, 40, False),
+                                                (2, 4, 8, 96, 96, True), (16, 16, 2, 19, 33, False)])
+def test_convlstm_recurrent_bwd_step_fused(hip_ops, ref_ops, F, cinp, n, H, W, first):
+    """Backward counterpart (wdg_convlstm_bwd_step): dh_{t-1} += conv_transpose(dgates_t) and the cell backward of timestep t-1
+    in the same launch, against the oracle's data gradient + wdg_lstm_bwd restatement.  first=True: t-1 = 0 (no c_prev, no
+    dc flowing on)."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    g, rg = ConvGeom(3, 3, 1, 1), RG(3, 3, 1, 1)
+    gen = torch.Generator().manual_seed(7 * F + W)
+    dev = hip_ops.device
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+    dg_next, gates = rn(n, H, W, 4 * F), rn(n, H, W, 4 * F) * 2
+    dh = torch.zeros(n, H, W, cinp, dtype=torch.float64)
+    dh[..., :F] = rn(n, H, W, F)
+    c_prev, c_cur, dc_in = (None if first else rn(n, H, W, F)), rn(n, H, W, F), rn(n, H, W, F)
+    w = rn(3, 3, F, 4 * F) * 0.3
+    pk_r, pk_g = ref_ops.pack_weights(w), hip_ops.pack_weights(w.float().to(dev).contiguous())
+    dh_r, dg_r = dh.clone(), torch.zeros(n, H, W, 4 * F, dtype=torch.float64)
+    dc_r = None if first else torch.zeros(n, H, W, F, dtype=torch.float64)
+    ref_ops.conv_dgrad(dg_next, pk_r, dh_r, rg, accumulate=True)
+    ref_ops.lstm_bwd(gates.view(-1, 4 * F), None if first else c_prev.view(-1, F), c_cur.view(-1, F), dh_r.view(-1, cinp),
+                     dc_in.view(-1, F), dg_r.view(-1, 4 * F), None if first else dc_r.view(-1, F), F)
+    f32 = lambda t: None if t is None else t.float().to(dev)
+    dh_g, dg_g = f32(dh), torch.zeros(n, H, W, 4 * F, device=dev)
+    dc_g = None if first else torch.zeros(n, H, W, F, device=dev)
+    assert hip_ops.convlstm_bwd_step_supported(dh_g, dg_g, pk_g, g, F)
+    hip_ops.convlstm_bwd_step(f32(dg_next), pk_g, dh_g, f32(gates), f32(c_prev), f32(c_cur), f32(dc_in), dg_g, dc_g, g, F)
+    assert rel_err(dh_g, dh_r) < TOL, "dh"
+    # the hard-sigmoid gradient is a step function: fp32 vs fp64 pre-activations may sit on different sides of a knot for a few
+    # elements, so dgates is compared robustly (99.9 % quantile) and in the mean
+    d = (dg_g.double().cpu() - dg_r).abs().flatten()
+    scale = float(dg_r.abs().max())
+    assert float(torch.quantile(d[:2_000_000], 0.999)) < 20 * TOL * scale and float(d.mean()) < TOL * scale, "dgates"
+    if not first:
+        assert rel_err(dc_g, dc_r) < 10 * TOL, "dc"

@@ -43,6 +43,15 @@ struct WdgHalo {
     const float* c_prev;
     float* c_out;
     float* h_out;
+    // backward step (lstm_bwd != 0, data-gradient direction, Ncols = lstm_F): Out is dh_{t-1} — the accumulated result is the
+    // complete gradient of h_{t-1}, so the cell backward of timestep t-1 follows in the epilogue: reads gates / c of t-1 and the
+    // dc flowing in from t, writes dgates_{t-1} and (dc_out != NULL) the dc flowing on to t-2.  c_prev == NULL at t-1 = 0.
+    int lstm_bwd;
+    const float* gates_t;     // [pixel][4 * lstm_F] pre-activations of the timestep whose cell is differentiated
+    const float* c_cur;       // its cell state
+    const float* dc_in;
+    float* dgates_out;
+    float* dc_out;
 };
 
 // WG = 1: the weight fragments are read straight from global memory (they are a few hundred KB, L1/L2
@@ -236,8 +245,66 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
             *reinterpret_cast<f32x4*>(dst + n) = v;
             if constexpr (NT == 4 || NT == 1) acc[a][b] = v;     // (the cell update below needs the complete pre-activations)
         }
+        if constexpr (NT == 1) {
+            if (p.lstm_bwd) {
+                // ConvLSTM cell backward (the arithmetic of wdg_lstm_bwd, pointwise.hip) for the features this lane holds
+                const int F = p.lstm_F;
+                const long long pix = (long long)img * p.Ho * p.Wo + (long long)oy * p.Wo + ox;
+                auto hs = [](float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); };
+                auto hsg = [](float x) { const float v = 0.2f * x + 0.5f; return (v >= 0.f && v <= 1.f) ? 0.2f : 0.f; };
+                if ((F & 3) == 0) {
+                    // 16 features: this lane's four features are contiguous in every slab -> 16-byte accesses
+                    const int f0 = 4 * lg;
+                    const float* g = p.gates_t + pix * 4 * F + f0;
+                    const f32x4 xi = *reinterpret_cast<const f32x4*>(g), xf = *reinterpret_cast<const f32x4*>(g + F);
+                    const f32x4 xc = *reinterpret_cast<const f32x4*>(g + 2 * F), xo = *reinterpret_cast<const f32x4*>(g + 3 * F);
+                    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 cp = p.c_prev ? *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.ldc + f0) : z4;
+                    const f32x4 cc = *reinterpret_cast<const f32x4*>(p.c_cur + pix * p.ldc + f0);
+                    const f32x4 dci = *reinterpret_cast<const f32x4*>(p.dc_in + pix * p.ldc + f0);
+                    f32x4 di, df, dcc, dob, dcp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gi = hs(xi[r]), gf = hs(xf[r]), gc = tanhf(xc[r]), go = hs(xo[r]);
+                        const float tc = tanhf(cc[r]);
+                        const float dhv = acc[a][0][r];
+                        const float dc = dhv * go * (1.f - tc * tc) + dci[r];
+                        di[r] = dc * gc * hsg(xi[r]);
+                        df[r] = dc * cp[r] * hsg(xf[r]);
+                        dcc[r] = dc * gi * (1.f - gc * gc);
+                        dob[r] = dhv * tc * hsg(xo[r]);
+                        dcp[r] = dc * gf;
+                    }
+                    float* dg = p.dgates_out + pix * 4 * F + f0;
+                    *reinterpret_cast<f32x4*>(dg) = di;
+                    *reinterpret_cast<f32x4*>(dg + F) = df;
+                    *reinterpret_cast<f32x4*>(dg + 2 * F) = dcc;
+                    *reinterpret_cast<f32x4*>(dg + 3 * F) = dob;
+                    if (p.dc_out) *reinterpret_cast<f32x4*>(p.dc_out + pix * p.ldc + f0) = dcp;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = 4 * lg + r;
+                        if (f >= F) continue;
+                        const float* g = p.gates_t + pix * 4 * F;
+                        const float xi = g[f], xf = g[F + f], xc = g[2 * F + f], xo = g[3 * F + f];
+                        const float gi = hs(xi), gf = hs(xf), gc = tanhf(xc), go = hs(xo);
+                        const float cp = p.c_prev ? p.c_prev[pix * p.ldc + f] : 0.f;
+                        const float tc = tanhf(p.c_cur[pix * p.ldc + f]);
+                        const float dhv = acc[a][0][r];
+                        const float dc = dhv * go * (1.f - tc * tc) + p.dc_in[pix * p.ldc + f];
+                        float* dg = p.dgates_out + pix * 4 * F;
+                        dg[f] = dc * gc * hsg(xi);
+                        dg[F + f] = dc * cp * hsg(xf);
+                        dg[2 * F + f] = dc * gi * (1.f - gc * gc);
+                        dg[3 * F + f] = dhv * tc * hsg(xo);
+                        if (p.dc_out) p.dc_out[pix * p.ldc + f] = dc * gf;
+                    }
+                }
+            }
+        }
         if constexpr (NT == 4 || NT == 1) {
-            if (p.lstm_F) {
+            if (p.lstm_F && !p.lstm_bwd) {
                 // cell update on the accumulators: Keras hard_sigmoid / tanh, c = f * c_prev + i * c~, h = o * tanh(c)
                 // (the same arithmetic as wdg_lstm_fwd, pointwise.hip)
                 auto hs = [](float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); };
@@ -468,6 +535,8 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     memset(&p, 0, sizeof(p));
     if (cell) {
         p.lstm_F = cell->F; p.c_prev = cell->c_prev; p.c_out = cell->c_out; p.h_out = cell->h_out; p.ldc = cell->ldc; p.ldh = cell->ldh;
+        p.lstm_bwd = cell->bwd; p.gates_t = cell->gates_t; p.c_cur = cell->c_cur; p.dc_in = cell->dc_in;
+        p.dgates_out = cell->dgates_out; p.dc_out = cell->dc_out;
     }
     p.A = A; p.B = Bw; p.Out = Out; p.bias = bias;
     p.n_img = g.n_img; p.ldA = ldA; p.imgStrideA = imgStrideA;
@@ -552,10 +621,10 @@ extern "C" int wdg_upconv_fwd(const wdg_conv_plan* pl, const float* x_low, int l
 
 // ---- ConvLSTM2D recurrent step in one launch (models.py:93,101 at n_timesteps > 1): recurrent 3x3 convolution of h_{t-1}
 // accumulated onto the input part of the gates (left in `gates` as the pre-activations the backward pass reads) + cell update.
-static int g_lstm_step_fused = 1;
+static int g_lstm_step_fused = 3;       // bit 0: forward step, bit 1: backward step
 void wdg_halo_set_lstm_fused(int v) { g_lstm_step_fused = v; }
 extern "C" int wdg_convlstm_step_supported(const wdg_conv_plan* pl, int F) {
-    if (!pl || !g_lstm_step_fused) return 0;
+    if (!pl || !(g_lstm_step_fused & 1)) return 0;
     const wdg_conv_geom& g = pl->g;
     if (g.Cout != 4 * F || g.stride != 1 || g.ldy != 4 * F || g.img_stride_y != (int64_t)g.Ho * g.Wo * 4 * F) return 0;
     return (F == 16 && pl->halo_fwd_nt == 4) || (F == 2 && pl->halo_fwd_nt == 1);
@@ -565,6 +634,31 @@ extern "C" int wdg_convlstm_step(const wdg_conv_plan* pl, const float* h_prev, c
     WDG_CHECK_ARG(pl && h_prev && wF && gates && c_prev && c_out && h_out && wdg_convlstm_step_supported(pl, F), "not supported for this geometry");
     WDG_CHECK_ARG(ldc >= F && ldh >= F && (F != 16 || (ldc % 4 == 0 && ldh % 4 == 0 && (((uintptr_t)c_prev | (uintptr_t)c_out | (uintptr_t)h_out) & 15) == 0)),
                   "bad strides / alignment");
-    WdgHaloLstm cell = {F, ldc, ldh, c_prev, c_out, h_out};
+    WdgHaloLstm cell;
+    memset(&cell, 0, sizeof(cell));
+    cell.F = F; cell.ldc = ldc; cell.ldh = ldh; cell.c_prev = c_prev; cell.c_out = c_out; cell.h_out = h_out;
     return wdg_halo_launch(pl, false, h_prev, pl->g.ldx, pl->g.img_stride_x, 0, wF, nullptr, gates, 0, 0.f, 1, (hipStream_t)stream, &cell);
+}
+
+// backward counterpart: dh_prev += conv_transpose(dgates_next, wD) — now the complete gradient of h_{t-1} — followed by the cell
+// backward of timestep t-1 in the epilogue (gates_t, c_prev (NULL at t-1 = 0), c_cur, dc_in -> dgates_out, dc_out (NULL: not needed))
+extern "C" int wdg_convlstm_bwd_step_supported(const wdg_conv_plan* pl, int F) {
+    if (!pl || !(g_lstm_step_fused & 2)) return 0;
+    const wdg_conv_geom& g = pl->g;
+    if (g.Cout != 4 * F || g.Cin != F || g.stride != 1 || g.ldy != 4 * F || g.img_stride_y != (int64_t)g.Ho * g.Wo * 4 * F ||
+        g.H != g.Ho || g.W != g.Wo)
+        return 0;
+    return (F == 16 || F == 2) && pl->halo_dgrad_nt == 1;
+}
+extern "C" int wdg_convlstm_bwd_step(const wdg_conv_plan* pl, const float* dgates_next, const float* wD, float* dh_prev,
+                                     const float* gates_t, const float* c_prev, const float* c_cur, const float* dc_in,
+                                     float* dgates_out, float* dc_out, int ldc, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && dgates_next && wD && dh_prev && gates_t && c_cur && dc_in && dgates_out && wdg_convlstm_bwd_step_supported(pl, F),
+                  "not supported for this geometry");
+    WDG_CHECK_ARG(ldc >= F, "bad stride");
+    WdgHaloLstm cell;
+    memset(&cell, 0, sizeof(cell));
+    cell.F = F; cell.ldc = ldc; cell.bwd = 1; cell.c_prev = c_prev; cell.gates_t = gates_t; cell.c_cur = c_cur; cell.dc_in = dc_in;
+    cell.dgates_out = dgates_out; cell.dc_out = dc_out;
+    return wdg_halo_launch(pl, true, dgates_next, pl->g.ldy, pl->g.img_stride_y, 0, wD, nullptr, dh_prev, 0, 0.f, 1, (hipStream_t)stream, &cell);
 }

@@ -66,11 +66,17 @@ void wdg_halo_set_th4(int v);
 void wdg_halo_set_max_cin(int v);
 void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
 void wdg_h16_set_lstm_fused(int v);
-struct WdgHaloLstm {   // ConvLSTM cell update in the epilogue of the recurrent convolution (conv_halo.hip)
+struct WdgHaloLstm {   // ConvLSTM cell update / cell backward in the epilogue of the recurrent convolution (conv_halo.hip)
     int F, ldc, ldh;
     const float* c_prev;
     float* c_out;
     float* h_out;
+    int bwd;
+    const float* gates_t;
+    const float* c_cur;
+    const float* dc_in;
+    float* dgates_out;
+    float* dc_out;
 };
 void wdg_halo_set_lstm_fused(int v);
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,

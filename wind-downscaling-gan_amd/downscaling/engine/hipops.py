@@ -368,6 +368,18 @@ class HipOps:
         native.check(self.lib.wdg_convlstm_step(plan, h_prev.data_ptr(), pk.wF.data_ptr(), gates_t.data_ptr(), c_prev.data_ptr(),
                                                 c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F, self.stream), "convlstm_step")
 
+    def convlstm_bwd_step_supported(self, dh_prev, dgates_t, pk, g, F):
+        plan, _, _ = self._plan(dh_prev, dgates_t, pk.cin, pk.cout, g)
+        return pk.wD is not None and bool(self.lib.wdg_convlstm_bwd_step_supported(plan, F))
+
+    def convlstm_bwd_step(self, dgates_next, pk, dh_prev, gates_t, c_prev, c_cur, dc_in, dgates_out, dc_out, g, F):
+        """dh_prev += conv_transpose(dgates_next); then the cell backward of that timestep -> dgates_out, dc_out (may be None)."""
+        plan, _, _ = self._plan(dh_prev, dgates_next, pk.cin, pk.cout, g)
+        _, ldc, _ = _v4(c_cur)
+        native.check(self.lib.wdg_convlstm_bwd_step(plan, dgates_next.data_ptr(), pk.wD.data_ptr(), dh_prev.data_ptr(), gates_t.data_ptr(),
+                                                    _ptr(c_prev), c_cur.data_ptr(), dc_in.data_ptr(), dgates_out.data_ptr(), _ptr(dc_out),
+                                                    ldc, F, self.stream), "convlstm_bwd_step")
+
     def convlstm16_supported(self, x, gates, pk, g, F):
         """16-bit ConvLSTM with the cell update in the recurrent convolution's epilogue (wdg_convlstm_step_h16)?"""
         plan, _, _ = self._plan(x, gates, pk.cin, pk.cout, g)

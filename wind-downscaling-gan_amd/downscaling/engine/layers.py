@@ -329,15 +329,25 @@ class ConvLSTM:
         if seq:
             o.convlstm_seq_bwd(self.gates, self.c, self.wh.value, dh, self.dgates, B, T, self.cin, F, self._seq_scratch)
         dc_in = None
+        # one launch per timestep where the halo-tile kernel runs the recurrent data gradient (the discriminator's ConvLSTMs):
+        # dh_{t-1} += conv_transpose(dgates_t) and, in the same epilogue, the cell backward of timestep t-1
+        bstep = (not seq) and T > 1 and hasattr(o, "convlstm_bwd_step_supported") and \
+            o.convlstm_bwd_step_supported(dh[:B], self.dgates[:B], self.pkh, self.g, F)
         for t in range(T - 1, -1, -1) if not seq else ():
             sl = slice(t * B, (t + 1) * B)
             pv = slice((t - 1) * B, t * B)
             dc_out = self.dc[t & 1] if t > 0 else None
-            o.lstm_bwd(v2(self.gates[sl]), v2(self.c[pv]) if t > 0 else None, v2(self.c[sl]), v2(dh[sl]),
-                       v2(dc_in) if dc_in is not None else None, v2(self.dgates[sl]),
-                       v2(dc_out) if dc_out is not None else None, F)
+            if not (bstep and t < T - 1):          # (fused mode: the previous iteration's launch already did this cell backward)
+                o.lstm_bwd(v2(self.gates[sl]), v2(self.c[pv]) if t > 0 else None, v2(self.c[sl]), v2(dh[sl]),
+                           v2(dc_in) if dc_in is not None else None, v2(self.dgates[sl]),
+                           v2(dc_out) if dc_out is not None else None, F)
             if t > 0:
-                o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
+                if bstep:
+                    pp = slice((t - 2) * B, (t - 1) * B)
+                    o.convlstm_bwd_step(self.dgates[sl], self.pkh, dh[pv], self.gates[pv], self.c[pp] if t > 1 else None, self.c[pv],
+                                        dc_out, self.dgates[pv], self.dc[(t - 1) & 1] if t > 1 else None, self.g, F)
+                else:
+                    o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
             dc_in = dc_out
         if need_wgrad:
             o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True)
