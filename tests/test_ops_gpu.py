@@ -818,3 +818,19 @@ def test_convlstm_recurrent_bwd_step_fused(hip_ops, ref_ops, F, cinp, n, H, W, f
     assert float(torch.quantile(d[:2_000_000], 0.999)) < 20 * TOL * scale and float(d.mean()) < TOL * scale, "dgates"
     if not first:
         assert rel_err(dc_g, dc_r) < 10 * TOL, "dc"
+
+
+@pytest.mark.parametrize("P,C,ld", [(100003, 64, 64), (5000, 4, 4), (7777, 8, 8), (9001, 16, 16), (30011, 128, 160), (4097, 512, 512),
+                                    (2500, 12, 12), (3001, 2, 4), (70000, 64, 68), (5, 64, 64)])
+def test_colsum_shapes(hip_ops, ref_ops, P, C, ld):
+    """Bias gradients (column sums over pixels): few and many channels, dense and strided rows, ragged row counts, overwrite and
+    accumulate.  (A 16-byte-per-lane form of the kernel was measured no faster — T = 24 step 107.1 vs 106.2 ms — and dropped.)"""
+    gen = torch.Generator().manual_seed(P + C)
+    x = torch.randn(P, ld, generator=gen, dtype=torch.float64)
+    xg = x.float().to(hip_ops.device)
+    for accumulate in (False, True):
+        o_r = torch.linspace(-1, 1, C, dtype=torch.float64)
+        o_g = o_r.float().to(hip_ops.device)
+        ref_ops.colsum(x[:, :C].float().double(), o_r, accumulate=accumulate)
+        hip_ops.colsum(xg[:, :C], o_g, accumulate=accumulate)
+        assert float((o_g.double().cpu() - o_r).abs().max()) < 2e-5 * max(1.0, float(o_r.abs().max())) * max(1.0, (P / 1e4) ** 0.5), accumulate
