@@ -87,6 +87,27 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // accumulate mode (the per-timestep recurrent convolutions): the tile's current contents are requested NOW, all at once,
+    // and consumed in the epilogue — read there one by one (each behind the previous store, which may alias) they cost one
+    // exposed memory round trip per 16-byte piece
+    constexpr bool PRE = TH == 4;          // (the 8-row tiles have no registers to spare: 216 -> 276 VGPRs with the prefetch)
+    f32x4 old[PRE ? NA : 1][PRE ? NT : 1];
+    if (PRE && p.accumulate) {
+        const int NcP0 = (p.Ncols + 3) & ~3;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int oy = oy0 + RPW * wave + (a >> 1);
+            const int ox = ox0 + (a & 1) * 16 + li;
+            const bool ok = oy < p.Ho && ox < p.Wo;
+            const float* src = p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = b * 16 + 4 * lg;
+                old[PRE ? a : 0][PRE ? b : 0] = (ok && n < NcP0) ? *reinterpret_cast<const f32x4*>(src + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+
     const int nchunk = (p.C4 + 3) >> 2;
     const bool flat = p.C4 < 4;   // fewer than 16 channels: pack (tap, channel-group) pairs densely into the MFMA k
     for (int ck = 0; ck < nchunk; ++ck) {
@@ -241,7 +262,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                 if (p.bias && n + r < p.Ncols) v[r] += p.bias[n + r];
                 if (p.act) v[r] = wdg_lrelu(v[r], p.slope);
             }
-            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst + n);
+            if (p.accumulate) v += PRE ? old[PRE ? a : 0][PRE ? b : 0] : *reinterpret_cast<const f32x4*>(dst + n);
             *reinterpret_cast<f32x4*>(dst + n) = v;
             if constexpr (NT == 4 || NT == 1) acc[a][b] = v;     // (the cell update below needs the complete pre-activations)
         }
@@ -469,8 +490,9 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
 // ---- host side -------------------------------------------------------------------------------------
 static int halo_nt(int ncols) { return ncols <= 16 ? 1 : ncols <= 32 ? 2 : ncols <= 64 ? 4 : 0; }
 
+static int g_halo_wg_small = 0;   // weight path of the 4-row (small-launch) tiles: 0 LDS, 1 global, -1 follow g_halo_wg
 static int g_halo_wg = 1;   // wdg_set_tuning("halo_weights_global", 0/1)
-void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; }
+void wdg_halo_set_wg(int v) { g_halo_wg = v != 0; g_halo_wg_small = v >= 2 ? -1 : (v != 0); }   // 0 / 1: both tile sizes; 2: 8-row tiles global, 4-row tiles follow -> used by A/B runs
 static int g_halo_persistent = 1;   // wdg_set_tuning("halo_persistent", 0/1)
 static int g_halo_th4 = 1;          // wdg_set_tuning("halo_th4", 0/1): 4-row tiles for launches with fewer than two tiles per CU
 void wdg_halo_set_th4(int v) { g_halo_th4 = v != 0; }
@@ -580,7 +602,10 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     p.npix = wdg_round_up(p.halo_h * p.halo_w, 16);
     p.tiles_h = (p.Ho + th - 1) / th;
     p.tiles_w = (p.Wo + HALO_TW - 1) / HALO_TW;
-    const int wg = upsample ? 1 : g_halo_wg;   // the low-res staging tile takes the LDS of the weight stage
+    // weights: read from global memory inside the tap loop (big launches: many workgroups hide the latency, LDS stays free), or
+    // staged into LDS once per workgroup (small launches — the per-timestep recurrent steps: -1 % of the T = 24 step);
+    // upsample mode: the low-res staging tile takes the LDS of the weight stage
+    const int wg = upsample ? 1 : (th == 4 && g_halo_wg_small >= 0) ? g_halo_wg_small : g_halo_wg;
     p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
     const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg, upsample, th);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
