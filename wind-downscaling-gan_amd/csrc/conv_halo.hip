@@ -151,29 +151,54 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                 lds_a[kg * p.npix + pix] = v;
             }
         } else
-        // ---- stage the input halo: lanes run over pixels (conflict-free ds_write_b128)
-        for (int idx = t; idx < kgs * npr; idx += 256) {
-            const int kg = idx / npr;
-            const int pix = idx - kg * npr;
-            const int hy = pix / p.halo_w;
-            const int hx = pix - hy * p.halo_w;
-            const int gy = hy0 + hy, gx = hx0 + hx;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc)
-                v = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + (4 * ck + kg) * 4);
-            lds_a[kg * p.npix + pix] = v;
+        // ---- stage the input halo: lanes run over pixels (conflict-free ds_write_b128); four slots per thread in flight (one
+        // memory round trip per batch, not per slot: the small per-timestep launches are bound by these latency chains)
+        for (int base = 0; base < kgs * npr; base += 4 * 256) {
+            f32x4 v[4];
+            int slot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + t;
+                const int kg = idx / npr;
+                const int pix = idx - kg * npr;
+                const int hy = pix / p.halo_w;
+                const int hx = pix - hy * p.halo_w;
+                const int gy = hy0 + hy, gx = hx0 + hx;
+                const bool in = idx < kgs * npr;
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (in && (unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc)
+                    v[u] = *reinterpret_cast<const f32x4*>(Aimg + ((long long)gy * p.W + gx) * p.ldA + (4 * ck + kg) * 4);
+                slot[u] = in ? kg * p.npix + pix : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (slot[u] >= 0) lds_a[slot[u]] = v[u];
         }
-        // ---- stage this chunk's weights: [tap][kg][n] (kg < kgs only)
+        // ---- stage this chunk's weights: [tap][kg][n] (kg < kgs only); the tap offsets first, then four weight slots in flight
         if (!WG)
-        for (int idx = t; idx < p.ntaps * kgs * NW; idx += 256) {
-            const int n = idx % NW;
-            const int r = idx / NW;
-            const int kg = r % kgs;
-            const int tap = r / kgs;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (n < p.Ncols)
-                v = *reinterpret_cast<const f32x4*>(Bw + (long long)n * p.ldB + p.taps[tap].z + (4 * ck + kg) * 4);
-            lds_w[idx] = v;
+        for (int base = 0; base < p.ntaps * kgs * NW; base += 4 * 256) {
+            int woff[4], n_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + t;
+                const int n = idx % NW;
+                const int r = idx / NW;
+                const int kg = r % kgs;
+                const int tap = r / kgs;
+                n_[u] = (idx < p.ntaps * kgs * NW && n < p.Ncols) ? n : -1;
+                woff[u] = (idx < p.ntaps * kgs * NW ? p.taps[tap].z : 0) + (4 * ck + kg) * 4;
+            }
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (n_[u] >= 0) v[u] = *reinterpret_cast<const f32x4*>(Bw + (long long)n_[u] * p.ldB + woff[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + t;
+                if (idx < p.ntaps * kgs * NW) lds_w[idx] = v[u];
+            }
         }
         __syncthreads();
         if (!flat) {
