@@ -22,7 +22,6 @@ def main():
     from downscaling.engine import runtime
     import downscaling.api as api
     from downscaling.gan.models import make_generator
-    from oracle import torch_model as TM
     ops = runtime.get_ops()
     out = {}
     # ---- configs[0]
@@ -42,11 +41,9 @@ def main():
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     dt = sorted(ts)[len(ts) // 2]
-    w = {k: torch.tensor(v, dtype=torch.float64) for k, v in g.get_weights_dict().items()}
-    ref = TM.generator_forward(w, torch.tensor(image), torch.tensor(noise), False)
-    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
-    out["config0_generator_forward_128"] = {"ms": 1e3 * dt, "rel_err_vs_oracle": err}
-    assert err < 1e-4
+    # (timing only: the parity of this configuration against the fp64 restatement is asserted by tests/test_configs_gpu.py —
+    # measurement tools do not import oracle/)
+    out["config0_generator_forward_128"] = {"ms": 1e3 * dt, "finite": bool(torch.isfinite(y).all())}
     del g
     # ---- configs[3]: 24 x 1200 x 1200 field
     network = api.get_network(allow_random_init=True, random_seed=5)
