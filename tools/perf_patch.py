@@ -63,7 +63,7 @@ def main():
                 if r > 0:
                     times[(name, label)].append(e0.elapsed_time(e1))
             if key is not None:
-                lib.wdg_set_tuning(key, 1 if key in (b"patch_h16", b"patch_nloop") else 0)   # back to the default
+                lib.wdg_set_tuning(key, 1 if key in (b"patch_h16", b"patch_nloop", b"patch_flat") else 0)   # back to the default
     print(f"{'layer':36s} " + " ".join(f"{c[0]:>16s}" for c in cols) + "   (us; default: TFLOP/s, in+out TB/s)")
     for name, fn, flops, nbytes in cases:
         med = lambda l: sorted(l)[len(l) // 2]

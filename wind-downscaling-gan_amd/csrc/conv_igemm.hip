@@ -1290,6 +1290,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_h16_set_lstm_fused(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "patch_flat")) {
+        wdg_patch_h16_set_flat(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "patch_nloop")) {
         wdg_patch_h16_set_nloop(value);
         return WDG_OK;

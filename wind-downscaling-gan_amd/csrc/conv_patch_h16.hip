@@ -48,6 +48,9 @@ struct WdgPatchH16 {
     int fw_shift, tfx;         // fragment width 1 << fw_shift (16 or 4), fragments per fragment-row of the tile
     int TH, TW, PH, PW, PWs, pitch;   // tile, patch, columns per parity plane, slots per channel-group plane
     int CK8, nchunk, kcn;      // channel groups per chunk, chunks, K-steps per tap and chunk
+    int flat, nent;            // flat: one chunk whose group count is not a multiple of 4 (24 or 40 channels) — the K-steps walk the
+                               // flattened (tap, channel group) list, 4 entries each, instead of padding every tap to 4 groups
+    wdg_fastdiv div_kw;
     int tiles_x, tiles_y, tiles_n, ntn_blk;   // tiles_n counts workgroups along the channels, each doing ntn_blk channel tiles
     wdg_fastdiv div_tn, div_tx, div_ty, div_ck, div_pw;
 };
@@ -111,7 +114,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         opix[a] = (oy0 + oyl) * p.Wo + ox0 + oxl;
     }
 
-    const int nks = p.kh * p.kw * p.kcn;            // K-steps per chunk
+    const int nks = p.flat ? (p.nent + 3) >> 2 : p.kh * p.kw * p.kcn;            // K-steps per chunk
     const int nstage = (nks + 1) >> 1;
     const int npatch = p.CK8 * p.PH * p.PW;
     const int dummy_slot = p.CK8 * p.pitch;         // one spare slot behind the patch takes the stores of the tail threads
@@ -180,14 +183,24 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         };
         auto fetch_stage = [&](u32x4 (&r_)[B_LOADS]) {
             // the two K-steps of the stage; this thread serves K-step bh, channel group bq
-            const int kc0 = f_kc, kx0 = f_kx, ky0 = f_ky;
-            advance(f_kc, f_kx, f_ky);
-            const int kc1 = f_kc, kx1 = f_kx, ky1 = f_ky;
-            advance(f_kc, f_kx, f_ky);
-            const int kc = bh ? kc1 : kc0, kx = bh ? kx1 : kx0, ky = bh ? ky1 : ky0;
-            const int g8 = kc * 4 + bq;              // channel group inside the chunk
-            const bool kok = ky < p.kh && g8 < p.CK8 && !(DBG & 1);
-            const int koff = (ky * p.kw + kx) * p.Cin_p + (ck * p.CK8 + g8) * 8;
+            bool kok;
+            int koff;
+            if (p.flat) {
+                // (f_kc counts K-steps) entry j = (tap, group) = 4 * K-step + bq; the weights' reduction index of entry j is 8 * j
+                const int j = 4 * (f_kc + bh) + bq;
+                f_kc += 2;
+                kok = j < p.nent && !(DBG & 1);
+                koff = 8 * j;
+            } else {
+                const int kc0 = f_kc, kx0 = f_kx, ky0 = f_ky;
+                advance(f_kc, f_kx, f_ky);
+                const int kc1 = f_kc, kx1 = f_kx, ky1 = f_ky;
+                advance(f_kc, f_kx, f_ky);
+                const int kc = bh ? kc1 : kc0, kx = bh ? kx1 : kx0, ky = bh ? ky1 : ky0;
+                const int g8 = kc * 4 + bq;              // channel group inside the chunk
+                kok = ky < p.kh && g8 < p.CK8 && !(DBG & 1);
+                koff = (ky * p.kw + kx) * p.Cin_p + (ck * p.CK8 + g8) * 8;
+            }
 #pragma unroll
             for (int r = 0; r < B_LOADS; ++r)
                 r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB, (kok && b_row[r] >= 0) ? (int)((unsigned)(b_row[r] + koff) << 1) : (int)WDG_SRD_OOB, 0, 0);
@@ -200,6 +213,15 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         // the slot offset of a K-step's tap and channel group for this lane (K-steps past the end: offset 0, their weights are zero;
         // lanes whose channel group is past the chunk read group 0 for the same reason)
         auto tap_offset = [&]() {
+            if (p.flat) {
+                // this lane group's own (tap, channel group) entry; entries past the end read slot 0 (their weights are zero)
+                const int j = 4 * c_kc + lq;
+                ++c_kc;
+                const int tap = (int)wdg_fastdiv_do((unsigned)j, p.div_ck), g8 = j - tap * p.CK8;
+                const int ky = (int)wdg_fastdiv_do((unsigned)tap, p.div_kw), kx = tap - ky * p.kw;
+                const int o = (((ky << p.sshift) + (kx & (s - 1))) * p.PWs) + (kx >> p.sshift) + g8 * p.pitch;
+                return j < p.nent ? o : 0;
+            }
             const int g8 = c_kc * 4 + lq;
             const int o = (((c_ky << p.sshift) + (c_kx & (s - 1))) * p.PWs) + (c_kx >> p.sshift) + (g8 < p.CK8 ? g8 : 0) * p.pitch;
             const int r = c_ky < p.kh ? o : 0;
@@ -338,6 +360,8 @@ static int g_patch_h16 = 1;
 static int g_patch_dbg = 0;   // timing experiments (builds with -DWDG_PATCH_EXPERIMENTS): template DBG bit 0 no weight fetch, 1 no patch
                               // loads, 2 no MFMA, 3 no fragment reads, 4 no output stores, 5 no stage barriers
 void wdg_patch_h16_set_dbg(int v) { g_patch_dbg = v; }
+static int g_patch_flat = 1;             // flattened (tap, channel group) K-steps for 24- / 40-channel layers (tuning key patch_flat)
+void wdg_patch_h16_set_flat(int v) { g_patch_flat = v; }
 static int g_patch_nloop = 1;            // a workgroup walks all channel tiles of its pixel tile when the patch holds every channel
 void wdg_patch_h16_set_nloop(int v) { g_patch_nloop = v; }
 static int g_patch_budget = 44 * 1024;     // LDS bytes of a patch chunk: with the 32 KiB of weight stages two workgroups share a CU
@@ -465,6 +489,9 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     p.div_tx = wdg_fastdiv_make((unsigned)p.tiles_x);
     p.div_ty = wdg_fastdiv_make((unsigned)p.tiles_y);
     p.div_ck = wdg_fastdiv_make((unsigned)p.CK8);
+    p.div_kw = wdg_fastdiv_make((unsigned)g.kw);
+    p.nent = g.kh * g.kw * p.CK8;
+    p.flat = g_patch_flat && p.nchunk == 1 && (p.CK8 & 3) != 0 && p.Cin_p == p.CK8 * 8;
     p.div_pw = wdg_fastdiv_make((unsigned)p.PW);
     const long long blocks = tiles_px * p.tiles_n;
     if (blocks <= 0 || blocks >= (1LL << 31)) return 1;

@@ -88,6 +88,7 @@ void wdg_patch_h16_set(int v);
 void wdg_patch_h16_set_budget(int kib);
 void wdg_patch_h16_set_dbg(int v);
 void wdg_patch_h16_set_nloop(int v);
+void wdg_patch_h16_set_flat(int v);
 int wdg_patch_h16_eligible(const wdg_conv_plan* pl);
 // ConvLSTM gate columns: F features, columns interleaved (gate n & 3 of feature n >> 2).  c_out == NULL: plain convolution
 // that writes its columns interleaved (the input part of the gates); else the recurrent step with the cell update in the epilogue.
