@@ -248,3 +248,23 @@ def test_gapped_kernel_round_trips_in_tf_shape(cpu_backend, tmp_path):
     assert float(g2.net.params.by_name(key).value[..., 6:8].abs().max()) == 0.0   # the alignment rows are zero again
     lim = np.sqrt(6.0 / (25 * (F // 8) + 25 * (F // 4 + F)))                 # Keras glorot_uniform limit of the TF shape
     assert np.abs(w[key]).max() <= lim
+
+
+def test_lazy_noise_matches_the_time_major_stream(cpu_backend):
+    """FlexibleNoiseGenerator.lazy: the generator model draws the noise straight into its time-major input buffer; the
+    result equals a call with the explicit tensor built from the same Philox stream in (time, batch, x, y, channel) order."""
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    from downscaling.gan.models import make_generator
+    from oracle.torch_backend import philox_normal_np
+    S, T, B, nz = 8, 2, 3, 2
+    g = make_generator(S, 3, nz, 2, T, feature_channels=16)
+    low = np.random.default_rng(0).standard_normal((B, T, S, S, 3))
+    ng = FlexibleNoiseGenerator((B, T, S, S, nz), std=0.3, random_seed=7)
+    lazy = ng.lazy(bs=B)
+    assert lazy.shape == (B, T, S, S, nz) and ng.prng.offset == 0            # nothing drawn yet
+    out_lazy = g([low, lazy]).double().cpu().numpy()
+    n = B * T * S * S * nz
+    assert ng.prng.offset == (n + 3) // 4
+    explicit = (philox_normal_np(n, 7, 0) * 0.3).reshape(T, B, S, S, nz).transpose(1, 0, 2, 3, 4)
+    out_explicit = g([low, np.ascontiguousarray(explicit)]).double().cpu().numpy()
+    assert np.abs(out_lazy - out_explicit).max() < 1e-6 * max(1.0, np.abs(out_explicit).max())

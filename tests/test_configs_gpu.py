@@ -176,8 +176,11 @@ def test_config3_tiled_inference_1200_bf16(hip_ops):
     mean = s1 / n
     std = np.sqrt(s2 / n - mean * mean)
     tiles = np.stack([(f[:, rows_of[sy], sx:sx + 96] - mean) / std for sx, sy in keys[:ntile]], 0)
-    nn = ntile * 24 * 96 * 96 * 20
-    noise = (philox_normal_np(nn, network.noise_generator.prng.seed, 0) * api.NOISE_STD).reshape(ntile, 24, 96, 96, 20)
+    # the driver draws each group's noise straight into the generator's time-major input buffer (FlexibleNoiseGenerator.lazy):
+    # stream order (time, tile of the 16-tile group, x, y, channel) -> the first `ntile` tiles of every timestep's block
+    per_tile = 96 * 96 * 20
+    noise = np.stack([(philox_normal_np(ntile * per_tile, network.noise_generator.prng.seed, t * 16 * per_tile // 4) * api.NOISE_STD)
+                      .reshape(ntile, 96, 96, 20) for t in range(24)], axis=1)
     w = {k: torch.tensor(v, dtype=torch.float64) for k, v in gen.get_weights_dict().items()}
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     with torch.no_grad():

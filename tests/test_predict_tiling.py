@@ -33,10 +33,15 @@ def reference_predict(fields, weights, seed, api, overlap_factor):
     tensors = (tensors - np.nanmean(tensors, axis=(0, 1, 2), keepdims=True)) / np.nanstd(tensors, axis=(0, 1, 2), keepdims=True)
     preds, offset = [], 0
     group = api.BATCH_SIZE * 2
-    for t in range(math.ceil(len(tiles) / group)):
+    ngroups = math.ceil(len(tiles) / group)
+    for t in range(ngroups):
         x = tensors[t * group:(t + 1) * group]
-        n = x.shape[0] * SEQ * IMG * IMG * NZ
-        noise = (philox_normal_np(n, seed, offset) * STD).reshape(x.shape[0], SEQ, IMG, IMG, NZ)
+        # the driver draws the group's noise straight into the generator's time-major input buffer (FlexibleNoiseGenerator.lazy):
+        # stream order (time, tile, x, y, channel) at the batch size of the call — a short last group runs padded to a full one
+        bc = group if (x.shape[0] < group and ngroups > 1) else x.shape[0]
+        n = bc * SEQ * IMG * IMG * NZ
+        noise = (philox_normal_np(n, seed, offset) * STD).reshape(SEQ, bc, IMG, IMG, NZ).transpose(1, 0, 2, 3, 4)[:x.shape[0]]
+        noise = np.ascontiguousarray(noise)
         offset += (n + 3) // 4
         with torch.no_grad():
             preds.append(TM.generator_forward(weights, torch.tensor(x, dtype=torch.float64), torch.tensor(noise), False).numpy())

@@ -66,7 +66,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        gen([tiles, network.noise_generator(bs=16, channels=20)])
+        gen([tiles, network.noise_generator.lazy(bs=16, channels=20)])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     gf = 3.799e9  # SURVEY §8 d: S=96, T=24 algorithmic forward FLOPs per tile-timestep
@@ -79,7 +79,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        gen([tiles, network.noise_generator(bs=16, channels=20)])
+        gen([tiles, network.noise_generator.lazy(bs=16, channels=20)])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     out["config3_generator_only_16tiles_T24_bf16"] = {"ms_per_group": 1e3 * dt, "tile_timesteps_per_s": 16 * 24 / dt,
@@ -99,7 +99,7 @@ def main():
     t0 = time.perf_counter()
     ens = []
     for r in range(64):
-        ens.append(gen([tiles8, network.noise_generator(bs=8, channels=20)]))
+        ens.append(gen([tiles8, network.noise_generator.lazy(bs=8, channels=20)]))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     spread = float(torch.stack(ens).std(0).mean())
@@ -110,7 +110,7 @@ def main():
         t0 = time.perf_counter()
         ens16 = []
         for r in range(64):
-            ens16.append(gen([tiles8, network.noise_generator(bs=8, channels=20)]))
+            ens16.append(gen([tiles8, network.noise_generator.lazy(bs=8, channels=20)]))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         dev = float((torch.stack(ens16).mean(0) - ref_ens).abs().max() / ref_ens.abs().max())

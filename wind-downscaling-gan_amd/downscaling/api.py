@@ -224,14 +224,14 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
         for t in range(rank, num_groups, world):
             tensor = tensors[t * group_size:(t + 1) * group_size, ...]
             n_real = tensor.shape[0]
-            noise = network.noise_generator(bs=n_real, channels=NOISE_CHANNELS)
-            lap('noise')
             if n_real < group_size and num_groups > 1:
                 # a short last group runs at the resident batch size (zero tiles behind the real ones, their outputs unused):
                 # inference treats every tile independently, and the generator keeps its buffers, plans and graph
-                pad = group_size - n_real
-                tensor = torch.cat([tensor, tensor.new_zeros((pad,) + tuple(tensor.shape[1:]))], dim=0)
-                noise = torch.cat([noise, noise.new_zeros((pad,) + tuple(noise.shape[1:]))], dim=0)
+                tensor = torch.cat([tensor, tensor.new_zeros((group_size - n_real,) + tuple(tensor.shape[1:]))], dim=0)
+            # fresh noise per group (api.py:136), drawn by the generator model straight into its input buffer
+            # (FlexibleNoiseGenerator.lazy: stream order (time, tile, x, y, channel) for the batch size of the call)
+            noise = network.noise_generator.lazy(bs=tensor.shape[0], channels=NOISE_CHANNELS)
+            lap('noise')
             pred = gen([tensor, noise])                                            # stays on the device (api.py:137)
             lap('generator')
             for j, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):

@@ -7,6 +7,20 @@ from downscaling.engine import runtime
 from downscaling.engine.trainer import PhiloxSource
 
 
+class LazyNoise(object):
+    """A pending FlexibleNoiseGenerator draw (see FlexibleNoiseGenerator.lazy): `shape` is the (batch, time, x, y, channels)
+    shape the tensor would have; `fill(view2d)` writes the draw into a [time * batch * x * y, channels] view."""
+
+    is_lazy_noise = True
+
+    def __init__(self, generator, shape, std):
+        self.generator, self.shape, self.std = generator, tuple(shape), std
+
+    def fill(self, view2d):
+        assert view2d.shape[0] * view2d.shape[1] == int(np.prod(self.shape))
+        self.generator.prng.normal_into(view2d, self.std)
+
+
 class FlexibleNoiseGenerator(object):
     def __init__(self, noise_shape, std=1, random_seed=None, rank=0):
         self.noise_shape = noise_shape
@@ -32,6 +46,15 @@ class FlexibleNoiseGenerator(object):
         self.rank = rank
         if self._prng is not None and self.random_seed is not None:
             self._prng = PhiloxSource(self._prng.ops, self.random_seed, rank)
+
+    def lazy(self, bs=None, channels=None, std=None):
+        """The same draw as __call__, deferred: the generator model that receives the returned LazyNoise writes the Philox
+        stream straight into its (time-major) input buffer instead of copying a (batch, time, x, y, channels) tensor there.
+        Element order of the stream: (time, batch, x, y, channel) — as in training (engine.trainer) — so the values of a
+        given tile depend on the batch size of the call.  Extension of this build; the reference passes tensors."""
+        bs = self.noise_shape[0] if bs is None else int(bs)
+        channels = self.noise_shape[4] if channels is None else channels
+        return LazyNoise(self, (bs, self.noise_shape[1], self.noise_shape[2], self.noise_shape[3], channels), std or self.std)
 
     def __call__(self, bs=None, channels=None, std=None):
         bs = self.noise_shape[0] if bs is None else int(bs)

@@ -144,12 +144,17 @@ class Generator(_Model):
     def __call__(self, inputs, training=False, mask=None, precision=None):
         image, noise = inputs
         ops, net = self.ops, self.net
-        image, noise = _to_dev(image, ops), _to_dev(noise, ops)
+        lazy = getattr(noise, "is_lazy_noise", False)   # data_generator.LazyNoise: drawn straight into the input buffer
+        image = _to_dev(image, ops)
+        noise = noise if lazy else _to_dev(noise, ops)
         B, T = image.shape[0], image.shape[1]
         assert tuple(image.shape[1:]) == (net.T, net.S, net.S, net.in_channels), image.shape
         assert tuple(noise.shape) == (B, net.T, net.S, net.S, net.noise_channels), noise.shape
         net.set_image(image)
-        net.set_noise(noise)
+        if lazy:
+            noise.fill(net.noise_view(B))
+        else:
+            net.set_noise(noise)
         precision = precision or ("fp32" if training else self.inference_precision)
         if training or not self.graph_inference:
             out_tm = net.forward(B, bool(training), precision=precision)
