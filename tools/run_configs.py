@@ -84,10 +84,13 @@ def main():
     dt = (time.perf_counter() - t0) / 5
     out["config3_generator_only_16tiles_T24_bf16"] = {"ms_per_group": 1e3 * dt, "tile_timesteps_per_s": 16 * 24 / dt,
                                                       "rel_err_vs_fp32_path": rel}
-    t0 = time.perf_counter()
-    pred16 = api.predict_array(fields, overlap_factor=0.05, network=network)
-    torch.cuda.synchronize()
-    out["config3_tiled_inference_1200x1200x24_bf16"] = {"seconds_end_to_end": time.perf_counter() - t0,
+    runs = []
+    for _ in range(2):                 # single-shot wall times of a 0.1 s job scatter (allocator, first use of a graph): both are kept
+        t0 = time.perf_counter()
+        pred16 = api.predict_array(fields, overlap_factor=0.05, network=network)
+        torch.cuda.synchronize()
+        runs.append(time.perf_counter() - t0)
+    out["config3_tiled_inference_1200x1200x24_bf16"] = {"seconds_end_to_end": min(runs), "seconds_each_run": [round(r, 4) for r in runs],
                                                         "finite": bool(np.isfinite(pred16[:, cnt[0] > 0]).all())}
     phases = {}
     api.predict_array(fields, overlap_factor=0.05, network=network, timings=phases)    # (synchronises after every phase)
