@@ -479,6 +479,18 @@ int wdg_sumsq_batch_ch(const float* x, int ldx, int64_t pixels_per_img, int T, i
 int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out,
                        wdg_stream stream);
 
+/* Tile bookkeeping of the inference driver (api.py:96-151, `predict`) on the device.
+ * wdg_tiles_gather_normalise: keys4[n] = {sx, row0, k, 0}; tile n = field[k*T .. k*T+T-1][row0, row0-1, ...][sx .. sx+S-1][:]
+ *   (latitude flipped, api.py:119) -> tiles [N][T][S][S][C]; NaN-aware mean / population std per (column inside the tile,
+ *   channel) over all tiles, timesteps and rows (np.nanmean / np.nanstd over axes (0,1,2), api.py:126-129; fp64 sums, fp32
+ *   results in mean_std [S*C][2]); tiles are normalised in place.  stats_scratch: replicas * S*C * 3 doubles.
+ * wdg_tiles_blend: the first n_real predictions of a group [B][T][S][S][ldp] (2 channels used), cropped by `crop` pixels per
+ *   side, are added into acc [NT][LAT][LON][2] (fp64) and counted in cnt [NT][LAT][LON] (api.py:139-150). */
+int wdg_tiles_gather_normalise(const float* field, int LAT, int LON, int C, const int32_t* keys4, int N, int T, int S, float* tiles,
+                               double* stats_scratch, int replicas, float* mean_std, wdg_stream stream);
+int wdg_tiles_blend(const float* pred, int ldp, const int32_t* keys4, int n_real, int T, int S, int crop, int LAT, int LON, double* acc,
+                    int32_t* cnt, wdg_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Generator evaluation metrics (gan/metrics.py; compiled into the GAN by api.py:77-81 and updated by
  * every train step, ganbase.py:71).  real / fake: dense [B][T][H][W][2] wind fields.

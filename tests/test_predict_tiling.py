@@ -100,3 +100,39 @@ def test_predict_array_gpu(hip_ops):
     fields = rng.standard_normal((24, 100, 110, 3)).astype(np.float32)
     fields[..., 2] = fields[..., 2] * 800 + 1500
     _check(api, network, fields, 0.05, 1e-4)
+
+
+@pytest.mark.gpu
+def test_tiling_kernels_gpu():
+    """csrc/tiling.hip against the literal expressions of the driver (api.py:117-129 tile gather + np.nanmean / np.nanstd
+    normalisation; api.py:139-150 cropped sum / count), NaNs in the field, overlapping tiles inside one group."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from downscaling.engine.hipops import HipOps
+    ops = HipOps("cuda:0")
+    dev = ops.device
+    rng = np.random.default_rng(5)
+    Ttot, LAT, LON, C, T, S = 4, 70, 90, 3, 2, 24
+    field = rng.standard_normal((Ttot, LAT, LON, C)).astype(np.float32) * np.array([3, 5, 0.7], np.float32) + np.array([1, -2, 4], np.float32)
+    field[rng.random(field.shape) < 0.01] = np.nan
+    keys = [(sx, row0, k) for sx in (0, 20, 60) for row0 in (S, S + 13, LAT - 1) for k in (0, 1)]      # row0 = highest row of a tile
+    tiles = np.stack([field[k * T:(k + 1) * T, row0 - np.arange(S)][:, :, sx:sx + S] for (sx, row0, k) in keys], 0)
+    want = (tiles - np.nanmean(tiles, axis=(0, 1, 2), keepdims=True)) / np.nanstd(tiles, axis=(0, 1, 2), keepdims=True)
+    keys4 = torch.tensor([[sx, row0, k, 0] for (sx, row0, k) in keys], dtype=torch.int32, device=dev)
+    got = ops.tiles_gather_normalise(torch.tensor(field, device=dev), keys4, T, S).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) < 2e-5 * np.nanmax(np.abs(want))
+    # blend: 5 "real" tiles of a group of 7, crop 2
+    B, n_real, crop = 7, 5, 2
+    pred = rng.standard_normal((B, T, S, S, 2)).astype(np.float32)
+    acc = np.zeros((Ttot, LAT, LON, 2))
+    cnt = np.zeros((Ttot, LAT, LON), np.int32)
+    for j, (sx, row0, k) in enumerate(keys[:n_real]):
+        rows = (row0 - np.arange(S))[crop:-crop]
+        acc[k * T:(k + 1) * T, rows[:, None], np.arange(sx + crop, sx + S - crop)[None, :]] += pred[j][:, crop:-crop, crop:-crop]
+        cnt[k * T:(k + 1) * T, rows[:, None], np.arange(sx + crop, sx + S - crop)[None, :]] += 1
+    acc_g = torch.zeros(Ttot, LAT, LON, 2, dtype=torch.float64, device=dev)
+    cnt_g = torch.zeros(Ttot, LAT, LON, dtype=torch.int32, device=dev)
+    ops.tiles_blend(torch.tensor(pred, device=dev), keys4[:B].contiguous(), n_real, acc_g, cnt_g, crop)
+    assert np.array_equal(cnt_g.cpu().numpy(), cnt)
+    assert np.abs(acc_g.cpu().numpy() - acc).max() < 1e-12

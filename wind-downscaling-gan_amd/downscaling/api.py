@@ -202,17 +202,24 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     lat_ok = pixels_lat > IMG_SIZE or all(sy != 0 for sy in plan['slices_start_y'])
     if not lat_ok:
         raise RuntimeError('the sy == 0 tile needs lat row 96 (reference slice(IMG_SIZE, 0, -1)): lat dimension too small')
-    rows = {sy: torch.as_tensor(_tile_lat_index(sy).copy(), device=dev) for sy in plan['slices_start_y']}
-    tensors = torch.stack([f[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH].index_select(1, rows[sy])[:, :, sx:sx + IMG_SIZE]
-                           for (sx, sy, k) in keys], dim=0)                         # (N, T, H, W, C)
-    # nanmean / nanstd over axes (0, 1, 2), keepdims: one statistic per (lon index inside the tile, channel) — api.py:126-129
-    valid = ~torch.isnan(tensors)
-    n_valid = valid.sum(dim=(0, 1, 2), keepdim=True).double()
-    t64 = torch.where(valid, tensors, torch.zeros((), dtype=tensors.dtype, device=dev)).double()
-    mean = t64.sum(dim=(0, 1, 2), keepdim=True) / n_valid
-    var = (torch.where(valid, t64 - mean, torch.zeros((), dtype=torch.float64, device=dev)) ** 2).sum(dim=(0, 1, 2), keepdim=True) / n_valid
-    del t64
-    tensors = ((tensors - mean.to(tensors.dtype)) / var.sqrt().to(tensors.dtype)).to(dt)
+    native_tiles = hasattr(ops, "tiles_gather_normalise") and f.is_cuda and IMG_SIZE * f.shape[3] <= 512
+    if native_tiles:
+        # csrc/tiling.hip: one gather pass with the NaN-aware sums, one normalisation pass (keys: first column, first = highest
+        # row of the flipped tile, sequence index)
+        keys4 = torch.tensor([[sx, int(_tile_lat_index(sy)[0]), k, 0] for (sx, sy, k) in keys], dtype=torch.int32, device=dev)
+        tensors = ops.tiles_gather_normalise(f.contiguous(), keys4, SEQUENCE_LENGTH, IMG_SIZE).to(dt)
+    else:
+        rows = {sy: torch.as_tensor(_tile_lat_index(sy).copy(), device=dev) for sy in plan['slices_start_y']}
+        tensors = torch.stack([f[k * SEQUENCE_LENGTH:(k + 1) * SEQUENCE_LENGTH].index_select(1, rows[sy])[:, :, sx:sx + IMG_SIZE]
+                               for (sx, sy, k) in keys], dim=0)                         # (N, T, H, W, C)
+        # nanmean / nanstd over axes (0, 1, 2), keepdims: one statistic per (lon index inside the tile, channel) — api.py:126-129
+        valid = ~torch.isnan(tensors)
+        n_valid = valid.sum(dim=(0, 1, 2), keepdim=True).double()
+        t64 = torch.where(valid, tensors, torch.zeros((), dtype=tensors.dtype, device=dev)).double()
+        mean = t64.sum(dim=(0, 1, 2), keepdim=True) / n_valid
+        var = (torch.where(valid, t64 - mean, torch.zeros((), dtype=torch.float64, device=dev)) ** 2).sum(dim=(0, 1, 2), keepdim=True) / n_valid
+        del t64
+        tensors = ((tensors - mean.to(tensors.dtype)) / var.sqrt().to(tensors.dtype)).to(dt)
     nt = plan['ntimeseq'] * SEQUENCE_LENGTH
     acc = torch.zeros(nt, pixels_lat, pixels_lon, NB_OUTPUTS, dtype=torch.float64, device=dev)
     cnt = torch.zeros(nt, pixels_lat, pixels_lon, dtype=torch.int32, device=dev)
@@ -234,12 +241,15 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
             lap('noise')
             pred = gen([tensor, noise])                                            # stays on the device (api.py:137)
             lap('generator')
-            for j, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):
-                r = _tile_lat_index(sy)[2:-2]                                      # api.py:148: descending, contiguous
-                ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
-                rs, cs = slice(int(r[-1]), int(r[0]) + 1), slice(sx + 2, sx + IMG_SIZE - 2)
-                acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
-                cnt[ts, rs, cs] += 1
+            if native_tiles and pred.dtype == torch.float32:
+                ops.tiles_blend(pred.contiguous(), keys4[t * group_size:(t + 1) * group_size].contiguous(), n_real, acc, cnt, 2)
+            else:
+                for j, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):
+                    r = _tile_lat_index(sy)[2:-2]                                  # api.py:148: descending, contiguous
+                    ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
+                    rs, cs = slice(int(r[-1]), int(r[0]) + 1), slice(sx + 2, sx + IMG_SIZE - 2)
+                    acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
+                    cnt[ts, rs, cs] += 1
             lap('blend')
             print(f'Predicted {(t + 1) / num_groups:.0%}')
     cnt2d = np.zeros((plan['ntimeseq'], pixels_lat, pixels_lon), dtype=np.int32)   # every rank: the global count (one map per sequence)

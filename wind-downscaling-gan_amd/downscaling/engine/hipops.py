@@ -354,6 +354,28 @@ class HipOps:
         native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
                         y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_16")
 
+    # ---- tile bookkeeping of the inference driver (csrc/tiling.hip) ----------------------------------------------
+    def tiles_gather_normalise(self, field, keys4, T, S):
+        """field [Ttot, LAT, LON, C] fp32, keys4 [N, 4] int32 {sx, row0, k, 0} -> normalised tiles [N, T, S, S, C] (api.py:117-129)."""
+        assert field.is_contiguous() and field.dtype == torch.float32 and keys4.dtype == torch.int32 and keys4.is_contiguous()
+        _, LAT, LON, C = field.shape
+        N = keys4.shape[0]
+        tiles = torch.empty(N, T, S, S, C, dtype=torch.float32, device=field.device)
+        R = 64
+        scratch = torch.empty(R * S * C * 3, dtype=torch.float64, device=field.device)
+        mean_std = torch.empty(S * C, 2, dtype=torch.float32, device=field.device)
+        native.check(self.lib.wdg_tiles_gather_normalise(field.data_ptr(), LAT, LON, C, keys4.data_ptr(), N, T, S, tiles.data_ptr(),
+                                                         scratch.data_ptr(), R, mean_std.data_ptr(), self.stream), "tiles_gather_normalise")
+        return tiles
+
+    def tiles_blend(self, pred, keys4, n_real, acc, cnt, crop):
+        """acc[t, lat, lon, :] += pred tile values, cnt += 1 for the first n_real tiles of the group (api.py:139-150)."""
+        B, T, S, _, ldp = pred.shape
+        assert pred.is_contiguous() and acc.is_contiguous() and cnt.is_contiguous() and acc.dtype == torch.float64 and cnt.dtype == torch.int32
+        _, LAT, LON, _ = acc.shape
+        native.check(self.lib.wdg_tiles_blend(pred.data_ptr(), ldp, keys4.data_ptr(), n_real, T, S, crop, LAT, LON, acc.data_ptr(),
+                                              cnt.data_ptr(), self.stream), "tiles_blend")
+
     def convlstm_step_supported(self, h_prev, gates_t, pk, g, F):
         """fp32 ConvLSTM recurrent step in one launch (wdg_convlstm_step: halo-tile kernel with the cell update in its epilogue)?"""
         plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)

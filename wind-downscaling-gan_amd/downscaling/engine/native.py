@@ -44,6 +44,8 @@ SIGNATURES = {
     "wdg_convlstm_h16_supported": (i32, [c_fp, i32]),
     "wdg_conv_fwd_h16_gates": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_step_h16": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
+    "wdg_tiles_gather_normalise": (i32, [c_fp, i32, i32, i32, c_fp, i32, i32, i32, c_fp, c_fp, i32, c_fp, c_fp]),
+    "wdg_tiles_blend": (i32, [c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     "wdg_split_bf16x3": (i32, [c_fp, c_fp, i64, c_fp]),
     "wdg_split_register": (i32, [c_fp, c_fp, i64]),
     "wdg_conv_plan_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom)]),
