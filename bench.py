@@ -425,7 +425,7 @@ def main():
         elif headline and world == 1 and not args.no_split_leg and hasattr(ops, "set_split_mode"):
             # NOT the headline: the same steps with the forward / data-gradient implicit GEMMs computing every fp32 product
             # from three exact bf16 slices per operand (conv_igemm.hip PIPE 4; fp32-rounding accuracy, all GPU parity tests
-            # pass with it at unchanged tolerances: profiles/r02w_gpu_tests_split.log).  Reported beside the fp32-MFMA line.
+            # pass with it at unchanged tolerances: profiles/r02zz_gpu_tests_split.log).  Reported beside the fp32-MFMA line.
             try:
                 ops.set_split_mode(True)
                 gan.train_step((low, high))

@@ -637,7 +637,7 @@ class HipOps:
     # ---- ConvLSTM over a whole sequence in one persistent launch (csrc/convlstm_seq.hip) ---------------
     def convlstm_seq_supported(self, cin, F, h=None):
         """(cin, F) has a sequence kernel, it is switched on, and (when given) the h buffer meets its line-alignment rule.
-        OFF by default: measured on MI355X (profiles/r02h_kernel_stats_T24_seq.csv) the persistent kernels are correct but
+        OFF by default: measured on MI355X (profiles/r02h_kernel_stats_T24_seq_negative.csv) the persistent kernels are correct but
         SLOWER than the per-timestep launches at the shipped shape (96 x 96 x 8 tiles, T = 24): 4.2 vs ~1.4 ms per pass
         for the 5 -> 16 layer — the per-tile hand-off (sequential polls of 8 neighbour counters + an agent-scope release
         that writes the L2 back) costs ~30 us per tile and step, and with 2.25 tiles per workgroup the scalar-fed fp32
