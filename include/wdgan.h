@@ -105,7 +105,9 @@ int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, 
  * is the exact sum of three bf16 slices and six slice products on v_mfma_f32_16x16x32_bf16 reproduce the fp32 product to
  * 2^-24 relative.  wdg_split_bf16x3 writes the three slices of n floats as [3][n] bf16 (dst3: 3*n*2 + 16 bytes);
  * wdg_split_register tells the conv entry points that `w32` (a packed weight buffer passed as wF / wD) has the up-to-date
- * slice copy `w3` (NULL: forget it) — unregistered weights are sliced inside the kernel.  No reference counterpart (TF
+ * slice copy `w3` (NULL: forget it) — unregistered weights are sliced inside the kernel.  The registry is a process-wide map
+ * keyed by device address, written and read on the launching thread only (not thread-safe; the Python side re-registers at
+ * every use because the allocator recycles addresses).  No reference counterpart (TF
  * computes these convolutions in fp32: gan/models.py:33-70). */
 int wdg_split_bf16x3(const float* src, void* dst3, int64_t n, wdg_stream stream);
 int wdg_split_register(const float* w32, const void* w3, int64_t n);
