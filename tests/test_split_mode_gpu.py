@@ -26,11 +26,12 @@ CASES = [
 
 @pytest.fixture()
 def split_ops(hip_ops):
+    before = hip_ops.split_mode             # (True when the whole suite runs with WDG_SPLIT=1)
     hip_ops.set_split_mode(True)
     try:
         yield hip_ops
     finally:
-        hip_ops.set_split_mode(False)
+        hip_ops.set_split_mode(before)
 
 
 def _mk(case, seed=3):
