@@ -158,4 +158,6 @@ def test_convlstm16_fused_step_matches_unfused(hip_ops, S, T, F, fmt):
     x = net.buffers(B)["cat4"][..., F // 2:]
     assert hip_ops.convlstm16_supported(x, net.lstm.gates, net.lstm.pkx, net.lstm.g, F), "the fused path must be the one tested"
     assert rel_err(outs[0][1], outs[1][1]) < 2e-5, "hidden states"
-    assert rel_err(outs[0][0], outs[1][0]) < 2e-4, "generator output (16-bit layers behind the ConvLSTM re-round the tiny difference)"
+    # behind the ConvLSTM every 16-bit layer re-rounds its input: a 1e-7 difference in h flips an occasional operand by one 16-bit
+    # ulp (bf16 4e-3, fp16 5e-4 relative), so the outputs agree to a few operand ulps at isolated pixels, not to fp32 noise
+    assert rel_err(outs[0][0], outs[1][0]) < (1e-2 if fmt == "bf16" else 2e-3), "generator output"

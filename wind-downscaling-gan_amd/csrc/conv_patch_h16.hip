@@ -304,16 +304,25 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             const int n = nw0 + b * 16 + 4 * lq;
             if (n >= p.Ncols) continue;
             const int f = n >> 2;
+            // all of this column tile's inputs first (one memory round trip), then the arithmetic and the stores: read one by
+            // one, every load waits behind the previous pixel's stores (possible aliases) — 12 exposed round trips per wave
+            f32x4 gx[MT];
+            float cp[MT];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
-                const f32x4 z = acc[a][b] + *reinterpret_cast<const f32x4*>(p.gates_x + pix * (4 * p.gate_F) + n);
+                gx[a] = *reinterpret_cast<const f32x4*>(p.gates_x + pix * (4 * p.gate_F) + n);
+                cp[a] = p.c_prev ? p.c_prev[pix * p.ldc + f] : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
+                const f32x4 z = acc[a][b] + gx[a];
                 const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
                 const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
                 const float gc = tanhf(z[2]);
                 const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
-                float cn = gi * gc;
-                if (p.c_prev) cn += gf * p.c_prev[pix * p.ldc + f];
+                const float cn = gi * gc + gf * cp[a];
                 p.c_out[pix * p.ldc + f] = cn;
                 outImg[(long long)opix[a] * p.ldO + f] = go * tanhf(cn);
             }
