@@ -268,3 +268,22 @@ def test_lazy_noise_matches_the_time_major_stream(cpu_backend):
     explicit = (philox_normal_np(n, 7, 0) * 0.3).reshape(T, B, S, S, nz).transpose(1, 0, 2, 3, 4)
     out_explicit = g([low, np.ascontiguousarray(explicit)]).double().cpu().numpy()
     assert np.abs(out_lazy - out_explicit).max() < 1e-6 * max(1.0, np.abs(out_explicit).max())
+
+
+def test_downscale_console_script_is_declared():
+    """/root/reference/setup.py:12-16 installs `downscale = downscaling.cli:main`; pyproject.toml declares the same entry
+    point and it resolves to the CLI's main (which parses the reference's flags: --era/--dem/--date required)."""
+    import importlib
+    from pathlib import Path
+
+    import pytest
+    import tomli
+    meta = tomli.loads((Path(__file__).resolve().parent.parent / "pyproject.toml").read_text())
+    target = meta["project"]["scripts"]["downscale"]
+    assert target == "downscaling.cli:main"
+    mod, fn = target.split(":")
+    main = getattr(importlib.import_module(mod), fn)
+    with pytest.raises(SystemExit) as e:
+        main([])                                  # argparse: the three required flags are missing
+    assert e.value.code == 2
+    assert meta["tool"]["setuptools"]["packages"]["find"]["where"] == ["wind-downscaling-gan_amd"]

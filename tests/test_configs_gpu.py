@@ -105,19 +105,26 @@ def test_config2_bench_launch_two_ranks():
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2+syncbn"
     assert out["config"]["global_batch"] == 4 and out["scaling"] == "weak" and out["steps"] == 1
     assert out["value"] > 0 and all(np.isfinite(v) for v in out["losses"].values())
+    # the line carries what the collectives spanned (here: two processes on the one device, host-staged gloo)
+    rc = out["rccl"]
+    assert rc["world_size"] == 2 and [d["rank"] for d in rc["devices"]] == [0, 1] and len({d["pid"] for d in rc["devices"]}) == 2
+    assert rc["backend"].startswith("gloo") and rc["d_grad_allreduce_bytes"] > 0 and rc["allreduce_ms"] > 0 and rc["sync_bn"]
 
 
 @pytest.mark.timeout(1200)
 def test_config2_rccl_collectives_single_rank():
     """The "nccl" (= RCCL) branch itself: init_process_group("nccl", device_id=...), asynchronous all-reduce of the flat
     gradient buffers on RCCL's stream, deferred Adam, SyncBN statistics (fp64) and the scalar-metric reduce, on a
-    one-rank group — identity collectives, so the step must equal the undistributed one to the last bit."""
+    one-rank group — identity collectives, so the step must equal the undistributed one (to 1e-4 on the logged losses: fp32
+    atomics in a few reductions make the last bits run-dependent, so bit equality is not asserted)."""
     common = ["--gpus", "1", "--batch", "2", "--size", "32", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
     a = _torchrun_bench({"WDG_DIST_BACKEND": "nccl", "WDG_DIST_ALWAYS": "1"}, 1, common)
     assert a["config"]["parallelism"] == "dp1+syncbn"
+    assert a["rccl"]["backend"].startswith("nccl") and a["rccl"]["world_size"] == 1 and a["rccl"]["distinct_devices"] == 1
+    assert a["rccl"]["devices"][0]["name"] and a["rccl"]["grad_allreduce_bytes_per_step"] > a["rccl"]["d_grad_allreduce_bytes"]
     b = _torchrun_bench({}, 1, common)
     assert b["config"]["parallelism"] == "dp1"
-    for k, v in b["losses"].items():          # (fp32 atomics in a few reductions make the last bits run-dependent)
+    for k, v in b["losses"].items():
         assert abs(a["losses"][k] - v) <= 1e-4 * max(1.0, abs(v)), (k, a["losses"][k], v)
 
 
@@ -246,6 +253,37 @@ def test_config4_ensemble_fp16(hip_ops):
         ref = TM.generator_forward(w, tiles[:1].double().cpu(), torch.tensor(nz), False)
     assert rel_err(e32[0, :1], ref) < 1e-4
     assert rel_err(e16[0, :1], ref) < 4e-3
+
+
+@pytest.mark.timeout(1200)
+def test_config4_predict_ensemble_api(hip_ops):
+    """api.predict_ensemble (configs[4]): every realisation on its own (seed, member)-keyed Philox stream, so the members do
+    not depend on how they are dealt to ranks (2-rank equality: tests/test_dist_cpu.py); fp16 members within the stated bound
+    of the fp32 members, and one fp32 member against the fp64 oracle fed the same stream (time, tile, x, y, channel order)."""
+    from downscaling.engine import runtime
+    from downscaling.engine.trainer import PhiloxSource
+    import downscaling.api as api
+    runtime.set_ops(hip_ops)
+    seed = 21
+    network = api.get_network(allow_random_init=True, random_seed=seed)
+    tiles = torch.randn(8, 24, 96, 96, 3, device=hip_ops.device, generator=torch.Generator(hip_ops.device).manual_seed(2))
+    e16 = api.predict_ensemble(tiles, 6, network=network, precision="fp16")
+    e32 = api.predict_ensemble(tiles, 6, network=network, precision="fp32")
+    assert tuple(e16.shape) == (6, 8, 24, 96, 96, 2) and bool(torch.isfinite(e16).all())
+    assert float((e16 - e32).abs().max()) / float(e32.abs().max()) < 4e-3
+    for m in range(1, 6):
+        assert float((e32[m] - e32[0]).abs().max()) > 1e-4
+    again = api.predict_ensemble(tiles, 3, network=network, precision="fp32")          # fewer draws: the same first members
+    assert torch.equal(again, e32[:3])
+    two = api.predict_ensemble(tiles[:2], 2, network=network, precision="fp32")
+    w = {k: torch.tensor(v, dtype=torch.float64) for k, v in network.generator.get_weights_dict().items()}
+    member = 1
+    nn = 24 * 2 * 96 * 96 * api.NOISE_CHANNELS
+    stream = philox_normal_np(nn, PhiloxSource(hip_ops, seed, rank=member).seed, 0) * api.NOISE_STD
+    nz = torch.tensor(stream.reshape(24, 2, 96, 96, api.NOISE_CHANNELS)).transpose(0, 1)[:1]
+    with torch.no_grad():
+        ref = TM.generator_forward(w, tiles[:1].double().cpu(), nz, False)
+    assert rel_err(two[member, :1], ref) < 1e-4
 
 
 @pytest.mark.timeout(1800)

@@ -167,3 +167,41 @@ def test_tile_sharded_inference_equals_single_process():
         for x in r:
             np.testing.assert_array_equal(x["cnt"], single["cnt"])
             np.testing.assert_allclose(x["out"], single["out"], rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
+def _ensemble_worker(rank, port, outdir):
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    from downscaling.engine import runtime
+    from downscaling.engine.trainer import DistSync
+    from oracle.torch_backend import TorchOps
+    import downscaling.api as api
+    runtime.set_ops(TorchOps(torch.float64))
+    api.IMG_SIZE, api.SEQUENCE_LENGTH, api.NOISE_CHANNELS, api.BATCH_SIZE = 20, 2, 5, 1    # groups of 2 tiles
+    network = api.get_network(allow_random_init=True, random_seed=11)
+    tiles = torch.randn(3, 2, 20, 20, 3, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    ens = api.predict_ensemble(tiles, draws=5, network=network, sync=DistSync())
+    np.save(os.path.join(outdir, f"ens{rank}.npy"), ens.numpy())
+    if rank == 0:
+        network2 = api.get_network(allow_random_init=True, random_seed=11)
+        np.save(os.path.join(outdir, "single.npy"), api.predict_ensemble(tiles, draws=5, network=network2).numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ensemble_sharded_over_ranks_equals_single_process_member_by_member():
+    """configs[4] multi-GPU path (api.predict_ensemble): noise realisations dealt round-robin to the ranks, every member on its
+    own (seed, member)-keyed Philox stream, one all-reduce of the result — every rank holds the single-process ensemble,
+    member by member, and the members differ from each other (5 draws over 2 ranks: an uneven deal, 3 tiles in groups of 2)."""
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_ensemble_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+        r = [np.load(os.path.join(out, f"ens{i}.npy")) for i in range(WORLD)]
+        single = np.load(os.path.join(out, "single.npy"))
+    assert single.shape == (5, 3, 2, 20, 20, 2)
+    for x in r:
+        np.testing.assert_array_equal(x, single)          # same arithmetic on the same streams: bit-identical
+    for m in range(1, 5):
+        assert np.abs(single[m] - single[0]).max() > 1e-6

@@ -11,7 +11,11 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-S, T, B_LOCAL, CIN, NZ, CH, WORLD = 32, 1, 2, 3, 4, 2, 2
+S, B_LOCAL, CIN, CH, WORLD = 32, 2, 3, 2, 2
+# (T, noise channels, generator feature_channels, discriminator feature_channels): a small pair, and the reference's DEFAULT
+# widths with a recurrence (models.py:16,83; 20 noise channels: api.py:68) — SyncBN over 128-channel BatchNorms, the split-K
+# ConvLSTM gates and the 16-feature fused recurrent step inside a two-rank train step
+CASES = {"small": (1, 4, 32, 8), "default_widths": (3, 20, 128, 16)}
 
 
 def _free_port():
@@ -20,21 +24,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(ops):
+def _build(ops, case):
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
     from tests.helpers import randomize
-    gen = GeneratorNet(ops, S, CIN, NZ, CH, T, feature_channels=32, seed=5)
-    disc = DiscriminatorNet(ops, S, S, CIN, CH, T, feature_channels=8, seed=6)
+    T, NZ, F, FD = CASES[case]
+    gen = GeneratorNet(ops, S, CIN, NZ, CH, T, feature_channels=F, seed=5)
+    disc = DiscriminatorNet(ops, S, S, CIN, CH, T, feature_channels=FD, seed=6)
     return gen, disc, randomize(gen, 21), randomize(disc, 22)
 
 
-def _data(rank, step):
+def _data(rank, step, T):
     g = torch.Generator().manual_seed(100 + 10 * step + rank)
     return (torch.randn(B_LOCAL, T, S, S, CIN, generator=g, dtype=torch.float64),
             torch.randn(B_LOCAL, T, S, S, CH, generator=g, dtype=torch.float64))
 
 
-def _worker(rank, port, outdir):
+def _worker(rank, port, outdir, case):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
@@ -47,11 +52,11 @@ def _worker(rank, port, outdir):
     from downscaling.engine.hipops import HipOps
     from downscaling.engine.trainer import AdamTF, DistSync, GanEngine, PhiloxSource
     ops = HipOps("cuda:0")
-    gen, disc, _, _ = _build(ops)
+    gen, disc, _, _ = _build(ops, case)
     eng = GanEngine(gen, disc, PhiloxSource(ops, seed=99, rank=rank), 0.1, n_critic=2, sync=DistSync(), sync_bn=True)
     g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
     for step in range(2):
-        low, high = _data(rank, step)
+        low, high = _data(rank, step, CASES[case][0])
         eng.train_step(low.float().to(ops.device), high.float().to(ops.device), g_opt, d_opt)
     torch.cuda.synchronize()
     torch.save({"g": {v.name: v.value.detach().cpu().clone() for v in gen.params.vars},
@@ -61,12 +66,14 @@ def _worker(rank, port, outdir):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_on_hip_backend_equal_global_batch_reference():
+@pytest.mark.parametrize("case", list(CASES))
+def test_two_ranks_on_hip_backend_equal_global_batch_reference(case):
+    T, NZ = CASES[case][:2]
     from oracle import torch_model as TM
     from oracle.torch_backend import TorchOps
     from tests.helpers import Draws, rel_err
     with tempfile.TemporaryDirectory() as out:
-        mp.spawn(_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(_free_port(), out, case), nprocs=WORLD, join=True)
         r = [torch.load(os.path.join(out, f"rank{i}.pt")) for i in range(WORLD)]
     for net in ("g", "d"):          # replicas bit-identical: deterministic SN + identical all-reduced gradients
         for k in r[0][net]:
@@ -85,11 +92,11 @@ def test_two_ranks_on_hip_backend_equal_global_batch_reference():
         def eps(self):
             return torch.cat([d.eps() for d in self.d], 0)
 
-    _, _, gw, dw = _build(TorchOps())
+    _, _, gw, dw = _build(TorchOps(), case)
     og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
     draws = GlobalDraws([x["seed"] for x in r])
     for step in range(2):
-        lows, highs = zip(*[_data(rank, step) for rank in range(WORLD)])
+        lows, highs = zip(*[_data(rank, step, T) for rank in range(WORLD)])
         TM.train_step(gw, dw, torch.cat(lows, 0), torch.cat(highs, 0), draws, og, od, n_critic=2)
     for net, w in (("g", gw), ("d", dw)):
         worst = max(rel_err(r[0][net][k], w[k]) for k in w)

@@ -84,20 +84,51 @@ def test_train_step_with_compiled_metrics(hip_ops):
                 discriminator_loss=train.discriminator_loss,
                 metrics=[M.discriminator_score_fake(), M.discriminator_score_real()])
     rng = np.random.default_rng(0)
-    low = rng.standard_normal((B, T, S, S, 3)).astype(np.float32)
-    high = (rng.standard_normal((B, T, S, S, 2)) * 3).astype(np.float32)
-    logs = gan.train_step((low, high))
-    assert {"g_acd", "g_lsd", "g_extreme_rmse", "g_ws_weighted_rmse", "g_spatial_ks", "d_fake", "d_real"} <= set(logs)
-    fake = torch.empty(B, T, S, S, 2, device=hip_ops.device)
-    g.net.from_time_major(gan.engine.last_fake_tm, fake)
-    fake = fake.cpu().numpy()
-    runtime.set_ops(TorchOps(torch.float64))
-    try:
-        th, tf_ = torch.from_numpy(high).double(), torch.from_numpy(fake).double()
-        want = {"g_acd": M.angular_cosine_distance(th, tf_).mean(), "g_lsd": M.log_spectral_distance(th, tf_).mean(),
-                "g_extreme_rmse": M.extreme_weighted_rmse(th, tf_).mean(), "g_ws_weighted_rmse": M.wind_speed_weighted_rmse(th, tf_).mean(),
-                "g_spatial_ks": M.spatially_convolved_ks_stat(th, tf_).mean()}
-    finally:
-        runtime.set_ops(hip_ops)
-    for k, v in want.items():
-        assert abs(float(logs[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), (k, float(logs[k]), float(v))
+    sums, per_step = {}, []
+    for step in range(3):
+        # a NEW batch every step, uploaded from numpy (lands in the allocator block the previous step's batch just freed) and a
+        # fresh `fake` tensor filled by a raw HIP kernel (version counter stays 0): the situation in which a cache keyed on
+        # id() / data_ptr() / _version would hand back the previous step's sums (gan/metrics.py)
+        low = rng.standard_normal((B, T, S, S, 3)).astype(np.float32)
+        high = (rng.standard_normal((B, T, S, S, 2)) * (3 + step)).astype(np.float32)
+        logs = gan.train_step((low, high))
+        assert {"g_acd", "g_lsd", "g_extreme_rmse", "g_ws_weighted_rmse", "g_spatial_ks", "d_fake", "d_real"} <= set(logs)
+        fake = torch.empty(B, T, S, S, 2, device=hip_ops.device)
+        g.net.from_time_major(gan.engine.last_fake_tm, fake)
+        fake = fake.cpu().numpy()
+        runtime.set_ops(TorchOps(torch.float64))
+        try:
+            th, tf_ = torch.from_numpy(high).double(), torch.from_numpy(fake).double()
+            now = {"g_acd": M.angular_cosine_distance(th, tf_).mean(), "g_lsd": M.log_spectral_distance(th, tf_).mean(),
+                   "g_extreme_rmse": M.extreme_weighted_rmse(th, tf_).mean(), "g_ws_weighted_rmse": M.wind_speed_weighted_rmse(th, tf_).mean(),
+                   "g_spatial_ks": M.spatially_convolved_ks_stat(th, tf_).mean()}
+        finally:
+            runtime.set_ops(hip_ops)
+        per_step.append({k: float(v) for k, v in now.items()})
+        for k, v in now.items():              # Keras metric objects are running means over the steps since the last reset
+            sums[k] = sums.get(k, 0.0) + float(v)
+            want = sums[k] / (step + 1)
+            assert abs(float(logs[k]) - want) <= 2e-5 * max(1.0, abs(want)), (step, k, float(logs[k]), want)
+    for k in ("g_acd", "g_extreme_rmse", "g_ws_weighted_rmse"):      # the batches differ: so must the per-step values
+        assert abs(per_step[0][k] - per_step[1][k]) > 1e-3 * abs(per_step[0][k]), k
+
+
+def test_pointwise_pass_is_not_cached_across_calls(hip_ops):
+    """Outside a `_Metrics.update_state` scope nothing is cached; inside one, the sums are matched by object identity of live
+    tensors only.  Overwriting a tensor in place through a raw kernel (no version bump) must change the result."""
+    from downscaling.gan.metrics import pointwise_scope
+    runtime.set_ops(hip_ops)
+    dev = hip_ops.device
+    real = torch.randn(2, 1, 16, 16, 2, device=dev)
+    fake = torch.randn(2, 1, 16, 16, 2, device=dev)
+    a = M.wind_speed_rmse(real, fake).clone()
+    fake2 = torch.randn(2, 1, 16, 16, 2, device=dev)
+    hip_ops.copy_channels(fake2.view(2, 16, 16, 2), fake.view(2, 16, 16, 2))     # raw HIP kernel: fake._version unchanged
+    b = M.wind_speed_rmse(real, fake).clone()
+    assert not torch.equal(a, b)
+    with pointwise_scope():
+        c = M.wind_speed_rmse(real, fake).clone()
+        d = M.angular_cosine_distance(real, fake)                                  # shares the pass
+        assert torch.equal(b, c) and d.shape == (2,)
+    from downscaling.gan import metrics as mm
+    assert "pointwise" not in mm._cache

@@ -126,6 +126,37 @@ def test_train_step(hip_ops, S, T):
                 assert rel_err(got[k], w[k]) < TOL, (step, k)
 
 
+@pytest.mark.parametrize("S,T,B,n_critic,steps", [(32, 3, 2, 3, 2), (96, 24, 1, 1, 1)])
+def test_train_step_default_widths(hip_ops, S, T, B, n_critic, steps):
+    """GanEngine.train_step at the reference's DEFAULT widths (generator feature_channels = 128, discriminator 16,
+    20 noise channels: models.py:16,83, api.py:68-72) against the fp64 restatement — the code paths that only exist at these
+    widths INSIDE a train step: split-K ConvLSTM gates of the 128-feature generator ConvLSTM, the 16-feature fused recurrent
+    step in both directions, BatchNorm hooks at 128 channels, the LayerNorm-in-second-stage route of the 8x8 / 2x2 blocks.
+    (96, 24): the SHIPPED shape of api.py:22,68-72 (one tile, one critic iteration: ~30 s of oracle time)."""
+    from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
+    from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
+    cin, nz, ch = 3, 20, 2
+    dev = hip_ops.device
+    gen = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=128, seed=5)
+    disc = DiscriminatorNet(hip_ops, S, S, cin, ch, T, feature_channels=16, seed=6)
+    gw, dw = randomize(gen, 21), randomize(disc, 22)
+    eng = GanEngine(gen, disc, PhiloxSource(hip_ops, seed=77), noise_std=0.1, n_critic=n_critic)
+    g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
+    og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
+    draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
+    for step in range(steps):
+        low, _, high = _inputs(B, T, S, cin, 1, ch, seed=70 + step)
+        res = eng.train_step(low.float().to(dev), high.float().to(dev), g_opt, d_opt)
+        ref = TM.train_step(gw, dw, low, high, draws, og, od, n_critic=n_critic)
+        for k in ("g_loss", "g_disc_loss", "d_loss", "d_gradient_pen", "g_gradient_param", "d_gradient_param", "_d_loss_train"):
+            a, b = float(res[k]), float(ref[k])
+            assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (step, k, a, b)
+        for net, w in ((gen, gw), (disc, dw)):
+            got = weights64(net)
+            for k in w:
+                assert rel_err(got[k], w[k]) < TOL, (step, k)
+
+
 def _relativistic(real_output, fake_output):
     return (torch.relu(1.0 - (real_output - fake_output.mean())).mean() + torch.relu(1.0 + (fake_output - real_output.mean())).mean())
 

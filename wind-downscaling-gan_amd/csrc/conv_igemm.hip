@@ -1328,10 +1328,13 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
 }
 
 // ---- three-slice bf16 copies of weight buffers for PIPE 4 (see the kernel): registered by the host after it filled them
+#include <mutex>
 #include <unordered_map>
 static std::unordered_map<const void*, std::pair<const void*, long long>> g_split_map;
+static std::mutex g_split_mutex;     // the registry may be touched from any host thread (register / unregister / launch look-up)
 extern "C" int wdg_split_register(const float* w32, const void* w3, int64_t n) {
     WDG_CHECK_ARG(w32 != nullptr && n >= 0, "bad argument");
+    std::lock_guard<std::mutex> lock(g_split_mutex);
     if (w3) g_split_map[w32] = std::make_pair(w3, (long long)n);
     else g_split_map.erase(w32);
     return WDG_OK;
@@ -1382,6 +1385,7 @@ static void set_b3(WdgIgemm& p, int k_per_tap) {
     p.B3 = nullptr;
     p.B3_slice = 0;
     if (g_igemm_pipe != 4 || (k_per_tap & 7)) return;
+    std::lock_guard<std::mutex> lock(g_split_mutex);
     auto it = g_split_map.find((const void*)p.B);
     if (it == g_split_map.end()) return;
     p.B3 = it->second.first;

@@ -12,21 +12,60 @@
 // k*T .. k*T+T-1.  field [Ttot][LAT][LON][C]; tiles [N][T][S][S][C].  stats [S*C][3] fp64: sum, sum of squares, count of the
 // non-NaN elements of column j, channel c over all tiles, timesteps and rows.
 // Every block keeps its sums in registers and adds them to one of R replica rows of `stats` at its end (atomics on S*C
-// addresses would serialise); the finish kernel folds the replicas and turns them into the fp32 mean / std the driver applies:
-// mean = sum / n, std = sqrt(sumsq / n - mean^2) in fp64 (population variance, as np.nanstd), then rounded to fp32.
-__global__ void __launch_bounds__(256) wdg_tiles_stats_finish_kernel(const double* __restrict__ stats, int R, int SC,
-                                                                     float* mean_std) {
+// addresses would serialise).  The variance is the TWO-PASS centred form np.nanstd uses — mean first, then the sum of squared
+// deviations from it (a one-pass sumsq / n - mean^2 cancels on a near-constant column and clamps a tiny positive variance to
+// zero, which turns a finite normalised value into inf / NaN): finish1 folds the replicas into the fp64 mean and the count
+// (kept in replica row 0, sum-of-squares slots of every row zeroed), the centred kernel re-reads the gathered tiles and
+// accumulates (v - mean)^2 into the zeroed slots, finish2 folds them: std = sqrt(sum / n) (population variance), fp32.
+__global__ void __launch_bounds__(256) wdg_tiles_stats_finish1_kernel(double* stats, int R, int SC, float* mean_std) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= SC) return;
-    double s = 0, q = 0, c = 0;
+    double s = 0, c = 0;
     for (int r = 0; r < R; ++r) {
-        const double* p = stats + ((long long)r * SC + e) * 3;
-        s += p[0]; q += p[1]; c += p[2];
+        double* p = stats + ((long long)r * SC + e) * 3;
+        s += p[0]; c += p[2];
+        p[1] = 0.0;
     }
     const double m = s / c;
-    const double var = q / c - m * m;
+    stats[(long long)e * 3] = m;
+    stats[(long long)e * 3 + 2] = c;
     mean_std[2 * e] = (float)m;
-    mean_std[2 * e + 1] = (float)sqrt(var > 0 ? var : 0.0);
+}
+
+__global__ void __launch_bounds__(256) wdg_tiles_centred_kernel(const float* __restrict__ tiles, double* stats, int R, int SC,
+                                                                long long lines) {
+    double q0[2] = {0, 0}, m0[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < SC) m0[u] = stats[(long long)e * 3];
+    }
+    for (long long line = blockIdx.x; line < lines; line += gridDim.x) {
+        const float* src = tiles + line * SC;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            if (e < SC) {
+                const float v = src[e];
+                if (v == v) { const double d = (double)v - m0[u]; q0[u] += d * d; }
+            }
+        }
+    }
+    double* row = stats + (long long)(blockIdx.x % R) * SC * 3;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < SC) atomicAdd(&row[3 * e + 1], q0[u]);
+    }
+}
+
+__global__ void __launch_bounds__(256) wdg_tiles_stats_finish2_kernel(const double* __restrict__ stats, int R, int SC,
+                                                                      float* mean_std) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= SC) return;
+    double q = 0;
+    for (int r = 0; r < R; ++r) q += stats[((long long)r * SC + e) * 3 + 1];
+    mean_std[2 * e + 1] = (float)sqrt(q / stats[(long long)e * 3 + 2]);
 }
 
 __global__ void __launch_bounds__(256) wdg_tiles_gather_rep_kernel(const float* __restrict__ field, int LAT, int LON, int C,
@@ -87,7 +126,11 @@ extern "C" int wdg_tiles_gather_normalise(const float* field, int LAT, int LON, 
     hipLaunchKernelGGL(wdg_tiles_gather_rep_kernel, dim3(blocks), dim3(256), 0, st, field, LAT, LON, C,
                        reinterpret_cast<const int4*>(keys4), N, T, S, tiles, stats_scratch, replicas, lines);
     WDG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wdg_tiles_stats_finish_kernel, dim3((SC + 255) / 256), dim3(256), 0, st, stats_scratch, replicas, SC, mean_std);
+    hipLaunchKernelGGL(wdg_tiles_stats_finish1_kernel, dim3((SC + 255) / 256), dim3(256), 0, st, stats_scratch, replicas, SC, mean_std);
+    WDG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wdg_tiles_centred_kernel, dim3(blocks), dim3(256), 0, st, tiles, stats_scratch, replicas, SC, lines);
+    WDG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wdg_tiles_stats_finish2_kernel, dim3((SC + 255) / 256), dim3(256), 0, st, stats_scratch, replicas, SC, mean_std);
     WDG_LAUNCH_CHECK();
     const long long total = lines * SC;
     hipLaunchKernelGGL(wdg_tiles_normalise_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0, st,

@@ -31,7 +31,7 @@ UPSAMPLING = {'latitude': 26, 'longitude': 18}
 
 __all__ = ['WEIGHTS_PATH', 'SEQUENCE_LENGTH', 'IMG_SIZE', 'BATCH_SIZE', 'NOISE_CHANNELS', 'NOISE_STD', 'NB_INPUTS',
            'NB_OUTPUTS', 'process_topo', 'process_era5', 'build_high_res_template_from_era5', 'get_network',
-           'predict', 'downscale', 'tile_plan', 'predict_array', 'GAN', 'make_generator', 'make_discriminator',
+           'predict', 'downscale', 'tile_plan', 'predict_array', 'predict_ensemble', 'GAN', 'make_generator', 'make_discriminator',
            'FlexibleNoiseGenerator', 'GridDataset']
 
 
@@ -265,6 +265,54 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     out, cnt = out.cpu().numpy(), cnt_host                                         # (the same integer bookkeeping: the count grid is not downloaded)
     lap('download')
     return (out, cnt) if return_count else out
+
+
+def predict_ensemble(tiles, draws, network=None, sync=None, precision=None, seed=None):
+    """Stochastic ensemble inference (BASELINE configs[4]: "64 noise realisations x batch 8"): `draws` realisations of the
+    generator on the SAME normalised tiles (N, 24, 96, 96, 3), each with its own noise field — the loop of api.py:132-138
+    repeated per realisation.  Returns a (draws, N, 24, 96, 96, 2) tensor on the generator's device.
+
+    Every realisation m draws from its OWN Philox stream, keyed by (seed, m) — not by the process that happens to compute
+    it — so member m is the same tensor whatever the number of ranks.  `sync` (engine.trainer.DistSync, one process per
+    GPU): realisations are independent, so they are dealt round-robin to the ranks (m % world == rank) with no exchange
+    inside the model, and the members are combined by ONE all-reduce of the zero-initialised result at the end (SURVEY §8 e);
+    every rank returns the full ensemble.  seed: base seed of the member streams (default: the network's noise
+    generator's `random_seed`; an unseeded generator takes a fresh one, agreed between the ranks).
+    precision: "fp32" | "bf16" | "fp16" for this call (default: the generator's `inference_precision`)."""
+    import torch
+    network = network or get_network()
+    gen = network.generator
+    ops = gen.ops
+    dev = getattr(ops, "device", "cpu")
+    tiles = torch.as_tensor(tiles).to(device=dev, dtype=ops.dtype)
+    if tiles.dim() != 5 or tuple(tiles.shape[1:]) != (SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NB_INPUTS):
+        raise ValueError(f'tiles must be (N, {SEQUENCE_LENGTH}, {IMG_SIZE}, {IMG_SIZE}, {NB_INPUTS}), got {tuple(tiles.shape)}')
+    draws, n = int(draws), tiles.shape[0]
+    if draws < 1:
+        raise ValueError('draws must be >= 1')
+    rank, world = (sync.rank, sync.world_size) if sync is not None else (0, 1)
+    noise_gen = network.noise_generator
+    if seed is None:
+        seed = noise_gen.random_seed
+    if seed is None:
+        base = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            base[0] = int.from_bytes(os.urandom(7), 'little')
+        if sync is not None and sync.active:
+            sync.all_reduce_sum(base)                              # the other ranks contribute 0: rank 0's draw for everyone
+        seed = int(base[0])
+    out = torch.zeros(draws, n, SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NB_OUTPUTS, dtype=ops.dtype, device=dev)
+    group_size = BATCH_SIZE * 2
+    kwargs = {} if precision is None else {'precision': precision}
+    with torch.no_grad():
+        for m in range(rank, draws, world):
+            member = FlexibleNoiseGenerator(noise_gen.noise_shape, std=noise_gen.std, random_seed=seed, rank=m)
+            for g0 in range(0, n, group_size):
+                group = tiles[g0:g0 + group_size]
+                out[m, g0:g0 + group.shape[0]] = gen([group, member.lazy(bs=group.shape[0], channels=NOISE_CHANNELS)], **kwargs)
+    if sync is not None and sync.active:
+        sync.all_reduce_sum(out)
+    return out
 
 
 def predict(inputs_era5, inputs_topo, high_res_template, overlap_factor=0.05, network=None):

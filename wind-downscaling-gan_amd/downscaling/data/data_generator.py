@@ -1,6 +1,10 @@
 """FlexibleNoiseGenerator with the reference signature
 (/root/reference/src/downscaling/data/data_generator.py:319-335), backed by the Philox4x32-10 HIP
 kernel (wdg_philox_normal) instead of tf.random.Generator."""
+import datetime as _dt
+from pathlib import Path as _Path
+
+import numpy as np
 import torch
 
 from downscaling.engine import runtime
@@ -54,7 +58,8 @@ class FlexibleNoiseGenerator(object):
         given tile depend on the batch size of the call.  Extension of this build; the reference passes tensors."""
         bs = self.noise_shape[0] if bs is None else int(bs)
         channels = self.noise_shape[4] if channels is None else channels
-        return LazyNoise(self, (bs, self.noise_shape[1], self.noise_shape[2], self.noise_shape[3], channels), std or self.std)
+        return LazyNoise(self, (bs, self.noise_shape[1], self.noise_shape[2], self.noise_shape[3], channels),
+                         std or self.std)       # same rule as __call__ (reference line 334: a falsy std selects self.std)
 
     def __call__(self, bs=None, channels=None, std=None):
         bs = self.noise_shape[0] if bs is None else int(bs)
@@ -62,7 +67,7 @@ class FlexibleNoiseGenerator(object):
         x = self.noise_shape[2]
         y = self.noise_shape[3]
         channels = self.noise_shape[4] if channels is None else channels
-        std = std or self.std
+        std = std or self.std        # as the reference (data_generator.py:334): std=0 / None both mean "the generator's std"
         ops = runtime.get_ops()
         out = ops.empty(bs, t, x, y, channels)
         self.prng.normal_into(out.view(-1, channels), std)
@@ -77,12 +82,6 @@ class FlexibleNoiseGenerator(object):
 # made, what the decoder sees, the flip / rot90 augmentation), so a user of the reference finds the same
 # classes with the same constructor arguments.
 # ----------------------------------------------------------------------------------------------------
-import datetime as _dt
-from pathlib import Path as _Path
-
-import numpy as np
-
-
 class Provider(object):
     """data_generator.py:21-33: `available_dates` + `provide(date)` (a context manager there; here it returns the
     day's {variable: array[time, x, y]} mapping directly)."""

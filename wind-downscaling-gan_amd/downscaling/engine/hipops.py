@@ -132,6 +132,17 @@ class PackedWeights:
         sub._parent, sub._range = self, (n0 * ld, n1 * ld)
         return sub
 
+    def __del__(self):
+        # the library's bf16-slice registry is keyed by device address: drop this object's entries before the allocator
+        # can hand the same address to another buffer (derived views own no entry)
+        try:
+            if getattr(self, "_split", None):
+                for which in self._split:
+                    src = self.wF if which == "wF" else self.wD
+                    self.ops.lib.wdg_split_register(src.data_ptr(), None, 0)
+        except Exception:
+            pass
+
     def mark_stale(self):
         self._bf16_stale = True
         if hasattr(self, "_split_stale"):
@@ -217,7 +228,7 @@ class HipOps:
         self._ws = None
         self._sn_scratch = None
         # fp32 implicit-GEMM products from three bf16 slices per operand (conv_igemm.hip PIPE 4; measurement mode, off by default):
-        # WDG_SPLIT=1 or set_split_mode(True) BEFORE the first convolution is planned
+        # WDG_SPLIT=1 or set_split_mode(True) at any time: the mode is read per launch, plans do not depend on it
         self.split_mode = False
         if os.environ.get("WDG_SPLIT", "0") == "1":
             self.set_split_mode(True)
@@ -662,8 +673,7 @@ class HipOps:
         native.check(self.lib.wdg_convlstm_seq_fwd(px, ldx, isx, wx.data_ptr(), wh.data_ptr(), bias.data_ptr(), ph, ldh, ish,
                                                    _ptr(gates), c.data_ptr(), B, T, H, W, cin, F, scratch.data_ptr(),
                                                    scratch.numel(), self.stream), "convlstm_seq_fwd")
-        if os.environ.get("WDG_SEQ_CHECK", "0") == "1":
-            self.convlstm_seq_check(scratch, B, H, W)
+        self._seq_check_after(scratch, B, H, W)
 
     def convlstm_seq_bwd(self, gates, c, wh, dh, dgates, B, T, cin, F, scratch):
         """dgates [T*B,H,W,4F] from the incoming gradient dh of every h_t (dh is not modified)."""
@@ -673,7 +683,13 @@ class HipOps:
         native.check(self.lib.wdg_convlstm_seq_bwd(gates.data_ptr(), c.data_ptr(), wh.data_ptr(), pdh, lddh, isdh,
                                                    dgates.data_ptr(), B, T, H, W, cin, F, scratch.data_ptr(), scratch.numel(),
                                                    self.stream), "convlstm_seq_bwd")
-        if os.environ.get("WDG_SEQ_CHECK", "0") == "1":
+        self._seq_check_after(scratch, B, H, W)
+
+    def _seq_check_after(self, scratch, B, H, W):
+        """The persistent kernel carries on with incomplete neighbour data after a timed-out wait and only raises a flag:
+        read the flag after EVERY launch of the opt-in path (one 4-byte download + stream sync; WDG_SEQ_CHECK=0 leaves it
+        to the caller; a stream capture cannot sync, the eager warm-up calls before it are checked)."""
+        if os.environ.get("WDG_SEQ_CHECK", "1") != "0" and not torch.cuda.is_current_stream_capturing():
             self.convlstm_seq_check(scratch, B, H, W)
 
     def convlstm_seq_check(self, scratch, B, H, W):

@@ -230,15 +230,131 @@ def encode_index(items):
 HEADER = b"\x08\x01\x1a\x02\x08\x01"    # BundleHeaderProto{num_shards: 1, version{producer: 1}}
 
 
-def write_bundle(prefix, tensors):
+OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+_DT_STRING = 7
+
+
+def _pstr(field, b):
+    return bytes([(field << 3) | 2]) + _pv(len(b)) + b
+
+
+def build_object_graph(names):
+    """Serialized `TrackableObjectGraph` (tensorflow/core/protobuf/trackable_object_graph.proto) for the variables `names`
+    (checkpoint names without the attribute suffix, e.g. `layer_with_weights-0/layer/w`): the entry Keras' TF-format
+    `load_weights` (ganbase.py:137-140) walks.  Its restore binds node 0 to the model and follows `children.local_name`
+    through the live object's tracked dependencies, so what must be right is the TREE of local names and every leaf's
+    `attributes{name: "VARIABLE_VALUE", checkpoint_key}`; both follow from the key paths themselves (a key IS the path of
+    local names from the root).  Nodes are numbered breadth-first from the root, children in first-seen key order, as
+    TensorFlow's graph view does.  A spectral-normalisation wrapper (children `layer`, `w`, `sn_u`: tf_utils.py:19-31)
+    additionally exposes its kernel as `layer/kernel` — the same variable node as `w`, which is how the wrapped Conv2D
+    reaches it.  Not reproduced (unknowable here: the blob holding the shipped graph is absent, only its size and CRC are in
+    the index): `full_name` strings with Keras' per-process layer-name counters, the `layer-<i>` aliases, and the
+    optimizer's slot-variable table — none of them take part in restoring model weights."""
+    children, order = {(): []}, [()]
+    for name in names:
+        parts = tuple(name.split("/"))
+        for i in range(len(parts)):
+            parent, node = parts[:i], parts[:i + 1]
+            if node not in children:
+                children[node] = []
+                children[parent].append((parts[i], node))
+    alias = {}
+    for node, ch in list(children.items()):
+        local = dict(ch)
+        if {"layer", "w", "sn_u"} <= set(local):
+            conv = local["layer"]
+            if not any(n == "kernel" for n, _ in children[conv]):
+                children[conv].insert(0, ("kernel", local["w"]))
+                alias[(conv, "kernel")] = local["w"]
+    ids, queue = {(): 0}, [()]
+    while queue:                                      # breadth-first numbering (aliases keep the id of their first visit)
+        node = queue.pop(0)
+        for _, child in children[node]:
+            if child not in ids:
+                ids[child] = len(ids)
+                order.append(child)
+                queue.append(child)
+    leaves = {tuple(n.split("/")) for n in names}
+    out = bytearray()
+    for node in sorted(ids, key=ids.get):
+        body = bytearray()
+        for local_name, child in children[node]:
+            ref = (b"\x08" + _pv(ids[child]) if ids[child] else b"") + _pstr(2, local_name.encode())
+            body += _pstr(1, ref)
+        if node in leaves:
+            key = "/".join(node)
+            attr = _pstr(1, b"VARIABLE_VALUE") + _pstr(2, "/".join(node[-2:]).encode()) + _pstr(3, (key + _SUFFIX).encode())
+            body += _pstr(2, attr)
+        out += _pstr(1, bytes(body))
+    return bytes(out)
+
+
+def parse_object_graph(blob):
+    """-> [(children [(local_name, node_id)], attributes [(name, full_name, checkpoint_key)])] per node."""
+    nodes = []
+    for nb in _proto(blob).get(1, []):
+        f = _proto(nb)
+        ch = []
+        for c in f.get(1, []):
+            cf = _proto(c)
+            ch.append((bytes(cf.get(2, [b""])[0]).decode(), cf.get(1, [0])[0]))
+        at = []
+        for a in f.get(2, []):
+            af = _proto(a)
+            at.append(tuple(bytes(af.get(i, [b""])[0]).decode() for i in (1, 2, 3)))
+        nodes.append((ch, at))
+    return nodes
+
+
+def encode_string_tensor(strings):
+    """Bytes of a DT_STRING tensor inside a bundle data file (tensor_bundle.cc, WriteStringTensor): the varint64 lengths,
+    the masked CRC-32C of the length bytes (4 bytes, little endian), then the strings; returns (bytes, unmasked CRC-32C the
+    BundleEntryProto records masked) — the entry checksum runs over lengths, length checksum and string bytes."""
+    lens = b"".join(_pv(len(x)) for x in strings)
+    cks = struct.pack("<I", _mask(crc32c(lens)))
+    body = b"".join(strings)
+    crc = crc32c(body, crc32c(cks, crc32c(lens)))
+    return lens + cks + body, crc
+
+
+def decode_string_tensor(raw, count=1):
+    i, lens = 0, []
+    for _ in range(count):
+        n, i = _varint(raw, i)
+        lens.append(n)
+    if struct.unpack("<I", raw[i:i + 4])[0] != _mask(crc32c(raw[:i])):
+        raise ValueError("string tensor: length checksum mismatch")
+    i += 4
+    out = []
+    for n in lens:
+        out.append(bytes(raw[i:i + n]))
+        i += n
+    return out
+
+
+def read_object_graph(prefix):
+    """The parsed `_CHECKPOINTABLE_OBJECT_GRAPH` of a bundle (None when the index has no such entry)."""
+    prefix = str(prefix)
+    for key, dt, shape, shard, off, size in read_index(prefix + ".index"):
+        if key == OBJECT_GRAPH_KEY and dt == _DT_STRING:
+            num_shards = read_num_shards(prefix + ".index")
+            with open(f"{prefix}.data-{shard:05d}-of-{num_shards:05d}", "rb") as f:
+                f.seek(off)
+                return parse_object_graph(decode_string_tensor(f.read(size))[0])
+    return None
+
+
+def write_bundle(prefix, tensors, object_graph=True):
     """{variable name: array} -> `<prefix>.index` + `<prefix>.data-00000-of-00001`, keys
-    `<name>/.ATTRIBUTES/VARIABLE_VALUE` as Keras' TF-format `save_weights` names them (ganbase.py:132-135).
-    Readable by `read_bundle` and by TensorFlow's checkpoint reader (`tf.train.load_checkpoint`); Keras'
-    `load_weights` additionally wants the `_CHECKPOINTABLE_OBJECT_GRAPH` entry, which is not written."""
+    `<name>/.ATTRIBUTES/VARIABLE_VALUE` as Keras' TF-format `save_weights` names them (ganbase.py:132-135), plus the
+    `_CHECKPOINTABLE_OBJECT_GRAPH` string tensor (last in the data file, first in key order, as TensorFlow lays it out) that
+    Keras' object-based `load_weights` walks (build_object_graph).  Readable by `read_bundle`, by TensorFlow's checkpoint
+    reader (`tf.train.load_checkpoint`) and by `keras.Model.load_weights` of a model with the same layer tree."""
     prefix = str(prefix)
     items, offset = [(b"", HEADER)], 0
+    order = sorted(tensors, key=lambda k: (k + _SUFFIX).encode())
     with open(prefix + ".data-00000-of-00001", "wb") as f:
-        for name in sorted(tensors, key=lambda k: (k + _SUFFIX).encode()):
+        for name in order:
             arr = np.ascontiguousarray(tensors[name])
             if arr.dtype not in _NP2DT:
                 arr = arr.astype(np.float32)
@@ -247,6 +363,11 @@ def write_bundle(prefix, tensors):
             items.append(((name + _SUFFIX).encode(), encode_entry(_NP2DT[arr.dtype], arr.shape, 0, offset, len(raw),
                                                                   _mask(crc32c(raw)))))
             offset += len(raw)
+        if object_graph:
+            raw, crc = encode_string_tensor([build_object_graph(order)])
+            f.write(raw)
+            items.append((OBJECT_GRAPH_KEY.encode(), encode_entry(_DT_STRING, (), 0, offset, len(raw), _mask(crc))))
+            items.sort(key=lambda kv: kv[0])
     with open(prefix + ".index", "wb") as f:
         f.write(encode_index(items))
 

@@ -51,7 +51,7 @@ class discriminator_score_fake(Mean):
 # Every function takes (real_output, fake_output) of shape (B, T, H, W, 2) and returns the reference's per-sample vector
 # (or the patch-position image for the spatial KS).  The arithmetic is the HIP kernels of csrc/metrics.hip: one fused
 # pass yields the sums of all pointwise metrics, so a train step with the five compiled metrics reads the two fields
-# once for them; the pass result is cached per (real, fake) pair for the sibling metrics evaluated right after.
+# once for them; the pass result is shared by the sibling metrics of one `_Metrics.update_state` call (pointwise_scope).
 import numpy as np
 
 from downscaling.engine import runtime
@@ -66,20 +66,36 @@ def _dev_pair(real_output, fake_output):
     return ops, _to_dev(real_output, ops), _to_dev(fake_output, ops)
 
 
+class pointwise_scope:
+    """While active (one `_Metrics.update_state` call), the fused pointwise pass is evaluated once per (real, fake)
+    pair and shared by the sibling metrics.  The cache holds the two tensor OBJECTS and is matched with `is`, and it is
+    dropped when the scope closes: nothing is ever keyed on id() / data_ptr() / version, which the caching allocator
+    and CPython both recycle from one train step to the next (raw HIP kernels do not bump torch's version counter)."""
+
+    def __enter__(self):
+        _cache["depth"] = _cache.get("depth", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _cache["depth"] -= 1
+        if _cache["depth"] == 0:
+            _cache.pop("pointwise", None)
+        return False
+
+
 def _pointwise(real_output, fake_output):
-    """(sums [B, 6], elements per sample) of the fused pointwise pass; cached while both tensors are unchanged."""
-    key = None
-    if torch.is_tensor(real_output) and torch.is_tensor(fake_output):     # (in-place edits bump torch's version counter)
-        key = tuple((id(t), t._version, t.data_ptr()) for t in (real_output, fake_output))
+    """(sums [B, 6], elements per sample) of the fused pointwise pass; shared inside a `pointwise_scope` only."""
+    scoped = _cache.get("depth", 0) > 0
+    if scoped:
         hit = _cache.get("pointwise")
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0] is real_output and hit[1] is fake_output:
+            return hit[2]
     ops, r, f = _dev_pair(real_output, fake_output)
     if r.shape[-1] != 2:
         raise ValueError("the wind metrics need the two wind components on the last axis")
     res = (ops.metrics_pointwise(r, f), r[0].numel() // 2, r.dtype)
-    if key is not None:
-        _cache["pointwise"] = (key, res)
+    if scoped:
+        _cache["pointwise"] = (real_output, fake_output, res)
     return res
 
 

@@ -29,8 +29,10 @@ class _Metrics:
         self.metrics = list(metrics or [])
 
     def update_state(self, y_true, y_pred, sample_weight=None):
-        for m in self.metrics:
-            m.update_state(y_true, y_pred, sample_weight)
+        from downscaling.gan.metrics import pointwise_scope
+        with pointwise_scope():       # the sibling metrics share ONE fused pass over (y_true, y_pred); dropped on exit
+            for m in self.metrics:
+                m.update_state(y_true, y_pred, sample_weight)
 
 
 class _Model:
