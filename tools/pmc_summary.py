@@ -5,7 +5,8 @@ and the dominant kernel's HBM traffic per launch for bench.py's `roofline.traffi
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-generator-leg --no-split-leg
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_write -o run -- python3 bench.py ...
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ... -d gpurun_out/pmc_sq ...
-    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq profiles/<tag>_pmc_summary.csv
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE ... -d gpurun_out/pmc_mfma ...
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/pmc_mfma profiles/<tag>_pmc_summary.csv
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are reported in KB;
 on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes -> doubled here (column *_x2).  The counters sit on
@@ -73,11 +74,16 @@ def main():
                     row[col] = t[cname] / wc
             if "SQ_LDS_BANK_CONFLICT" in t and "SQ_LDS_IDX_ACTIVE" in t:
                 row["lds_bank_conflict_frac"] = t["SQ_LDS_BANK_CONFLICT"] / max(t["SQ_LDS_IDX_ACTIVE"], 1.0)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in t and "GRBM_GUI_ACTIVE" in t:
+            # SQ_VALU_MFMA_BUSY_CYCLES: matrix-pipe busy cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE: active cycles
+            # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back) -> fraction of the matrix pipe's cycles in use
+            row["mfma_busy_frac"] = t["SQ_VALU_MFMA_BUSY_CYCLES"] / max(t["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0, 1.0)
+            row["clock_ghz_under_pmc"] = t["GRBM_GUI_ACTIVE"] / 8.0 / max(sum(dur[k]) * 1e3, 1.0)
         row["_total_us"] = sum(dur[k])
         rows.append(row)
     rows.sort(key=lambda r: -r["_total_us"])
     cols = ["kernel", "launches", "avg_us_under_pmc", "fetch_kb_per_launch_raw", "fetch_mb_per_launch_x2", "write_mb_per_launch",
-            "l2_hit", "wait_any_frac", "wait_inst_frac", "active_frac", "lds_bank_conflict_frac"]
+            "l2_hit", "wait_any_frac", "wait_inst_frac", "active_frac", "lds_bank_conflict_frac", "mfma_busy_frac", "clock_ghz_under_pmc"]
     with open(out, "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore")
         w.writeheader()
@@ -99,7 +105,7 @@ def main():
             h.update(f.name.encode())
             h.update(f.read_bytes())
         tj = {"source": f"{out} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 "
-                        f"--no-cpu-baseline --no-generator-leg --no-split-leg)",
+                        f"--no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs)",
               "kernel": "wdg_igemm_kernel<128,128>",
               # bench.py quotes the figure only when these two match what it runs (same kernel sources, same launch mix)
               "csrc_sha256": h.hexdigest(), "launches_per_step": float(dom["launches"]),

@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun):  bash tools/profile_round.sh <tag> [quick]
 #   1. default bench line                      -> gpurun_out/<tag>_bench.json
 #   2. rocprofv3 --kernel-trace --stats        -> gpurun_out/<tag>_kernel_stats.csv  (bench.py --steps 1 --warmup 1: 2 steps in the trace)
-#   3. three --pmc passes + tools/pmc_summary  -> gpurun_out/<tag>_pmc_summary.csv + pmc_traffic.json   (skipped with "quick")
+#   3. four --pmc passes (fabric fetch, fabric write + L2 hit, SQ wait / LDS, MFMA busy) + tools/pmc_summary  -> gpurun_out/<tag>_pmc_summary.csv + pmc_traffic.json   (skipped with "quick")
 # The summaries are then copied into profiles/ by hand (gpurun_out/ is scratch).
 set -u
 TAG=${1:-r02}
@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-generator-leg --no-split-leg"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_trace -o run -- $BENCH --steps 1 --warmup 1 > $ROOT/$OUT/${TAG}_trace.log 2>&1 )
 STATS=$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/${TAG}_kernel_stats.csv && head -25 $OUT/${TAG}_kernel_stats.csv
@@ -22,7 +22,9 @@ if [ -z "$QUICK" ]; then
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc1.log 2>&1 )
   ( cd /tmp && rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $ROOT/$OUT/pmc_write -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc2.log 2>&1 )
   ( cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_sq -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc3.log 2>&1 )
-  python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/${TAG}_pmc_summary.csv > $OUT/${TAG}_pmc_summary.log 2>&1
+  # direct matrix-pipe utilisation: busy cycles of the MFMA pipe (summed over the 1024 SIMDs) against the kernel's active cycles
+  ( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_mfma -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc4.log 2>&1 )
+  python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_mfma $OUT/${TAG}_pmc_summary.csv > $OUT/${TAG}_pmc_summary.log 2>&1
   head -30 $OUT/${TAG}_pmc_summary.csv
-  rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_mfma
 fi
