@@ -24,16 +24,15 @@ __device__ __forceinline__ f32x2 cl_pk_fma(float x, f32x2 w, f32x2 acc) {
 
 constexpr int CL_TH = 4, CL_TW = 32;   // backward tile: 128 centre pixels, 2 threads (feature halves) per pixel
 
-// tanh in ~12 branch-free instructions (ocml's tanhf is ~35 with a divergent range split, and the cell evaluates two
-// per feature): |x| < 0.1: odd Taylor polynomial to x^7 (rel. error < 3e-10); otherwise (1 - e) / (1 + e) with
-// e = exp(-2|x|) <= 0.82 through v_exp_f32 / v_rcp_f32 (rel. error < 5e-7, no cancellation).
+// tanh(x) = 1 - 2 / (1 + exp(2x)) in five instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma): the cell evaluates two per
+// feature and pixel, and on the fp32 path the matrix instructions share the vector unit's multipliers, so every vector
+// instruction of the cell is paid in full.  ABSOLUTE error <= ~2.5e-7 (one ulp each in exp and rcp around r = 0.5); the relative
+// error grows as |x| -> 0 (the difference 1 - 2r cancels), which the cell does not care about: tanh enters h = o * tanh(c) and
+// the factors (1 - tanh^2) of the backward pass by its value.  Saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1.
+// (The 12-instruction form it replaces — odd Taylor polynomial below |x| = 0.1, (1 - e) / (1 + e) above — held 5e-7 RELATIVE.)
 __device__ __forceinline__ float cl_tanh(float x) {
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
-    const float e = __expf(-2.f * ax);
-    const float big = copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
-    return ax < 0.1f ? poly : big;
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // exp(2x) = 2^(2x log2 e)
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);
 }
 
 __device__ __forceinline__ float cl_hsig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f); }
@@ -170,6 +169,115 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
     for (int f = 0; f < FH; ++f) hp[f] = cl_hsig(go[f]) * cl_tanh(cl_hsig(gi[f]) * cl_tanh(gc[f]));
 }
 
+// ---- forward on the matrix pipe (5 -> 16): gates of 16 pixels per MFMA tile, weights resident in REGISTERS --------------------
+// GEMM view per fragment of 16 consecutive pixels of a row: gates[n][pixel] = sum_k W[k][n] x[pixel][k], k = the 9 * 5 = 45
+// flattened (tap, channel) pairs padded to 48 (12 steps of v_mfma_f32_16x16x4_f32), n = the 3 x 16 live gate columns (i, c~, o:
+// with h_0 = c_0 = 0 the forget gate plays no role).  The weights are the MFMA's ROW operand: a lane (li = lane & 15,
+// lq = lane >> 4) supplies W[k = 4 ks + lq][gate g][feature li] — 36 values that do not depend on the pixel, loaded once per
+// persistent workgroup and kept in registers (the earlier LDS-resident form paid one ds_read per MFMA) — and ends up with gates
+// i, c~, o of features 4 lq .. 4 lq + 3 of pixel li, so the cell runs on the accumulators and h leaves as one 16-byte store per
+// lane.  x comes from a halo tile in LDS, one plane per channel (consecutive pixels = consecutive banks).  Per 16 pixels: 36
+// MFMAs (1,152 matrix-pipe cycles) beside ~150 vector instructions of cell math from other waves — the two pipes overlap
+// across the resident waves, which the all-VALU form (2,160 FMAs per pixel on the vector pipe alone) cannot.
+constexpr int CLF_TH = 8, CLF_TW = 32;           // 256 pixels = 16 fragments per tile, 4 per wave
+template <int CIN, int F>
+__global__ void __launch_bounds__(256) wdg_convlstm1_fwd_mfma_kernel(const WdgCl1 p, const float* __restrict__ Wx,
+                                                                     const float* __restrict__ bias) {
+    static_assert(F == 16, "one 16-feature MFMA tile per gate");
+    constexpr int KP = (9 * CIN + 3) / 4 * 4, KS = KP / 4;
+    constexpr int XH = CLF_TH + 2, XW = CLF_TW + 2;
+    constexpr int PLANE = XH * XW + 12;          // 352: consecutive channel planes start 0 mod 32 banks apart -> lq groups offset by tap shifts only
+    __shared__ float xs[CIN * PLANE];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lq = lane >> 4;
+    // weights / bias / x offsets of this lane (tile-invariant)
+    float wreg[KS][3];
+    int xoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + lq;
+        int off = 0;
+        if (k < 9 * CIN) {
+            const int tap = k / CIN, c = k - tap * CIN;
+            const int th = tap / 3, tw = tap - 3 * th;
+            off = c * PLANE + th * XW + tw;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) wreg[ks][g] = Wx[k * 4 * F + (g == 0 ? 0 : g + 1) * F + li];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) wreg[ks][g] = 0.f;     // padding rows: zero weights, any valid x address
+        }
+        xoff[ks] = off;
+    }
+    float bi[4], bc[4], bo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bi[r] = bias[4 * lq + r];
+        bc[r] = bias[2 * F + 4 * lq + r];
+        bo[r] = bias[3 * F + 4 * lq + r];
+    }
+    const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tx = b % p.tiles_w;
+        b /= p.tiles_w;
+        const int ty = b % p.tiles_h;
+        const int img = b / p.tiles_h;
+        const int oy0 = ty * CLF_TH, ox0 = tx * CLF_TW;
+        const float* Ximg = p.X + (long long)img * p.imgStrideX;
+        // x halo -> channel planes (zero outside the image = the conv's zero padding)
+        for (int pix = t; pix < XH * XW; pix += 256) {
+            const int hy = pix / XW, hx = pix - hy * XW;
+            const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+                const float* src = Ximg + ((long long)gy * p.W + gx) * p.ldx;
+#pragma unroll
+                for (int c4 = 0; c4 < (CIN + 3) / 4; ++c4) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(src + 4 * c4);
+                    v[4 * c4] = q[0]; v[4 * c4 + 1] = q[1]; v[4 * c4 + 2] = q[2]; v[4 * c4 + 3] = q[3];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xs[c * PLANE + pix] = v[c];
+        }
+        __syncthreads();
+        // 16 fragments (8 rows x 2 half rows of 16 pixels): wave wv takes rows 2 wv, 2 wv + 1.  Software-pipelined: the 36 MFMAs
+        // of fragment fi + 1 stand before the cell arithmetic of fragment fi in program order, so the cell's instructions issue
+        // while the matrix instructions drain instead of waiting for their own fragment's last one
+        auto gates = [&](int fi, f32x4 (&ga)[3]) {
+            const int pbase = (2 * wv + (fi >> 1)) * XW + (fi & 1) * 16 + li;
+            ga[0] = (f32x4){bi[0], bi[1], bi[2], bi[3]};      // the accumulators start at the bias
+            ga[1] = (f32x4){bc[0], bc[1], bc[2], bc[3]};
+            ga[2] = (f32x4){bo[0], bo[1], bo[2], bo[3]};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float xv = xs[pbase + xoff[ks]];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ks][g], xv, ga[g], 0, 0, 0);
+            }
+        };
+        auto cell = [&](int fi, const f32x4 (&ga)[3]) {
+            const int gy = oy0 + 2 * wv + (fi >> 1), gx = ox0 + (fi & 1) * 16 + li;
+            f32x4 h4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                h4[r] = cl_hsig(ga[2][r]) * cl_tanh(cl_hsig(ga[0][r]) * cl_tanh(ga[1][r]));
+            if (gy < p.H && gx < p.W)
+                *reinterpret_cast<f32x4*>(p.Hout + (long long)img * p.imgStrideH + ((long long)gy * p.W + gx) * p.ldh + 4 * lq) = h4;
+        };
+        f32x4 g0[3], g1[3];
+        gates(0, g0);
+        gates(1, g1);
+        cell(0, g0);
+        gates(2, g0);
+        cell(1, g1);
+        gates(3, g1);
+        cell(2, g0);
+        cell(3, g1);
+        __syncthreads();   // the next tile overwrites xs
+    }
+}
+
 // ---- backward: 4x32 centre tile; dgates recomputed on the 6x34 halo into LDS, dx gathered from it --------
 // WG = true additionally forms the layer's weight and bias gradient in the same pass: with x and dgates of the tile
 // already in LDS, dW[(tap,ci)][gate] += sum_pixels x[p + tap - 1][ci] * dgates[p][gate] is 9 (2 for the 2-channel
@@ -179,8 +287,8 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
 // in block order.  This replaces writing the dense 4F-channel dgates tensor (537 MB at the headline shape) and
 // reading it back in a separate weight-gradient kernel.
 // MF = true (F = 16 only): the gate recompute of stage 2 runs on the MATRIX pipe — rows = halo pixels (16 per tile), columns
-// = the 3F = 48 live gate columns, k = the 9 * CIN = 45 (padded 48) flattened (tap, channel) pairs, weights resident in LDS
-// for the life of the persistent block — and the cell backward runs on the transposed accumulators (a lane holds gates
+// = the 3F = 48 live gate columns, k = the 9 * CIN = 45 (padded 48) flattened (tap, channel) pairs, weights resident in REGISTERS
+// for the life of the persistent block (36 per lane: the MFMA's row operand does not depend on the pixel) — and the cell backward runs on the transposed accumulators (a lane holds gates
 // i, c~, o of four features of one pixel).  The vector pipe keeps the cell math and the input-gradient stage; with three
 // workgroups per CU in different stages the two pipes overlap (MI355X_MICROARCH.md: MFMA and VALU issue are separate).
 template <int CIN, int F, bool WG, bool MF = false>
@@ -200,7 +308,6 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     __shared__ float dxp[128 * CIN];
     __shared__ float red_extra[(WG && !RED_IN_DGS) ? 4 * WN : 1];
     constexpr int KP = (9 * CIN + 3) / 4 * 4;        // flattened (tap, channel) rows padded to the MFMA k granule
-    __shared__ float wl[MF ? KP * 3 * F : 1];        // [k][gate column i | c~ | o]: row stride 48 = 16 mod 32 words: the two 16-lane k groups of a b32 read hit disjoint banks
 
     const int t = threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(t >> 7);
@@ -228,24 +335,23 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     }
 
     int xoff[MF ? KP / 4 : 1];
+    float wreg[MF ? KP / 4 : 1][3];                        // MF: this lane's weights W[k = 4 ks + lq][gate][feature li], in registers
     if constexpr (MF) {
-        for (int idx = t; idx < KP * 3 * F; idx += 256) {
-            const int k = idx / (3 * F), n = idx - k * (3 * F);
-            const int g = n / F, f = n - g * F;
-            wl[idx] = k < 9 * CIN ? Wx[k * 4 * F + (g == 0 ? 0 : g + 1) * F + f] : 0.f;
-        }
 #pragma unroll
         for (int ks = 0; ks < KP / 4; ++ks) {
             const int k = 4 * ks + lq;
             int off = 0;                                   // padding rows: any valid address (their weights are zero)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) wreg[ks][g] = 0.f;
             if (k < 9 * CIN) {
                 const int tap = k / CIN, c = k - tap * CIN;
                 const int th = tap / 3, tw = tap - 3 * th;
                 off = (((c >> 2) * (XH * XW) + th * XW + tw) << 2) + (c & 3);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wreg[ks][g] = Wx[k * 4 * F + (g == 0 ? 0 : g + 1) * F + li];
             }
             xoff[ks] = off;
         }
-        __syncthreads();
     }
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -285,9 +391,8 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
 #pragma unroll
             for (int ks = 0; ks < KP / 4; ++ks) {
                 const float xv = xsf2[pix0 + xoff[ks]];
-                const float* wr = &wl[(4 * ks + lq) * 3 * F + li];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g * F], xv, ga[g], 0, 0, 0);
+                for (int g = 0; g < 3; ++g) ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ks][g], xv, ga[g], 0, 0, 0);
             }
             // accumulator reg r of lane (li, lq): gate g of feature 4*lq + r of halo pixel li
             const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
@@ -487,8 +592,9 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_wgrad_reduce_kernel(const f
 }
 
 // ---- host -------------------------------------------------------------------------------------------------
-static int g_cl1_mfma = 0;     // wdg_set_tuning("convlstm1_mfma", 0/1): gate recompute of the 5 -> 16 backward on the matrix pipe
-void wdg_convlstm1_set_mfma(int v) { g_cl1_mfma = v != 0; }
+static int g_cl1_mfma = 0;     // wdg_set_tuning("convlstm1_mfma", bit 0): gate recompute of the 5 -> 16 backward on the matrix pipe
+static int g_cl1_fwd_mfma = 1; // bit 1 of the same knob CLEARS it: 5 -> 16 forward on the matrix pipe with register-resident weights
+void wdg_convlstm1_set_mfma(int v) { g_cl1_mfma = (v & 1) != 0; g_cl1_fwd_mfma = (v & 2) == 0; }
 static int cl1_cus() {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -513,7 +619,13 @@ extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, 
     dim3 grid((unsigned)((P + 127) / 128)), block(256);
     if (cin == 2)
         hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
-    else
+    else if (g_cl1_fwd_mfma && ldh % 4 == 0 && ((uintptr_t)h & 15) == 0 && img_stride_h % 4 == 0) {
+        p.tiles_h = (H + CLF_TH - 1) / CLF_TH;
+        p.tiles_w = (W + CLF_TW - 1) / CLF_TW;
+        const long long ntiles = (long long)n_img * p.tiles_h * p.tiles_w;
+        dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 4));     // persistent: weights loaded once per workgroup
+        hipLaunchKernelGGL((wdg_convlstm1_fwd_mfma_kernel<5, 16>), pgrid, block, 0, (hipStream_t)stream, p, wx, bias);
+    } else
         hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
@@ -545,7 +657,7 @@ static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* w
             hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false>), grid, block, 0, st, p, wx, bias);
         else {
             // persistent like the weight-gradient form: the LDS-resident weights are loaded once per workgroup
-            dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 2));   // 61 KB of LDS: two resident workgroups per CU
+            dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 2));   // (three fit — 52 KB of LDS, <= 168 registers — and measured slower: 594 vs 480 us with the weight gradient)
             hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false, true>), pgrid, block, 0, st, p, wx, bias);
         }
         WDG_LAUNCH_CHECK();
