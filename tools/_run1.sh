@@ -1,10 +1,5 @@
-python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py tests/test_fullsize_gpu.py -x -q 2>&1 | tail -2
+python -m pytest tests/test_model_gpu.py tests/test_metrics_gpu.py tests/test_dist_gpu.py tests/test_fullsize_gpu.py -x -q 2>&1 | tail -3
+F="--no-cpu-baseline --size 96 --timesteps 24 --batch 8 --steps 6 --warmup 2"
+for m in 0 1 0 1; do WDG_OVERLAP_GEN=$m python bench.py $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('T24 overlap_gen=$m', round(d['value'],1), round(d['ms_per_step'],2))"; done
 F="--no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs --steps 8 --warmup 3"
-python bench.py $F > gpurun_out/r03d.json 2>/dev/null
-python bench.py $F --tune convlstm1_mfma=2 > gpurun_out/r03d_fwdvalu.json 2>/dev/null
-python - <<'PY'
-import json
-for k in ('r03d','r03d_fwdvalu'):
-    d=json.loads(open(f'gpurun_out/{k}.json').read().strip().splitlines()[-1])
-    print(k, d['value'], d['ms_per_step'])
-PY
+for m in 0 1 0 1; do WDG_OVERLAP_GEN=$m python bench.py $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline overlap_gen=$m', round(d['value'],1), round(d['ms_per_step'],2))"; done

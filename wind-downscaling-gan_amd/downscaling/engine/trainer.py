@@ -42,13 +42,24 @@ class PhiloxSource:
         self.seed = (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & (2 ** 64 - 1)
         self.offset = 0
 
+    def reserve(self, n_elements):
+        """Claims the next ceil(n / 4) Philox blocks of the stream and returns their offset: a draw can then be LAUNCHED later
+        (or on another HIP stream) than its place in the reference's draw order."""
+        off = self.offset
+        self.offset += (int(n_elements) + 3) // 4
+        return off
+
+    def normal_at(self, view2d, std, offset, add=None):
+        self.ops.philox_normal(view2d, self.seed, offset, float(std), add)
+
+    def uniform_at(self, vec, offset):
+        self.ops.philox_uniform(vec, self.seed, offset)
+
     def normal_into(self, view2d, std, add=None):
-        self.ops.philox_normal(view2d, self.seed, self.offset, float(std), add)
-        self.offset += (view2d.shape[0] * view2d.shape[1] + 3) // 4
+        self.normal_at(view2d, std, self.reserve(view2d.shape[0] * view2d.shape[1]), add)
 
     def uniform_into(self, vec):
-        self.ops.philox_uniform(vec, self.seed, self.offset)
-        self.offset += (vec.numel() + 3) // 4
+        self.uniform_at(vec, self.reserve(vec.numel()))
 
 
 class DistSync:
@@ -102,6 +113,11 @@ class GanEngine:
             gen.sync = sync
         self._tmp = {}
         self._pending = {}
+        # the generator forward of critic iteration i + 1 (and of the generator step) runs on its own HIP stream under the
+        # discriminator passes of iteration i, D(real) of the metrics recompute under the generator's backward
+        # (WDG_OVERLAP_GEN=0 disables; single-process runs only) — _critic_pipelined
+        self.overlap_generator = os.environ.get("WDG_OVERLAP_GEN", "1")
+        self._gen_stream = None
 
     def _buf(self, key, *shape):
         t = self._tmp.get(key)
@@ -193,6 +209,68 @@ class GanEngine:
         disc.params.grads.add_(twin.params.grads)
         return loss.detach(), real_scores.mean(), fake_scores.mean()
 
+    def _critic_pipelined(self, B, T, real, comb, noisy, eps, gsq, ones, dscore, sw_mean, d_opt):
+        """The critic iterations (ganbase.py:26-47) with the generator forward of iteration i + 1 on a second HIP stream under
+        the three discriminator passes of iteration i.  Within a train step the generator's weights do not depend on the
+        discriminator's, so the only ordering the reference imposes between them is the data: fake_i feeds the interpolate and
+        the generated pass of iteration i.  Both consumers run first (the instance-noised copy of fake_i into its own
+        buffer), then the generator is free to overwrite its activations.  At the shipped sequence length the discriminator's
+        passes are chains of small per-timestep launches that leave most of the chip idle; the generator's large kernels
+        fill it.  Every random draw keeps the Philox offset of its place in the reference's draw order (reserved up front:
+        generator noise, eps, instance noise of the real pass, of the generated pass, per iteration), so the arithmetic —
+        and the oracle replay of tests/helpers.Draws — is unchanged.  Returns (disc_loss, gnorm, dscale, the generator step's
+        forward output)."""
+        gen, disc, ops, noise = self.gen, self.disc, self.ops, self.noise
+        S, ch = gen.S, disc.ch
+        N, ppi = T * B, S * S
+        nview = gen.noise_view(B)
+        n_g, n_i = nview.shape[0] * nview.shape[1], N * ppi * ch
+        offs = [(noise.reserve(n_g), noise.reserve(B), noise.reserve(n_i), noise.reserve(n_i)) for _ in range(self.n_critic)]
+        o_gstep = noise.reserve(n_g)                                              # the generator step's noise (:51) comes next
+        nf = self._buf("noisy_fake", *noisy.shape)
+        if self._gen_stream is None:
+            self._gen_stream = torch.cuda.Stream(device=ops.device)
+        gs, main = self._gen_stream, torch.cuda.current_stream(ops.device)
+        noise.normal_at(nview, self.noise_std, offs[0][0])                        # :28
+        fake = gen.forward(B, training=True, need_backward=False)                 # :29
+        for i in range(self.n_critic):
+            o_g, o_e, o_r, o_f = offs[i]
+            noise.uniform_at(eps, o_e)                                            # :30
+            ops.lerp_batch(v2(real), v2(fake), eps, v2(comb), ppi, B)             # :31
+            noise.normal_at(v2(nf[..., :ch]), self.noise_std, o_f, add=v2(fake[..., :ch]))      # :42 (drawn now, used below)
+            gs.wait_stream(main)                                                  # fake_i has been consumed
+            with torch.cuda.stream(gs):
+                if i + 1 < self.n_critic:
+                    noise.normal_at(nview, self.noise_std, offs[i + 1][0])
+                    fake = gen.forward(B, training=True, need_backward=False)
+                else:
+                    # the forward of the GENERATOR step (:50-52) does not read the discriminator either: under the last
+                    # iteration's passes
+                    gen.params.zero_grad()
+                    noise.normal_at(nview, self.noise_std, o_gstep)
+                    fake = gen.forward(B, training=True, need_backward=True)
+            self._flush(disc)
+            disc.set_high_tm(comb, B)
+            disc.forward(B, training=True)                                        # :32-34
+            dcomb = disc.backward(B, ones, need_wgrad=False)                      # :35
+            ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                         # :36
+            gnorm = torch.sqrt(gsq[:, :ch])
+            gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()               # :37
+            disc.params.zero_grad()
+            noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
+            disc.set_high_tm(noisy, B)
+            real_mean = disc.forward(B, training=True).mean()                     # :41
+            dscore.fill_(-sw_mean / B)
+            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+            disc.set_high_tm(nf, B)
+            fake_mean = disc.forward(B, training=True).mean()                     # :43
+            dscore.fill_(sw_mean / B)
+            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+            disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45
+            dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
+            main.wait_stream(gs)
+        return disc_loss, gnorm, dscale, fake
+
     def train_step(self, low, high, g_opt, d_opt, sample_weight=None, reconstruction_loss=None, d_loss_fn=None):
         """One GAN.train_step (ganbase.py:21-94).  low [B,T,S,S,cl], high [B,T,S,S,ch] device tensors.
         d_loss_fn: the discriminator's compiled loss when it is not the built-in Wasserstein form (None = built-in)."""
@@ -212,7 +290,12 @@ class GanEngine:
         ones.fill_(1.0)
         dscore = self._buf("dscore", B)
 
-        for _ in range(self.n_critic):                                            # ganbase.py:26
+        mode = self.overlap_generator
+        pipelined = (d_loss_fn is None and getattr(ops, "supports_graphs", False) and mode != "0"
+                     and not (self.sync is not None and self.sync.active))
+        if pipelined:
+            disc_loss, gnorm, dscale, fake = self._critic_pipelined(B, T, real, comb, noisy, eps, gsq, ones, dscore, sw_mean, d_opt)
+        for _ in range(0 if pipelined else self.n_critic):                        # ganbase.py:26
             noise.normal_into(gen.noise_view(B), self.noise_std)                   # :28
             fake = gen.forward(B, training=True, need_backward=False)             # :29 (outside any tape)
             noise.uniform_into(eps)                                               # :30
@@ -242,9 +325,10 @@ class GanEngine:
             disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
             disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45, train.py:11-12
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
-        gen.params.zero_grad()                                                    # generator step, :50-61
-        noise.normal_into(gen.noise_view(B), self.noise_std)
-        fake = gen.forward(B, training=True, need_backward=True)                  # overlaps the last D exchange
+        if not pipelined:
+            gen.params.zero_grad()                                                # generator step, :50-61
+            noise.normal_into(gen.noise_view(B), self.noise_std)
+            fake = gen.forward(B, training=True, need_backward=True)              # overlaps the last D exchange
         self._flush(disc)
         d_gradient_param = self._grad_param_metric(disc, dscale)
 
@@ -257,11 +341,22 @@ class GanEngine:
             reco_loss, dreco = self._reco_grad(reconstruction_loss, low, fake, B, T)
             gen_loss = gen_loss + reco_loss
             ops.copy_channels(dreco, dfake[..., :ch], accumulate=True)
+        if pipelined:
+            # metrics recompute, :63-65: D(real) in inference mode reads neither the generator nor anything its backward
+            # writes — on the second stream under the generator's backward pass (the discriminator's activations are free:
+            # its last backward has produced dfake)
+            gs, main = self._gen_stream, torch.cuda.current_stream(ops.device)
+            gs.wait_stream(main)
+            with torch.cuda.stream(gs):
+                disc.set_high_tm(real, B)
+                real_mean = disc.forward(B, training=False).mean()
         gen.backward(B, dfake)
         gscale = self._reduce_and_step(gen, g_opt)
-
-        disc.set_high_tm(real, B)                                                 # metrics recompute, :63-68
-        real_mean = disc.forward(B, training=False).mean()                        # overlaps the generator's exchange
+        if pipelined:
+            main.wait_stream(gs)
+        else:
+            disc.set_high_tm(real, B)                                             # metrics recompute, :63-68
+            real_mean = disc.forward(B, training=False).mean()                    # overlaps the generator's exchange
         self._flush(gen)
         g_gradient_param = self._grad_param_metric(gen, gscale)
         noise.normal_into(gen.noise_view(B), self.noise_std)
