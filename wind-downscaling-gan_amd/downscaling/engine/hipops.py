@@ -191,11 +191,12 @@ class _PrepBatch:
 
 
 class _Fork:
-    def __init__(self, ops):
+    def __init__(self, ops, name="side"):
         self.ops = ops
-        if getattr(ops, "_side_stream", None) is None:
-            ops._side_stream = torch.cuda.Stream(device=ops.device)
-        self.side = ops._side_stream
+        streams = ops.__dict__.setdefault("_side_streams", {})
+        if name not in streams:
+            streams[name] = torch.cuda.Stream(device=ops.device)
+        self.side = streams[name]
         self.ctx = None
 
     def __enter__(self):
@@ -264,11 +265,12 @@ class HipOps:
             ws = self._ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
         return ws
 
-    def fork(self):
-        """Context manager: run the enclosed launches on a side stream that starts after everything enqueued so far;
-        `join()` on the returned object makes the main stream wait for them.  Only worth it for chains of small
-        launches (the per-timestep recurrent kernels at T > 1); full-size kernels fill the chip on their own."""
-        return _Fork(self)
+    def fork(self, name="side"):
+        """Context manager: run the enclosed launches on the side stream `name` that starts after everything enqueued so far
+        on the current stream; `join()` on the returned object makes the current stream wait for them.  Used for chains of
+        small launches (the per-timestep recurrent kernels at T > 1) and for work off the critical path of a pass (the
+        weight gradients of a backward pass: name "wgrad")."""
+        return _Fork(self, name)
 
     def set_split_mode(self, on):
         self.split_mode = bool(on)

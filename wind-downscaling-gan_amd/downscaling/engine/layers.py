@@ -350,9 +350,15 @@ class ConvLSTM:
                     o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
             dc_in = dc_out
         if need_wgrad:
-            o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True)
-            if T > 1:
-                o.conv_wgrad(h[:(T - 1) * B], self.dgates[B:], self.pkh, self.wh.grad, self.g, accumulate=True)
-            o.colsum(v2(self.dgates), self.b.grad, accumulate=True)
+            def weight_grads():
+                o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True)
+                if T > 1:
+                    o.conv_wgrad(h[:(T - 1) * B], self.dgates[B:], self.pkh, self.wh.grad, self.g, accumulate=True)
+                o.colsum(v2(self.dgates), self.b.grad, accumulate=True)
+            joins = getattr(self.net, "_bwd_joins", None)
+            if joins is not None:
+                self.net._wgrad(weight_grads, joins)      # under the input gradient below (the network's pass joins)
+            else:
+                weight_grads()
         if dx is not None:
             o.conv_dgrad(self.dgates, self.pkx, dx, self.g, accumulate=accumulate_dx)

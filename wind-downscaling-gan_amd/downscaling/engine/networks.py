@@ -48,6 +48,29 @@ class _Net:
         self._prep.run(sn=training, pack_all=self._packed_version != self.params.version)
         self._packed_version = self.params.version
 
+    # ---- weight gradients off the critical path ---------------------------------------------------
+    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "1") != "0"
+
+    def _wgrad(self, fn, joins):
+        """Runs `fn` (the weight-gradient launches of one layer) on the "wgrad" side stream, after everything enqueued so far
+        (its operands are ready), while the caller goes on with the data gradient on the current stream: the two read the
+        same dz and write different buffers, and nothing needs dW before the optimizer step.  On the small maps of the
+        discriminator's stack and at T > 1 neither kernel fills the chip, and everywhere the one's tail runs under the
+        other.  `joins` collects the forks; the pass joins them before it returns (the next pass overwrites the
+        activations and gradient buffers the weight gradients read)."""
+        if not self.wgrad_stream:
+            fn()
+            return
+        with self.ops.fork("wgrad") as side:
+            fn()
+        joins.append(side)
+
+    @staticmethod
+    def _join(joins):
+        for side in joins[-1:]:          # one stream: its last fork's join covers the earlier ones
+            side.join()
+        joins.clear()
+
     # ---- [B,T,...] <-> time-major ---------------------------------------------------------------
     def to_time_major(self, src, dst):
         """src [B,T,H,W,C] (API layout) -> dst[..., :C] of a [T*B,H,W,C'] buffer."""
@@ -275,8 +298,9 @@ class GeneratorNet(_Net):
         o, F, IF, T = self.ops, self.F, self.IF, self.T
         res2, res4 = b["cat2"][..., self.F4p:], b["cat4"][..., F // 2:]
         # c11 (linear)
+        joins = self._bwd_joins = []
         o.colsum(v2(dout[..., :self.out_channels]), self.c11.b.grad, accumulate=True)
-        self.c11.backward_weights(b["z9"], dout)
+        self._wgrad(lambda: self.c11.backward_weights(b["z9"], dout), joins)
         self.c11.backward_input(dout, g["dz9"])
         # bn10 + LeakyReLU of c9
         self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad_pad)
@@ -285,24 +309,25 @@ class GeneratorNet(_Net):
         # bn8 + c7
         d7 = g["dcat2"][..., :self.F4p]
         self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad_pad)
-        self.c7.backward_weights(b["cat4"], d7)
+        self._wgrad(lambda: self.c7.backward_weights(b["cat4"], d7), joins)
         self.c7.backward_input(d7, g["dcat4"])
         # bn6 + c5
         d5 = g["dcat4"][..., :F // 2]
         self.bn6.backward(v2(d5), v2(b["y5"]), v2(d5), self.c5.b.grad_pad)
-        self.c5.backward_weights(b["h"], d5)
+        self._wgrad(lambda: self.c5.backward_weights(b["h"], d5), joins)
         self.c5.backward_input(d5, g["dh"])
         # ConvLSTM; its input gradient adds to the skip gradient already in dcat4[..., F/2:]
         dres4 = g["dcat4"][..., F // 2:]
         self.lstm.backward(res4, b["h"], g["dh"], dres4, B, T, need_wgrad=True, accumulate_dx=True)
         # bn3 + c2
         self.bn3.backward(v2(dres4), v2(b["y2"]), v2(dres4), self.c2.b.grad_pad)
-        self.c2.backward_weights(res2, dres4)
+        self._wgrad(lambda: self.c2.backward_weights(res2, dres4), joins)
         dres2 = g["dcat2"][..., self.F4p:]
         self.c2.backward_input(dres4, dres2, accumulate=True)
         # bn1 + c0
         self.bn1.backward(v2(dres2), v2(b["y0"]), v2(dres2), self.c0.b.grad_pad)
         self.c0.backward_weights(b["x0"], dres2)
+        self._join(joins)
 
 
 def discriminator_plan(size, channels):
@@ -564,6 +589,7 @@ class DiscriminatorNet(_Net):
         o, Fd, T = self.ops, self.Fd, self.T
         x = self._last
         N = T * B
+        joins = self._bwd_joins = []
         if self.blocks:
             dx = b["dzs"][-1]
         else:
@@ -581,7 +607,7 @@ class DiscriminatorNet(_Net):
             xin = b["zs"][i - 1] if i > 0 else b["cat"]
             dxin = b["dzs"][i - 1] if i > 0 else b["dcat"]
             if need_wgrad:
-                conv.backward_weights(xin, dz)
+                self._wgrad(lambda conv=conv, xin=xin, dz=dz: conv.backward_weights(xin, dz), joins)
             conv.backward_input(dz, dxin)
             if split:
                 self._shortcut_bwd(b, b["sc_dz"], xin, dxin, need_wgrad)
@@ -601,6 +627,7 @@ class DiscriminatorNet(_Net):
         else:
             branch_a()
             branch_b()
+        self._join(joins)
         if not need_input_grad:
             return None
         # d(high) = d(hi) + d(mix)[cl:cl+ch]
