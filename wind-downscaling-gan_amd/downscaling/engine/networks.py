@@ -410,8 +410,10 @@ class DiscriminatorNet(_Net):
         sc = discriminator_shortcut(S, 2 * Fd) if shortcut_variant else None
         self.blocks = []
         self.shortcut = None
-        # T > 1 only: the two input branches on two streams (WDG_OVERLAP_BRANCHES=0 disables, for A/B runs)
+        # the two input branches on two streams (WDG_OVERLAP_BRANCHES=0 disables, =3 restricts it to T > 1, for A/B runs): at
+        # T = 1 worth 0.6 ms per step once the generator runs beside the discriminator (70.95 -> 70.35 ms, same box)
         self.overlap_branches = os.environ.get("WDG_OVERLAP_BRANCHES", "1") != "0"
+        self.overlap_branches_t1 = os.environ.get("WDG_OVERLAP_BRANCHES", "1") != "3"   # "3": T > 1 only (the round-2 behaviour)
         idx = 6
         for n, (k, s, p, ci, co, osz) in enumerate(plan):
             conv = self._add(Conv(self, L + str(idx), k, ci, co, s, p, sn=True))              # :113-114,122-123,134
@@ -509,11 +511,11 @@ class DiscriminatorNet(_Net):
         o, Fd, T = self.ops, self.Fd, self.T
         self._prepare(training)
         # (the persistent sequence kernels size their grids to be fully resident: never two of them side by side)
-        overlap = T > 1 and self.overlap_branches and not self.lstm_b._seq(T, b["hb"])
+        overlap = (T > 1 or self.overlap_branches_t1) and self.overlap_branches and not self.lstm_b._seq(T, b["hb"])
         self._overlap_now = overlap
         if overlap:
             # the two input branches are independent chains of small per-timestep launches: run the high-res-only one
-            # on a side stream under the other (at T = 1 every kernel fills the chip and the overlap gains nothing)
+            # on a side stream under the other
             with o.fork() as side:
                 self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
                 self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
@@ -577,7 +579,7 @@ class DiscriminatorNet(_Net):
         else:
             ln.backward(v2(dz), v2(y), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
             if need_wgrad:
-                conv.backward_weights(x, dz)
+                self._wgrad(lambda: conv.backward_weights(x, dz), self._bwd_joins)
             conv.backward_input(dz, dx)
 
     def backward(self, B, dscore, need_wgrad, need_input_grad=True):
