@@ -139,6 +139,13 @@ int wdg_conv_dgrad_bn(const wdg_conv_plan* plan, const float* dy, const float* w
 int wdg_conv_fwd_ln(const wdg_conv_plan* plan, const float* x, const float* wF, const float* bias, float* y, float* z,
                     const float* gamma, const float* beta, float eps, float* mean_rstd, int act, float slope,
                     void* ws, size_t ws_bytes, wdg_stream stream);
+/* The same with z in a view of its own (pixel stride ldz, image stride img_stride_z): the discriminator writes the normalised
+ * branch straight into its half of the [hr | mix] concatenation (models.py:102-108) while y keeps its own buffer.  The thin
+ * full-resolution 16 -> 16 layer runs the norm in the epilogue of the halo-tile kernel; elsewhere a z view different from y's
+ * takes the convolution followed by wdg_ln_fwd. */
+int wdg_conv_fwd_ln_strided(const wdg_conv_plan* plan, const float* x, const float* wF, const float* bias, float* y, float* z,
+                            int ldz, int64_t img_stride_z, const float* gamma, const float* beta, float eps, float* mean_rstd,
+                            int act, float slope, void* ws, size_t ws_bytes, wdg_stream stream);
 
 /* Fused UpSampling2D(2,'bilinear') + Conv2DTranspose forward: y = act(convT(upsample2x(x_low), wD) + bias).
  * `plan` is the transposed conv's plan on the UPSAMPLED grid (conv-output side 2H x 2W, stride 1, k <= 5,

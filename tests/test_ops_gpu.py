@@ -484,6 +484,8 @@ LN_CASES = [
     ("tail_3x3s2", 4, 3, 3, 256, 512, 3, 2, 0),
     ("encoder_5x5s3", 3, 40, 40, 4, 8, 5, 3, 1),
     ("cout128_one_tile", 2, 64, 64, 128, 128, 3, 1, 1),          # 128x128 tile, epilogue
+    ("d_conv_b_16to16_halo", 3, 40, 52, 16, 16, 3, 1, 1),        # thin full-resolution layer: norm in the halo-tile kernel's epilogue (ragged tiles)
+    ("d_conv_b_16to16_halo_256", 2, 256, 256, 16, 16, 3, 1, 1),
 ]
 
 
@@ -505,9 +507,15 @@ def test_conv_layernorm_fused(case, hip_ops, ref_ops):
     res = {}
     for tag, ops, cv, G in (("ref", ref_ops, lambda t: t.clone(), RG), ("hip", hip_ops, lambda t: t.float().to(dev).contiguous(), ConvGeom)):
         pk, g = ops.pack_weights(cv(w)), G(k, k, s_, p_)
-        y, z = ops.zeros(n, Ho, Wo, cout), ops.zeros(n, Ho, Wo, cout)
+        y = ops.zeros(n, Ho, Wo, cout)
+        # the thin-layer cases write z into the second half of a wider buffer, as the discriminator does (models.py:102-108)
+        zbuf = ops.zeros(n, Ho, Wo, 2 * cout) if "halo" in name else ops.zeros(n, Ho, Wo, cout)
+        z = zbuf[..., cout:] if "halo" in name else zbuf
         mr = ops.empty(n * Ho * Wo, 2)
         ops.conv_fwd_ln(cv(x), pk, cv(bias), y, z, g, cv(gamma), cv(beta), 1e-3, mr, act=True, slope=0.2)
+        if "halo" in name:
+            assert float(zbuf[..., :cout].abs().max()) == 0.0          # the other half of the concatenation is untouched
+            z = z.contiguous()
         y2 = ops.zeros(n, Ho, Wo, cout)
         ops.conv_fwd(cv(x), pk, cv(bias), y2, g, act=True, slope=0.2)
         res[tag] = dict(y=y, z=z, mr=mr, y2=y2)

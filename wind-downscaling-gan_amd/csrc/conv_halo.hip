@@ -46,6 +46,16 @@ struct WdgHalo {
     // backward step (lstm_bwd != 0, data-gradient direction, Ncols = lstm_F): Out is dh_{t-1} — the accumulated result is the
     // complete gradient of h_{t-1}, so the cell backward of timestep t-1 follows in the epilogue: reads gates / c of t-1 and the
     // dc flowing in from t, writes dgates_{t-1} and (dc_out != NULL) the dc flowing on to t-2.  c_prev == NULL at t-1 = 0.
+    // LayerNormalization over the 16 output channels in the epilogue of the persistent 3x3 kernel (ln_gamma != NULL; models.py
+    // :102-105): Out keeps y = act(conv + bias) for the backward pass, Out2 (own pixel / image stride) receives z, mean_rstd the
+    // per-pixel statistics
+    float* Out2;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float* mean_rstd;
+    float ln_eps;
+    int ldO2;
+    long long imgStrideO2;
     int lstm_bwd;
     const float* gates_t;     // [pixel][4 * lstm_F] pre-activations of the timestep whose cell is differentiated
     const float* c_cur;       // its cell state
@@ -494,6 +504,43 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = 4 * lg + r < p.Ncols ? p.bias[4 * lg + r] : 0.f;
             }
+            if (p.ln_gamma) {
+                // conv -> bias -> LeakyReLU -> LayerNormalization over the 16 channels of a pixel: they sit in the four lanes
+                // li, li + 16, li + 32, li + 48 (four registers each), so the two reductions (sum, centred sum of squares — the
+                // two-pass form of wdg_ln_fwd) are two xor-shuffles each; y and z leave as 16-byte stores, no pass re-reads y
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * lg), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * lg);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int oy = ty * HALO_TH + 2 * wave + (a >> 1);
+                    const int ox = tx * HALO_TW + (a & 1) * 16 + li;
+                    f32x4 v = acc[a] + bv;
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
+                    }
+                    float s_ = (v[0] + v[1]) + (v[2] + v[3]);
+                    s_ += __shfl_xor(s_, 16, 64);
+                    s_ += __shfl_xor(s_, 32, 64);
+                    const float mean = s_ * (1.f / 16.f);
+                    const f32x4 d = v - mean;
+                    float q_ = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                    q_ += __shfl_xor(q_, 16, 64);
+                    q_ += __shfl_xor(q_, 32, 64);
+                    const float rstd = 1.f / sqrtf(q_ * (1.f / 16.f) + p.ln_eps);
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    const long long pix = (long long)oy * p.Wo + ox;
+                    *reinterpret_cast<f32x4*>(p.Out + (long long)img * p.imgStrideO + pix * p.ldO + 4 * lg) = v;
+                    f32x4 z;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = d[r] * rstd * gm[r] + bt[r];
+                    *reinterpret_cast<f32x4*>(p.Out2 + (long long)img * p.imgStrideO2 + pix * p.ldO2 + 4 * lg) = z;
+                    if (p.mean_rstd && lg == 0) {
+                        const long long pi = (long long)img * p.Ho * p.Wo + pix;
+                        p.mean_rstd[2 * pi] = mean;
+                        p.mean_rstd[2 * pi + 1] = rstd;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int oy = ty * HALO_TH + 2 * wave + (a >> 1);
@@ -507,6 +554,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
                 }
                 if (p.accumulate) v += *dst;
                 *dst = v;
+            }
             }
         }
     }
@@ -574,12 +622,25 @@ void wdg_halo_plan_free(wdg_conv_plan* pl) {
     if (pl->d_taps_dgrad) (void)hipFree(pl->d_taps_dgrad);
 }
 
+// forward conv of this plan runs in the persistent 3x3 kernel with exactly 16 output channels: its epilogue can normalise them
+static int g_halo_ln = 1;           // wdg_set_tuning("halo_ln", 0/1)
+void wdg_halo_set_ln(int v) { g_halo_ln = v != 0; }
+bool wdg_halo_ln_eligible(const wdg_conv_plan* pl) {
+    const wdg_conv_geom& g = pl->g;
+    return g_halo_ln && pl->halo_auto_fwd && pl->halo_fwd_nt == 1 && g_halo_persistent && pl->Cin_p == 16 && pl->taps == 9 && g.kh == 3 &&
+           g.Cout == 16;
+}
+
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
-                    hipStream_t st, const WdgHaloLstm* cell) {
+                    hipStream_t st, const WdgHaloLstm* cell, const WdgHaloLn* ln) {
     const wdg_conv_geom& g = pl->g;
     WdgHalo p;
     memset(&p, 0, sizeof(p));
+    if (ln) {
+        p.Out2 = ln->z; p.ldO2 = ln->ldz; p.imgStrideO2 = ln->img_stride_z; p.ln_gamma = ln->gamma; p.ln_beta = ln->beta;
+        p.ln_eps = ln->eps; p.mean_rstd = ln->mean_rstd;
+    }
     if (cell) {
         p.lstm_F = cell->F; p.c_prev = cell->c_prev; p.c_out = cell->c_out; p.h_out = cell->h_out; p.ldc = cell->ldc; p.ldh = cell->ldh;
         p.lstm_bwd = cell->bwd; p.gates_t = cell->gates_t; p.c_cur = cell->c_cur; p.dc_in = cell->dc_in;
@@ -634,6 +695,10 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
     const size_t lds = halo_lds_bytes(g.kh, g.kw, nt, wg, upsample, th);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
+    if (ln && !persistent1) {
+        wdg_set_error("halo: the LayerNorm epilogue exists in the persistent 3x3 kernel only (wdg_halo_ln_eligible)");
+        return WDG_ERR_ARG;
+    }
     if (persistent1) {
         // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
         const size_t lds1 = ((size_t)4 * p.npix + 9 * 64) * sizeof(f32x4);

@@ -1278,6 +1278,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         if (value > 1) g_n_fastest_bytes = (long long)value << 10;   // value > 1: B-operand limit in KiB
         return WDG_OK;
     }
+    if (key && !strcmp(key, "halo_ln")) {
+        wdg_halo_set_ln(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "halo_th4")) {
         wdg_halo_set_th4(value);
         return WDG_OK;
@@ -1585,13 +1589,29 @@ static int conv_dgrad_impl(const wdg_conv_plan* pl, const float* dy, const float
 extern "C" int wdg_conv_fwd_ln(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y, float* z,
                                const float* gamma, const float* beta, float eps, float* mean_rstd, int act, float slope,
                                void* ws, size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl, "null plan");
+    return wdg_conv_fwd_ln_strided(pl, x, wF, bias, y, z, pl->g.ldy, pl->g.img_stride_y, gamma, beta, eps, mean_rstd, act, slope, ws,
+                                   ws_bytes, stream);
+}
+
+extern "C" int wdg_conv_fwd_ln_strided(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y, float* z,
+                                       int ldz, int64_t img_stride_z, const float* gamma, const float* beta, float eps,
+                                       float* mean_rstd, int act, float slope, void* ws, size_t ws_bytes, wdg_stream stream) {
     WDG_CHECK_ARG(pl && x && wF && y && z && gamma && beta, "null argument");
+    WDG_CHECK_ARG(ldz % 4 == 0 && ldz >= wdg_round_up(pl->g.Cout, 4), "z: pixel stride must be a multiple of 4 and >= the padded channel count");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
                   ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0, "x / wF / y / z / gamma / beta must be 16-byte aligned");
     const wdg_conv_geom& g = pl->g;
     const int64_t P = (int64_t)g.n_img * g.Ho * g.Wo;
     bool fused = false;
-    if (!(pl->halo_auto_fwd && pl->halo_fwd_nt) && g.Cout % 4 == 0) {
+    const bool same_view = ldz == g.ldy && img_stride_z == g.img_stride_y;
+    if (wdg_halo_ln_eligible(pl) && act) {
+        // thin full-resolution 16 -> 16 layer (models.py:102-105): the norm in the epilogue of the persistent halo-tile kernel
+        WdgHaloLn ln;
+        ln.z = z; ln.ldz = ldz; ln.img_stride_z = img_stride_z; ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.mean_rstd = mean_rstd;
+        return wdg_halo_launch(pl, false, x, g.ldx, g.img_stride_x, 0, wF, bias, y, act, slope, 0, (hipStream_t)stream, nullptr, &ln);
+    }
+    if (!(pl->halo_auto_fwd && pl->halo_fwd_nt) && g.Cout % 4 == 0 && same_view) {
         WdgIgemm p;
         memset(&p, 0, sizeof(p));
         p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
@@ -1615,11 +1635,11 @@ extern "C" int wdg_conv_fwd_ln(const wdg_conv_plan* pl, const float* x, const fl
         const int rc = conv_fwd_impl(pl, x, wF, bias, y, act, slope, 0, nullptr, ws, ws_bytes, stream);
         if (rc != WDG_OK) return rc;
     }
-    if (g.img_stride_y != (int64_t)g.Ho * g.Wo * g.ldy) {
+    if (g.img_stride_y != (int64_t)g.Ho * g.Wo * g.ldy || img_stride_z != (int64_t)g.Ho * g.Wo * ldz) {
         wdg_set_error("wdg_conv_fwd_ln: the unfused path needs contiguous output images");
         return WDG_ERR_ARG;
     }
-    return wdg_ln_fwd(y, g.ldy, gamma, beta, eps, z, g.ldy, mean_rstd, P, g.Cout, stream);
+    return wdg_ln_fwd(y, g.ldy, gamma, beta, eps, z, ldz, mean_rstd, P, g.Cout, stream);
 }
 
 extern "C" int wdg_conv_fwd(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias,

@@ -79,9 +79,20 @@ struct WdgHaloLstm {   // ConvLSTM cell update / cell backward in the epilogue o
     float* dc_out;
 };
 void wdg_halo_set_lstm_fused(int v);
+struct WdgHaloLn {     // LayerNormalization of the 16 output channels in the persistent 3x3 kernel's epilogue (conv_halo.hip)
+    float* z;
+    int ldz;
+    long long img_stride_z;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float* mean_rstd;
+};
+bool wdg_halo_ln_eligible(const wdg_conv_plan* pl);
+void wdg_halo_set_ln(int v);
 int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA, int upsample,
                     const float* Bw, const float* bias, float* Out, int act, float slope, int accumulate,
-                    hipStream_t st, const WdgHaloLstm* cell = nullptr);
+                    hipStream_t st, const WdgHaloLstm* cell = nullptr, const WdgHaloLn* ln = nullptr);
 
 // conv_patch_h16.hip
 void wdg_patch_h16_set(int v);

@@ -336,12 +336,13 @@ class HipOps:
         the epilogue that owns complete rows, or as the standalone pass behind the conv)."""
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
-        assert z.shape == y.shape and z.stride() == y.stride()
+        assert z.shape[:3] == y.shape[:3]
+        _, ldz, isz = _v4(z)            # z may live in a wider buffer (a channel slice of a concatenation)
         if self.split_mode:
             pk.split3("wF")
-        native.check(self.lib.wdg_conv_fwd_ln(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), z.data_ptr(),
-                                              gamma.data_ptr(), beta.data_ptr(), eps, _ptr(mean_rstd), int(act), slope,
-                                              ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_ln")
+        native.check(self.lib.wdg_conv_fwd_ln_strided(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), z.data_ptr(),
+                                                      ldz, isz, gamma.data_ptr(), beta.data_ptr(), eps, _ptr(mean_rstd), int(act),
+                                                      slope, ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_ln")
 
     def conv_dgrad(self, dy, pk, dx, g, bias=None, act=False, accumulate=False, slope=0.2, bn_stats=None, bn_affine=None):
         """dx = act(conv_transpose(dy, W) + bias) (+ dx);  the geometry is that of the forward conv.  bn_stats / bn_affine
@@ -522,11 +523,11 @@ class HipOps:
             t = pool[key] = self.empty(*shape)
         return t
 
-    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g, pool=None):
+    def upconv_bwd(self, x_low, dpre, pk, dw, dx_low, g, pool=None, wgrad_async=None):
         """Backward of y = convT(bilinear_x2(x_low), W) given dpre = dL/dy (before bias/activation):
         dw += dL/dW, dx_low = dL/dx_low.  pk/g as in upconv_fwd.  5x5 layers with 4/8/16 output channels run in
         column form on the low-res grid (csrc/upconv_col.hip: a quarter of the multiply-adds); anything else
-        through the materialised upsampled tensor."""
+        through the materialised upsampled tensor.  wgrad_async(fn): runs the weight-gradient launch off the caller's stream."""
         n, Hl, Wl, C = x_low.shape
         lib = self.lib
         if self.upconv_col and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
@@ -535,8 +536,12 @@ class HipOps:
             col = self._scratch("upc_col", n, Hl, Wl, 25 * pk.cin, pool=pool)
             native.check(lib.wdg_upconv_col(pdy, lddy, isdy, col.data_ptr(), n, Hl, Wl, pk.cin, self.stream), "upconv_col")
             pk1, g1 = pk.as_1x1(), ConvGeom(1, 1, 1, 0)
+            wg = lambda: self.conv_wgrad(col, x_low, pk1, dw.view(1, 1, 25 * pk.cin, pk.cout), g1, accumulate=True)  # noqa: E731
+            if wgrad_async is not None:
+                wgrad_async(wg)            # (the caller's pass joins before the column scratch is written again)
+            else:
+                wg()
             self.conv_fwd(col, pk1, None, dx_low, g1, act=False)
-            self.conv_wgrad(col, x_low, pk1, dw.view(1, 1, 25 * pk.cin, pk.cout), g1, accumulate=True)
             return
         up = self._scratch("upc_up", n, 2 * Hl, 2 * Wl, C, pool=pool)
         dup = self._scratch("upc_dup", n, 2 * Hl, 2 * Wl, C, pool=pool)

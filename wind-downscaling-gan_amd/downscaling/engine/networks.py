@@ -305,7 +305,8 @@ class GeneratorNet(_Net):
         # bn10 + LeakyReLU of c9
         self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad_pad)
         o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g,   # :60-64 backward
-                     pool=self._scratch_pool(b))
+                     pool=self._scratch_pool(b), **({"wgrad_async": lambda fn: self._wgrad(fn, joins)}
+                                                    if getattr(o, "supports_graphs", False) else {}))
         # bn8 + c7
         d7 = g["dcat2"][..., :self.F4p]
         self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad_pad)
@@ -568,8 +569,7 @@ class DiscriminatorNet(_Net):
             # z only: the backward recomputes the pre-norm activation and its statistics from the 2-channel input
             self.ops.convln_fwd(x, conv.w.value, conv.b.value, ln.gamma.value, ln.beta.value, LN_EPS, LRELU, None, z, None)
         else:
-            conv.forward(x, y)
-            ln.forward(v2(y), v2(z))
+            conv.forward_ln(x, y, z, ln)     # (z: a channel slice of the concatenation — wdg_conv_fwd_ln_strided)
 
     def _conv_ln_bwd(self, conv, ln, dz, y, x, dx, need_wgrad):
         if self._fused_conv_ln(conv):
