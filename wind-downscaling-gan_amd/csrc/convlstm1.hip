@@ -415,12 +415,19 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
                 }
             }
         }
-    } else
-    // 2. dgates on the (GH x GW) halo: work item = (halo pixel, half); halves are wave-uniform
-    for (int base = 0; base < GH * GW; base += 128) {
-        const int hp_ = base + (t & 127);
-        if (hp_ < GH * GW && half_on) {
-            const int hy = hp_ / GW, hx = hp_ - hy * GW;
+    } else {
+    // 2. dgates on the (GH x GW) halo: work item = (halo pixel, half); halves are wave-uniform.  Without an input gradient (the
+    // weights-only pass of the critic update: 6 of the 10 launches of a train step) nothing reads the halo ring — the weight
+    // gradient contracts over the centre pixels only — so the gates are recomputed for the 128 centre pixels: one round of
+    // work items instead of two.
+    const int n_items = p.dX ? GH * GW : CL_TH * CL_TW;
+    for (int base = 0; base < n_items; base += 128) {
+        const int item = base + (t & 127);
+        const int hy_ = p.dX ? item / GW : 1 + item / CL_TW;
+        const int hx_ = p.dX ? item - (item / GW) * GW : 1 + item % CL_TW;
+        const int hp_ = hy_ * GW + hx_;
+        if (item < n_items && half_on) {
+            const int hy = hy_, hx = hx_;
             const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
             const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             float dgi[FH], dgc[FH], dgo[FH];
@@ -462,6 +469,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
                 d[2 * F + f] = dgo[f];
             }
         }
+    }
     }
     __syncthreads();
     if constexpr (WG) {
