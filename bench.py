@@ -438,6 +438,9 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="print a per-layer table of the timed conv launches to stderr")
     ap.add_argument("--no-generator-leg", action="store_true", help="skip the generator-forward-at-batch-64 leg of the default line")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the configs[0] / [3] / [4] legs of the default line")
+    ap.add_argument("--no-serial-pass", action="store_true",
+                    help="skip the extra single-stream train steps the per-kernel roofline figures are taken from (profiling runs: "
+                         "the figures then come from the timed region, whatever its stream schedule)")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the extra leg that repeats the timed steps with the implicit-GEMM kernels in bf16-slice mode")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp16"], default="fp32", help="gen_fwd only: inference precision")
@@ -524,13 +527,47 @@ def main():
         dt = float(tt.item())
 
     rccl_info = rccl_evidence(dist, gan, world, rank, dev) if dist_on else None
+    # ---- per-kernel figures on ONE stream.  The default schedule runs the generator beside the discriminator, weight gradients
+    # beside data gradients and the discriminator's two input branches beside each other on separate HIP streams: kernels of
+    # different streams share the chip, so a per-launch duration inside the timed region (HIP events or a kernel trace alike)
+    # measures the sharing, not the kernel.  The roofline of the dominant kernel is therefore taken from extra train steps with
+    # every overlap switched off (same kernels, same launches, one stream), timed with the same per-launch HIP events; the
+    # figures of the timed region are kept beside it ("concurrent").  Every rank runs the extra steps (collectives).
+    concurrent_records = timer.records
+    timer.records = []
+    saved = (gan.engine.overlap_generator, generator.net.wgrad_stream, discriminator.net.wgrad_stream,
+             discriminator.net.overlap_branches)
+    gan.engine.overlap_generator = "0"
+    generator.net.wgrad_stream = discriminator.net.wgrad_stream = False
+    discriminator.net.overlap_branches = False
+    serial_steps = 2
+    if args.no_serial_pass:
+        serial_steps, dt_serial, timer.records = args.steps, dt, concurrent_records
+    try:
+        if not args.no_serial_pass:
+            gan.train_step((low, high))
+            timer.records = []
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(serial_steps):
+                gan.train_step((low, high))
+            barrier()
+            dt_serial = time.perf_counter() - t1
+    finally:
+        (gan.engine.overlap_generator, generator.net.wgrad_stream, discriminator.net.wgrad_stream,
+         discriminator.net.overlap_branches) = saved
+    serial_records = timer.records
     if rank == 0:
         # algorithmic FLOPs of one reference step per sample: 7*Gf + 28*Df (SURVEY §8 d), T = 1
         gf, df = 22.385e9, 2.994e9
         step_flops = (7 * gf + 28 * df) * B
+        timer.records = serial_records
         agg = timer.summary()
+        timer.records = concurrent_records
+        agg_conc = timer.summary()
+        timer.records = serial_records
         if args.per_layer:
-            for layer, kern, calls, ms, tf, tot in timer.per_layer(args.steps):
+            for layer, kern, calls, ms, tf, tot in timer.per_layer(serial_steps):
                 print(f"{tot:7.3f} ms/step  {calls:4.0f} x {ms:7.3f} ms  {tf:6.1f} TF/s  {kern:28s} {layer}", file=sys.stderr)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         conv_time = sum(a[1] for a in agg.values())
@@ -563,9 +600,19 @@ def main():
                          "achieved": dom[1][0] / dom[1][1] * 1e-12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom[1][0] / dom[1][1] * 1e-12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "launches": dom[1][2], "avg_launch_ms": 1e3 * dom[1][1] / dom[1][2],
-                         "all_conv_kernels": {k: {"tflops": v[0] / v[1] * 1e-12, "ms_per_step": 1e3 * v[1] / args.steps,
-                                                   "launches_per_step": v[2] / args.steps} for k, v in agg.items()},
-                         "conv_share_of_step": conv_time / dt, "all_conv_tflops": conv_flops / conv_time * 1e-12,
+                         "all_conv_kernels": {k: {"tflops": v[0] / v[1] * 1e-12, "ms_per_step": 1e3 * v[1] / serial_steps,
+                                                   "launches_per_step": v[2] / serial_steps} for k, v in agg.items()},
+                         "conv_share_of_step": conv_time / dt_serial, "all_conv_tflops": conv_flops / conv_time * 1e-12,
+                         "measured": f"HIP events around every launch in {serial_steps} extra train steps on ONE stream (all overlaps off: "
+                                     f"{1e3 * dt_serial / serial_steps:.2f} ms per step) after the timed region — under the default "
+                                     "multi-stream schedule kernels of different streams share the chip and a per-launch duration "
+                                     "measures the sharing, not the kernel; profiles/*_kernel_stats_serial.csv is the kernel trace of "
+                                     "the same single-stream schedule (WDG_OVERLAP_GEN=0 WDG_WGRAD_STREAM=0 WDG_OVERLAP_BRANCHES=0)",
+                         "single_stream_ms_per_step": 1e3 * dt_serial / serial_steps,
+                         "concurrent": {"achieved": agg_conc[dom[0]][0] / agg_conc[dom[0]][1] * 1e-12 if dom[0] in agg_conc else None,
+                                        "frac": agg_conc[dom[0]][0] / agg_conc[dom[0]][1] * 1e-12 / PEAK_F32_MFMA_TFLOPS if dom[0] in agg_conc else None,
+                                        "avg_launch_ms": 1e3 * agg_conc[dom[0]][1] / agg_conc[dom[0]][2] if dom[0] in agg_conc else None,
+                                        "note": "the same events inside the timed region (kernels of two or three streams in flight)"},
                          "measured_mfma_issue_ceiling_tflops": {"constant_operands": 155.7, "random_operands": 151.2,
                                                                 "source": "tools/mfma_peak.hip, profiles/r01q_mfma_peak_probe.log"}},
             "losses": {k: float(v) for k, v in logs.items() if v is not None},
@@ -578,7 +625,7 @@ def main():
         if tj.exists():
             t = json.loads(tj.read_text())
             same = (t.get("kernel") == dom[0] and t.get("csrc_sha256") == csrc_hash()
-                    and t.get("launches_per_step") == dom[1][2] / args.steps)
+                    and t.get("launches_per_step") == dom[1][2] / serial_steps)
             if same:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]

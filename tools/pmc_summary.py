@@ -105,7 +105,7 @@ def main():
             h.update(f.name.encode())
             h.update(f.read_bytes())
         tj = {"source": f"{out} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 "
-                        f"--no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs)",
+                        f"--no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs --no-serial-pass, single-stream schedule: WDG_OVERLAP_GEN=0 WDG_WGRAD_STREAM=0 WDG_OVERLAP_BRANCHES=0)",
               "kernel": "wdg_igemm_kernel<128,128>",
               # bench.py quotes the figure only when these two match what it runs (same kernel sources, same launch mix)
               "csrc_sha256": h.hexdigest(), "launches_per_step": float(dom["launches"]),

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun):  bash tools/profile_round.sh <tag> [quick]
 #   1. default bench line                      -> gpurun_out/<tag>_bench.json
-#   2. rocprofv3 --kernel-trace --stats        -> gpurun_out/<tag>_kernel_stats.csv  (bench.py --steps 1 --warmup 1: 2 steps in the trace)
+#   2. rocprofv3 --kernel-trace --stats        -> gpurun_out/<tag>_kernel_stats.csv  (bench.py --steps 1 --warmup 1; default multi-stream schedule)
+#                                                 gpurun_out/<tag>_kernel_stats_serial.csv  (the same on one stream: per-kernel durations)
 #   3. four --pmc passes (fabric fetch, fabric write + L2 hit, SQ wait / LDS, MFMA busy) + tools/pmc_summary  -> gpurun_out/<tag>_pmc_summary.csv + pmc_traffic.json   (skipped with "quick")
 # The summaries are then copied into profiles/ by hand (gpurun_out/ is scratch).
 set -u
@@ -13,10 +14,17 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs --no-serial-pass"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_trace -o run -- $BENCH --steps 1 --warmup 1 > $ROOT/$OUT/${TAG}_trace.log 2>&1 )
 STATS=$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/${TAG}_kernel_stats.csv && head -25 $OUT/${TAG}_kernel_stats.csv
+rm -rf $OUT/${TAG}_trace
+# the same on ONE stream (every overlap off): per-kernel durations that measure the kernel, not the sharing of the chip between
+# streams — what bench.py's roofline figures are taken from and must agree with.  The PMC passes below run in this mode too.
+export WDG_OVERLAP_GEN=0 WDG_WGRAD_STREAM=0 WDG_OVERLAP_BRANCHES=0
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_trace -o run -- $BENCH --steps 1 --warmup 1 > $ROOT/$OUT/${TAG}_trace_serial.log 2>&1 )
+STATS=$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)
+[ -n "$STATS" ] && cp "$STATS" $OUT/${TAG}_kernel_stats_serial.csv
 rm -rf $OUT/${TAG}_trace
 if [ -z "$QUICK" ]; then
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc1.log 2>&1 )
