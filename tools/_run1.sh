@@ -1,3 +1,2 @@
-bash tools/profile_round.sh r03i > gpurun_out/r03i_profile.log 2>&1
-cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
-python bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs > gpurun_out/r03i_bench_check.json 2>/dev/null
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline', round(d['value'],1), round(d['ms_per_step'],2), d['roofline']['frac'], d['step_frac_of_mfma_f32_peak'])"

@@ -506,11 +506,13 @@ class DiscriminatorNet(_Net):
             b["hi_view"] = b["hi"]
         self.ops.copy_channels(high_tm[..., :self.ch], b["mix"][..., self.cl:self.cl + self.ch])
 
-    def forward(self, B, training):
-        """Scores [B] for the resident (low, high) buffers."""
+    def forward(self, B, training, prepared=False):
+        """Scores [B] for the resident (low, high) buffers.  prepared=True: the caller has run _prepare(training) for this
+        call already (the trainer's two-network critic schedule separates the weight preparation from the pass)."""
         b = self.buffers(B)
         o, Fd, T = self.ops, self.Fd, self.T
-        self._prepare(training)
+        if not prepared:
+            self._prepare(training)
         # (the persistent sequence kernels size their grids to be fully resident: never two of them side by side)
         overlap = (T > 1 or self.overlap_branches_t1) and self.overlap_branches and not self.lstm_b._seq(T, b["hb"])
         self._overlap_now = overlap

@@ -118,6 +118,10 @@ class GanEngine:
         # (WDG_OVERLAP_GEN=0 disables; single-process runs only) — _critic_pipelined
         self.overlap_generator = os.environ.get("WDG_OVERLAP_GEN", "1")
         self._gen_stream = None
+        # the discriminator's gradient-penalty pass beside its real pass on a twin network (WDG_OVERLAP_DISC=0 disables):
+        # 69.0 -> 68.6 ms at the headline shape, +0.8 % at T = 24 (same-box A/B) — see _critic_pipelined
+        self.overlap_discriminator = os.environ.get("WDG_OVERLAP_DISC", "1") != "0"
+        self._disc_stream = None
 
     def _buf(self, key, *shape):
         t = self._tmp.get(key)
@@ -250,22 +254,70 @@ class GanEngine:
                     noise.normal_at(nview, self.noise_std, o_gstep)
                     fake = gen.forward(B, training=True, need_backward=True)
             self._flush(disc)
-            disc.set_high_tm(comb, B)
-            disc.forward(B, training=True)                                        # :32-34
-            dcomb = disc.backward(B, ones, need_wgrad=False)                      # :35
-            ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                         # :36
-            gnorm = torch.sqrt(gsq[:, :ch])
-            gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()               # :37
-            disc.params.zero_grad()
-            noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
-            disc.set_high_tm(noisy, B)
-            real_mean = disc.forward(B, training=True).mean()                     # :41
-            dscore.fill_(-sw_mean / B)
-            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
-            disc.set_high_tm(nf, B)
-            fake_mean = disc.forward(B, training=True).mean()                     # :43
-            dscore.fill_(sw_mean / B)
-            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+            if self.overlap_discriminator:
+                # The three discriminator passes of an iteration on TWO networks (this one and its twin: own variables and
+                # activations) and two streams.  What orders the passes in the reference is the spectral-norm chain of the
+                # weights — pass k + 1 reads SN(weights of pass k) — not the passes' results: the real pass' weights are ready
+                # as soon as the gradient-penalty pass' weights exist.  So: prepare W1 here; the twin takes a copy, prepares
+                # W2 = SN(W1) and runs the real pass (forward + weights-only backward) on its own stream while the
+                # gradient-penalty pass (forward + input gradient, W1) runs here; then this network takes W2 from the twin,
+                # prepares W3 and runs the generated pass beside the tail of the real one.  The weight gradients of the two
+                # passes are summed before the optimizer step (R + F, the same sum the single-network form accumulates).
+                twin = disc.twin()
+                ds = self._disc_stream
+                if ds is None:
+                    ds = self._disc_stream = torch.cuda.Stream(device=ops.device)
+                    twin.set_low(self._low)
+                disc._prepare(True)                                               # W0 -> W1 (SN of the gradient-penalty pass)
+                ds.wait_stream(main)
+                with torch.cuda.stream(ds):
+                    twin.params.flat.copy_(disc.params.flat)
+                    twin.params.state.copy_(disc.params.state)
+                    twin.params.version += 1
+                    twin.params.zero_grad()
+                    twin._prepare(True)                                           # W1 -> W2 (SN of the real pass)
+                    w2_ready = torch.cuda.Event()
+                    w2_ready.record(ds)
+                    noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
+                    twin.set_high_tm(noisy, B)
+                    real_mean = twin.forward(B, training=True, prepared=True).mean()                    # :41
+                    dsc2 = self._buf("dscore2", B)
+                    dsc2.fill_(-sw_mean / B)
+                    twin.backward(B, dsc2, need_wgrad=True, need_input_grad=False)
+                disc.set_high_tm(comb, B)
+                disc.forward(B, training=True, prepared=True)                     # :32-34 (W1)
+                dcomb = disc.backward(B, ones, need_wgrad=False)                  # :35
+                ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                     # :36
+                gnorm = torch.sqrt(gsq[:, :ch])
+                gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()           # :37
+                disc.params.zero_grad()
+                main.wait_event(w2_ready)
+                disc.params.flat.copy_(twin.params.flat)                          # W2 (the twin only reads it from here on)
+                disc.params.state.copy_(twin.params.state)
+                disc.params.version += 1
+                disc.set_high_tm(nf, B)
+                fake_mean = disc.forward(B, training=True).mean()                 # :43 (prepares W3 = SN(W2))
+                dscore.fill_(sw_mean / B)
+                disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+                main.wait_stream(ds)
+                disc.params.grads.add_(twin.params.grads)
+            else:
+                disc.set_high_tm(comb, B)
+                disc.forward(B, training=True)                                    # :32-34
+                dcomb = disc.backward(B, ones, need_wgrad=False)                  # :35
+                ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                     # :36
+                gnorm = torch.sqrt(gsq[:, :ch])
+                gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()           # :37
+                disc.params.zero_grad()
+                noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
+                disc.set_high_tm(noisy, B)
+                real_mean = disc.forward(B, training=True).mean()                 # :41
+                dscore.fill_(-sw_mean / B)
+                disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+                disc.set_high_tm(nf, B)
+                fake_mean = disc.forward(B, training=True).mean()                 # :43
+                dscore.fill_(sw_mean / B)
+                disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
             disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
             main.wait_stream(gs)
@@ -282,6 +334,9 @@ class GanEngine:
         sw_mean = 1.0 if sample_weight is None else float(torch.as_tensor(sample_weight).double().mean())
         gen.set_image(low)
         disc.set_low(low)
+        self._low = low
+        if self._disc_stream is not None:
+            disc.twin().set_low(low)
         real = self._buf("real", N, S, S, chp)
         gen.to_time_major(high, real)
         comb, noisy = self._buf("comb", N, S, S, chp), self._buf("noisy", N, S, S, chp)
