@@ -189,6 +189,15 @@ int wdg_conv_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16
 int wdg_convlstm_step_supported(const wdg_conv_plan* plan, int F);
 int wdg_convlstm_step(const wdg_conv_plan* plan, const float* h_prev, const float* wF, float* gates, const float* c_prev,
                       float* c_out, int ldc, float* h_out, int ldh, int F, wdg_stream stream);
+/* The same step for layers the implicit GEMM runs (the generator's 128-feature ConvLSTM, models.py:45): gates += conv(h_prev),
+ * cell update in the GEMM's epilogue, one launch per timestep instead of three.  wF_il: the packed forward weights
+ * [4F][taps][Cin_p] with GATE-INTERLEAVED rows — row n holds gate n & 3 of feature n >> 2, i.e. row (n & 3) * F + (n >> 2) of the
+ * standard layout — so that a lane's four accumulator registers are i, f, c~, o of one feature of one pixel.  gates keeps the
+ * standard column order [i | f | c~ | o] (input part in, pre-activation sums out).  F % 16 == 0. */
+int wdg_convlstm_step_gemm_supported(const wdg_conv_plan* plan, int F);
+int wdg_convlstm_step_gemm(const wdg_conv_plan* plan, const float* h_prev, const float* wF_il, float* gates, const float* c_prev,
+                           float* c_out, int ldc, float* h_out, int ldh, int F, wdg_stream stream);
+
 /* Backward counterpart (BPTT of the same layers): dh_prev += conv_transpose(dgates_next, wD) completes the gradient of
  * h_{t-1}; the epilogue then differentiates the cell of timestep t-1 (gates_t, c_prev [NULL at t-1 = 0], c_cur, dc_in ->
  * dgates_out and, unless NULL, dc_out).  Replaces wdg_conv_dgrad(accumulate) + wdg_lstm_bwd of the next loop iteration. */

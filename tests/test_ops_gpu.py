@@ -761,11 +761,14 @@ def test_convlstm_sequence_kernels(cin, F, B, T, H, W, hip_ops, ref_ops, monkeyp
         assert float(err.max()) < 0.2, (k, float(err.max()))
 
 
-@pytest.mark.parametrize("F,cinp,n,H,W", [(16, 16, 3, 24, 40), (16, 16, 8, 96, 96), (2, 4, 3, 24, 40), (2, 4, 8, 96, 96), (16, 16, 2, 19, 33)])
+@pytest.mark.parametrize("F,cinp,n,H,W", [(16, 16, 3, 24, 40), (16, 16, 8, 96, 96), (2, 4, 3, 24, 40), (2, 4, 8, 96, 96), (16, 16, 2, 19, 33),
+                                          (128, 128, 8, 24, 24), (128, 128, 2, 17, 13), (32, 32, 3, 8, 24)])
 def test_convlstm_recurrent_step_fused(hip_ops, ref_ops, F, cinp, n, H, W):
     """fp32 ConvLSTM recurrent step in one launch (wdg_convlstm_step: halo-tile convolution with the cell update in its
-    epilogue; the discriminator's 16- and 2-feature ConvLSTMs at n_timesteps > 1, models.py:93,101) against the oracle's
-    accumulating convolution + cell update: pre-activation gates (read by the backward pass), c_t and h_t."""
+    epilogue; the discriminator's 16- and 2-feature ConvLSTMs at n_timesteps > 1, models.py:93,101 — and
+    wdg_convlstm_step_gemm: the generator's 128-feature layer, models.py:45, through the implicit GEMM with gate-interleaved
+    weight rows) against the oracle's accumulating convolution + cell update: pre-activation gates (read by the backward
+    pass), c_t and h_t."""
     from downscaling.engine.hipops import ConvGeom
     from oracle.torch_backend import ConvGeom as RG
     g, rg = ConvGeom(3, 3, 1, 1), RG(3, 3, 1, 1)

@@ -59,6 +59,14 @@ struct WdgIgemm {
     const float* ln_beta;
     float* mean_rstd;
     float ln_eps;
+    // ConvLSTM2D recurrent step (EPI 4; models.py:45 at n_timesteps > 1): the B rows are gate-interleaved (column n = gate n & 3
+    // of feature n >> 2), so a lane's four accumulator registers are i, f, c~, o of one feature of one pixel; Out is the gates slab
+    // [pixel][4 F] in the standard order (it holds the input part, receives the pre-activation sums the backward pass reads),
+    // the cell update runs on the accumulators and writes c_out / h_out
+    int lstm_F, ldc, ldh;
+    const float* c_prev;
+    float* c_out;
+    float* h_out;
     WdgPhase ph[9];
 };
 
@@ -533,6 +541,51 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
                 const long long pixi = (long long)img * PaPb + pa * ph.Pb + pb;
                 p.mean_rstd[2 * pixi] = mean[a];
                 p.mean_rstd[2 * pixi + 1] = rstd[a];
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == 4) {
+        // ConvLSTM cell on the accumulators (Keras hard_sigmoid / tanh, gate order i, f, c, o; same arithmetic as wdg_lstm_fwd
+        // behind an accumulating convolution).  One phase, stride 1, no split-K (checked by the host).
+        const int F = p.lstm_F;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
+            if (m >= Mph) continue;
+            int img, pa, pb;
+            wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
+            const long long pix = (long long)img * PaPb + (long long)pa * ph.Pb + pb;
+            float* g = p.Out + pix * (4 * F);
+            // every column tile's inputs first (one memory round trip), then the arithmetic and the stores
+            float gx[NT][4], cp[NT];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+                const int f = n >> 2;
+                const bool on = n < p.Ncols;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gx[b][r] = on ? g[r * F + f] : 0.f;
+                cp[b] = on ? p.c_prev[pix * p.ldc + f] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+                if (n >= p.Ncols) continue;
+                const int f = n >> 2;
+                float z[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z[r] = acc[a][b][r] + gx[b][r];
+                    g[r * F + f] = z[r];
+                }
+                const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
+                const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
+                const float gc = tanhf(z[2]);
+                const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
+                const float cn = gi * gc + gf * cp[b];
+                p.c_out[pix * p.ldc + f] = cn;
+                p.h_out[pix * p.ldh + f] = go * tanhf(cn);
             }
         }
         return;
@@ -1445,7 +1498,11 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     // fused BatchNorm hooks: only without split-K (the reduce kernel owns the epilogue then; callers fall back to the
     // standalone passes — see conv_fused_bn) and only on the default pipeline
     const bool ln_ok = p.ln_gamma && split == 1 && tiles_n == 1 && nphase == 1 && (p.Ncols & 3) == 0;
-    const int epi = (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
+    const int epi = p.lstm_F ? 4 : (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
+    if (epi == 4 && (split != 1 || nphase != 1 || pipe == 4)) {
+        wdg_set_error("igemm: the ConvLSTM step epilogue needs one phase, no split-K and the fp32 pipeline");
+        return WDG_ERR_ARG;
+    }
     if (bn_fused) *bn_fused = epi != 0;
 #define WDG_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                              \
     if (tc.BM == BM_ && tc.BN == BN_) {                                                                 \
@@ -1453,6 +1510,10 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         else if (pipe == 4 && epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 4, 2>(grid, block, st, p); \
         else if (pipe == 4 && epi == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 4, 3>(grid, block, st, p); \
         else if (pipe == 4) rc = launch_variant<BM_, BN_, WM_, WN_, 4>(grid, block, st, p);             \
+        else if (epi == 4) {                                                                            \
+            if constexpr (BN_ % 64 == 0 && BM_ <= 128) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p); \
+            else rc = WDG_ERR_ARG;                                                                      \
+        }                                                                                               \
         else if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);           \
         else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \
         else if (epi == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);           \
@@ -1586,6 +1647,44 @@ static int conv_dgrad_impl(const wdg_conv_plan* pl, const float* dy, const float
 // the backward pass.  The normalisation runs in the epilogue that owns complete rows — the implicit-GEMM epilogue when one
 // tile spans all output channels, the split-K second stage otherwise — and as the standalone wdg_ln_fwd pass behind the
 // convolution on every other route; results do not depend on the route.
+// ---- ConvLSTM2D recurrent step through the implicit GEMM (the generator's 128-feature layer at n_timesteps > 1): one launch
+// per timestep instead of three (accumulating convolution + its split-K second stage + cell kernel).  wF_il: the packed forward
+// weights with gate-interleaved rows (row n = gate n & 3 of feature n >> 2), see wdgan.h.
+extern "C" int wdg_convlstm_step_gemm_supported(const wdg_conv_plan* pl, int F) {
+    if (!pl || F <= 0 || (F & 15)) return 0;
+    const wdg_conv_geom& g = pl->g;
+    if (g.Cout != 4 * F || g.stride != 1 || g.H != g.Ho || g.W != g.Wo || g.ldy != 4 * F ||
+        g.img_stride_y != (int64_t)g.Ho * g.Wo * 4 * F)
+        return 0;
+    if (pl->halo_auto_fwd && pl->halo_fwd_nt) return 0;           // (the halo-tile kernel owns the thin layers: wdg_convlstm_step)
+    const TileCfg tc = pick_tile(g.Cout, true, (long long)g.n_img * g.Ho * g.Wo);
+    return tc.BN % 64 == 0 && tc.BM <= 128 && g_igemm_pipe != 4;
+}
+
+extern "C" int wdg_convlstm_step_gemm(const wdg_conv_plan* pl, const float* h_prev, const float* wF_il, float* gates,
+                                      const float* c_prev, float* c_out, int ldc, float* h_out, int ldh, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && h_prev && wF_il && gates && c_prev && c_out && h_out && wdg_convlstm_step_gemm_supported(pl, F),
+                  "not supported for this geometry");
+    WDG_CHECK_ARG(ldc >= F && ldh >= F && ((uintptr_t)h_prev & 15) == 0 && ((uintptr_t)wF_il & 15) == 0, "bad strides / alignment");
+    const wdg_conv_geom& g = pl->g;
+    WdgIgemm p;
+    memset(&p, 0, sizeof(p));
+    p.A = h_prev; p.B = wF_il; p.Out = gates; p.ktab = pl->d_tab_fwd;
+    p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
+    p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
+    p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
+    p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p;
+    p.a_mul = 1; p.o_mul = 1;
+    p.Mmax = g.n_img * g.Ho * g.Wo;
+    p.lstm_F = F; p.ldc = ldc; p.ldh = ldh; p.c_prev = c_prev; p.c_out = c_out; p.h_out = h_out;
+    WdgPhase ph;
+    ph.Pa = g.Ho; ph.Pb = g.Wo; ph.a_off_h = -g.pad_h; ph.a_off_w = -g.pad_w;
+    ph.o_off_h = 0; ph.o_off_w = 0; ph.K4 = pl->K4_fwd; ph.tab_off = 0;
+    wdg_phase_finish(ph);
+    p.ph[0] = ph;
+    return launch_igemm(p, 1, pl->K4_fwd, 1, nullptr, 0, (hipStream_t)stream);
+}
+
 extern "C" int wdg_conv_fwd_ln(const wdg_conv_plan* pl, const float* x, const float* wF, const float* bias, float* y, float* z,
                                const float* gamma, const float* beta, float eps, float* mean_rstd, int act, float slope,
                                void* ws, size_t ws_bytes, wdg_stream stream) {

@@ -110,6 +110,25 @@ class PackedWeights:
             cache["ver"] = self._hver
         return cache["wF"], cache["wD"]
 
+    def interleaved(self, F):
+        """wF with gate-interleaved rows for the ConvLSTM step in the implicit GEMM's epilogue (wdg_convlstm_step_gemm): row n =
+        gate n & 3 of feature n >> 2.  A gathered copy, rebuilt lazily after the master weights changed."""
+        cache = self.__dict__.setdefault("_il", {"buf": None, "ver": -1, "perm": None})
+        if self._bf16_stale:            # (shares the staleness counter of the 16-bit copies)
+            self._hver += 1
+            self._bf16_stale = False
+        if cache["ver"] != self._hver:
+            L = self.wF.numel() // self.cout
+            if cache["perm"] is None:
+                n = torch.arange(4 * F, device=self.wF.device)
+                cache["perm"] = (n & 3) * F + (n >> 2)
+            src = self.wF.view(self.cout, L)
+            if cache["buf"] is None:
+                cache["buf"] = torch.empty_like(src)
+            torch.index_select(src, 0, cache["perm"], out=cache["buf"])
+            cache["ver"] = self._hver
+        return cache["buf"]
+
     def as_1x1(self):
         """The same weights as a 1x1 convolution with taps*cin input channels: w[t][i][o] viewed as [t*cin + i][o].
         Both kernel layouts coincide with this object's (wF is [cout][taps][cin], wD is w itself), so the view shares
@@ -390,10 +409,17 @@ class HipOps:
         native.check(self.lib.wdg_tiles_blend(pred.data_ptr(), ldp, keys4.data_ptr(), n_real, T, S, crop, LAT, LON, acc.data_ptr(),
                                               cnt.data_ptr(), self.stream), "tiles_blend")
 
+    lstm_step_gemm = os.environ.get("WDG_LSTM_STEP_GEMM", "1") != "0"   # the implicit-GEMM form of the fused step (A/B switch)
+
     def convlstm_step_supported(self, h_prev, gates_t, pk, g, F):
-        """fp32 ConvLSTM recurrent step in one launch (wdg_convlstm_step: halo-tile kernel with the cell update in its epilogue)?"""
+        """fp32 ConvLSTM recurrent step in one launch?  The halo-tile kernel with the cell update in its epilogue
+        (wdg_convlstm_step: the discriminator's thin layers) or the implicit GEMM with gate-interleaved weight rows
+        (wdg_convlstm_step_gemm: the generator's 128-feature layer)."""
         plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
-        return bool(self.lib.wdg_convlstm_step_supported(plan, F))
+        if self.lib.wdg_convlstm_step_supported(plan, F):
+            return True
+        return bool(self.lstm_step_gemm and not self.split_mode and pk.cout == 4 * F and
+                    self.lib.wdg_convlstm_step_gemm_supported(plan, F))
 
     def convlstm_step(self, h_prev, pk, gates_t, c_prev, c_out, h_out, g, F):
         """gates_t += conv(h_prev); c_out, h_out from the cell update (gates_t keeps the pre-activations for the backward)."""
@@ -401,6 +427,11 @@ class HipOps:
         _, ldc, _ = _v4(c_out)
         _, ldh, _ = _v4(h_out)
         assert _v4(c_prev)[1] == ldc
+        if not self.lib.wdg_convlstm_step_supported(plan, F):
+            native.check(self.lib.wdg_convlstm_step_gemm(plan, h_prev.data_ptr(), pk.interleaved(F).data_ptr(), gates_t.data_ptr(),
+                                                         c_prev.data_ptr(), c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F,
+                                                         self.stream), "convlstm_step_gemm")
+            return
         native.check(self.lib.wdg_convlstm_step(plan, h_prev.data_ptr(), pk.wF.data_ptr(), gates_t.data_ptr(), c_prev.data_ptr(),
                                                 c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F, self.stream), "convlstm_step")
 

@@ -39,6 +39,8 @@ SIGNATURES = {
     "wdg_set_tuning": (i32, [C.c_char_p, i32]),
     "wdg_convlstm_step_supported": (i32, [c_fp, i32]),
     "wdg_convlstm_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, c_fp]),
+    "wdg_convlstm_step_gemm_supported": (i32, [C.c_void_p, i32]),
+    "wdg_convlstm_step_gemm": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_bwd_step_supported": (i32, [c_fp, i32]),
     "wdg_convlstm_bwd_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_h16_supported": (i32, [c_fp, i32]),
