@@ -357,15 +357,44 @@ __global__ void __launch_bounds__(256) wdg_copy_channels_kernel(const float* __r
     }
 }
 
+// the same for totals below 2^31 elements (every call of the train / inference paths): the three index divisions as
+// multiply-high operations — the 64-bit divisions above cost ~100 instructions per copied float (26-120 us for 2-20 channel copies)
+__global__ void __launch_bounds__(256) wdg_copy_channels32_kernel(const float* __restrict__ src, int lds_, int64_t iss, int64_t oss,
+                                                                  float* dst, int ldd, int64_t isd, int64_t osd, int n_inner,
+                                                                  unsigned total, unsigned ppi, int C, int accumulate,
+                                                                  wdg_fastdiv div_c, wdg_fastdiv div_ppi, wdg_fastdiv div_inner) {
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned p = wdg_fastdiv_do(idx, div_c);
+        const int c = (int)(idx - p * (unsigned)C);
+        const unsigned img = wdg_fastdiv_do(p, div_ppi), q = p - img * ppi;
+        const unsigned o = wdg_fastdiv_do(img, div_inner), i = img - o * (unsigned)n_inner;
+        const float v = src[(int64_t)o * oss + (int64_t)i * iss + (int64_t)q * lds_ + c];
+        float* d = dst + (int64_t)o * osd + (int64_t)i * isd + (int64_t)q * ldd + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+static int copy_channels_launch(const float* src, int lds_, int64_t iss, int64_t oss, float* dst, int ldd, int64_t isd, int64_t osd,
+                                int n_inner, int n_img, int64_t ppi, int C, int accumulate, hipStream_t st) {
+    const int64_t total = (int64_t)n_img * ppi * C;
+    if (total < (1LL << 31) && ppi < (1LL << 31)) {
+        hipLaunchKernelGGL(wdg_copy_channels32_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, src, lds_, iss, oss, dst, ldd, isd, osd,
+                           n_inner, (unsigned)total, (unsigned)ppi, C, accumulate, wdg_fastdiv_make((unsigned)C),
+                           wdg_fastdiv_make((unsigned)ppi), wdg_fastdiv_make((unsigned)n_inner));
+    } else {
+        hipLaunchKernelGGL(wdg_copy_channels_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, src, lds_, iss, oss, dst, ldd, isd, osd,
+                           n_inner, n_img, ppi, C, accumulate);
+    }
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
 extern "C" int wdg_copy_channels(const float* src, int lds_, int64_t img_stride_src, float* dst, int ldd,
                                  int64_t img_stride_dst, int n_img, int64_t pixels_per_img, int C,
                                  int accumulate, wdg_stream stream) {
     WDG_CHECK_ARG(src && dst && C > 0 && n_img > 0 && pixels_per_img > 0, "bad argument");
-    hipLaunchKernelGGL(wdg_copy_channels_kernel, dim3(ew_blocks((int64_t)n_img * pixels_per_img * C)), dim3(256),
-                       0, (hipStream_t)stream, src, lds_, img_stride_src, (int64_t)0, dst, ldd, img_stride_dst, (int64_t)0,
-                       n_img, n_img, pixels_per_img, C, accumulate);
-    WDG_LAUNCH_CHECK();
-    return WDG_OK;
+    return copy_channels_launch(src, lds_, img_stride_src, 0, dst, ldd, img_stride_dst, 0, n_img, n_img, pixels_per_img, C, accumulate,
+                                (hipStream_t)stream);
 }
 
 extern "C" int wdg_copy_channels_2level(const float* src, int lds_, int64_t inner_stride_src, int64_t outer_stride_src,
@@ -374,11 +403,8 @@ extern "C" int wdg_copy_channels_2level(const float* src, int lds_, int64_t inne
                                         wdg_stream stream) {
     WDG_CHECK_ARG(src && dst && C > 0 && n_outer > 0 && n_inner > 0 && pixels_per_img > 0, "bad argument");
     const int n_img = n_outer * n_inner;
-    hipLaunchKernelGGL(wdg_copy_channels_kernel, dim3(ew_blocks((int64_t)n_img * pixels_per_img * C)), dim3(256),
-                       0, (hipStream_t)stream, src, lds_, inner_stride_src, outer_stride_src, dst, ldd, inner_stride_dst,
-                       outer_stride_dst, n_inner, n_img, pixels_per_img, C, accumulate);
-    WDG_LAUNCH_CHECK();
-    return WDG_OK;
+    return copy_channels_launch(src, lds_, inner_stride_src, outer_stride_src, dst, ldd, inner_stride_dst, outer_stride_dst, n_inner,
+                                n_img, pixels_per_img, C, accumulate, (hipStream_t)stream);
 }
 
 // ---- column sum (bias gradients): block = 64 channels x 4 pixel rows ----------------------------
@@ -540,10 +566,67 @@ __global__ void __launch_bounds__(256) wdg_philox_normal_kernel(float* out, int 
     }
 }
 
+// the same stream of values for totals below 2^31: element -> (pixel, channel) by multiply-high instead of four 64-bit divisions
+// per Philox block, and — when a block's four values fall into one pixel (C % 4 == 0, 16-byte aligned views: the generator's 20
+// noise channels) — one 16-byte store
+template <bool VEC>
+__global__ void __launch_bounds__(256) wdg_philox_normal32_kernel(float* out, int ldo, const float* __restrict__ add, int lda,
+                                                                  unsigned total, int C, uint64_t seed, uint64_t offset, float stdv,
+                                                                  wdg_fastdiv div_c) {
+    const unsigned groups = (total + 3u) / 4u;
+    for (unsigned gi = blockIdx.x * 256u + threadIdx.x; gi < groups; gi += gridDim.x * 256u) {
+        const uint64_t cnt = offset + (uint64_t)gi;
+        uint32_t ctr[4] = {(uint32_t)cnt, (uint32_t)(cnt >> 32), 0u, 0u};
+        wdg_philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u0 = wdg_u01(ctr[2 * h]), u1 = wdg_u01(ctr[2 * h + 1]);
+            const float rad = sqrtf(-2.f * logf(u0));
+            const float ang = 6.283185307179586f * u1;
+            z[2 * h] = rad * cosf(ang);
+            z[2 * h + 1] = rad * sinf(ang);
+        }
+        const unsigned e0 = gi * 4u;
+        if (VEC) {
+            const unsigned p = wdg_fastdiv_do(e0, div_c);
+            const int c = (int)(e0 - p * (unsigned)C);
+            f32x4 v = (f32x4){stdv * z[0], stdv * z[1], stdv * z[2], stdv * z[3]};
+            if (add) v += *reinterpret_cast<const f32x4*>(add + (int64_t)p * lda + c);
+            *reinterpret_cast<f32x4*>(out + (int64_t)p * ldo + c) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned e = e0 + j;
+                if (e < total) {
+                    const unsigned p = wdg_fastdiv_do(e, div_c);
+                    const int c = (int)(e - p * (unsigned)C);
+                    float v = stdv * z[j];
+                    if (add) v += add[(int64_t)p * lda + c];
+                    out[(int64_t)p * ldo + c] = v;
+                }
+            }
+        }
+    }
+}
+
 extern "C" int wdg_philox_normal(float* out, int ldo, const float* add, int lda, int64_t P, int C, uint64_t seed,
                                  uint64_t offset, float std, wdg_stream stream) {
     WDG_CHECK_ARG(out && P >= 0 && C > 0, "bad argument");
     if (P == 0) return WDG_OK;
+    if (P * C < (1LL << 31)) {
+        const bool vec = C % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+                         (!add || (lda % 4 == 0 && ((uintptr_t)add & 15) == 0));
+        const wdg_fastdiv dc = wdg_fastdiv_make((unsigned)C);
+        if (vec)
+            hipLaunchKernelGGL(wdg_philox_normal32_kernel<true>, dim3(ew_blocks((P * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out,
+                               ldo, add, lda, (unsigned)(P * C), C, seed, offset, std, dc);
+        else
+            hipLaunchKernelGGL(wdg_philox_normal32_kernel<false>, dim3(ew_blocks((P * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out,
+                               ldo, add, lda, (unsigned)(P * C), C, seed, offset, std, dc);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
     hipLaunchKernelGGL(wdg_philox_normal_kernel, dim3(ew_blocks((P * C + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, out, ldo, add, lda, P, C, seed, offset, std);
     WDG_LAUNCH_CHECK();
