@@ -402,7 +402,9 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
 // two barriers.  Here a block walks tiles with a grid stride, the NEXT tile's halo is fetched into registers while
 // the current one is multiplied (one barrier pair per tile, no exposed load latency), and the nine taps' weight
 // fragments stay in registers for the block's whole life.
-template <int TAPS>
+// LN: the LayerNorm epilogue as a separate instantiation — in one kernel its registers cost the plain launches (data gradient,
+// 16 -> 2 output conv) their fourth wave per SIMD (110 -> 142 registers: 104 -> ~125 us per launch)
+template <int TAPS, bool LN = false>
 __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, const float* __restrict__ Bw) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem1[];
     f32x4* lds_a = smem1;   // [4][npix]
@@ -504,7 +506,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = 4 * lg + r < p.Ncols ? p.bias[4 * lg + r] : 0.f;
             }
-            if (p.ln_gamma) {
+            if constexpr (LN) {
                 // conv -> bias -> LeakyReLU -> LayerNormalization over the 16 channels of a pixel: they sit in the four lanes
                 // li, li + 16, li + 32, li + 48 (four registers each), so the two reductions (sum, centred sum of squares — the
                 // two-pass form of wdg_ln_fwd) are two xor-shuffles each; y and z leave as 16-byte stores, no pass re-reads y
@@ -702,8 +704,11 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     if (persistent1) {
         // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
         const size_t lds1 = ((size_t)4 * p.npix + 9 * 64) * sizeof(f32x4);
-        const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * g_halo1_bpc);
-        hipLaunchKernelGGL((wdg_conv_halo1_kernel<9>), dim3(nb), block, lds1, st, p, Bw);
+        const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * (ln ? std::min(g_halo1_bpc, 3) : g_halo1_bpc));
+        if (ln)
+            hipLaunchKernelGGL((wdg_conv_halo1_kernel<9, true>), dim3(nb), block, lds1, st, p, Bw);
+        else
+            hipLaunchKernelGGL((wdg_conv_halo1_kernel<9>), dim3(nb), block, lds1, st, p, Bw);
         WDG_LAUNCH_CHECK();
         return WDG_OK;
     }

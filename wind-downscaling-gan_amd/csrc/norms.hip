@@ -186,11 +186,12 @@ extern "C" int wdg_bn_finalize_infer(const float* gamma, const float* beta, cons
 
 __global__ void __launch_bounds__(256) wdg_bn_apply_kernel(const float* __restrict__ x, int ldx,
                                                            const float* __restrict__ ss, float* z, int ldz,
-                                                           int64_t P, int C) {
+                                                           int64_t P, int C, wdg_fastdiv div_c4n) {
     const int c4n = C / 4;
     const int64_t total = P * c4n;
+    const bool small = total < (1LL << 31);          // index split by multiply-high instead of a 64-bit division per float4
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t p = idx / c4n;
+        const int64_t p = small ? (int64_t)wdg_fastdiv_do((unsigned)idx, div_c4n) : idx / c4n;
         const int c = 4 * (int)(idx - p * c4n);
         const f32x4 a = *reinterpret_cast<const f32x4*>(x + p * ldx + c);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(ss + c);
@@ -208,7 +209,7 @@ extern "C" int wdg_bn_apply(const float* x, int ldx, const float* scale_shift, f
     const int64_t total = P * (C / 4);
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));
     hipLaunchKernelGGL(wdg_bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       scale_shift, z, ldz, P, C);
+                       scale_shift, z, ldz, P, C, wdg_fastdiv_make((unsigned)(C / 4)));
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -36,11 +36,11 @@ __global__ void __launch_bounds__(256) wdg_lstm_fwd_kernel(const float* __restri
 // float4 variant (F % 4 == 0, every stride % 4 == 0): one thread = 4 features of one pixel
 __global__ void __launch_bounds__(256) wdg_lstm_fwd4_kernel(const float* __restrict__ gates, int ldg,
                                                             const float* __restrict__ c_prev, int ldcp, float* c,
-                                                            int ldc, float* h, int ldh, int64_t P, int F) {
+                                                            int ldc, float* h, int ldh, int64_t P, int F, wdg_fastdiv div_f4n) {
     const int f4n = F / 4;
     const int64_t total = P * f4n;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t p = idx / f4n;
+        const int64_t p = total < (1LL << 31) ? (int64_t)wdg_fastdiv_do((unsigned)idx, div_f4n) : idx / f4n;
         const int f = 4 * (int)(idx - p * f4n);
         const float* g = gates + p * ldg + f;
         const f32x4 xi = *reinterpret_cast<const f32x4*>(g);
@@ -71,7 +71,7 @@ extern "C" int wdg_lstm_fwd(const float* gates, int ldg, const float* c_prev, in
     WDG_CHECK_ARG(gates && c && h && F > 0, "bad argument");
     if (F % 4 == 0 && wdg_al4(gates, ldg) && wdg_al4(c_prev, ldcp) && wdg_al4(c, ldc) && wdg_al4(h, ldh)) {
         hipLaunchKernelGGL(wdg_lstm_fwd4_kernel, dim3(ew_blocks(P * (F / 4))), dim3(256), 0, (hipStream_t)stream,
-                           gates, ldg, c_prev, ldcp, c, ldc, h, ldh, P, F);
+                           gates, ldg, c_prev, ldcp, c, ldc, h, ldh, P, F, wdg_fastdiv_make((unsigned)(F / 4)));
         WDG_LAUNCH_CHECK();
         return WDG_OK;
     }
@@ -115,12 +115,12 @@ __global__ void __launch_bounds__(256) wdg_lstm_bwd4_kernel(const float* __restr
                                                             const float* __restrict__ dh, int lddh,
                                                             const float* __restrict__ dc_in, int lddci,
                                                             float* dgates, int lddg, float* dc_prev, int lddcp,
-                                                            int64_t P, int F) {
+                                                            int64_t P, int F, wdg_fastdiv div_f4n) {
     const int f4n = F / 4;
     const int64_t total = P * f4n;
     const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t p = idx / f4n;
+        const int64_t p = total < (1LL << 31) ? (int64_t)wdg_fastdiv_do((unsigned)idx, div_f4n) : idx / f4n;
         const int f = 4 * (int)(idx - p * f4n);
         const float* g = gates + p * ldg + f;
         const f32x4 xi = *reinterpret_cast<const f32x4*>(g), xf = *reinterpret_cast<const f32x4*>(g + F);
@@ -157,7 +157,8 @@ extern "C" int wdg_lstm_bwd(const float* gates, int ldg, const float* c_prev, in
     if (F % 4 == 0 && wdg_al4(gates, ldg) && wdg_al4(c_prev, ldcp) && wdg_al4(c, ldc) && wdg_al4(dh, lddh) &&
         wdg_al4(dc_in, lddci) && wdg_al4(dgates, lddg) && wdg_al4(dc_prev, lddcp)) {
         hipLaunchKernelGGL(wdg_lstm_bwd4_kernel, dim3(ew_blocks(P * (F / 4))), dim3(256), 0, (hipStream_t)stream,
-                           gates, ldg, c_prev, ldcp, c, ldc, dh, lddh, dc_in, lddci, dgates, lddg, dc_prev, lddcp, P, F);
+                           gates, ldg, c_prev, ldcp, c, ldc, dh, lddh, dc_in, lddci, dgates, lddg, dc_prev, lddcp, P, F,
+                           wdg_fastdiv_make((unsigned)(F / 4)));
         WDG_LAUNCH_CHECK();
         return WDG_OK;
     }
