@@ -448,6 +448,15 @@ int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, float* col, 
 int wdg_upconv_gather(const float* z, const float* bias, const float* affine, float* y, int ldy,
                       int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope,
                       double* stats, int stats_rep, wdg_stream stream);
+/* The same pair with z in the 16-bit operand format (inference precision only): the column GEMM rounds its fp32 sums to bf16 /
+ * fp16 on store (z16 [n, Hl, Wl, 25 * C] 16-bit elements), the gather widens them on load — z is the largest tensor of the 16-bit
+ * forward and has exactly one writer and one reader.  `plan`: 1 x 1 plan with x side = z, y side = x_low (as for
+ * wdg_conv_dgrad_bf16).  fmt: 0 bf16, 1 fp16. */
+int wdg_upconv_colgemm_h16_supported(const wdg_conv_plan* plan);   /* 1 when the patch kernel takes this map; else use the fp32 z route */
+int wdg_upconv_colgemm_h16(const wdg_conv_plan* plan, const float* x_low, const void* wD16, void* z16, int fmt, wdg_stream stream);
+int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias, const float* affine, float* y, int ldy, int64_t img_stride_y,
+                          int n_img, int Hl, int Wl, int C, int act, float slope, wdg_stream stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Flatten + Dense(1) per timestep + GlobalAveragePooling1D over T.             models.py:137-140

@@ -203,6 +203,29 @@ class TorchOps:
         if self.upconv_colfwd and (g.kh, g.kw, g.stride, g.pad) == (5, 5, 1, 2) and pk.cout % 8 == 0 and pk.cin in (4, 8, 16):
             # column form: the 16-bit GEMM operands are the LOW-RES input and the weights; the bilinear interpolation
             # acts on the exact products afterwards (it commutes with the channel mixing)
+            if getattr(self, "z16", False):
+                # the column GEMM's result z[r, (t, o)] = sum_c x[r, c] w[t][o][c] is itself stored in the 16-bit format
+                # (wdg_upconv_colgemm_h16): per tap t, round z_t, interpolate it, shift it by the tap and add
+                n, Hl, Wl, _ = x_low.shape
+                xr, wr = self._r16(x_low[..., :pk.cout], fmt), self._r16(pk.w, fmt)       # w [5][5][o][c]
+                acc = torch.zeros(n, 2 * Hl, 2 * Wl, pk.cin, dtype=x_low.dtype)
+                for ta in range(5):
+                    for tb in range(5):
+                        zt = self._r16(torch.einsum("nhwc,oc->nhwo", xr, wr[ta, tb]), fmt)
+                        ut = torch.zeros(n, 2 * Hl, 2 * Wl, pk.cin, dtype=x_low.dtype)
+                        self.upsample2x_fwd(zt, ut)
+                        # transposed conv: y[u + t - 2] += U(z_t)[u] (positions outside the image drop: 'same' padding)
+                        dy, dx = ta - 2, tb - 2
+                        ys, xs = slice(max(0, dy), 2 * Hl - max(0, -dy)), slice(max(0, dx), 2 * Wl - max(0, -dx))
+                        yd, xd = slice(max(0, -dy), 2 * Hl - max(0, dy)), slice(max(0, -dx), 2 * Wl - max(0, dx))
+                        acc[:, ys, xs] += ut[:, yd, xd]
+                out = acc + (bias if bias is not None else 0)
+                if act:
+                    out = torch.where(out > 0, out, out * slope)
+                if affine is not None:
+                    out = out * affine[:pk.cin] + affine[pk.cin:]
+                y[..., :pk.cin] = out
+                return
             self.upsample2x_fwd(self._r16(x_low, fmt), up)
             out = torch.zeros(y.shape[:3] + (pk.cin,), dtype=x_low.dtype)
             self.conv_dgrad(up, PackedWeights(self, self._r16(pk.w, fmt)), out, g, bias=bias, act=act, slope=slope)

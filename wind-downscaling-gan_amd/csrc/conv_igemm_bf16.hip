@@ -326,6 +326,28 @@ extern "C" int wdg_conv_dgrad_f16(const wdg_conv_plan* pl, const float* dy, cons
     return conv_dgrad_h16(pl, dy, wD16, bias, affine, dx, act, slope, accumulate, 1, stream);
 }
 
+// Column GEMM of the column-form upsample + 5x5 transposed-conv layer (models.py:62-64, csrc/upconv_col.hip) with a 16-BIT
+// result: z16[r, (t, o)] = sum_c x_low[r, c] * w[t][o][c] (16-bit operands, fp32 accumulation, rounded to the operand format
+// on store).  z is the largest tensor of the inference forward — 400 columns per low-resolution pixel, 1.4 GB per 16-tile group
+// in fp32 — and its only reader is the bilinear gather (wdg_upconv_gather_h16).  `plan`: the 1 x 1 plan whose x side is z
+// ([n, H, W, 25 * C]) and whose y side is x_low.  fmt: 0 bf16, 1 fp16.
+extern "C" int wdg_upconv_colgemm_h16_supported(const wdg_conv_plan* pl) {
+    if (!pl || pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w || pl->Cout_p % 8) return 0;
+    return wdg_patch_h16_eligible_t(pl);
+}
+
+extern "C" int wdg_upconv_colgemm_h16(const wdg_conv_plan* pl, const float* x_low, const void* wD16, void* z16, int fmt,
+                                      wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x_low && wD16 && z16 && (fmt == 0 || fmt == 1), "bad argument");
+    WDG_CHECK_ARG(((uintptr_t)x_low & 15) == 0 && ((uintptr_t)wD16 & 15) == 0 && ((uintptr_t)z16 & 15) == 0 && pl->Cout_p % 8 == 0, "alignment");
+    const int rc = wdg_patch_h16_launch(pl, 1, x_low, wD16, nullptr, nullptr, (float*)z16, 0, 0.f, 0, fmt, (hipStream_t)stream, nullptr, 1);
+    if (rc == 1) {
+        wdg_set_error("wdg_upconv_colgemm_h16: geometry outside the patch kernel (use the fp32 z route)");
+        return WDG_ERR_ARG;
+    }
+    return rc;
+}
+
 // ---- 16-bit ConvLSTM2D inference (gan/models.py:45): input part of the gates with interleaved columns, then one launch per
 // timestep = recurrent convolution + cell update (conv_patch_h16.hip, LSTM epilogue)
 static int g_lstm16_fused = 1;

@@ -38,6 +38,8 @@ struct WdgPatchH16 {
     int pad_h, pad_w;
     int act, accumulate;
     float slope;
+    int out16;                 // the output is stored in the 16-bit operand format (Out points to 16-bit elements; ldO / imgStrideO in
+                               // elements): the column GEMM of the upsample layer, whose only reader is the bilinear gather
     int gate_F;                // > 0: ConvLSTM gate columns interleaved — column n is gate n & 3 of feature n >> 2, i.e. weight row
                                // and bias index (n & 3) * gate_F + (n >> 2); a lane's 4 accumulator registers are then i, f, c~, o
     const float* gates_x;      // LSTM step (template LSTM): input part of the gates, interleaved columns [pixel][4 * gate_F]
@@ -341,6 +343,24 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                     if (p.bias) bias4[r] = p.bias[nb];
                     if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[p.Ncols + nb]; }
                 }
+            if (p.out16) {
+                // 16-bit result (no bias / activation / accumulate on this route): four channels = one 8-byte store
+                typedef wdg_h16<FMT> h16x4 __attribute__((ext_vector_type(4)));
+                wdg_h16<FMT>* out16 = reinterpret_cast<wdg_h16<FMT>*>(p.Out) + (long long)img * p.imgStrideO;
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const f32x4 v = acc[a][b];
+                    wdg_h16<FMT>* dst = out16 + (long long)opix[a] * p.ldO + n;
+                    if (full) {
+                        *reinterpret_cast<h16x4*>(dst) = (h16x4){(wdg_h16<FMT>)v[0], (wdg_h16<FMT>)v[1], (wdg_h16<FMT>)v[2], (wdg_h16<FMT>)v[3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.Ncols) dst[r] = (wdg_h16<FMT>)v[r];
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 float* dst = outImg + (long long)opix[a] * p.ldO + n;
@@ -445,6 +465,13 @@ int wdg_patch_h16_eligible(const wdg_conv_plan* pl) {
     return patch_plan(patch_view(pl, false), p) ? 1 : 0;
 }
 
+// ... of the transposed 1 x 1 view (x side = result, y side = operand)
+int wdg_patch_h16_eligible_t(const wdg_conv_plan* pl) {
+    WdgPatchH16 p;
+    memset(&p, 0, sizeof(p));
+    return patch_plan(patch_view(pl, true), p) ? 1 : 0;
+}
+
 template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, bool LSTM = false>
 static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_t st) {
     static size_t lds_set = 0;
@@ -462,13 +489,14 @@ static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_
 // transposed1x1: x is dy, y is dx and w16 the data-gradient packing [Cin][Cout_p] of a 1 x 1, stride-1 plan.
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
                          const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
-                         const WdgPatchGates* gx) {
+                         const WdgPatchGates* gx, int out16) {
+    if (out16 && (gx || bias || affine || act || accumulate)) return 1;
     if (transposed1x1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
     const WdgPatchView g = patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;
     memset(&p, 0, sizeof(p));
     if (!patch_plan(g, p)) return 1;
-    p.A = x; p.B = w16; p.Out = y; p.bias = bias; p.affine = affine;
+    p.A = x; p.B = w16; p.Out = y; p.bias = bias; p.affine = affine; p.out16 = out16;
     p.imgStrideA = g.imgStrideA; p.imgStrideO = g.imgStrideO;
     p.H = g.H; p.W = g.W; p.ldA = g.ldA; p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldO;
     p.Ncols = g.Ncols; p.ldB = g.kh * g.kw * g.K_p; p.Cin_p = g.K_p;

@@ -101,6 +101,7 @@ void wdg_patch_h16_set_dbg(int v);
 void wdg_patch_h16_set_nloop(int v);
 void wdg_patch_h16_set_flat(int v);
 int wdg_patch_h16_eligible(const wdg_conv_plan* pl);
+int wdg_patch_h16_eligible_t(const wdg_conv_plan* pl);
 // ConvLSTM gate columns: F features, columns interleaved (gate n & 3 of feature n >> 2).  c_out == NULL: plain convolution
 // that writes its columns interleaved (the input part of the gates); else the recurrent step with the cell update in the epilogue.
 struct WdgPatchGates {
@@ -115,7 +116,7 @@ struct WdgPatchGates {
 };
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
                          const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
-                         const WdgPatchGates* gx = nullptr);
+                         const WdgPatchGates* gx = nullptr, int out16 = 0);
 
 // convlstm1.hip
 void wdg_convlstm1_set_mfma(int v);

@@ -113,8 +113,13 @@ extern "C" int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, f
 // that + 2), so the sum separates into a horizontal pass (10 terms) and a vertical pass (10 terms) instead of 100.
 // One workgroup = an 8x8 low-res tile = 16x16 output pixels; per tap row ty the 12x12 low-res window of z (80 floats per
 // pixel) is staged in LDS, reduced horizontally into H[12][16][C], and each thread adds its two vertical terms.
-template <int CQ>
-__global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+// ZF: element format of z — 0 fp32, 1 bf16, 2 fp16 (16-bit: wdg_upconv_colgemm_h16 wrote it; a thread's slot is then 4 values =
+// 8 bytes, widened to fp32 on the way into LDS; everything behind the load is the fp32 kernel)
+template <int ZF> struct WdgZT { typedef float T; };
+template <> struct WdgZT<1> { typedef __bf16 T; };
+template <> struct WdgZT<2> { typedef _Float16 T; };
+template <int CQ, int ZF = 0>
+__global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename WdgZT<ZF>::T* __restrict__ z, const float* __restrict__ bias,
                                                                 const float* __restrict__ affine, float* __restrict__ y,
                                                                 int ldy, long long isy, int Hl, int Wl, int act, float slope,
                                                                 double* stats, int stats_rep) {
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __r
     const int t = threadIdx.x;
     const int qyl = t >> 4, qxl = t & 15;            // this thread's output pixel within the 16x16 tile
     const int qy = 2 * i0 + qyl, qx = 2 * j0 + qxl;
-    const float* zimg = z + n * Hl * Wl * (100LL * CQ);
+    const typename WdgZT<ZF>::T* zimg = z + n * Hl * Wl * (100LL * CQ);
     f32x4 acc[CQ];
 #pragma unroll
     for (int o4 = 0; o4 < CQ; ++o4) acc[o4] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -147,7 +152,18 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __r
     auto load_slice = [&](int ty_) {
 #pragma unroll
         for (int s_ = 0; s_ < NSLOT; ++s_)
-            zr[s_] = zoff[s_] >= 0 ? *reinterpret_cast<const f32x4*>(zimg + zoff[s_] + ty_ * (20 * CQ)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            if constexpr (ZF == 0) {
+                zr[s_] = zoff[s_] >= 0 ? *reinterpret_cast<const f32x4*>(zimg + zoff[s_] + ty_ * (20 * CQ)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+                typedef typename WdgZT<ZF>::T zt4 __attribute__((ext_vector_type(4)));
+                zr[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (zoff[s_] >= 0) {
+                    const zt4 q = *reinterpret_cast<const zt4*>(zimg + zoff[s_] + ty_ * (20 * CQ));
+                    zr[s_] = (f32x4){(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+                }
+            }
+        }
     };
     load_slice(0);
     for (int ty = 0; ty < 5; ++ty) {
@@ -237,6 +253,29 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const float* __r
             atomicAdd(slab + 4 * CQ + t, (double)s2);
         }
     }
+}
+
+extern "C" int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias, const float* affine, float* y, int ldy,
+                                     int64_t img_stride_y, int n_img, int Hl, int Wl, int C, int act, float slope, wdg_stream stream) {
+    WDG_CHECK_ARG(z16 && y && (fmt == 0 || fmt == 1) && n_img > 0 && n_img < 65536 && Hl > 0 && Wl > 0 && ldy % 4 == 0, "bad argument");
+    WDG_CHECK_ARG(wdg_upconv_col_supported(C), "channel count must be 4, 8 or 16");
+    WDG_CHECK_ARG(((uintptr_t)z16 & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)affine & 15) == 0, "z / y / bias / affine must be 16-byte aligned");
+    const int tiles = ((Hl + TS - 1) / TS) * ((Wl + TS - 1) / TS);
+    dim3 grid(tiles, n_img), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define WDG_GATHER16(CQ_)                                                                                                          \
+    if (fmt == 0)                                                                                                                  \
+        hipLaunchKernelGGL((wdg_upconv_gather_kernel<CQ_, 1>), grid, block, 0, st, (const __bf16*)z16, bias, affine, y, ldy,      \
+                           (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0);                                     \
+    else                                                                                                                           \
+        hipLaunchKernelGGL((wdg_upconv_gather_kernel<CQ_, 2>), grid, block, 0, st, (const _Float16*)z16, bias, affine, y, ldy,    \
+                           (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0);
+    if (C == 16) { WDG_GATHER16(4) }
+    else if (C == 8) { WDG_GATHER16(2) }
+    else { WDG_GATHER16(1) }
+#undef WDG_GATHER16
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
 }
 
 extern "C" int wdg_upconv_gather(const float* z, const float* bias, const float* affine, float* y, int ldy,

@@ -254,6 +254,7 @@ class HipOps:
             self.set_split_mode(True)
         self.upconv4 = True   # fused upsample + 5x5 transposed conv through the composite-kernel path
         self.upconv_col = True   # its backward in column form on the low-res grid
+        self.z16 = os.environ.get("WDG_Z16", "0") == "1"   # 16-bit inference: the column GEMM's result z in the operand format
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
         self._scratch_bufs = {}
 
@@ -487,7 +488,29 @@ class HipOps:
         if self.upconv_colfwd and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
                 x_low.shape[3] == pk.cout and pk.cout % 8 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
                 pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (affine is None or affine.data_ptr() % 16 == 0):
-            # column form with 16-bit GEMM operands: z = x * W (fp32 result), then the fp32 bilinear gather
+            # column form with 16-bit GEMM operands: z = x * W, then the fp32 bilinear gather.  z16 (WDG_Z16=1, opt-in): z itself is
+            # stored in the operand format — 400 columns per low-resolution pixel make it the largest tensor of the forward (1.4 GB
+            # per 16-tile group in fp32), written once and read once.  Measured SLOWER than fp32 z (16-tile group 3.78 -> 4.23 ms):
+            # both kernels are bound by instruction issue, not by bytes, and 8-byte accesses run at 0.54-0.70x the 16-byte rate
+            plan16 = None
+            if self.z16:
+                plan16, _, _ = self._plan_dims(n, H // 2, W // 2, 25 * pk.cin, 25 * pk.cin, (H // 2) * (W // 2) * 25 * pk.cin,
+                                               H // 2, W // 2, pk.cout, *_v4(x_low)[1:], ConvGeom(1, 1, 1, 0))
+                if not self.lib.wdg_upconv_colgemm_h16_supported(plan16):
+                    plan16 = None           # map outside the patch kernel's tile shapes: fp32 z route below
+            if plan16 is not None:
+                plan = plan16
+                pool_ = self._scratch_bufs if pool is None else pool
+                key, tdt = "upc_col16_" + fmt, (torch.bfloat16 if fmt == "bf16" else torch.float16)
+                z16 = pool_.get(key)
+                if z16 is None or tuple(z16.shape) != (n, H // 2, W // 2, 25 * pk.cin):
+                    z16 = pool_[key] = torch.empty(n, H // 2, W // 2, 25 * pk.cin, dtype=tdt, device=self.device)
+                f = 0 if fmt == "bf16" else 1
+                native.check(self.lib.wdg_upconv_colgemm_h16(plan, x_low.data_ptr(), pk.half(fmt)[1].data_ptr(), z16.data_ptr(), f,
+                                                             self.stream), "upconv_colgemm_h16")
+                native.check(self.lib.wdg_upconv_gather_h16(z16.data_ptr(), f, _ptr(bias), _ptr(affine), py, ldy, isy, n, H // 2, W // 2,
+                                                            pk.cin, int(act), slope, self.stream), "upconv_gather_h16")
+                return
             z = self._scratch("upc_col", n, H // 2, W // 2, 25 * pk.cin, pool=pool)
             plan, _, _ = self._plan(z, x_low, 25 * pk.cin, pk.cout, ConvGeom(1, 1, 1, 0))
             fn = self.lib.wdg_conv_dgrad_bf16 if fmt == "bf16" else self.lib.wdg_conv_dgrad_f16
