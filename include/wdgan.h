@@ -48,6 +48,7 @@ const char* wdg_version(void);
  *                 them in LDS;
  *   "xcd_swizzle": 1 (default) XCD-aware workgroup -> tile remap in the implicit-GEMM kernel, 0 off. */
 int wdg_set_tuning(const char* key, int value);
+int wdg_tuning_epoch(void);   /* number of wdg_set_tuning calls so far: key of launch sequences cached by the caller (HIP graphs) */
 /* Number of compute units of the current device (used by the host-side split-K heuristic). */
 int wdg_device_cus(void);
 
@@ -205,6 +206,18 @@ int wdg_convlstm_bwd_step_supported(const wdg_conv_plan* plan, int F);
 int wdg_convlstm_bwd_step(const wdg_conv_plan* plan, const float* dgates_next, const float* wD, float* dh_prev,
                           const float* gates_t, const float* c_prev, const float* c_cur, const float* dc_in,
                           float* dgates_out, float* dc_out, int ldc, int F, wdg_stream stream);
+
+/* The same two steps for the 16-feature layer (models.py:101) in kernels of their own (convlstm16.hip: 3 x 3, 16 -> 64, every
+ * request ordered by first use; 33 -> 2x us forward, 44 -> 3x us backward per timestep at batch 8).  The recurrent kernel
+ * [3][3][16][64] is handed over in the kernels' LDS layouts, written by wdg_convlstm16_pack (9216 floats each).  `plan` as for
+ * wdg_convlstm_step; wdg_convlstm16_supported: 1 when the plan is that layer (else use wdg_convlstm_step / _bwd_step). */
+int wdg_convlstm16_supported(const wdg_conv_plan* plan);
+int wdg_convlstm16_pack(const float* w_hwio, float* wl_fwd, float* wl_bwd, wdg_stream stream);
+int wdg_convlstm16_step(const wdg_conv_plan* plan, const float* h_prev, const float* wl_fwd, float* gates, const float* c_prev,
+                        float* c_out, int ldc, float* h_out, int ldh, wdg_stream stream);
+int wdg_convlstm16_bwd_step(const wdg_conv_plan* plan, const float* dgates_next, const float* wl_bwd, float* dh_prev,
+                            const float* gates_t, const float* c_prev, const float* c_cur, const float* dc_in,
+                            float* dgates_out, float* dc_out, int ldc, wdg_stream stream);
 
 /* 16-bit ConvLSTM2D inference (gan/models.py:45; TimeDistributed ConvLSTM2D(F, 3, padding='same', return_sequences=True)):
  * the input part of the gates for all timesteps, written with INTERLEAVED gate columns (column n = gate n & 3 of feature

@@ -100,6 +100,48 @@ def test_discriminator(hip_ops, S, T, Fd, variant):
     assert rel_err(dhigh, ghigh) < TOL
 
 
+def test_time_loops_replayed_from_hip_graphs(hip_ops):
+    """At n_timesteps > 2 the ConvLSTM time loops are captured into HIP graphs at their second call and replayed from then on
+    (HipOps.chain): score and gradients of later calls — on new inputs and after a weight update, which rewrites the packed /
+    LDS-layout weights the captured launches read — must equal the eager launches' (to the run-to-run spread of the atomically
+    accumulated weight gradients: 1e-5; a loop replayed on stale weights or buffers is off by orders of magnitude more)."""
+    from downscaling.engine.networks import DiscriminatorNet
+    S, T, B, cl, ch = 32, 4, 2, 3, 2
+    dev = hip_ops.device
+
+    def run(graphs):
+        hip_ops.chain_graphs = graphs
+        hip_ops._chains.clear()
+        hip_ops._chain_seen.clear()
+        net = DiscriminatorNet(hip_ops, S, S, cl, ch, T, feature_channels=16, seed=4)
+        randomize(net, 12)
+        out = []
+        for it in range(4):
+            low, _, high = _inputs(B, T, S, cl, 1, ch, seed=20 + it)
+            net.set_low(low.float().to(dev))
+            high_tm = hip_ops.zeros(T * B, S, S, 4)
+            net.to_time_major(high.float().to(dev), high_tm)
+            net.set_high_tm(high_tm, B)
+            score = net.forward(B, training=True).clone()
+            net.params.zero_grad()
+            dhigh = net.backward(B, torch.ones(B, device=dev), need_wgrad=True).clone()
+            out.append((score, dhigh, net.params.grads.clone()))
+            net.params.flat.sub_(0.05 * net.params.grads)          # a weight update between the calls
+            net.params.version += 1
+        return out, len(hip_ops._chains)
+
+    try:
+        eager, n0 = run(False)
+        replayed, n1 = run(True)
+    finally:
+        hip_ops.chain_graphs = True
+    assert n0 == 0 and n1 >= 4            # forward + backward loops of the two ConvLSTMs
+    for it, (a, b) in enumerate(zip(eager, replayed)):
+        for x, y in zip(a, b):
+            assert rel_err(x, y) < 1e-5, (it, rel_err(x, y))
+    assert rel_err(eager[0][0], eager[3][0]) > 1e-3      # (the updates do move the score)
+
+
 @pytest.mark.parametrize("S,T", [(32, 2), (20, 1), (96, 1)])
 def test_train_step(hip_ops, S, T):
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet

@@ -786,11 +786,18 @@ def test_convlstm_recurrent_step_fused(hip_ops, ref_ops, F, cinp, n, H, W):
     g_g, hp_g, cp_g = gates.float().to(dev), h_prev.float().to(dev), c_prev.float().to(dev)
     c_g, h_g = torch.zeros(n, H, W, F, device=dev), torch.zeros(n, H, W, cinp, device=dev)
     assert hip_ops.convlstm_step_supported(hp_g, g_g, pk_g, g, F)
-    hip_ops.convlstm_step(hp_g, pk_g, g_g, cp_g, c_g, h_g, g, F)
-    assert rel_err(g_g, g_r) < TOL, "pre-activation gates"
-    # a hard-sigmoid knot or tanh amplifies nothing here: c and h are smooth in the gates up to the clip points
-    assert rel_err(c_g, c_r) < 5 * TOL and rel_err(h_g[..., :F], h_r[..., :F]) < 5 * TOL
-    assert float(h_g[..., F:].abs().max()) == 0.0 if cinp > F else True
+    # 16 features: the step kernels of csrc/convlstm16.hip (default) and the halo-tile kernel's cell epilogue behind them
+    for own16 in ((1, 0) if F == 16 else (1,)):
+        assert hip_ops.lib.wdg_set_tuning(b"lstm16_step", own16) == 0
+        try:
+            g_g, c_g, h_g = gates.float().to(dev), torch.zeros(n, H, W, F, device=dev), torch.zeros(n, H, W, cinp, device=dev)
+            hip_ops.convlstm_step(hp_g, pk_g, g_g, cp_g, c_g, h_g, g, F)
+        finally:
+            hip_ops.lib.wdg_set_tuning(b"lstm16_step", 1)
+        assert rel_err(g_g, g_r) < TOL, "pre-activation gates"
+        # a hard-sigmoid knot or tanh amplifies nothing here: c and h are smooth in the gates up to the clip points
+        assert rel_err(c_g, c_r) < 5 * TOL and rel_err(h_g[..., :F], h_r[..., :F]) < 5 * TOL
+        assert float(h_g[..., F:].abs().max()) == 0.0 if cinp > F else True
 
 
 @pytest.mark.parametrize("F,cinp,n,H,W,first", [(16, 16, 3, 24, 40, False), (16, 16, 8, 96, 96, True), (2, 4, 3, 24, 40, False),
@@ -820,15 +827,22 @@ def test_convlstm_recurrent_bwd_step_fused(hip_ops, ref_ops, F, cinp, n, H, W, f
     dh_g, dg_g = f32(dh), torch.zeros(n, H, W, 4 * F, device=dev)
     dc_g = None if first else torch.zeros(n, H, W, F, device=dev)
     assert hip_ops.convlstm_bwd_step_supported(dh_g, dg_g, pk_g, g, F)
-    hip_ops.convlstm_bwd_step(f32(dg_next), pk_g, dh_g, f32(gates), f32(c_prev), f32(c_cur), f32(dc_in), dg_g, dc_g, g, F)
-    assert rel_err(dh_g, dh_r) < TOL, "dh"
-    # the hard-sigmoid gradient is a step function: fp32 vs fp64 pre-activations may sit on different sides of a knot for a few
-    # elements, so dgates is compared robustly (99.9 % quantile) and in the mean
-    d = (dg_g.double().cpu() - dg_r).abs().flatten()
-    scale = float(dg_r.abs().max())
-    assert float(torch.quantile(d[:2_000_000], 0.999)) < 20 * TOL * scale and float(d.mean()) < TOL * scale, "dgates"
-    if not first:
-        assert rel_err(dc_g, dc_r) < 10 * TOL, "dc"
+    for own16 in ((1, 0) if F == 16 else (1,)):          # (csrc/convlstm16.hip, then the halo-tile kernel's epilogue)
+        assert hip_ops.lib.wdg_set_tuning(b"lstm16_step", own16) == 0
+        try:
+            dh_g, dg_g = f32(dh), torch.zeros(n, H, W, 4 * F, device=dev)
+            dc_g = None if first else torch.zeros(n, H, W, F, device=dev)
+            hip_ops.convlstm_bwd_step(f32(dg_next), pk_g, dh_g, f32(gates), f32(c_prev), f32(c_cur), f32(dc_in), dg_g, dc_g, g, F)
+        finally:
+            hip_ops.lib.wdg_set_tuning(b"lstm16_step", 1)
+        assert rel_err(dh_g, dh_r) < TOL, "dh"
+        # the hard-sigmoid gradient is a step function: fp32 vs fp64 pre-activations may sit on different sides of a knot for a few
+        # elements, so dgates is compared robustly (99.9 % quantile) and in the mean
+        d = (dg_g.double().cpu() - dg_r).abs().flatten()
+        scale = float(dg_r.abs().max())
+        assert float(torch.quantile(d[:2_000_000], 0.999)) < 20 * TOL * scale and float(d.mean()) < TOL * scale, "dgates"
+        if not first:
+            assert rel_err(dc_g, dc_r) < 10 * TOL, "dc"
 
 
 @pytest.mark.parametrize("P,C,ld", [(100003, 64, 64), (5000, 4, 4), (7777, 8, 8), (9001, 16, 16), (30011, 128, 160), (4097, 512, 512),

@@ -58,6 +58,13 @@ __device__ __forceinline__ unsigned wdg_fastdiv_do(unsigned n, wdg_fastdiv f) {
 }
 
 __device__ __forceinline__ float wdg_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// tanh(x) = 1 - 2 / (1 + exp(2x)) on the hardware exp2 / rcp: 4 instructions (libm's tanhf is ~40 with two branches), absolute
+// error ~1e-7 (relative error grows below |x| ~ 1e-3, where the result is added to or multiplied with O(1) quantities in every
+// LSTM cell that uses it).  Saturates cleanly: exp -> inf gives 1, exp -> 0 gives -1.
+__device__ __forceinline__ float wdg_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);
+}
 
 // wave-level sum (64 lanes)
 __device__ __forceinline__ float wdg_wave_sum(float v) {

@@ -321,8 +321,8 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                     f32x4 di, df, dcc, dob, dcp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float gi = hs(xi[r]), gf = hs(xf[r]), gc = tanhf(xc[r]), go = hs(xo[r]);
-                        const float tc = tanhf(cc[r]);
+                        const float gi = hs(xi[r]), gf = hs(xf[r]), gc = wdg_tanh(xc[r]), go = hs(xo[r]);
+                        const float tc = wdg_tanh(cc[r]);
                         const float dhv = acc[a][0][r];
                         const float dc = dhv * go * (1.f - tc * tc) + dci[r];
                         di[r] = dc * gc * hsg(xi[r]);
@@ -344,9 +344,9 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                         if (f >= F) continue;
                         const float* g = p.gates_t + pix * 4 * F;
                         const float xi = g[f], xf = g[F + f], xc = g[2 * F + f], xo = g[3 * F + f];
-                        const float gi = hs(xi), gf = hs(xf), gc = tanhf(xc), go = hs(xo);
+                        const float gi = hs(xi), gf = hs(xf), gc = wdg_tanh(xc), go = hs(xo);
                         const float cp = p.c_prev ? p.c_prev[pix * p.ldc + f] : 0.f;
-                        const float tc = tanhf(p.c_cur[pix * p.ldc + f]);
+                        const float tc = wdg_tanh(p.c_cur[pix * p.ldc + f]);
                         const float dhv = acc[a][0][r];
                         const float dc = dhv * go * (1.f - tc * tc) + p.dc_in[pix * p.ldc + f];
                         float* dg = p.dgates_out + pix * 4 * F;
@@ -371,8 +371,8 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                     f32x4 cn, hn;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        cn[r] = hs(acc[a][1][r]) * cp[r] + hs(acc[a][0][r]) * tanhf(acc[a][2][r]);
-                        hn[r] = hs(acc[a][3][r]) * tanhf(cn[r]);
+                        cn[r] = hs(acc[a][1][r]) * cp[r] + hs(acc[a][0][r]) * wdg_tanh(acc[a][2][r]);
+                        hn[r] = hs(acc[a][3][r]) * wdg_tanh(cn[r]);
                     }
                     *reinterpret_cast<f32x4*>(p.c_out + pix * p.ldc + 4 * lg) = cn;
                     *reinterpret_cast<f32x4*>(p.h_out + pix * p.ldh + 4 * lg) = hn;
@@ -384,9 +384,9 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
                     if (lg == 0) {
 #pragma unroll
                         for (int f = 0; f < 2; ++f) {
-                            const float cn = hs(acc[a][0][2 + f]) * p.c_prev[pix * p.ldc + f] + hs(acc[a][0][f]) * tanhf(other[f]);
+                            const float cn = hs(acc[a][0][2 + f]) * p.c_prev[pix * p.ldc + f] + hs(acc[a][0][f]) * wdg_tanh(other[f]);
                             p.c_out[pix * p.ldc + f] = cn;
-                            p.h_out[pix * p.ldh + f] = hs(other[2 + f]) * tanhf(cn);
+                            p.h_out[pix * p.ldh + f] = hs(other[2 + f]) * wdg_tanh(cn);
                         }
                     }
                 }
@@ -776,9 +776,9 @@ __global__ void __launch_bounds__(256) wdg_convlstm2_fwd_kernel(const float* __r
     auto hs = [](float v) { return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); };
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        const float cn = hs(z[2 + f]) * c_prev[idx * ldc + f] + hs(z[f]) * tanhf(z[4 + f]);
+        const float cn = hs(z[2 + f]) * c_prev[idx * ldc + f] + hs(z[f]) * wdg_tanh(z[4 + f]);
         c_out[idx * ldc + f] = cn;
-        h_out[idx * ldh + f] = hs(z[6 + f]) * tanhf(cn);
+        h_out[idx * ldh + f] = hs(z[6 + f]) * wdg_tanh(cn);
     }
 }
 
@@ -821,9 +821,9 @@ __global__ void __launch_bounds__(256) wdg_convlstm2_bwd_kernel(const float* __r
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const float xi = g[f], xf = g[2 + f], xc = g[4 + f], xo = g[6 + f];
-        const float gi = hs(xi), gf = hs(xf), gc = tanhf(xc), go = hs(xo);
+        const float gi = hs(xi), gf = hs(xf), gc = wdg_tanh(xc), go = hs(xo);
         const float cp = c_prev ? c_prev[idx * ldc + f] : 0.f;
-        const float tc = tanhf(c_cur[idx * ldc + f]);
+        const float tc = wdg_tanh(c_cur[idx * ldc + f]);
         const float dc = dh[f] * go * (1.f - tc * tc) + dc_in[idx * ldc + f];
         dg[f] = dc * gc * hsg(xi);
         dg[2 + f] = dc * cp * hsg(xf);

@@ -581,11 +581,11 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
                 }
                 const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
                 const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
-                const float gc = tanhf(z[2]);
+                const float gc = wdg_tanh(z[2]);
                 const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
                 const float cn = gi * gc + gf * cp[b];
                 p.c_out[pix * p.ldc + f] = cn;
-                p.h_out[pix * p.ldh + f] = go * tanhf(cn);
+                p.h_out[pix * p.ldh + f] = go * wdg_tanh(cn);
             }
         }
         return;
@@ -1275,10 +1275,17 @@ static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase:
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
+static int g_tuning_epoch = 0;
+extern "C" int wdg_tuning_epoch(void) { return g_tuning_epoch; }
 extern "C" int wdg_set_tuning(const char* key, int value) {
+    ++g_tuning_epoch;          // (callers that cache launch sequences — captured HIP graphs — key them on this)
     if (key && !strcmp(key, "igemm_pipe")) {
         if (value < 0 || value > 4) return WDG_ERR_ARG;   // 4 = fp32 products from three bf16 slices per operand (PIPE == 4)
         g_igemm_pipe = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "lstm16_step")) {
+        wdg_lstm16_set_step(value);
         return WDG_OK;
     }
     if (key && !strcmp(key, "halo_weights_global")) {

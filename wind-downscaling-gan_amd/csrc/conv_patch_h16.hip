@@ -322,11 +322,11 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 const f32x4 z = acc[a][b] + gx[a];
                 const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
                 const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
-                const float gc = tanhf(z[2]);
+                const float gc = wdg_tanh(z[2]);
                 const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
                 const float cn = gi * gc + gf * cp[a];
                 p.c_out[pix * p.ldc + f] = cn;
-                outImg[(long long)opix[a] * p.ldO + f] = go * tanhf(cn);
+                outImg[(long long)opix[a] * p.ldO + f] = go * wdg_tanh(cn);
             }
         }
     } else {

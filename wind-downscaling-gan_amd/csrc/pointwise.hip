@@ -24,12 +24,12 @@ __global__ void __launch_bounds__(256) wdg_lstm_fwd_kernel(const float* __restri
         const int f = (int)(idx - p * F);
         const float* g = gates + p * ldg;
         const float gi = wdg_hsig(g[f]);
-        const float gc = tanhf(g[2 * F + f]);
+        const float gc = wdg_tanh(g[2 * F + f]);
         const float go = wdg_hsig(g[3 * F + f]);
         float cn = gi * gc;
         if (c_prev) cn += wdg_hsig(g[F + f]) * c_prev[p * ldcp + f];
         c[p * ldc + f] = cn;
-        h[p * ldh + f] = go * tanhf(cn);
+        h[p * ldh + f] = go * wdg_tanh(cn);
     }
 }
 
@@ -54,10 +54,10 @@ __global__ void __launch_bounds__(256) wdg_lstm_fwd4_kernel(const float* __restr
         f32x4 cn, hn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v = wdg_hsig(xi[j]) * tanhf(xc[j]);
+            float v = wdg_hsig(xi[j]) * wdg_tanh(xc[j]);
             if (c_prev) v += wdg_hsig(xf[j]) * cp[j];
             cn[j] = v;
-            hn[j] = wdg_hsig(xo[j]) * tanhf(v);
+            hn[j] = wdg_hsig(xo[j]) * wdg_tanh(v);
         }
         *reinterpret_cast<f32x4*>(c + p * ldc + f) = cn;
         *reinterpret_cast<f32x4*>(h + p * ldh + f) = hn;
@@ -94,9 +94,9 @@ __global__ void __launch_bounds__(256) wdg_lstm_bwd_kernel(const float* __restri
         const int f = (int)(idx - p * F);
         const float* g = gates + p * ldg;
         const float xi = g[f], xf = g[F + f], xc = g[2 * F + f], xo = g[3 * F + f];
-        const float gi = wdg_hsig(xi), gf = wdg_hsig(xf), gc = tanhf(xc), go = wdg_hsig(xo);
+        const float gi = wdg_hsig(xi), gf = wdg_hsig(xf), gc = wdg_tanh(xc), go = wdg_hsig(xo);
         const float cp = c_prev ? c_prev[p * ldcp + f] : 0.f;
-        const float tc = tanhf(c[p * ldc + f]);
+        const float tc = wdg_tanh(c[p * ldc + f]);
         const float dhv = dh[p * lddh + f];
         float dc = dhv * go * (1.f - tc * tc);
         if (dc_in) dc += dc_in[p * lddci + f];
@@ -132,8 +132,8 @@ __global__ void __launch_bounds__(256) wdg_lstm_bwd4_kernel(const float* __restr
         f32x4 di, df, dcg, dout, dcp;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float gi = wdg_hsig(xi[j]), gf = wdg_hsig(xf[j]), gc = tanhf(xc[j]), go = wdg_hsig(xo[j]);
-            const float tc = tanhf(cc[j]);
+            const float gi = wdg_hsig(xi[j]), gf = wdg_hsig(xf[j]), gc = wdg_tanh(xc[j]), go = wdg_hsig(xo[j]);
+            const float tc = wdg_tanh(cc[j]);
             const float dc = dhv[j] * go * (1.f - tc * tc) + dci[j];
             di[j] = dc * gc * wdg_hsig_grad(xi[j]);
             df[j] = dc * cp[j] * wdg_hsig_grad(xf[j]);

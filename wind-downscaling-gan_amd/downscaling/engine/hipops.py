@@ -129,6 +129,21 @@ class PackedWeights:
             cache["ver"] = self._hver
         return cache["buf"]
 
+    def lstm16(self):
+        """(wl_fwd, wl_bwd): the recurrent kernel [3][3][16][64] in the LDS layouts of the 16-feature step kernels
+        (wdg_convlstm16_pack), rebuilt lazily after the master weights changed."""
+        cache = self.__dict__.setdefault("_l16", {"f": None, "b": None, "ver": -1})
+        if self._bf16_stale:            # (shares the staleness counter of the 16-bit copies)
+            self._hver += 1
+            self._bf16_stale = False
+        if cache["ver"] != self._hver:
+            if cache["f"] is None:
+                cache["f"], cache["b"] = torch.empty(9216, device=self.w.device), torch.empty(9216, device=self.w.device)
+            native.check(self.ops.lib.wdg_convlstm16_pack(self.w.data_ptr(), cache["f"].data_ptr(), cache["b"].data_ptr(),
+                                                          self.ops.stream), "convlstm16_pack")
+            cache["ver"] = self._hver
+        return cache["f"], cache["b"]
+
     def as_1x1(self):
         """The same weights as a 1x1 convolution with taps*cin input channels: w[t][i][o] viewed as [t*cin + i][o].
         Both kernel layouts coincide with this object's (wF is [cout][taps][cin], wD is w itself), so the view shares
@@ -257,6 +272,37 @@ class HipOps:
         self.z16 = os.environ.get("WDG_Z16", "0") == "1"   # 16-bit inference: the column GEMM's result z in the operand format
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
         self._scratch_bufs = {}
+        # per-timestep launch chains (the ConvLSTM time loops at n_timesteps > 1) replayed from captured HIP graphs: see chain()
+        self.chain_graphs = os.environ.get("WDG_CHAIN_GRAPHS", "1") != "0"
+        self._chains, self._chain_seen = {}, {}
+
+    def chain(self, key, fn):
+        """Runs fn() — a chain of dependent per-timestep launches on FIXED buffers with no host-side effects (a ConvLSTM's time
+        loop) — from a HIP graph.  At the shipped sequence length a train step issues ~1,650 such launches of 8-45 us each;
+        through Python / ctypes the host needs ~30 us per launch, so it cannot run ahead of the device and the streams that
+        should overlap (generator / discriminator / twin discriminator) are fed one after the other.  The first call with a key
+        runs eagerly (plans and scratch come into being), the second is captured, later ones are one graph launch.
+        `key` must name every buffer address and shape the chain touches; the library's tuning epoch is added here."""
+        if not self.chain_graphs or self.split_mode or torch.cuda.is_current_stream_capturing():
+            return fn()               # (split mode refreshes its weight slices lazily on the host path: never from a graph)
+        key = key + (int(self.lib.wdg_tuning_epoch()),)
+        graph = self._chains.get(key)
+        if graph is None:
+            seen = self._chain_seen[key] = self._chain_seen.get(key, 0) + 1
+            if seen < 2:
+                return fn()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    fn()
+            except Exception:                     # capture not possible here: stay eager from now on
+                torch.cuda.synchronize()
+                self.chain_graphs = False
+                return fn()
+            if len(self._chains) > 256:           # (buffers of networks long gone)
+                self._chains.clear()
+            self._chains[key] = graph
+        graph.replay()
 
     # ---- plumbing ---------------------------------------------------------------------------
     @property
@@ -422,12 +468,31 @@ class HipOps:
         return bool(self.lstm_step_gemm and not self.split_mode and pk.cout == 4 * F and
                     self.lib.wdg_convlstm_step_gemm_supported(plan, F))
 
+    def convlstm_step_prepare(self, h_prev, pk, gates_t, g, F):
+        """Host-side, once before a time loop of convlstm_step calls: the lazily rebuilt weight layout of the GEMM form must be
+        current BEFORE the loop — the loop itself may be replayed from a captured graph (chain)."""
+        plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
+        if self._lstm16(plan, pk, F):
+            pk.lstm16()
+        elif not self.lib.wdg_convlstm_step_supported(plan, F):
+            pk.interleaved(F)
+
+    def _lstm16(self, plan, pk, F):
+        """The 16-feature recurrent steps in their own kernels (csrc/convlstm16.hip)?"""
+        return F == 16 and pk.w is not None and tuple(pk.w.shape) == (3, 3, 16, 64) and pk.w.is_contiguous() and \
+            bool(self.lib.wdg_convlstm16_supported(plan))
+
     def convlstm_step(self, h_prev, pk, gates_t, c_prev, c_out, h_out, g, F):
         """gates_t += conv(h_prev); c_out, h_out from the cell update (gates_t keeps the pre-activations for the backward)."""
         plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
         _, ldc, _ = _v4(c_out)
         _, ldh, _ = _v4(h_out)
         assert _v4(c_prev)[1] == ldc
+        if self._lstm16(plan, pk, F):
+            native.check(self.lib.wdg_convlstm16_step(plan, h_prev.data_ptr(), pk.lstm16()[0].data_ptr(), gates_t.data_ptr(),
+                                                      c_prev.data_ptr(), c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, self.stream),
+                         "convlstm16_step")
+            return
         if not self.lib.wdg_convlstm_step_supported(plan, F):
             native.check(self.lib.wdg_convlstm_step_gemm(plan, h_prev.data_ptr(), pk.interleaved(F).data_ptr(), gates_t.data_ptr(),
                                                          c_prev.data_ptr(), c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F,
@@ -444,6 +509,11 @@ class HipOps:
         """dh_prev += conv_transpose(dgates_next); then the cell backward of that timestep -> dgates_out, dc_out (may be None)."""
         plan, _, _ = self._plan(dh_prev, dgates_next, pk.cin, pk.cout, g)
         _, ldc, _ = _v4(c_cur)
+        if self._lstm16(plan, pk, F):
+            native.check(self.lib.wdg_convlstm16_bwd_step(plan, dgates_next.data_ptr(), pk.lstm16()[1].data_ptr(), dh_prev.data_ptr(),
+                                                          gates_t.data_ptr(), _ptr(c_prev), c_cur.data_ptr(), dc_in.data_ptr(),
+                                                          dgates_out.data_ptr(), _ptr(dc_out), ldc, self.stream), "convlstm16_bwd_step")
+            return
         native.check(self.lib.wdg_convlstm_bwd_step(plan, dgates_next.data_ptr(), pk.wD.data_ptr(), dh_prev.data_ptr(), gates_t.data_ptr(),
                                                     _ptr(c_prev), c_cur.data_ptr(), dc_in.data_ptr(), dgates_out.data_ptr(), _ptr(dc_out),
                                                     ldc, F, self.stream), "convlstm_bwd_step")

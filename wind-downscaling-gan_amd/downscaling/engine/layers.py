@@ -299,17 +299,28 @@ class ConvLSTM:
         # (the discriminator's 2- and 16-feature ConvLSTMs): one launch per timestep instead of two
         step1 = (not bf16) and T > 1 and hasattr(o, "convlstm_step_supported") and \
             o.convlstm_step_supported(h[:B], self.gates[:B], self.pkh, self.g, F)
-        for t in range(T):
-            sl = slice(t * B, (t + 1) * B)
-            if t > 0:
-                pv = slice((t - 1) * B, t * B)
-                if step1:
-                    o.convlstm_step(h[pv], self.pkh, self.gates[sl], self.c[pv], self.c[sl], h[sl], self.g, F)
-                    continue
-                conv(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
-                o.lstm_fwd(v2(self.gates[sl]), v2(self.c[pv]), v2(self.c[sl]), v2(h[sl]), F)
-            else:
-                o.lstm_fwd(v2(self.gates[sl]), None, v2(self.c[sl]), v2(h[sl]), F)
+        def time_loop():
+            for t in range(T):
+                sl = slice(t * B, (t + 1) * B)
+                if t > 0:
+                    pv = slice((t - 1) * B, t * B)
+                    if step1:
+                        o.convlstm_step(h[pv], self.pkh, self.gates[sl], self.c[pv], self.c[sl], h[sl], self.g, F)
+                        continue
+                    conv(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
+                    o.lstm_fwd(v2(self.gates[sl]), v2(self.c[pv]), v2(self.c[sl]), v2(h[sl]), F)
+                else:
+                    o.lstm_fwd(v2(self.gates[sl]), None, v2(self.c[sl]), v2(h[sl]), F)
+
+        # the recurrence is a chain of T (or 2T) small dependent launches on this layer's resident buffers: replayed from a HIP
+        # graph where the backend offers it (HipOps.chain)
+        if step1 and hasattr(o, "convlstm_step_prepare"):
+            o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F)
+        if T > 2 and not bf16 and hasattr(o, "chain"):
+            o.chain(("lstm_fwd", h.data_ptr(), tuple(h.shape), self.gates.data_ptr(), self.c.data_ptr(), self.pkh.wF.data_ptr(),
+                     B, T, bool(bf16), fmt, bool(step1)), time_loop)
+        else:
+            time_loop()
 
     def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False):
         """dh: total gradient w.r.t. every h_t (modified in place by the BPTT recursion);
@@ -328,27 +339,39 @@ class ConvLSTM:
         seq = self._seq(T, h) and getattr(self, "_seq_scratch", None) is not None
         if seq:
             o.convlstm_seq_bwd(self.gates, self.c, self.wh.value, dh, self.dgates, B, T, self.cin, F, self._seq_scratch)
-        dc_in = None
         # one launch per timestep where the halo-tile kernel runs the recurrent data gradient (the discriminator's ConvLSTMs):
         # dh_{t-1} += conv_transpose(dgates_t) and, in the same epilogue, the cell backward of timestep t-1
         bstep = (not seq) and T > 1 and hasattr(o, "convlstm_bwd_step_supported") and \
             o.convlstm_bwd_step_supported(dh[:B], self.dgates[:B], self.pkh, self.g, F)
-        for t in range(T - 1, -1, -1) if not seq else ():
-            sl = slice(t * B, (t + 1) * B)
-            pv = slice((t - 1) * B, t * B)
-            dc_out = self.dc[t & 1] if t > 0 else None
-            if not (bstep and t < T - 1):          # (fused mode: the previous iteration's launch already did this cell backward)
-                o.lstm_bwd(v2(self.gates[sl]), v2(self.c[pv]) if t > 0 else None, v2(self.c[sl]), v2(dh[sl]),
-                           v2(dc_in) if dc_in is not None else None, v2(self.dgates[sl]),
-                           v2(dc_out) if dc_out is not None else None, F)
-            if t > 0:
-                if bstep:
-                    pp = slice((t - 2) * B, (t - 1) * B)
-                    o.convlstm_bwd_step(self.dgates[sl], self.pkh, dh[pv], self.gates[pv], self.c[pp] if t > 1 else None, self.c[pv],
-                                        dc_out, self.dgates[pv], self.dc[(t - 1) & 1] if t > 1 else None, self.g, F)
-                else:
-                    o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
-            dc_in = dc_out
+        def time_loop():
+            dc_in = None
+            for t in range(T - 1, -1, -1):
+                sl = slice(t * B, (t + 1) * B)
+                pv = slice((t - 1) * B, t * B)
+                dc_out = self.dc[t & 1] if t > 0 else None
+                if not (bstep and t < T - 1):          # (fused mode: the previous iteration's launch already did this cell backward)
+                    o.lstm_bwd(v2(self.gates[sl]), v2(self.c[pv]) if t > 0 else None, v2(self.c[sl]), v2(dh[sl]),
+                               v2(dc_in) if dc_in is not None else None, v2(self.dgates[sl]),
+                               v2(dc_out) if dc_out is not None else None, F)
+                if t > 0:
+                    if bstep:
+                        pp = slice((t - 2) * B, (t - 1) * B)
+                        o.convlstm_bwd_step(self.dgates[sl], self.pkh, dh[pv], self.gates[pv], self.c[pp] if t > 1 else None,
+                                            self.c[pv], dc_out, self.dgates[pv], self.dc[(t - 1) & 1] if t > 1 else None, self.g, F)
+                    else:
+                        o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
+                dc_in = dc_out
+
+        if bstep and hasattr(o, "convlstm_step_prepare"):
+            o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F)      # (weight layouts current before a replayed loop)
+        if seq:
+            pass
+        elif T > 2 and hasattr(o, "chain"):
+            o.chain(("lstm_bwd", h.data_ptr(), tuple(h.shape), dh.data_ptr(), self.gates.data_ptr(), self.c.data_ptr(),
+                     self.dgates.data_ptr(), self.dc[0].data_ptr(), self.dc[1].data_ptr(), self.pkh.wD.data_ptr(), B, T, bool(bstep)),
+                    time_loop)
+        else:
+            time_loop()
         if need_wgrad:
             def weight_grads():
                 o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True)

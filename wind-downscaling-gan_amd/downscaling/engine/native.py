@@ -37,10 +37,15 @@ SIGNATURES = {
     "wdg_device_cus": (i32, []),
     "wdg_crc32c": (C.c_uint32, [C.c_void_p, szt, C.c_uint32]),
     "wdg_set_tuning": (i32, [C.c_char_p, i32]),
+    "wdg_tuning_epoch": (i32, []),
     "wdg_convlstm_step_supported": (i32, [c_fp, i32]),
     "wdg_convlstm_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_step_gemm_supported": (i32, [C.c_void_p, i32]),
     "wdg_convlstm_step_gemm": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, c_fp]),
+    "wdg_convlstm16_supported": (i32, [c_fp]),
+    "wdg_convlstm16_pack": (i32, [c_fp, c_fp, c_fp, c_fp]),
+    "wdg_convlstm16_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, c_fp]),
+    "wdg_convlstm16_bwd_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp]),
     "wdg_convlstm_bwd_step_supported": (i32, [c_fp, i32]),
     "wdg_convlstm_bwd_step": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_h16_supported": (i32, [c_fp, i32]),

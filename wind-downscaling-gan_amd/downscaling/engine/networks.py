@@ -411,10 +411,15 @@ class DiscriminatorNet(_Net):
         sc = discriminator_shortcut(S, 2 * Fd) if shortcut_variant else None
         self.blocks = []
         self.shortcut = None
-        # the two input branches on two streams (WDG_OVERLAP_BRANCHES=0 disables, =3 restricts it to T > 1, for A/B runs): at
-        # T = 1 worth 0.6 ms per step once the generator runs beside the discriminator (70.95 -> 70.35 ms, same box)
-        self.overlap_branches = os.environ.get("WDG_OVERLAP_BRANCHES", "1") != "0"
-        self.overlap_branches_t1 = os.environ.get("WDG_OVERLAP_BRANCHES", "1") != "3"   # "3": T > 1 only (the round-2 behaviour)
+        # the two input branches on two streams.  WDG_OVERLAP_BRANCHES: 0 never, 1 (default) at T = 1 only, 2 always, 3 at T > 1
+        # only (the round-2 behaviour).  T = 1: worth 0.6 ms per step once the generator runs beside the discriminator (70.95 ->
+        # 70.35 ms, same box).  T > 1: two chains of small DEPENDENT launches side by side are slower than one after the other
+        # (two 16-feature step chains: 75 us per step pair on two streams, 52 us on one — every kernel boundary of one chain
+        # writes back / invalidates the per-XCD L2s under the other's running kernel); 91.6 -> 88.4 ms per T = 24 step without it
+        mode = os.environ.get("WDG_OVERLAP_BRANCHES", "1")
+        self.overlap_branches = mode != "0"
+        self.overlap_branches_t1 = mode in ("1", "2")
+        self.overlap_branches_tn = mode in ("2", "3")
         idx = 6
         for n, (k, s, p, ci, co, osz) in enumerate(plan):
             conv = self._add(Conv(self, L + str(idx), k, ci, co, s, p, sn=True))              # :113-114,122-123,134
@@ -514,7 +519,8 @@ class DiscriminatorNet(_Net):
         if not prepared:
             self._prepare(training)
         # (the persistent sequence kernels size their grids to be fully resident: never two of them side by side)
-        overlap = (T > 1 or self.overlap_branches_t1) and self.overlap_branches and not self.lstm_b._seq(T, b["hb"])
+        overlap = (self.overlap_branches_tn if T > 1 else self.overlap_branches_t1) and self.overlap_branches and \
+            not self.lstm_b._seq(T, b["hb"])
         self._overlap_now = overlap
         if overlap:
             # the two input branches are independent chains of small per-timestep launches: run the high-res-only one
