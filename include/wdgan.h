@@ -395,6 +395,14 @@ int wdg_convlstm1_supported(int cin, int F);
 int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
                       float* h, int ldh, int64_t img_stride_h, int n_img, int H, int W, int cin, int F,
                       wdg_stream stream);
+
+/* n_timesteps > 1 (models.py:101): the input part of the 5 -> 16-feature layer's gate pre-activations for ALL timesteps in one
+ * launch, gates[n, y, x, i | f | c~ | o] = conv(x, kernel) + bias — the tensor the recurrent steps (wdg_convlstm16_step)
+ * accumulate onto.  Same matrix-pipe kernel as wdg_convlstm1_fwd (45-row reduction, weights in registers), storing the four
+ * accumulators instead of running the cell.  wx: the kernel [3][3][5][64] (HWIO); gates: dense [n][H][W][64], 16-byte aligned. */
+int wdg_convlstm_gates_x_supported(int cin, int F);
+int wdg_convlstm_gates_x(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias, float* gates,
+                         int n_img, int H, int W, int cin, int F, wdg_stream stream);
 int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
                       const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
                       int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,

@@ -800,6 +800,28 @@ def test_convlstm_recurrent_step_fused(hip_ops, ref_ops, F, cinp, n, H, W):
         assert float(h_g[..., F:].abs().max()) == 0.0 if cinp > F else True
 
 
+@pytest.mark.parametrize("n,H,W", [(3, 19, 33), (5, 96, 96), (2, 8, 32), (1, 41, 70)])
+def test_convlstm_gates_x(hip_ops, ref_ops, n, H, W):
+    """Input part of the 5 -> 16-feature ConvLSTM's gate pre-activations for all timesteps (wdg_convlstm_gates_x: the matrix-pipe
+    kernel of the single-timestep layer storing its four accumulators; models.py:101 at n_timesteps > 1) against the oracle's
+    convolution + bias, ragged maps included."""
+    from oracle.torch_backend import ConvGeom as RG
+    gen = torch.Generator().manual_seed(H * W)
+    dev = hip_ops.device
+    x = torch.zeros(n, H, W, 8, dtype=torch.float64)
+    x[..., :5] = torch.randn(n, H, W, 5, generator=gen, dtype=torch.float64)
+    w = torch.randn(3, 3, 5, 64, generator=gen, dtype=torch.float64) * 0.3
+    b = torch.randn(64, generator=gen, dtype=torch.float64)
+    y_r = torch.zeros(n, H, W, 64, dtype=torch.float64)
+    ref_ops.conv_fwd(x, ref_ops.pack_weights(w), b, y_r, RG(3, 3, 1, 1), act=False)
+    y_g = torch.full((n, H, W, 64), float("nan"), device=dev)
+    x_g = x.float().to(dev)
+    x_g[..., 5:] = 7.0          # the pad channels of the stored input are not part of the layer
+    assert hip_ops.convlstm_gates_x_supported(x_g, y_g, 5, 16)
+    hip_ops.convlstm_gates_x(x_g, w.float().to(dev).contiguous(), b.float().to(dev), y_g, 5, 16)
+    assert rel_err(y_g, y_r) < TOL
+
+
 @pytest.mark.parametrize("F,cinp,n,H,W,first", [(16, 16, 3, 24, 40, False), (16, 16, 8, 96, 96, True), (2, 4, 3, 24, 40, False),
                                                 (2, 4, 8, 96, 96, True), (16, 16, 2, 19, 33, False)])
 def test_convlstm_recurrent_bwd_step_fused(hip_ops, ref_ops, F, cinp, n, H, W, first):

@@ -100,8 +100,13 @@ __device__ __forceinline__ void wdg_row_to_pixel(const WdgPhase& ph, int PaPb, i
 
 // EPI: 0 plain epilogue, 1 = + BatchNorm batch statistics of the output (training-mode producer), 2 = + inference-mode
 // BatchNorm affine.  Separate instantiations: the plain kernels keep their register allocation.
-template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0>
-__global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
+// KG = 2: the reduction is split over two groups of four waves INSIDE the workgroup (512 threads; each group runs the K loop
+// on its half with its own LDS stage, the second hands its accumulators to the first through LDS, the first owns the epilogue).
+// For launches with fewer tiles than CUs and a deep reduction whose epilogue needs the complete sums (the generator's recurrent
+// step at batch 8: 144 tiles of 128 x 128, K = 1152): twice the waves on the tile's MFMAs, no workspace, no second kernel.
+template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
+__global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
+    static_assert(KG == 1 || (KG == 2 && PIPE == 3 && (EPI == 0 || EPI == 4)), "in-workgroup split: rotated loop, barrier-free epilogues");
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;
     constexpr int A_LOADS = BM / 32;
@@ -110,10 +115,12 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     static_assert(MT >= 1 && NT >= 1, "tile");
 
     // one LDS array (dynamic): [stage][A tile | B tile]; PIPE >= 1 uses two stages
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds_all[];
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds_raw[];
     constexpr int STAGE = 8 * (BM + BN);
+    const int kgrp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+    f32x4* const lds_all = lds_raw + (KG > 1 ? kgrp * STAGE : 0);
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -142,7 +149,7 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
     const int Mph = p.n_img * PaPb;
     if (m0 >= Mph) return;
 
-    const int k4_begin = blockIdx.y * p.k4_per_split;
+    const int k4_begin = (KG > 1 ? kgrp : (int)blockIdx.y) * p.k4_per_split;
     int k4_end = k4_begin + p.k4_per_split;
     if (k4_end > ph.K4) k4_end = ph.K4;
     const int nk = k4_end > k4_begin ? (k4_end - k4_begin) >> 3 : 0;
@@ -453,6 +460,23 @@ __global__ void __launch_bounds__(256) wdg_igemm_kernel(const WdgIgemm p) {
             __syncthreads();
             if (kt + 2 < nk) load_tile(kt + 2);
         }
+    }
+
+    if constexpr (KG > 1) {
+        // the second group's partial sums -> LDS (both stages are free now; slot = the same (tile, thread) in both groups)
+        __syncthreads();
+        if (kgrp == 1) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) lds_raw[(a * NT + b) * 256 + t] = acc[a][b];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] += lds_raw[(a * NT + b) * 256 + t];
     }
 
     // ---- epilogue: one pixel per (row tile a), four consecutive output channels per (column tile b)
@@ -1275,6 +1299,7 @@ static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase:
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
+static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
 static int g_tuning_epoch = 0;
 extern "C" int wdg_tuning_epoch(void) { return g_tuning_epoch; }
 extern "C" int wdg_set_tuning(const char* key, int value) {
@@ -1282,6 +1307,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     if (key && !strcmp(key, "igemm_pipe")) {
         if (value < 0 || value > 4) return WDG_ERR_ARG;   // 4 = fp32 products from three bf16 slices per operand (PIPE == 4)
         g_igemm_pipe = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "igemm_kg2")) {
+        g_igemm_kg2 = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "lstm16_step")) {
@@ -1426,20 +1455,21 @@ extern "C" int wdg_split_bf16x3(const float* src, void* dst3, int64_t n, wdg_str
 }
 static void set_b3(WdgIgemm& p, int k_per_tap);
 
-template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0>
+template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
     constexpr size_t lds = PIPE == 4 ? (size_t)12 * (BM + BN) * 16     // three bf16 slices per operand: 1.5x the fp32 stage
-                                     : (size_t)((PIPE == 0 || PIPE == 3) ? 1 : 2) * 8 * (BM + BN) * sizeof(f32x4);
+                                     : (size_t)((PIPE == 0 || PIPE == 3) ? KG : 2) * 8 * (BM + BN) * sizeof(f32x4);
+    static_assert(KG == 1 || lds >= (size_t)BM * BN * sizeof(float), "the second group's accumulators fit the two stages");
     static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
     static_assert(EPI != 3 || lds >= (size_t)BM * 4 * WGN * sizeof(float), "LayerNorm scratch fits the K-loop stage");
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 48 * 1024)
-            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI>),
+            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI, KG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI>), grid, block, lds, st, p);
+    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI, KG>), grid, dim3(block.x * KG), lds, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
@@ -1459,6 +1489,16 @@ static void set_b3(WdgIgemm& p, int k_per_tap) {
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
                         hipStream_t st, bool* bn_fused = nullptr) {
     TileCfg tc = pick_tile(p.Ncols, true, p.Mmax);
+    // ConvLSTM step epilogue (complete sums needed, no split-K across workgroups): with fewer tiles than CUs the reduction is
+    // split inside the workgroup instead — the widest tile that still gives every other CU a workgroup
+    int kg = 1;
+    if (p.lstm_F && g_igemm_kg2 && split == 1 && nphase == 1 && g_igemm_pipe == 3 && K4max % 16 == 0 && p.Ncols % 64 == 0) {
+        const int cus = wdg_device_cus();
+        const long long t128 = (long long)((p.Mmax + 127) / 128) * ((p.Ncols + 127) / 128);
+        const long long t64 = (long long)((p.Mmax + 63) / 64) * ((p.Ncols + 63) / 64);
+        if (g_igemm_kg2 == 3 && p.Ncols % 128 == 0 && t128 <= cus && 2 * t128 >= cus) { tc.BM = 128; tc.BN = 128; kg = 2; }
+        else if (t64 <= (g_igemm_kg2 == 2 ? 3 : 1) * cus) { tc.BM = 64; tc.BN = 64; kg = 2; }
+    }
     const int tiles_m = (p.Mmax + tc.BM - 1) / tc.BM;
     const int tiles_n = (p.Ncols + tc.BN - 1) / tc.BN;
     if (p.Mmax <= 0) return WDG_OK;
@@ -1470,6 +1510,7 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     // drop empty trailing splits
     split = (K4max + per - 1) / per;
     p.splitk = split;
+    if (kg == 2) p.k4_per_split = K4max / 2;       // (a multiple of 8: both groups run the same number of K-steps)
     if (split > 1) {
         const size_t need = (size_t)split * nphase * p.Mmax * wdg_round_up(p.Ncols, 4) * sizeof(float);
         if (!ws || ws_bytes < need) {
@@ -1518,8 +1559,12 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         else if (pipe == 4 && epi == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 4, 3>(grid, block, st, p); \
         else if (pipe == 4) rc = launch_variant<BM_, BN_, WM_, WN_, 4>(grid, block, st, p);             \
         else if (epi == 4) {                                                                            \
-            if constexpr (BN_ % 64 == 0 && BM_ <= 128) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p); \
-            else rc = WDG_ERR_ARG;                                                                      \
+            if constexpr (BN_ % 64 == 0 && BM_ <= 128) {                                                \
+                if constexpr (BM_ == BN_) {                                                             \
+                    if (kg == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4, 2>(grid, block, st, p);  \
+                    else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p);             \
+                } else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p);               \
+            } else rc = WDG_ERR_ARG;                                                                    \
         }                                                                                               \
         else if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);           \
         else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \

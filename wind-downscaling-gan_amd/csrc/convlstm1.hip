@@ -180,17 +180,22 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_kernel(const WdgCl1 p, 
 // MFMAs (1,152 matrix-pipe cycles) beside ~150 vector instructions of cell math from other waves — the two pipes overlap
 // across the resident waves, which the all-VALU form (2,160 FMAs per pixel on the vector pipe alone) cannot.
 constexpr int CLF_TH = 8, CLF_TW = 32;           // 256 pixels = 16 fragments per tile, 4 per wave
-template <int CIN, int F>
+// PRE = true (n_timesteps > 1, models.py:101): the same pass leaves the input part of ALL FOUR gates' pre-activations
+// (conv(x, kernel) + bias, [pixel][i | f | c~ | o]) for the recurrent steps (convlstm16.hip) instead of running the cell — the
+// T-batched producer of a tensor of 64 floats per pixel (453 MB at batch 8, T = 24); the general kernels wrote it at 1.2-1.4 TB/s
+// (halo tile 395 us, implicit GEMM 324 us), padding the 45-row reduction to 72 / 80.
+template <int CIN, int F, bool PRE = false>
 __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_mfma_kernel(const WdgCl1 p, const float* __restrict__ Wx,
                                                                      const float* __restrict__ bias) {
     static_assert(F == 16, "one 16-feature MFMA tile per gate");
+    constexpr int NG = PRE ? 4 : 3;
     constexpr int KP = (9 * CIN + 3) / 4 * 4, KS = KP / 4;
     constexpr int XH = CLF_TH + 2, XW = CLF_TW + 2;
     constexpr int PLANE = XH * XW + 12;          // 352: consecutive channel planes start 0 mod 32 banks apart -> lq groups offset by tap shifts only
     __shared__ float xs[CIN * PLANE];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lq = lane >> 4;
     // weights / bias / x offsets of this lane (tile-invariant)
-    float wreg[KS][3];
+    float wreg[KS][NG];
     int xoff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -201,20 +206,18 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_mfma_kernel(const WdgCl
             const int th = tap / 3, tw = tap - 3 * th;
             off = c * PLANE + th * XW + tw;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wreg[ks][g] = Wx[k * 4 * F + (g == 0 ? 0 : g + 1) * F + li];
+            for (int g = 0; g < NG; ++g) wreg[ks][g] = Wx[k * 4 * F + (PRE ? g : (g == 0 ? 0 : g + 1)) * F + li];
         } else {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wreg[ks][g] = 0.f;     // padding rows: zero weights, any valid x address
+            for (int g = 0; g < NG; ++g) wreg[ks][g] = 0.f;     // padding rows: zero weights, any valid x address
         }
         xoff[ks] = off;
     }
-    float bi[4], bc[4], bo[4];
+    f32x4 bg[NG];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bi[r] = bias[4 * lq + r];
-        bc[r] = bias[2 * F + 4 * lq + r];
-        bo[r] = bias[3 * F + 4 * lq + r];
-    }
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bg[g][r] = bias[(PRE ? g : (g == 0 ? 0 : g + 1)) * F + 4 * lq + r];
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b = tile;
@@ -244,20 +247,27 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_mfma_kernel(const WdgCl
         // 16 fragments (8 rows x 2 half rows of 16 pixels): wave wv takes rows 2 wv, 2 wv + 1.  Software-pipelined: the 36 MFMAs
         // of fragment fi + 1 stand before the cell arithmetic of fragment fi in program order, so the cell's instructions issue
         // while the matrix instructions drain instead of waiting for their own fragment's last one
-        auto gates = [&](int fi, f32x4 (&ga)[3]) {
+        auto gates = [&](int fi, f32x4 (&ga)[NG]) {
             const int pbase = (2 * wv + (fi >> 1)) * XW + (fi & 1) * 16 + li;
-            ga[0] = (f32x4){bi[0], bi[1], bi[2], bi[3]};      // the accumulators start at the bias
-            ga[1] = (f32x4){bc[0], bc[1], bc[2], bc[3]};
-            ga[2] = (f32x4){bo[0], bo[1], bo[2], bo[3]};
+#pragma unroll
+            for (int g = 0; g < NG; ++g) ga[g] = bg[g];       // the accumulators start at the bias
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const float xv = xs[pbase + xoff[ks]];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ks][g], xv, ga[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g) ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ks][g], xv, ga[g], 0, 0, 0);
             }
         };
-        auto cell = [&](int fi, const f32x4 (&ga)[3]) {
+        auto cell = [&](int fi, const f32x4 (&ga)[NG]) {
             const int gy = oy0 + 2 * wv + (fi >> 1), gx = ox0 + (fi & 1) * 16 + li;
+            if constexpr (PRE) {
+                if (gy < p.H && gx < p.W) {
+                    float* dst = p.Hout + (long long)img * p.imgStrideH + ((long long)gy * p.W + gx) * p.ldh + 4 * lq;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) *reinterpret_cast<f32x4*>(dst + g * F) = ga[g];
+                }
+                return;
+            }
             f32x4 h4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -265,7 +275,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_fwd_mfma_kernel(const WdgCl
             if (gy < p.H && gx < p.W)
                 *reinterpret_cast<f32x4*>(p.Hout + (long long)img * p.imgStrideH + ((long long)gy * p.W + gx) * p.ldh + 4 * lq) = h4;
         };
-        f32x4 g0[3], g1[3];
+        f32x4 g0[NG], g1[NG];
         gates(0, g0);
         gates(1, g1);
         cell(0, g0);
@@ -635,6 +645,27 @@ extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, 
         hipLaunchKernelGGL((wdg_convlstm1_fwd_mfma_kernel<5, 16>), pgrid, block, 0, (hipStream_t)stream, p, wx, bias);
     } else
         hipLaunchKernelGGL((wdg_convlstm1_fwd_kernel<5, 16>), grid, block, 0, (hipStream_t)stream, p, wx, bias);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// Input part of the gate pre-activations of the 5 -> 16-feature ConvLSTM2D for all timesteps (n_timesteps > 1, models.py:101):
+// gates[n, y, x, i | f | c~ | o] = conv(x, kernel)[...] + bias.  wx: the kernel [3][3][5][64] (HWIO) as stored.
+extern "C" int wdg_convlstm_gates_x_supported(int cin, int F) { return g_cl1_fwd_mfma && cin == 5 && F == 16; }
+extern "C" int wdg_convlstm_gates_x(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias, float* gates,
+                                    int n_img, int H, int W, int cin, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(x && wx && bias && gates && wdg_convlstm_gates_x_supported(cin, F), "unsupported");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)gates & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x / gates alignment, ld");
+    WdgCl1 p;
+    memset(&p, 0, sizeof(p));
+    p.X = x; p.Wx = wx; p.bias = bias; p.Hout = gates;
+    p.imgStrideX = img_stride_x; p.imgStrideH = (long long)H * W * 4 * F;
+    p.n_img = n_img; p.H = H; p.W = W; p.ldx = ldx; p.ldh = 4 * F;
+    p.tiles_h = (H + CLF_TH - 1) / CLF_TH;
+    p.tiles_w = (W + CLF_TW - 1) / CLF_TW;
+    const long long ntiles = (long long)n_img * p.tiles_h * p.tiles_w;
+    dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 4)), block(256);
+    hipLaunchKernelGGL((wdg_convlstm1_fwd_mfma_kernel<5, 16, true>), pgrid, block, 0, (hipStream_t)stream, p, wx, bias);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

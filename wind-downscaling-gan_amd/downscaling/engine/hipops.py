@@ -273,6 +273,7 @@ class HipOps:
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
         self._scratch_bufs = {}
         # per-timestep launch chains (the ConvLSTM time loops at n_timesteps > 1) replayed from captured HIP graphs: see chain()
+        self.gates_x = os.environ.get("WDG_GATES_X", "1") != "0"      # T > 1: the 5 -> 16 ConvLSTM's input convolution in its own kernel
         self.chain_graphs = os.environ.get("WDG_CHAIN_GRAPHS", "1") != "0"
         self._chains, self._chain_seen = {}, {}
 
@@ -838,6 +839,17 @@ class HipOps:
         n, H, W, _ = x.shape
         native.check(self.lib.wdg_convlstm1_fwd(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), ph, ldh, ish, n, H, W,
                                                 cin, F, self.stream), "convlstm1_fwd")
+
+    def convlstm_gates_x_supported(self, x, gates, cin, F):
+        return bool(self.gates_x and self.lib.wdg_convlstm_gates_x_supported(cin, F)) and gates.is_contiguous() and \
+            gates.shape[3] == 4 * F and gates.data_ptr() % 16 == 0
+
+    def convlstm_gates_x(self, x, wx, bias, gates, cin, F):
+        """gates [N,H,W,4F] = conv(x, wx) + bias for all timesteps (the input part of the ConvLSTM pre-activations)."""
+        px, ldx, isx = _v4(x)
+        n, H, W, _ = x.shape
+        native.check(self.lib.wdg_convlstm_gates_x(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), gates.data_ptr(), n, H, W, cin, F,
+                                                   self.stream), "convlstm_gates_x")
 
     def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False, dw=None, dbias=None):
         """dgates [N,H,W,4F] (dense, optional) and dx[..., :cin] (optional) from x and dh, recomputing the gates.

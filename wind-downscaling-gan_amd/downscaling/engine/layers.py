@@ -293,6 +293,9 @@ class ConvLSTM:
                 self.gates[..., F:2 * F].zero_()
             conv(x, self._pk_i, self.b.value[:F], self.gates[..., :F], self.g, act=False)
             conv(x, self._pk_co, self.b.value[2 * F:], self.gates[..., 2 * F:], self.g, act=False)
+        elif not bf16 and hasattr(o, "convlstm_gates_x_supported") and o.convlstm_gates_x_supported(x, self.gates, self.cin, F):
+            # (the 5 -> 16 layer: 45-row reduction on the matrix pipe with the weights in registers, csrc/convlstm1.hip)
+            o.convlstm_gates_x(x, self.wx.value, self.b.value, self.gates, self.cin, F)
         else:
             conv(x, self.pkx, self.b.value, self.gates, self.g, act=False)
         # fp32, T > 1: the recurrent convolution with the cell update in its epilogue where the halo-tile kernel runs the layer
