@@ -1309,6 +1309,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_igemm_pipe = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "patch_lstm_small")) {
+        wdg_patch_h16_set_lstm_small(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "igemm_kg2")) {
         g_igemm_kg2 = value;
         return WDG_OK;

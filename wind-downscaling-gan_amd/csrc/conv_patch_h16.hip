@@ -430,13 +430,18 @@ static int patch_shapes(const WdgPatchView& g, WdgPatchCfg* c) {
     return n;
 }
 
-static bool patch_plan(const WdgPatchView& g, WdgPatchH16& p) {
+static int g_patch_lstm_small = 1;       // the recurrent step on the smallest tile shape (tuning key patch_lstm_small)
+void wdg_patch_h16_set_lstm_small(int v) { g_patch_lstm_small = v != 0; }
+// small_first: the candidate shapes from the smallest — the per-timestep recurrent convolution has few pixel tiles (48 of 8 x 24 on
+// the shipped 24 x 24 map x 16 tiles -> 384 workgroups, 1.5 per CU: half the CUs carry two); 4 x 24 gives every CU three
+static bool patch_plan(const WdgPatchView& g, WdgPatchH16& p, bool small_first = false) {
     if (!g_patch_h16 || (g.stride != 1 && g.stride != 2) || g.K_p % 8 || g.Ncols < 32 || g.ldO % 4) return false;
     WdgPatchCfg cand[3];
     const int ncand = patch_shapes(g, cand);
     const int s = g.stride;
     const int C8 = g.K_p / 8;
-    for (int ci = 0; ci < ncand; ++ci) {
+    for (int cj = 0; cj < ncand; ++cj) {
+        const int ci = small_first ? ncand - 1 - cj : cj;
         const WdgPatchCfg& c = cand[ci];
         const int PH = (c.TH - 1) * s + g.kh, PW = (c.TW - 1) * s + g.kw;
         int PWs = (PW + s - 1) / s;
@@ -495,7 +500,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     const WdgPatchView g = patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;
     memset(&p, 0, sizeof(p));
-    if (!patch_plan(g, p)) return 1;
+    if (!patch_plan(g, p, g_patch_lstm_small && gx && gx->c_out)) return 1;
     p.A = x; p.B = w16; p.Out = y; p.bias = bias; p.affine = affine; p.out16 = out16;
     p.imgStrideA = g.imgStrideA; p.imgStrideO = g.imgStrideO;
     p.H = g.H; p.W = g.W; p.ldA = g.ldA; p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldO;
