@@ -67,10 +67,10 @@ def test_netcdf3_packed_era5_day_roundtrip(tmp_path):
     both = open_mfdataset(halves)
     assert np.array_equal(both.coords["time"], ds.coords["time"])
     np.testing.assert_array_equal(both["u10"], ds["u10"])
-    with open(tmp_path / "fake_nc4.nc", "wb") as f:
-        f.write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(OSError, match="NetCDF-4"):
-        open_dataset(tmp_path / "fake_nc4.nc")
+    with open(tmp_path / "not_netcdf.nc", "wb") as f:
+        f.write(b"GRIB" + b"\0" * 64)
+    with pytest.raises(OSError, match="neither"):
+        open_dataset(tmp_path / "not_netcdf.nc")
 
 
 @pytest.mark.parametrize("compression,dtype,predictor", [("raw", np.uint16, 1), ("tiff_lzw", np.uint16, 1),

@@ -1,11 +1,11 @@
 """Day files of the `downscale` CLI (/root/reference/src/downscaling/cli.py:22-26: `xr.open_mfdataset` of
 `<date>*surface*.nc`, `Dataset.to_netcdf`).  netCDF4 / h5py are not part of the GPU image; what is there is scipy's
-NetCDF-3 reader / writer, and NetCDF-3 (classic / 64-bit offset, int16-packed with scale_factor / add_offset) is what
-the Climate Data Store served for ERA5 single-level requests when the reference was written.  So:
+NetCDF-3 reader / writer — NetCDF-3 (classic / 64-bit offset, int16-packed with scale_factor / add_offset) is what the
+Climate Data Store served for ERA5 single-level requests when the reference was written — and this package's own read-only
+HDF5 parser for the NetCDF-4 files it serves now (io/hdf5.py).  So:
 
-  * `.nc` files are read and written as NetCDF-3 through `scipy.io.netcdf_file` (CF packing, fill values and
-    "<unit> since <epoch>" time axes decoded as xarray's `decode_cf` does); an HDF5-based NetCDF-4 file raises a
-    clear error naming the limitation;
+  * `.nc` files are read as NetCDF-3 through `scipy.io.netcdf_file` or as NetCDF-4 through `io.hdf5` (by magic number; CF
+    packing, fill values and "<unit> since <epoch>" time axes decoded as xarray's `decode_cf` does) and written as NetCDF-3;
   * `.npz` files hold the same content as named arrays (coordinates + variables + a `__dims__` table).
 """
 import json
@@ -40,16 +40,49 @@ def _attr(var, name):
     return v.decode() if isinstance(v, bytes) else v
 
 
+def _cf_decode(raw, attrs):
+    """xarray's `decode_cf` for one variable: _FillValue / missing_value -> NaN, scale_factor / add_offset (float32 for packed
+    data of <= 2 bytes, else float64)."""
+    fill = [attrs[a] for a in ("_FillValue", "missing_value") if attrs.get(a) is not None]
+    scale, offset = attrs.get("scale_factor"), attrs.get("add_offset")
+    packed = scale is not None or offset is not None
+    data = raw.astype(np.float32 if (packed and raw.dtype.itemsize <= 2) or raw.dtype == np.float32 else np.float64) \
+        if (packed or fill) and raw.dtype.kind in "iuf" else raw
+    if fill and data.dtype.kind == "f":
+        mask = np.zeros(raw.shape, dtype=bool)
+        for fv in fill:
+            fv = np.asarray(fv).reshape(-1)[0]
+            mask |= np.isnan(raw) if (raw.dtype.kind == "f" and np.isnan(fv)) else (raw == fv)
+        data = np.where(mask, np.nan, data).astype(data.dtype)
+    if packed:
+        data = data * data.dtype.type(1.0 if scale is None else np.asarray(scale).reshape(-1)[0]) \
+            + data.dtype.type(0.0 if offset is None else np.asarray(offset).reshape(-1)[0])
+    return data
+
+
+def _read_netcdf4(path):
+    """HDF5-based NetCDF-4 (what the Climate Data Store serves today) through the package's own HDF5 reader (io/hdf5.py)."""
+    from .hdf5 import read_netcdf4
+    raw_coords, raw_vars, gattrs = read_netcdf4(path)
+    coords = {}
+    for name, (values, attrs) in raw_coords.items():
+        units = attrs.get("units")
+        coords[name] = _decode_time(values, units) if units and " since " in str(units) else values
+    variables = {name: (dims, _cf_decode(data, attrs)) for name, (dims, data, attrs) in raw_vars.items()}
+    return GridDataset(coords, variables, {k: v for k, v in gattrs.items() if isinstance(v, (str, int, float))})
+
+
 def read_netcdf(path):
-    """One NetCDF-3 file -> GridDataset with CF-decoded variables (float32 for packed ones, as xarray)."""
+    """One NetCDF file -> GridDataset with CF-decoded variables (float32 for packed ones, as xarray): NetCDF-3 (classic /
+    64-bit offset) through scipy, NetCDF-4 through io/hdf5.py."""
     from scipy.io import netcdf_file
     path = str(path)
     with open(path, "rb") as f:
         magic = f.read(4)
+    if magic == b"\x89HDF":
+        return _read_netcdf4(path)
     if magic[:3] != b"CDF":
-        kind = "HDF5-based NetCDF-4" if magic == b"\x89HDF" else "unknown"
-        raise OSError(f"{path}: {kind} file — this build reads NetCDF-3 (classic / 64-bit offset) through scipy and "
-                      f".npz day files; convert with `nccopy -k classic` or save the arrays with numpy.savez")
+        raise OSError(f"{path}: neither a NetCDF-3 (CDF) nor a NetCDF-4 (HDF5) file")
     coords, variables = {}, {}
     with netcdf_file(path, "r", mmap=False, maskandscale=False) as nc:
         for name, var in nc.variables.items():
@@ -59,20 +92,8 @@ def read_netcdf(path):
                 units = _attr(var, "units")
                 coords[name] = _decode_time(raw, units) if units and " since " in str(units) else raw
                 continue
-            fill = [getattr(var, a) for a in ("_FillValue", "missing_value") if hasattr(var, a)]
-            scale, offset = getattr(var, "scale_factor", None), getattr(var, "add_offset", None)
-            packed = scale is not None or offset is not None
-            data = raw.astype(np.float32 if (packed and raw.dtype.itemsize <= 2) or raw.dtype == np.float32 else np.float64) \
-                if (packed or fill) and raw.dtype.kind in "iuf" else raw
-            if fill and data.dtype.kind == "f":
-                mask = np.zeros(raw.shape, dtype=bool)
-                for fv in fill:
-                    mask |= raw == np.asarray(fv).reshape(-1)[0]
-                data = np.where(mask, np.nan, data).astype(data.dtype)
-            if packed:
-                data = data * data.dtype.type(1.0 if scale is None else np.asarray(scale).reshape(-1)[0]) \
-                    + data.dtype.type(0.0 if offset is None else np.asarray(offset).reshape(-1)[0])
-            variables[name] = (dims, data)
+            attrs = {a: getattr(var, a) for a in ("_FillValue", "missing_value", "scale_factor", "add_offset") if hasattr(var, a)}
+            variables[name] = (dims, _cf_decode(raw, attrs))
         attrs = {k: (v.decode() if isinstance(v, bytes) else v) for k, v in nc._attributes.items()}
     return GridDataset(coords, variables, attrs)
 
