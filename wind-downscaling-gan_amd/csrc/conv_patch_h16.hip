@@ -344,20 +344,29 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                     if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[p.Ncols + nb]; }
                 }
             if (p.out16) {
-                // 16-bit result (no bias / activation / accumulate on this route): four channels = one 8-byte store
+                // 16-bit result (no bias / activation / accumulate on this route; column count a multiple of 16).  A lane's four
+                // channels are 8 bytes — stores of that width ran at 0.6x the rate and made the 16-bit z slower than the fp32 one.
+                // So the column tiles go in pairs: the two lanes that share a pixel's eight consecutive channels (lq even / odd)
+                // swap one quad each, the even one stores tile b, the odd one tile b + 1, 16 bytes per lane.
+                static_assert(NT % 2 == 0, "column tiles in pairs");
+                if (b & 1) continue;
                 typedef wdg_h16<FMT> h16x4 __attribute__((ext_vector_type(4)));
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 wdg_h16<FMT>* out16 = reinterpret_cast<wdg_h16<FMT>*>(p.Out) + (long long)img * p.imgStrideO;
+                const bool odd = lq & 1;
+                const int nst = nw0 + (b + (odd ? 1 : 0)) * 16 + 8 * (lq >> 1);
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
-                    const f32x4 v = acc[a][b];
-                    wdg_h16<FMT>* dst = out16 + (long long)opix[a] * p.ldO + n;
-                    if (full) {
-                        *reinterpret_cast<h16x4*>(dst) = (h16x4){(wdg_h16<FMT>)v[0], (wdg_h16<FMT>)v[1], (wdg_h16<FMT>)v[2], (wdg_h16<FMT>)v[3]};
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < p.Ncols) dst[r] = (wdg_h16<FMT>)v[r];
-                    }
+                    const f32x4 v0 = acc[a][b], v1 = acc[a][b + 1];
+                    const u32x2 t0 = __builtin_bit_cast(u32x2, (h16x4){(wdg_h16<FMT>)v0[0], (wdg_h16<FMT>)v0[1], (wdg_h16<FMT>)v0[2], (wdg_h16<FMT>)v0[3]});
+                    const u32x2 t1 = __builtin_bit_cast(u32x2, (h16x4){(wdg_h16<FMT>)v1[0], (wdg_h16<FMT>)v1[1], (wdg_h16<FMT>)v1[2], (wdg_h16<FMT>)v1[3]});
+                    const u32x2 mine = odd ? t1 : t0, give = odd ? t0 : t1;
+                    u32x2 got;
+                    got[0] = (unsigned)__shfl_xor((int)give[0], 16, 64);
+                    got[1] = (unsigned)__shfl_xor((int)give[1], 16, 64);
+                    const u32x4 o = odd ? (u32x4){got[0], got[1], mine[0], mine[1]} : (u32x4){mine[0], mine[1], got[0], got[1]};
+                    if (nst < p.Ncols) *reinterpret_cast<u32x4*>(out16 + (long long)opix[a] * p.ldO + nst) = o;
                 }
                 continue;
             }
@@ -496,6 +505,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
                          const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
                          const WdgPatchGates* gx, int out16) {
     if (out16 && (gx || bias || affine || act || accumulate)) return 1;
+    if (out16 && (pl->g.Cin % 16 || pl->g.ldx % 8)) return 1;       // (transposed 1 x 1 view: the x side is the result — whole 16-column tiles)
     if (transposed1x1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
     const WdgPatchView g = patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;

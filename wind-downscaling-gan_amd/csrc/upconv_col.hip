@@ -113,8 +113,8 @@ extern "C" int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, f
 // that + 2), so the sum separates into a horizontal pass (10 terms) and a vertical pass (10 terms) instead of 100.
 // One workgroup = an 8x8 low-res tile = 16x16 output pixels; per tap row ty the 12x12 low-res window of z (80 floats per
 // pixel) is staged in LDS, reduced horizontally into H[12][16][C], and each thread adds its two vertical terms.
-// ZF: element format of z — 0 fp32, 1 bf16, 2 fp16 (16-bit: wdg_upconv_colgemm_h16 wrote it; a thread's slot is then 4 values =
-// 8 bytes, widened to fp32 on the way into LDS; everything behind the load is the fp32 kernel)
+// ZF: element format of z — 0 fp32, 1 bf16, 2 fp16 (16-bit: wdg_upconv_colgemm_h16 wrote it; a thread's slot is then 8 values =
+// 16 bytes, widened to fp32 on the way into LDS; everything behind the load is the fp32 kernel)
 template <int ZF> struct WdgZT { typedef float T; };
 template <> struct WdgZT<1> { typedef __bf16 T; };
 template <> struct WdgZT<2> { typedef _Float16 T; };
@@ -137,30 +137,36 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
     f32x4 acc[CQ];
 #pragma unroll
     for (int o4 = 0; o4 < CQ; ++o4) acc[o4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // window slots of this thread (tile-invariant): element offset within a tap-row slice, or -1 outside the image
-    constexpr int NSLOT = (ZW * ZW * PX + 255) / 256;
+    // window slots of this thread (tile-invariant): element offset within a tap-row slice, or -1 outside the image.  A slot is one
+    // 16-byte load: four fp32 values, or EIGHT 16-bit values that become two consecutive float4 of the LDS window (8-byte loads of
+    // four values ran at 0.6x the rate and made the 16-bit z slower than the fp32 one)
+    constexpr int VPS = ZF ? 2 : 1;                  // float4 per slot
+    static_assert(ZF == 0 || PX % 2 == 0, "16-bit z: channel count a multiple of 8");
+    constexpr int NSL = ZW * ZW * PX / VPS;          // slots of the window
+    constexpr int NSLOT = (NSL + 255) / 256;
     long long zoff[NSLOT];
-    f32x4 zr[NSLOT];
+    f32x4 zr[NSLOT][VPS];
 #pragma unroll
     for (int s_ = 0; s_ < NSLOT; ++s_) {
         const int i = t + 256 * s_;
-        const int k = i % PX, px = i / PX;
+        const int k = i % (PX / VPS), px = i / (PX / VPS);
         const int ry = i0 - 2 + px / ZW, rx = j0 - 2 + px % ZW;
-        zoff[s_] = (i < ZW * ZW * PX && (unsigned)ry < (unsigned)Hl && (unsigned)rx < (unsigned)Wl)
-                       ? ((long long)ry * Wl + rx) * (100LL * CQ) + 4 * k : -1;
+        zoff[s_] = (i < NSL && (unsigned)ry < (unsigned)Hl && (unsigned)rx < (unsigned)Wl)
+                       ? ((long long)ry * Wl + rx) * (100LL * CQ) + 4 * VPS * k : -1;
     }
     auto load_slice = [&](int ty_) {
 #pragma unroll
         for (int s_ = 0; s_ < NSLOT; ++s_)
         {
             if constexpr (ZF == 0) {
-                zr[s_] = zoff[s_] >= 0 ? *reinterpret_cast<const f32x4*>(zimg + zoff[s_] + ty_ * (20 * CQ)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                zr[s_][0] = zoff[s_] >= 0 ? *reinterpret_cast<const f32x4*>(zimg + zoff[s_] + ty_ * (20 * CQ)) : (f32x4){0.f, 0.f, 0.f, 0.f};
             } else {
-                typedef typename WdgZT<ZF>::T zt4 __attribute__((ext_vector_type(4)));
-                zr[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                typedef typename WdgZT<ZF>::T zt8 __attribute__((ext_vector_type(8)));
+                zr[s_][0] = zr[s_][VPS - 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (zoff[s_] >= 0) {
-                    const zt4 q = *reinterpret_cast<const zt4*>(zimg + zoff[s_] + ty_ * (20 * CQ));
-                    zr[s_] = (f32x4){(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+                    const zt8 q = *reinterpret_cast<const zt8*>(zimg + zoff[s_] + ty_ * (20 * CQ));
+                    zr[s_][0] = (f32x4){(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+                    zr[s_][VPS - 1] = (f32x4){(float)q[4], (float)q[5], (float)q[6], (float)q[7]};
                 }
             }
         }
@@ -171,7 +177,10 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
         //    loaded under the previous tap row's passes
 #pragma unroll
         for (int s_ = 0; s_ < NSLOT; ++s_)
-            if (t + 256 * s_ < ZW * ZW * PX) Z[t + 256 * s_] = zr[s_];
+            if (t + 256 * s_ < NSL) {
+#pragma unroll
+                for (int v = 0; v < VPS; ++v) Z[(t + 256 * s_) * VPS + v] = zr[s_][v];
+            }
         __syncthreads();
         if (ty + 1 < 5) load_slice(ty + 1);
         // 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
@@ -272,7 +281,10 @@ extern "C" int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias
                            (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0);
     if (C == 16) { WDG_GATHER16(4) }
     else if (C == 8) { WDG_GATHER16(2) }
-    else { WDG_GATHER16(1) }
+    else {
+        wdg_set_error("wdg_upconv_gather_h16: channel count must be 8 or 16 (16-byte slots of eight 16-bit values)");
+        return WDG_ERR_ARG;
+    }
 #undef WDG_GATHER16
     WDG_LAUNCH_CHECK();
     return WDG_OK;

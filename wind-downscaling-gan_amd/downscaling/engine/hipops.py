@@ -561,10 +561,12 @@ class HipOps:
                 pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (affine is None or affine.data_ptr() % 16 == 0):
             # column form with 16-bit GEMM operands: z = x * W, then the fp32 bilinear gather.  z16 (WDG_Z16=1, opt-in): z itself is
             # stored in the operand format — 400 columns per low-resolution pixel make it the largest tensor of the forward (1.4 GB
-            # per 16-tile group in fp32), written once and read once.  Measured SLOWER than fp32 z (16-tile group 3.78 -> 4.23 ms):
-            # both kernels are bound by instruction issue, not by bytes, and 8-byte accesses run at 0.54-0.70x the 16-byte rate
+            # per 16-tile group in fp32), written once and read once.  Measured SLOWER than fp32 z twice: with 8-byte accesses of
+            # four values (16-tile group 3.78 -> 4.23 ms) and with 16-byte accesses of eight (lane-pair exchange in the GEMM's
+            # epilogue, eight-value slots in the gather: 3.82 -> 3.97 ms) — neither kernel is bound by z's bytes: the 400-column
+            # GEMM has a reduction of only 160 (five MFMA K-steps per 16 stores) and the gather is bound by its LDS passes
             plan16 = None
-            if self.z16:
+            if self.z16 and pk.cin % 8 == 0:
                 plan16, _, _ = self._plan_dims(n, H // 2, W // 2, 25 * pk.cin, 25 * pk.cin, (H // 2) * (W // 2) * 25 * pk.cin,
                                                H // 2, W // 2, pk.cout, *_v4(x_low)[1:], ConvGeom(1, 1, 1, 0))
                 if not self.lib.wdg_upconv_colgemm_h16_supported(plan16):
