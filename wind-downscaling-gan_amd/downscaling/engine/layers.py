@@ -377,10 +377,11 @@ class ConvLSTM:
             time_loop()
         if need_wgrad:
             def weight_grads():
-                o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True)
+                # (the bias gradient — the column sums of dgates, 453 MB at batch 8 x T 24 — rides on the input kernel's weight
+                # gradient where that kernel has a spare constant-1 row: the discriminator's 5- and 2-channel layers)
+                o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True, dbias=self.b.grad)
                 if T > 1:
                     o.conv_wgrad(h[:(T - 1) * B], self.dgates[B:], self.pkh, self.wh.grad, self.g, accumulate=True)
-                o.colsum(v2(self.dgates), self.b.grad, accumulate=True)
             joins = getattr(self.net, "_bwd_joins", None)
             if joins is not None:
                 self.net._wgrad(weight_grads, joins)      # under the input gradient below (the network's pass joins)
