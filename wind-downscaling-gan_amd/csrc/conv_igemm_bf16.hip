@@ -333,7 +333,7 @@ extern "C" int wdg_conv_dgrad_f16(const wdg_conv_plan* pl, const float* dy, cons
 // ([n, H, W, 25 * C]) and whose y side is x_low.  fmt: 0 bf16, 1 fp16.
 extern "C" int wdg_upconv_colgemm_h16_supported(const wdg_conv_plan* pl) {
     if (!pl || pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w || pl->Cout_p % 8) return 0;
-    if (pl->g.Cin % 200 || pl->g.ldx != pl->g.Cin) return 0;          // z rows: 25 taps x a multiple of 8 channels, dense
+    if (pl->g.Cin % 400 || pl->g.ldx != pl->g.Cin) return 0;          // z rows: 25 taps x a multiple of 16 channels (whole 16-column tiles in pairs of lanes), dense
     return wdg_patch_h16_eligible_t(pl);
 }
 
