@@ -321,7 +321,19 @@ def other_config_legs(dev, ops):
             runs.append(time.perf_counter() - t0)
         phases = {}
         api.predict_array(fields, overlap_factor=0.05, network=network, timings=phases)
+        # the same with a caller-owned page-locked result buffer (predict_array(out=...)): the download at the link's rate
+        pinned = torch.empty(24, 1200, 1200, 2, dtype=torch.float32, pin_memory=True)
+        api.predict_array(fields, overlap_factor=0.05, network=network, out=pinned)
+        runs_p = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            api.predict_array(fields, overlap_factor=0.05, network=network, out=pinned)
+            torch.cuda.synchronize()
+            runs_p.append(time.perf_counter() - t0)
+        del pinned
     out["config3_end_to_end_1200"] = {"seconds": sorted(runs)[1], "seconds_min": min(runs), "tiles": 225,
+                                      "seconds_pinned_result": sorted(runs_p)[1],
                                       "tile_timesteps_per_s": 225 * 24 / sorted(runs)[1], "dtype": "bf16 operands, f32 accumulate",
                                       "phase_seconds": {k: round(v, 4) for k, v in phases.items() if k != "laps"},
                                       "note": "api.predict_array on a host fp32 field (24,1200,1200,3), overlap_factor 0.05: upload, tile gather + "

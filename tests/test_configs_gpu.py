@@ -151,6 +151,13 @@ def test_config3_tiled_inference_1200_bf16(hip_ops):
     gen.inference_precision = "bf16"
     _reset_noise(network, seed)
     out16, cnt16 = api.predict_array(fields, overlap_factor=0.05, network=network, return_count=True)
+    # a caller-owned (page-locked) result buffer: filled in place and returned, the same values
+    _reset_noise(network, seed)
+    pinned = torch.empty(out16.shape, dtype=torch.float32, pin_memory=True)
+    got = api.predict_array(fields, overlap_factor=0.05, network=network, out=pinned)
+    assert np.shares_memory(got, pinned.numpy()) and np.array_equal(got, out16, equal_nan=True)
+    with pytest.raises(ValueError, match="`out` must be"):
+        api.predict_array(fields, overlap_factor=0.05, network=network, out=np.zeros((3, 3), np.float32))
     gen.inference_precision = "fp32"
     assert np.array_equal(cnt, cnt16)
     covered = cnt[0] > 0

@@ -159,7 +159,7 @@ def _tile_lat_index(sy):
     return np.arange(IMG_SIZE, 0, -1)
 
 
-def predict_array(fields, overlap_factor=0.05, network=None, return_count=False, sync=None, timings=None):
+def predict_array(fields, overlap_factor=0.05, network=None, return_count=False, sync=None, timings=None, out=None):
     """Array core of predict (api.py:96-151).  fields: (time, lat, lon, 3) float array with channels
     [u10, v10, elevation in metres].  Returns (ntimeseq*24, lat, lon, 2) with NaN where no tile
     contributes (the reference's dataframe simply has no such rows).
@@ -169,6 +169,10 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     reduction (accumulated in fp64), every group of 16 tiles goes through the generator without leaving HBM, and the
     2-pixel-cropped tiles are summed / counted into the output grid there; one download at the end.  (The reference
     does this part with numpy / pandas on the host: 3.3 of the 3.5 s of a 1200 x 1200 x 24 h field.)
+
+    `out` (optional): a caller-owned float32 host array / CPU tensor of the result's shape to download into — page-locked
+    (`torch.empty(..., pin_memory=True)`) it takes the 276 MB of a 1200 x 1200 x 24 h result at the link's rate instead of the
+    ~8 GB/s of a fresh pageable array (34 -> ~8 ms); the same array is returned.
 
     `sync` (engine.trainer.DistSync, one process per GPU): tiles are independent, so the groups of 16 are dealt
     round-robin to the ranks and the per-rank sum / count grids are all-reduced once at the end — no exchange
@@ -188,6 +192,7 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
             timings.setdefault('laps', []).append((name, round(now - lap.t0, 5)))
             lap.t0 = now
     lap.t0 = time.perf_counter()
+    out_host = out
     network = network or get_network()
     gen = network.generator
     ops = gen.ops
@@ -262,7 +267,15 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
         sync.all_reduce_sum(cnt)
     out = (acc / cnt[..., None].double()).float()                                  # api.py:149-150 (uniform mean); 0/0 -> NaN
     lap('mean')
-    out, cnt = out.cpu().numpy(), cnt_host                                         # (the same integer bookkeeping: the count grid is not downloaded)
+    if out_host is not None:
+        host = out_host if torch.is_tensor(out_host) else torch.from_numpy(out_host)
+        if tuple(host.shape) != tuple(out.shape) or host.dtype != torch.float32 or not host.is_contiguous():
+            raise ValueError(f"predict_array: `out` must be a contiguous float32 array of shape {tuple(out.shape)}")
+        host.copy_(out)
+        out = out_host.numpy() if torch.is_tensor(out_host) else out_host
+    else:
+        out = out.cpu().numpy()
+    cnt = cnt_host                                                                 # (the same integer bookkeeping: the count grid is not downloaded)
     lap('download')
     return (out, cnt) if return_count else out
 
