@@ -41,6 +41,37 @@ def synthetic_batch(B, seed, device):
     return torch.from_numpy(low).to(device), torch.from_numpy(high).to(device)
 
 
+def generator_flops(net, executed=False):
+    """Forward FLOPs of make_generator per tile-timestep (2 x MACs of every convolution, models.py:32-71), derived from the
+    layer objects of the network that runs — kernel size, channels and the map each layer writes.  executed=True prices the
+    upsample + 5x5 transposed-conv block as the kernels run it (column form on the low-resolution grid: a 1x1 GEMM with
+    25 * C_out columns per low-res pixel instead of 25 taps per high-res pixel)."""
+    S, T = net.S, net.T
+    conv = lambda c, px: 2.0 * c.g.kh * c.g.kw * c.cin * c.cout * px      # noqa: E731
+    lstm = net.lstm
+    f = conv(net.c0, (S // 2) ** 2) + conv(net.c2, (S // 4) ** 2) + conv(net.c5, (S // 4) ** 2)
+    f += 2.0 * 9 * lstm.cin * 4 * lstm.F * (S // 4) ** 2                  # input convolution of the gates
+    f += 2.0 * 9 * lstm.F * 4 * lstm.F * (S // 4) ** 2 * (T - 1) / T      # recurrent convolution (absent at t = 0)
+    f += 2.0 * net.c7.cout * net.c7.cin * (S // 2) ** 2                   # 2x2 stride-2 transposed: one tap per output pixel
+    c9 = net.c9
+    f += 2.0 * c9.cout * 25 * c9.cin * (S // 2) ** 2 if executed else conv(c9, S * S)
+    f += conv(net.c11, S * S)
+    return f
+
+
+def discriminator_flops(net):
+    """Forward FLOPs of make_discriminator per tile-timestep (models.py:93-138), from the layer objects."""
+    S, T = net.S, net.T
+    f = 0.0
+    for l in (net.lstm_a, net.lstm_b):
+        f += 2.0 * 9 * l.cin * 4 * l.F * S * S + 2.0 * 9 * l.F * 4 * l.F * S * S * (T - 1) / T
+    for c in (net.conv_a, net.conv_b):
+        f += 2.0 * 9 * c.cin * c.cout * S * S
+    for conv, _, osz, _ in net.blocks:
+        f += 2.0 * conv.g.kh * conv.g.kw * conv.cin * conv.cout * osz * osz
+    return f + 2.0 * net.K
+
+
 class ConvTimer:
     """HIP-event timing of every conv launch on the stream it is launched on (torch's current stream)."""
 
@@ -162,7 +193,19 @@ def cpu_baseline(batch=4):
         per_step.append(time.perf_counter() - t0)
     dt = sum(per_step)
     med, best = sorted(per_step)[len(per_step) // 2], min(per_step)
+    # BASELINE.md section 3 words the baseline as "all host cores": the same step at os.cpu_count() threads beside the
+    # 32-thread figure (one warm-up + one timed step; torch-CPU's conv kernels do not scale to the node's thread count)
+    all_cores = os.cpu_count() or 1
+    value_all = None
+    if all_cores != cores:
+        torch.set_num_threads(all_cores)
+        TM.train_step(gw, dw, low, high, draws, og, od)
+        t0 = time.perf_counter()
+        TM.train_step(gw, dw, low, high, draws, og, od)
+        value_all = batch / (time.perf_counter() - t0)
+        torch.set_num_threads(cores)
     out = {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
+           "value_all_host_threads": value_all, "host_threads": all_cores,
            "value_best": batch / best, "s_per_step_median": med, "s_per_step_min": best,
            "sample": f"1 warm-up + {nsteps} timed full GAN train steps (n_critic=3), batch {batch}, {S}x{S}, T={T}, torch-CPU fp32 "
                      f"restatement (oracle/torch_model.py; TensorFlow is not installable here), {dt:.1f} s timed; value = batch / "
@@ -225,9 +268,7 @@ def generator_leg(generator, gan, dev, batch=64, warm=3, iters=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    gf_alg = 22.385e9
-    up_alg, up_exec = 2.0 * 25 * 160 * 16 * S * S, 2.0 * 160 * 400 * (S // 2) * (S // 2)
-    gf_exec = gf_alg - up_alg + up_exec
+    gf_alg, gf_exec = generator_flops(net), generator_flops(net, executed=True)   # 22.385 / 16.09 GFLOP at S = 256, T = 1
     return {"ms": ms, "batch": batch, "samples_per_s": batch / ms * 1e3,
             "tflops_algorithmic": gf_alg * batch / ms * 1e-9,
             "tflops_executed": gf_exec * batch / ms * 1e-9, "frac_executed": gf_exec * batch / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS,
@@ -281,7 +322,7 @@ def other_config_legs(dev, ops):
     noise = torch.from_numpy((0.1 * np.random.default_rng(2).standard_normal((1, 1, 128, 128, NZ))).astype(np.float32)).to(dev)
     g0 = make_generator(128, CIN, NZ, CH, 1)
     med, best = events(lambda: g0([image, noise], training=False), 4, 20)
-    gf0 = 5.596e9                                            # S = 128, T = 1 algorithmic forward FLOPs
+    gf0 = generator_flops(g0.net)                            # 5.596 GFLOP (S = 128, T = 1)
     out["config0_fwd_128"] = {"ms": med, "ms_min": best, "tflops": gf0 / med * 1e-9, "frac_of_mfma_f32_peak": gf0 / med * 1e-9 / PEAK_F32_MFMA_TFLOPS,
                               "dtype": "f32", "note": "G(128,3,20,2,T=1), batch 1, inputs resident, HIP-graph replay of the inference forward; one "
                                                       "tile cannot fill 256 CUs: latency-, not roofline-bound (5.6 GFLOP)"}
@@ -293,7 +334,8 @@ def other_config_legs(dev, ops):
     gen.inference_precision = "bf16"
     med, best = events(lambda: gen([tiles, network.noise_generator.lazy(bs=16, channels=api.NOISE_CHANNELS)]), 4, 10)
     tts = 16 * api.SEQUENCE_LENGTH
-    fl = tts * 3.799e9                                       # S = 96, T = 24 algorithmic FLOPs per tile-timestep
+    gf_tt = generator_flops(gen.net)                         # 3.799 GFLOP per tile-timestep (S = 96, T = 24)
+    fl = tts * gf_tt
     act_bytes = int(getattr(gen.net, "activation_bytes_16", 4))      # bytes per stored activation element on the 16-bit path
     by = tts * generator_activation_elements(api.IMG_SIZE) * act_bytes
     out["config3_bf16_group16_T24"] = {
@@ -349,9 +391,60 @@ def other_config_legs(dev, ops):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["config4_fp16_64x8"] = {"seconds": dt, "realisations_per_s": 64 * 8 / dt, "tile_timesteps_per_s": 64 * 8 * 24 / dt,
-                                "tflops": 64 * 8 * 24 * 3.799e9 / dt * 1e-12, "frac_of_16bit_mfma_peak": 64 * 8 * 24 * 3.799e9 / dt * 1e-12 / PEAK_16BIT_MFMA_TFLOPS,
+                                "tflops": 64 * 8 * 24 * gf_tt / dt * 1e-12, "frac_of_16bit_mfma_peak": 64 * 8 * 24 * gf_tt / dt * 1e-12 / PEAK_16BIT_MFMA_TFLOPS,
                                 "dtype": "fp16 operands, f32 accumulate", "finite": bool(torch.isfinite(ens).all()),
                                 "note": "api.predict_ensemble(8 tiles, 64 draws), member-keyed Philox streams; parity bound 4e-3 vs the fp64 oracle"}
+    return out
+
+
+def child_legs(headline_ms):
+    """Two driver-timed legs that need a process of their own (this one is idle meanwhile; N = 1 only):
+
+    dp_path_one_rank — the data-parallel step as an 8-GPU run executes it per GPU: the same bench at batch 32, 256 x 256 in a
+    ONE-rank RCCL process group (WDG_DIST_ALWAYS=1: asynchronous gradient all-reduces with the deferred Adam, SyncBN's
+    statistics all-reduces, the metric reduce — real RCCL collectives with identity results).  It must be the headline's
+    schedule (generator beside discriminator, twin discriminator): ms_per_step next to the headline's.
+
+    train_T24_S96_b8 — the train step at the shipped shape (api.py:22 SEQUENCE_LENGTH = 24, 96 x 96 tiles, batch 8): the
+    only configuration whose training exercises the ConvLSTM recurrence (models.py:45,93,101)."""
+    import subprocess
+    out = {}
+
+    def run(extra_args, extra_env, timeout=600):
+        env = dict(os.environ)
+        env.update(extra_env)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-serial-pass", "--no-generator-leg",
+               "--no-config-legs", "--no-split-leg", "--no-child-legs"] + extra_args
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"child bench rc={r.returncode}: {r.stderr[-400:]}")
+        return json.loads(lines[-1])
+
+    try:
+        j = run(["--steps", "6", "--warmup", "2"], {"WDG_DIST_ALWAYS": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29571"})
+        out["dp_path_one_rank"] = {
+            "ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "vs_headline_ms": j["ms_per_step"] / headline_ms,
+            "backend": j.get("rccl", {}).get("backend"), "sync_bn": j.get("rccl", {}).get("sync_bn"),
+            "parallelism": j["config"]["parallelism"], "steps": j["steps"], "warmup": j["warmup"],
+            "allreduce_ms_one_rank": j.get("rccl", {}).get("allreduce_ms"),
+            "note": "fresh process, one-rank RCCL group (WDG_DIST_ALWAYS=1), batch 32, 256 x 256: the per-GPU step of the "
+                    "data-parallel run — same multi-stream schedule as the headline plus the exchange code path"}
+    except Exception as exc:          # a leg must never cost the headline line
+        out["dp_path_one_rank"] = {"error": repr(exc)}
+    try:
+        j = run(["--size", "96", "--timesteps", "24", "--batch", "8", "--steps", "5", "--warmup", "2"], {})
+        out["train_T24_S96_b8"] = {
+            "tile_timesteps_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+            "step_tflops_algorithmic": j.get("step_tflops_algorithmic"),
+            "frac_of_mfma_f32_peak_algorithmic": j.get("step_frac_of_mfma_f32_peak"), "frac_executed": j.get("step_frac_executed"),
+            "host_enqueue_ms_per_step": j.get("host_enqueue_ms_per_step"),
+            "note": "GAN.train_step on G(96,3,20,2,T=24) + D(96,96,3,2,T=24), batch 8 (192 tile-timesteps per step), fresh process; "
+                    "41.7 GFLOP algorithmic per tile-timestep (7 Gf + 28 Df)"}
+    except Exception as exc:
+        out["train_T24_S96_b8"] = {"error": repr(exc)}
     return out
 
 
@@ -384,7 +477,7 @@ def bench_generator_forward(args, generator, gan, low, world, rank, dev):
         dt = float(tt.item())
         dist.destroy_process_group()
     if rank == 0:
-        gf = 22.385e9  # SURVEY §8 d: algorithmic generator-forward FLOPs per sample at S=256, T=1
+        gf = generator_flops(net)  # 22.385 GFLOP per sample at S=256, T=1 (SURVEY §8 d)
         tf = gf * B * args.steps / dt * 1e-12
         print(json.dumps({
             "metric": "generator forward samples/s, 32x32->256x256 wind tiles", "value": world * B * args.steps / dt,
@@ -461,6 +554,9 @@ def main():
     ap.add_argument("--workload", choices=["train", "gen_fwd"], default="train",
                     help="train: the headline GAN train step (default); gen_fwd: generator-only forward (inference "
                          "mode) at --batch tiles, the 'generator conv stack at batch 64' figure of BASELINE.json")
+    ap.add_argument("--no-child-legs", action="store_true",
+                    help="skip the two legs that run in fresh child processes (dp_path_one_rank, train_T24_S96_b8): profiling runs "
+                         "— a profiler's preloaded library must not see this process start other GPU programs")
     ap.add_argument("--no-sync-bn", action="store_true", help="per-replica BatchNorm statistics instead of SyncBN")
     ap.add_argument("--size", type=int, default=256, help="train only: tile edge (headline 256; the shipped network uses 96)")
     ap.add_argument("--timesteps", type=int, default=1,
@@ -533,13 +629,20 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logs = gan.train_step((low, high))
-    host_dt = time.perf_counter() - t0          # all launches enqueued (the host thread runs ahead of the device)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # host cost of enqueueing ONE step on an idle device (after a synchronize: no queue back-pressure in the figure; over many
+    # back-to-back steps the host runs into the launch queue's depth and the same clock would read the device's time)
+    concurrent_records = timer.records
+    timer.records = []
+    t1 = time.perf_counter()
+    gan.train_step((low, high))
+    host_dt = time.perf_counter() - t1
+    barrier()
 
     rccl_info = rccl_evidence(dist, gan, world, rank, dev) if dist_on else None
     # ---- per-kernel figures on ONE stream.  The default schedule runs the generator beside the discriminator, weight gradients
@@ -548,11 +651,10 @@ def main():
     # measures the sharing, not the kernel.  The roofline of the dominant kernel is therefore taken from extra train steps with
     # every overlap switched off (same kernels, same launches, one stream), timed with the same per-launch HIP events; the
     # figures of the timed region are kept beside it ("concurrent").  Every rank runs the extra steps (collectives).
-    concurrent_records = timer.records
     timer.records = []
     saved = (gan.engine.overlap_generator, generator.net.wgrad_stream, discriminator.net.wgrad_stream,
              discriminator.net.overlap_branches)
-    gan.engine.overlap_generator = "0"
+    gan.engine.overlap_generator = False
     generator.net.wgrad_stream = discriminator.net.wgrad_stream = False
     discriminator.net.overlap_branches = False
     serial_steps = 2
@@ -573,9 +675,11 @@ def main():
          discriminator.net.overlap_branches) = saved
     serial_records = timer.records
     if rank == 0:
-        # algorithmic FLOPs of one reference step per sample: 7*Gf + 28*Df (SURVEY §8 d), T = 1
-        gf, df = 22.385e9, 2.994e9
-        step_flops = (7 * gf + 28 * df) * B
+        # algorithmic FLOPs of one reference step per tile-timestep: 7*Gf + 28*Df (SURVEY §8 d; 240.5 GFLOP at S = 256, T = 1,
+        # 41.7 at S = 96, T = 24), Gf / Df from the layer objects of the networks that ran
+        gf, df = generator_flops(generator.net), discriminator_flops(discriminator.net)
+        gf_exec = generator_flops(generator.net, executed=True)
+        step_flops = (7 * gf + 28 * df) * B * T
         timer.records = serial_records
         agg = timer.summary()
         timer.records = concurrent_records
@@ -595,7 +699,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+            "ms_per_step": 1e3 * dt / args.steps, "host_enqueue_ms_per_step": 1e3 * host_dt,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -606,11 +710,11 @@ def main():
                                    (", configs[1]" if headline else " (not the headline configuration)"),
                        "per_gpu_batch": B, "global_batch": world * B, "image_size": S, "n_timesteps": T,
                        "parallelism": f"dp{world}" + ("" if args.no_sync_bn or not dist_on else "+syncbn")},
-            "step_tflops_algorithmic": step_flops * 1e-12 if headline else None,
-            "step_frac_of_mfma_f32_peak": step_flops / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12) if headline else None,
+            "step_tflops_algorithmic": step_flops * 1e-12,
+            "step_frac_of_mfma_f32_peak": step_flops / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
             # the same on the multiply-adds the kernels EXECUTE: the upsample + 5x5 block runs in column form in all seven
-            # generator passes (16.09 instead of 22.385 GFLOP per sample and pass)
-            "step_frac_executed": (7 * 16.093e9 + 28 * df) * B / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12) if headline else None,
+            # generator passes (16.09 instead of 22.385 GFLOP per sample and pass at S = 256)
+            "step_frac_executed": (7 * gf_exec + 28 * df) * B * T / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": dom[0],
                          "achieved": dom[1][0] / dom[1][1] * 1e-12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom[1][0] / dom[1][1] * 1e-12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -655,6 +759,8 @@ def main():
                 out["other_configs"] = other_config_legs(dev, ops)
             except Exception as exc:      # the extra legs must never cost the headline line
                 out["other_configs"] = {"error": repr(exc)}
+        if headline and world == 1 and not dist_on and not args.no_child_legs:
+            out.update(child_legs(out["ms_per_step"]))
         if rccl_info is not None:
             out["rccl"] = rccl_info
         if getattr(ops, "split_mode", False):

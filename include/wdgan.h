@@ -366,24 +366,6 @@ int wdg_lstm_bwd(const float* gates, int ldg, const float* c_prev, int ldcp, con
                  float* dgates, int lddg, float* dc_prev, int lddcp, int64_t P, int F,
                  wdg_stream stream);
 
-/* ConvLSTM2D over a whole sequence (n_timesteps > 1) in one persistent launch for the same few-channel layers
- * (models.py:93,101): a workgroup owns a pixel tile for all timesteps; neighbouring tiles exchange the one-pixel ring of
- * h_{t-1} (backward: dgates_{t+1}) through per-tile step counters with agent-scope release / acquire.  Activations are
- * time-major (image n = t*B + b).  Forward writes h [T*B,H,W,ldh], c [T*B,H,W,F] and — when `gates` is non-NULL — the gate
- * pre-activations [T*B,H,W,4F] (i|f|c|o) the backward pass reads.  Backward takes the incoming gradient dh of every h_t and
- * writes dgates [T*B,H,W,4F]; kernel / bias / input gradients are wdg_conv_wgrad / wdg_colsum / wdg_conv_dgrad over it.
- * Rows of h and dgates must start on 128-byte lines (W*ld % 32 == 0).  scratch: wdg_convlstm_seq_scratch_bytes bytes, owned
- * by the caller; wdg_convlstm_seq_check returns 1 if a bounded wait of the launches on that scratch timed out. */
-int wdg_convlstm_seq_supported(int cin, int F);
-size_t wdg_convlstm_seq_scratch_bytes(int B, int H, int W, int F);
-int wdg_convlstm_seq_fwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* wh,
-                         const float* bias, float* h, int ldh, int64_t img_stride_h, float* gates, float* c,
-                         int B, int T, int H, int W, int cin, int F, void* scratch, size_t scratch_bytes,
-                         wdg_stream stream);
-int wdg_convlstm_seq_bwd(const float* gates, const float* c, const float* wh, const float* dh, int lddh,
-                         int64_t img_stride_dh, float* dgates, int B, int T, int H, int W, int cin, int F,
-                         void* scratch, size_t scratch_bytes, wdg_stream stream);
-int wdg_convlstm_seq_check(void* scratch, int B, int H, int W, wdg_stream stream);
 /* Single-timestep ConvLSTM2D with few channels, fused (models.py:93,101 at n_timesteps = 1, where
  * h_0 = c_0 = 0 removes the recurrent conv and the forget path):  h = hs(o)*tanh(hs(i)*tanh(c~)) with
  * (i,f,c~,o) = conv3x3_same(x, wx) + bias.  wx is the master HWIO kernel [3][3][cin][4F].

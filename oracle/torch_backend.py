@@ -458,11 +458,6 @@ class TorchOps:
         if dc_prev is not None:
             dc_prev[:, :F_] = dc * gf
 
-    def convlstm_seq_supported(self, cin, F_, h=None):
-        """HipOps' persistent sequence kernels are a launch-structure optimisation: the oracle backend runs the generic
-        per-timestep program (engine.layers.ConvLSTM), which restates the reference recurrence step by step."""
-        return False
-
     def convlstm1_supported(self, cin, F_):
         return (cin, F_) in ((2, 2), (5, 16))
 

@@ -711,15 +711,12 @@ def test_structured_noise_generator(hip_ops):
 
 @pytest.mark.parametrize("cin,F,B,T,H,W", [(5, 16, 2, 3, 24, 32), (5, 16, 8, 6, 96, 96), (2, 2, 3, 4, 40, 64), (2, 2, 8, 5, 96, 96),
                                             (5, 16, 1, 2, 7, 40), (5, 16, 40, 3, 64, 64)])
-def test_convlstm_sequence_kernels(cin, F, B, T, H, W, hip_ops, ref_ops, monkeypatch):
-    """csrc/convlstm_seq.hip: ConvLSTM2D(return_sequences=True) over T > 1 steps in one persistent launch per direction
-    (neighbouring tiles hand the one-pixel ring of h_{t-1} / dgates_{t+1} over through per-tile counters) against the
-    per-timestep program of the layer on the oracle backend: h, the input gradient, and the kernel / recurrent kernel /
-    bias gradients.  (40 images of 64 x 64: more tiles than resident workgroups — several tiles per workgroup.)"""
+def test_convlstm_layer_sequences(cin, F, B, T, H, W, hip_ops, ref_ops):
+    """ConvLSTM2D(return_sequences=True) over T > 1 steps (models.py:93,101): the layer's per-timestep launches on the HIP
+    backend (fused recurrent steps, T-batched input convolution, time loops replayed from HIP graphs) against the same
+    layer program on the oracle backend: h, the input gradient, and the kernel / recurrent kernel / bias gradients."""
     from downscaling.engine.layers import ConvLSTM
     from downscaling.engine.params import ParamStore
-    monkeypatch.setenv("WDG_SEQ_CHECK", "1")
-    monkeypatch.setenv("WDG_CONVLSTM_SEQ", "1")      # opt-in path (see HipOps.convlstm_seq_supported)
     dev = hip_ops.device
     gen = torch.Generator().manual_seed(41)
     big = B * T * H * W > 100_000
@@ -740,7 +737,6 @@ def test_convlstm_sequence_kernels(cin, F, B, T, H, W, hip_ops, ref_ops, monkeyp
         rng = np.random.default_rng(6)
         net.params.set_weights({v.name: rng.normal(0, wscale, v.shape) for v in net.params.vars})
         layer.build()
-        assert (tag == "hip") == bool(layer._seq(T, ops.zeros(T * B, H, W, ldh)))
         h = ops.zeros(T * B, H, W, ldh)
         x, dh = cv(x64), cv(dh64)
         layer.forward(x, h, B, T)

@@ -251,6 +251,7 @@ class HipOps:
     name = "hip"
     dtype = torch.float32
     supports_graphs = True     # launches go to torch's current stream, so torch.cuda.graph captures them
+    supports_streams = True    # ... and work can be forked onto side streams (fork(), the trainer's multi-stream schedule)
 
     def __init__(self, device=None):
         if not torch.cuda.is_available():
@@ -275,35 +276,52 @@ class HipOps:
         # per-timestep launch chains (the ConvLSTM time loops at n_timesteps > 1) replayed from captured HIP graphs: see chain()
         self.gates_x = os.environ.get("WDG_GATES_X", "1") != "0"      # T > 1: the 5 -> 16 ConvLSTM's input convolution in its own kernel
         self.chain_graphs = os.environ.get("WDG_CHAIN_GRAPHS", "1") != "0"
-        self._chains, self._chain_seen = {}, {}
+        self._chains = {}
+        self._capture_ws = None      # chain(): scratch dict of the graph being captured
 
-    def chain(self, key, fn):
+    def chain(self, key, fn, graphs=None):
         """Runs fn() — a chain of dependent per-timestep launches on FIXED buffers with no host-side effects (a ConvLSTM's time
         loop) — from a HIP graph.  At the shipped sequence length a train step issues ~1,650 such launches of 8-45 us each;
         through Python / ctypes the host needs ~30 us per launch, so it cannot run ahead of the device and the streams that
         should overlap (generator / discriminator / twin discriminator) are fed one after the other.  The first call with a key
         runs eagerly (plans and scratch come into being), the second is captured, later ones are one graph launch.
-        `key` must name every buffer address and shape the chain touches; the library's tuning epoch is added here."""
+        `key` must name every buffer address and shape the chain touches — activations AND the lazily rebuilt weight layouts
+        the step kernels read (convlstm_step_prepare returns those); the library's tuning epoch is added here.
+        `graphs`: the dict that owns the captured graphs — the caller's (a layer's), so the graphs die with the buffers whose
+        addresses they hold; without one, a process-wide dict.  Split-K scratch requested while capturing is allocated for
+        that graph alone (see _workspace): graphs replayed at the same time on different streams never share scratch."""
         if not self.chain_graphs or self.split_mode or torch.cuda.is_current_stream_capturing():
             return fn()               # (split mode refreshes its weight slices lazily on the host path: never from a graph)
+        if graphs is None:
+            graphs = self._chains
         key = key + (int(self.lib.wdg_tuning_epoch()),)
-        graph = self._chains.get(key)
-        if graph is None:
-            seen = self._chain_seen[key] = self._chain_seen.get(key, 0) + 1
-            if seen < 2:
+        entry = graphs.get(key)
+        if entry is None:
+            seen = graphs.setdefault("seen", {})
+            seen[key] = seen.get(key, 0) + 1
+            if seen[key] < 2:
                 return fn()
+            own_ws = {}
+            self._capture_ws = own_ws
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     fn()
-            except Exception:                     # capture not possible here: stay eager from now on
+            except Exception as exc:              # capture not possible here: stay eager from now on, and say so
                 torch.cuda.synchronize()
                 self.chain_graphs = False
+                import warnings
+                warnings.warn(f"HipOps.chain: HIP graph capture failed ({type(exc).__name__}: {exc}); "
+                              "time loops run as eager launches from now on", RuntimeWarning)
                 return fn()
-            if len(self._chains) > 256:           # (buffers of networks long gone)
-                self._chains.clear()
-            self._chains[key] = graph
-        graph.replay()
+            finally:
+                self._capture_ws = None
+            if len(graphs) > 64:                  # (keys of replaced buffers / older tuning epochs)
+                for k in [k for k in graphs if k != "seen"]:
+                    del graphs[k]
+            seen.pop(key, None)
+            entry = graphs[key] = (graph, own_ws)  # (the graph's private scratch lives exactly as long as the graph)
+        entry[0].replay()
 
     # ---- plumbing ---------------------------------------------------------------------------
     @property
@@ -324,6 +342,14 @@ class HipOps:
 
     def _workspace(self, nbytes):
         """Split-K / split-pixel scratch of the CURRENT stream (work forked onto a side stream gets its own)."""
+        if self._capture_ws is not None:
+            # inside chain()'s capture: the captured kernels bake this address in, and the graph may later be replayed on any
+            # stream beside other graphs — the scratch belongs to this graph alone
+            ws = self._capture_ws.get("ws")
+            if ws is None or ws.numel() < nbytes:
+                assert ws is None or nbytes == 0, "chain capture: scratch grew between launches of one chain"
+                ws = self._capture_ws["ws"] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            return ws
         if self._ws is None:
             self._ws = {}
         key = self.stream
@@ -403,7 +429,7 @@ class HipOps:
         the epilogue that owns complete rows, or as the standalone pass behind the conv)."""
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
-        assert z.shape[:3] == y.shape[:3]
+        assert z.shape[:3] == y.shape[:3] and z.shape[3] == pk.cout
         _, ldz, isz = _v4(z)            # z may live in a wider buffer (a channel slice of a concatenation)
         if self.split_mode:
             pk.split3("wF")
@@ -471,12 +497,15 @@ class HipOps:
 
     def convlstm_step_prepare(self, h_prev, pk, gates_t, g, F):
         """Host-side, once before a time loop of convlstm_step calls: the lazily rebuilt weight layout of the GEMM form must be
-        current BEFORE the loop — the loop itself may be replayed from a captured graph (chain)."""
+        current BEFORE the loop — the loop itself may be replayed from a captured graph (chain).  Returns the device addresses of
+        those layouts: they are part of the identity of a captured loop (chain's key)."""
         plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
         if self._lstm16(plan, pk, F):
-            pk.lstm16()
-        elif not self.lib.wdg_convlstm_step_supported(plan, F):
-            pk.interleaved(F)
+            f, b = pk.lstm16()
+            return (f.data_ptr(), b.data_ptr())
+        if not self.lib.wdg_convlstm_step_supported(plan, F):
+            return (pk.interleaved(F).data_ptr(),)
+        return ()
 
     def _lstm16(self, plan, pk, F):
         """The 16-feature recurrent steps in their own kernels (csrc/convlstm16.hip)?"""
@@ -778,58 +807,6 @@ class HipOps:
         pdcp, lddcp = _v2(dc_prev) if dc_prev is not None else (0, 0)
         native.check(self.lib.wdg_lstm_bwd(pg, ldg, pcp, ldcp, pc, ldc, pdh, lddh, pdci, lddci, pdg, lddg, pdcp,
                                            lddcp, gates.shape[0], F, self.stream), "lstm_bwd")
-
-    # ---- ConvLSTM over a whole sequence in one persistent launch (csrc/convlstm_seq.hip) ---------------
-    def convlstm_seq_supported(self, cin, F, h=None):
-        """(cin, F) has a sequence kernel, it is switched on, and (when given) the h buffer meets its line-alignment rule.
-        OFF by default: measured on MI355X (profiles/r02h_kernel_stats_T24_seq_negative.csv) the persistent kernels are correct but
-        SLOWER than the per-timestep launches at the shipped shape (96 x 96 x 8 tiles, T = 24): 4.2 vs ~1.4 ms per pass
-        for the 5 -> 16 layer — the per-tile hand-off (sequential polls of 8 neighbour counters + an agent-scope release
-        that writes the L2 back) costs ~30 us per tile and step, and with 2.25 tiles per workgroup the scalar-fed fp32
-        FMAs are no faster than the MFMA halo kernel they replace.  WDG_CONVLSTM_SEQ=1 enables them (parity tests do)."""
-        if os.environ.get("WDG_CONVLSTM_SEQ", "0") != "1" or not self.lib.wdg_convlstm_seq_supported(cin, F):
-            return False
-        if h is not None:
-            n, H, W, ld = h.shape[0], h.shape[1], h.shape[2], h.stride(2)
-            if (W * ld) % 32 or h.data_ptr() % 128 or (W * 4 * F) % 32 or h.stride(0) % 32:
-                return False
-        return True
-
-    def convlstm_seq_scratch(self, B, H, W, F):
-        return torch.zeros(int(self.lib.wdg_convlstm_seq_scratch_bytes(B, H, W, F)), dtype=torch.uint8, device=self.device)
-
-    def convlstm_seq_fwd(self, x, wx, wh, bias, h, gates, c, B, T, cin, F, scratch):
-        """x [T*B,H,W,>=cin] time-major -> h [T*B,H,W,>=F], c [T*B,H,W,F], gates [T*B,H,W,4F] (None: not stored)."""
-        px, ldx, isx = _v4(x)
-        ph, ldh, ish = _v4(h)
-        _, H, W, _ = h.shape
-        assert c.is_contiguous() and (gates is None or gates.is_contiguous())
-        native.check(self.lib.wdg_convlstm_seq_fwd(px, ldx, isx, wx.data_ptr(), wh.data_ptr(), bias.data_ptr(), ph, ldh, ish,
-                                                   _ptr(gates), c.data_ptr(), B, T, H, W, cin, F, scratch.data_ptr(),
-                                                   scratch.numel(), self.stream), "convlstm_seq_fwd")
-        self._seq_check_after(scratch, B, H, W)
-
-    def convlstm_seq_bwd(self, gates, c, wh, dh, dgates, B, T, cin, F, scratch):
-        """dgates [T*B,H,W,4F] from the incoming gradient dh of every h_t (dh is not modified)."""
-        pdh, lddh, isdh = _v4(dh)
-        _, H, W, _ = dh.shape
-        assert gates.is_contiguous() and c.is_contiguous() and dgates.is_contiguous()
-        native.check(self.lib.wdg_convlstm_seq_bwd(gates.data_ptr(), c.data_ptr(), wh.data_ptr(), pdh, lddh, isdh,
-                                                   dgates.data_ptr(), B, T, H, W, cin, F, scratch.data_ptr(), scratch.numel(),
-                                                   self.stream), "convlstm_seq_bwd")
-        self._seq_check_after(scratch, B, H, W)
-
-    def _seq_check_after(self, scratch, B, H, W):
-        """The persistent kernel carries on with incomplete neighbour data after a timed-out wait and only raises a flag:
-        read the flag after EVERY launch of the opt-in path (one 4-byte download + stream sync; WDG_SEQ_CHECK=0 leaves it
-        to the caller; a stream capture cannot sync, the eager warm-up calls before it are checked)."""
-        if os.environ.get("WDG_SEQ_CHECK", "1") != "0" and not torch.cuda.is_current_stream_capturing():
-            self.convlstm_seq_check(scratch, B, H, W)
-
-    def convlstm_seq_check(self, scratch, B, H, W):
-        rc = int(self.lib.wdg_convlstm_seq_check(scratch.data_ptr(), B, H, W, self.stream))
-        if rc != 0:
-            raise native.NativeError("persistent ConvLSTM kernel: a bounded inter-workgroup wait timed out (results invalid)")
 
     def convlstm1_supported(self, cin, F):
         return bool(self.lib.wdg_convlstm1_supported(cin, F))

@@ -236,6 +236,7 @@ class ConvLSTM:
         self.pkh = self.ops.pack_weights(self.wh.value)
         self._shape = None
         self._pk_i = None
+        self._chain_graphs = {}      # captured time loops of THIS layer (HipOps.chain)
 
     def prep_entries(self):
         return [(self.pkx, None), (self.pkh, None)]
@@ -248,11 +249,8 @@ class ConvLSTM:
             self.dgates = None
             self.dgates1 = None
             self._pk_i = None
+            self._chain_graphs.clear()   # (captured on the previous buffers)
             self._shape = (N, H, W)
-
-    def _seq(self, T, h):
-        """Sequence length > 1 + few channels: the whole recurrence in one persistent launch (convlstm_seq.hip)."""
-        return T > 1 and self.ops.convlstm_seq_supported(self.cin, self.F, h)
 
     def _fused1(self, T):
         """Single timestep + few channels: the fused, gate-recomputing kernels (convlstm1.hip)."""
@@ -267,12 +265,6 @@ class ConvLSTM:
             o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
             return
         self._buffers(N, H, W)
-        if not bf16 and self._seq(T, h):
-            if getattr(self, "_seq_scratch", None) is None or self._seq_key != (B, H, W):
-                self._seq_scratch, self._seq_key = o.convlstm_seq_scratch(B, H, W, F), (B, H, W)
-            o.convlstm_seq_fwd(x, self.wx.value, self.wh.value, self.b.value, h, self.gates, self.c, B, T, self.cin, F,
-                               self._seq_scratch)
-            return
         if bf16 and T > 1 and hasattr(o, "convlstm16_supported") and \
                 o.convlstm16_supported(x[:B], self.gates[:B], self.pkh, self.g, F) and \
                 o.convlstm16_supported(x, self.gates, self.pkx, self.g, F):
@@ -317,11 +309,13 @@ class ConvLSTM:
 
         # the recurrence is a chain of T (or 2T) small dependent launches on this layer's resident buffers: replayed from a HIP
         # graph where the backend offers it (HipOps.chain)
+        packs = ()
         if step1 and hasattr(o, "convlstm_step_prepare"):
-            o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F)
+            packs = o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F) or ()
         if T > 2 and not bf16 and hasattr(o, "chain"):
+            # (graphs are owned by this layer: they hold its buffers' addresses and die with them)
             o.chain(("lstm_fwd", h.data_ptr(), tuple(h.shape), self.gates.data_ptr(), self.c.data_ptr(), self.pkh.wF.data_ptr(),
-                     B, T, bool(bf16), fmt, bool(step1)), time_loop)
+                     B, T, bool(bf16), fmt, bool(step1)) + tuple(packs), time_loop, graphs=self._chain_graphs)
         else:
             time_loop()
 
@@ -339,12 +333,9 @@ class ConvLSTM:
         if self.dgates is None:
             self.dgates = o.empty(N, H, W, 4 * F)
             self.dc = [o.empty(B, H, W, F), o.empty(B, H, W, F)]
-        seq = self._seq(T, h) and getattr(self, "_seq_scratch", None) is not None
-        if seq:
-            o.convlstm_seq_bwd(self.gates, self.c, self.wh.value, dh, self.dgates, B, T, self.cin, F, self._seq_scratch)
         # one launch per timestep where the halo-tile kernel runs the recurrent data gradient (the discriminator's ConvLSTMs):
         # dh_{t-1} += conv_transpose(dgates_t) and, in the same epilogue, the cell backward of timestep t-1
-        bstep = (not seq) and T > 1 and hasattr(o, "convlstm_bwd_step_supported") and \
+        bstep = T > 1 and hasattr(o, "convlstm_bwd_step_supported") and \
             o.convlstm_bwd_step_supported(dh[:B], self.dgates[:B], self.pkh, self.g, F)
         def time_loop():
             dc_in = None
@@ -365,14 +356,13 @@ class ConvLSTM:
                         o.conv_dgrad(self.dgates[sl], self.pkh, dh[pv], self.g, accumulate=True)
                 dc_in = dc_out
 
+        packs = ()
         if bstep and hasattr(o, "convlstm_step_prepare"):
-            o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F)      # (weight layouts current before a replayed loop)
-        if seq:
-            pass
-        elif T > 2 and hasattr(o, "chain"):
+            packs = o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F) or ()   # (weight layouts current before a replayed loop)
+        if T > 2 and hasattr(o, "chain"):
             o.chain(("lstm_bwd", h.data_ptr(), tuple(h.shape), dh.data_ptr(), self.gates.data_ptr(), self.c.data_ptr(),
-                     self.dgates.data_ptr(), self.dc[0].data_ptr(), self.dc[1].data_ptr(), self.pkh.wD.data_ptr(), B, T, bool(bstep)),
-                    time_loop)
+                     self.dgates.data_ptr(), self.dc[0].data_ptr(), self.dc[1].data_ptr(), self.pkh.wD.data_ptr(), B, T, bool(bstep))
+                    + tuple(packs), time_loop, graphs=self._chain_graphs)
         else:
             time_loop()
         if need_wgrad:

@@ -102,12 +102,6 @@ SIGNATURES = {
     "wdg_lstm_fwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, i64, i32, c_fp]),
     "wdg_lstm_bwd": (i32, [c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32, c_fp, i32,
                             i64, i32, c_fp]),
-    "wdg_convlstm_seq_supported": (i32, [i32, i32]),
-    "wdg_convlstm_seq_scratch_bytes": (szt, [i32, i32, i32, i32]),
-    "wdg_convlstm_seq_fwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp, i32, i32, i32, i32, i32, i32,
-                                    c_fp, szt, c_fp]),
-    "wdg_convlstm_seq_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i32, i32, i32, i32, i32, c_fp, szt, c_fp]),
-    "wdg_convlstm_seq_check": (i32, [c_fp, i32, i32, i32, c_fp]),
     "wdg_convlstm1_supported": (i32, [i32, i32]),
     "wdg_convlstm_gates_x_supported": (i32, [i32, i32]),
     "wdg_convlstm_gates_x": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),

@@ -306,7 +306,7 @@ class GeneratorNet(_Net):
         self.bn10.backward(v2(g["dz9"]), v2(b["y9"]), v2(g["dz9"]), self.c9.b.grad_pad)
         o.upconv_bwd(b["cat2"], g["dz9"], self.c9.pk, self.c9.w.grad, g["dcat2"], self.c9.g,   # :60-64 backward
                      pool=self._scratch_pool(b), **({"wgrad_async": lambda fn: self._wgrad(fn, joins)}
-                                                    if getattr(o, "supports_graphs", False) else {}))
+                                                    if getattr(o, "supports_streams", False) else {}))
         # bn8 + c7
         d7 = g["dcat2"][..., :self.F4p]
         self.bn8.backward(v2(d7), v2(b["y7"]), v2(d7), self.c7.b.grad_pad)
@@ -518,9 +518,7 @@ class DiscriminatorNet(_Net):
         o, Fd, T = self.ops, self.Fd, self.T
         if not prepared:
             self._prepare(training)
-        # (the persistent sequence kernels size their grids to be fully resident: never two of them side by side)
-        overlap = (self.overlap_branches_tn if T > 1 else self.overlap_branches_t1) and self.overlap_branches and \
-            not self.lstm_b._seq(T, b["hb"])
+        overlap = (self.overlap_branches_tn if T > 1 else self.overlap_branches_t1) and self.overlap_branches
         self._overlap_now = overlap
         if overlap:
             # the two input branches are independent chains of small per-timestep launches: run the high-res-only one

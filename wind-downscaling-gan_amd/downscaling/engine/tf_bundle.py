@@ -348,8 +348,10 @@ def write_bundle(prefix, tensors, object_graph=True):
     """{variable name: array} -> `<prefix>.index` + `<prefix>.data-00000-of-00001`, keys
     `<name>/.ATTRIBUTES/VARIABLE_VALUE` as Keras' TF-format `save_weights` names them (ganbase.py:132-135), plus the
     `_CHECKPOINTABLE_OBJECT_GRAPH` string tensor (last in the data file, first in key order, as TensorFlow lays it out) that
-    Keras' object-based `load_weights` walks (build_object_graph).  Readable by `read_bundle`, by TensorFlow's checkpoint
-    reader (`tf.train.load_checkpoint`) and by `keras.Model.load_weights` of a model with the same layer tree."""
+    Keras' object-based `load_weights` walks (build_object_graph).  Readable by `read_bundle` and, by construction of the
+    SSTable / CRC layout (tensor_bundle.cc), by TensorFlow's checkpoint reader (`tf.train.load_checkpoint`).  The object
+    graph is SYNTHESISED from the key paths — structurally valid, but untested against Keras (no TensorFlow in this image):
+    `keras.Model.load_weights` may still want the name-based route (`by_name` / `tf.train.load_checkpoint` + assign)."""
     prefix = str(prefix)
     items, offset = [(b"", HEADER)], 0
     order = sorted(tensors, key=lambda k: (k + _SUFFIX).encode())

@@ -115,8 +115,10 @@ class GanEngine:
         self._pending = {}
         # the generator forward of critic iteration i + 1 (and of the generator step) runs on its own HIP stream under the
         # discriminator passes of iteration i, D(real) of the metrics recompute under the generator's backward
-        # (WDG_OVERLAP_GEN=0 disables; single-process runs only) — _critic_pipelined
-        self.overlap_generator = os.environ.get("WDG_OVERLAP_GEN", "1")
+        # (WDG_OVERLAP_GEN=0 disables) — _critic_pipelined.  The data-parallel step runs the SAME schedule: the gradient
+        # all-reduce of iteration i is started where the single-process step runs Adam and lands at the next _flush(disc), the
+        # generator stream runs under it; SyncBN's small all-reduces are issued from the generator's stream
+        self.overlap_generator = os.environ.get("WDG_OVERLAP_GEN", "1") != "0"
         self._gen_stream = None
         # the discriminator's gradient-penalty pass beside its real pass on a twin network (WDG_OVERLAP_DISC=0 disables):
         # 69.0 -> 68.6 ms at the headline shape, +0.8 % at T = 24 (same-box A/B) — see _critic_pipelined
@@ -267,7 +269,6 @@ class GanEngine:
                 ds = self._disc_stream
                 if ds is None:
                     ds = self._disc_stream = torch.cuda.Stream(device=ops.device)
-                    twin.set_low(self._low)
                 disc._prepare(True)                                               # W0 -> W1 (SN of the gradient-penalty pass)
                 ds.wait_stream(main)
                 with torch.cuda.stream(ds):
@@ -281,6 +282,7 @@ class GanEngine:
                     noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
                     twin.set_high_tm(noisy, B)
                     real_mean = twin.forward(B, training=True, prepared=True).mean()                    # :41
+                    real_mean.record_stream(main)                                 # (allocated on `ds`, consumed on the main stream)
                     dsc2 = self._buf("dscore2", B)
                     dsc2.fill_(-sw_mean / B)
                     twin.backward(B, dsc2, need_wgrad=True, need_input_grad=False)
@@ -332,11 +334,14 @@ class GanEngine:
         chp = round4(ch)
         N, ppi = T * B, S * S
         sw_mean = 1.0 if sample_weight is None else float(torch.as_tensor(sample_weight).double().mean())
+        # (supports_streams: the backend launches on torch's current HIP stream, so work can be forked onto side streams; the
+        # oracle backend runs the serial program.  n_critic < 1: nothing to pipeline)
+        pipelined = (d_loss_fn is None and getattr(ops, "supports_streams", False) and bool(self.overlap_generator)
+                     and self.n_critic >= 1)
         gen.set_image(low)
         disc.set_low(low)
-        self._low = low
-        if self._disc_stream is not None:
-            disc.twin().set_low(low)
+        if pipelined and self.overlap_discriminator:
+            disc.twin().set_low(low)          # (the twin network of the two-stream critic schedule reads the same low-res input)
         real = self._buf("real", N, S, S, chp)
         gen.to_time_major(high, real)
         comb, noisy = self._buf("comb", N, S, S, chp), self._buf("noisy", N, S, S, chp)
@@ -345,9 +350,6 @@ class GanEngine:
         ones.fill_(1.0)
         dscore = self._buf("dscore", B)
 
-        mode = self.overlap_generator
-        pipelined = (d_loss_fn is None and getattr(ops, "supports_graphs", False) and mode != "0"
-                     and not (self.sync is not None and self.sync.active))
         if pipelined:
             disc_loss, gnorm, dscale, fake = self._critic_pipelined(B, T, real, comb, noisy, eps, gsq, ones, dscore, sw_mean, d_opt)
         for _ in range(0 if pipelined else self.n_critic):                        # ganbase.py:26
@@ -405,6 +407,7 @@ class GanEngine:
             with torch.cuda.stream(gs):
                 disc.set_high_tm(real, B)
                 real_mean = disc.forward(B, training=False).mean()
+                real_mean.record_stream(main)
         gen.backward(B, dfake)
         gscale = self._reduce_and_step(gen, g_opt)
         if pipelined:
