@@ -193,19 +193,8 @@ def cpu_baseline(batch=4):
         per_step.append(time.perf_counter() - t0)
     dt = sum(per_step)
     med, best = sorted(per_step)[len(per_step) // 2], min(per_step)
-    # BASELINE.md section 3 words the baseline as "all host cores": the same step at os.cpu_count() threads beside the
-    # 32-thread figure (one warm-up + one timed step; torch-CPU's conv kernels do not scale to the node's thread count)
-    all_cores = os.cpu_count() or 1
-    value_all = None
-    if all_cores != cores:
-        torch.set_num_threads(all_cores)
-        TM.train_step(gw, dw, low, high, draws, og, od)
-        t0 = time.perf_counter()
-        TM.train_step(gw, dw, low, high, draws, og, od)
-        value_all = batch / (time.perf_counter() - t0)
-        torch.set_num_threads(cores)
     out = {"value": batch / med, "unit": "samples/s", "cores": cores, "kind": "port",
-           "value_all_host_threads": value_all, "host_threads": all_cores,
+           "host_threads": os.cpu_count() or 1,
            "value_best": batch / best, "s_per_step_median": med, "s_per_step_min": best,
            "sample": f"1 warm-up + {nsteps} timed full GAN train steps (n_critic=3), batch {batch}, {S}x{S}, T={T}, torch-CPU fp32 "
                      f"restatement (oracle/torch_model.py; TensorFlow is not installable here), {dt:.1f} s timed; value = batch / "
@@ -227,8 +216,24 @@ def cpu_baseline(batch=4):
             TM.generator_forward(gw0, image, noise, False)
             each.append(time.perf_counter() - t0)
     dt0, best0 = sorted(each)[len(each) // 2], min(each)
+    # BASELINE.md section 3 words the baseline as "all host cores".  torch-CPU's conv kernels collapse when oversubscribed: the
+    # full train step at the GPU node's 256 hardware threads took 376 s per step (0.0106 samples/s, profiles/r04a_bench.json)
+    # against 2.5 s at 32 threads, so the all-thread figure is taken on the configs[0] forward only, bounded to ~10 s
+    all_threads, ms_all = os.cpu_count() or 1, None
+    if all_threads != cores:
+        torch.set_num_threads(all_threads)
+        with torch.no_grad():
+            TM.generator_forward(gw0, image, noise, False)
+            ts, t_end = [], time.perf_counter() + 10.0
+            while len(ts) < 10 and time.perf_counter() < t_end:
+                t0 = time.perf_counter()
+                TM.generator_forward(gw0, image, noise, False)
+                ts.append(time.perf_counter() - t0)
+        ms_all = 1e3 * sorted(ts)[len(ts) // 2]
+        torch.set_num_threads(cores)
     out["configs0_generator_forward_128"] = {"ms_per_forward": 1e3 * dt0, "ms_per_forward_min": 1e3 * best0, "samples_per_s": 1.0 / dt0,
                                              "cores": cores, "kind": "port",
+                                             "ms_per_forward_all_host_threads": ms_all, "host_threads": all_threads,
                                              "sample": "G(128,3,20,2,T=1) forward, batch 1, 3 warm-up + 10 timed (median; min beside it), "
                                                        "torch-CPU fp32 restatement"}
     return out
@@ -584,7 +589,8 @@ def main():
     # WDG_DIST_ALWAYS=1 with --gpus 1: a one-rank RCCL group, so the exchange code path (async all-reduce, deferred Adam,
     # SyncBN, metric reduce) runs on real collectives on a single-GPU box (functional check, not the headline)
     dist_on = world > 1 or os.environ.get("WDG_DIST_ALWAYS", "0") == "1"
-    if dist_on:
+    init_only = os.environ.get("WDG_DIST_INIT_ONLY", "0") == "1"      # A/B: the process group exists, the step does not use it
+    if dist_on or init_only:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
@@ -763,6 +769,9 @@ def main():
             out.update(child_legs(out["ms_per_step"]))
         if rccl_info is not None:
             out["rccl"] = rccl_info
+        if getattr(ops, "_cstreams_probe", None):
+            # how the generator / twin-discriminator streams were placed (HipOps.concurrent_streams: measured, not assumed)
+            out["stream_placement"] = dict(ops._cstreams_probe, gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"))
         if getattr(ops, "split_mode", False):
             out["dtype"] = "f32 via 3 bf16 slices per operand (6 slice products on bf16 MFMA, fp32 accumulate)"
         elif headline and world == 1 and not args.no_split_leg and hasattr(ops, "set_split_mode"):

@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs --no-serial-pass"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-generator-leg --no-split-leg --no-config-legs --no-serial-pass --no-child-legs"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_trace -o run -- $BENCH --steps 1 --warmup 1 > $ROOT/$OUT/${TAG}_trace.log 2>&1 )
 STATS=$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/${TAG}_kernel_stats.csv && head -25 $OUT/${TAG}_kernel_stats.csv

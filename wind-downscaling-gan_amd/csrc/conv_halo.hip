@@ -404,10 +404,17 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_kernel(const WdgHalo p, con
 // fragments stay in registers for the block's whole life.
 // LN: the LayerNorm epilogue as a separate instantiation — in one kernel its registers cost the plain launches (data gradient,
 // 16 -> 2 output conv) their fourth wave per SIMD (110 -> 142 registers: 104 -> ~125 us per launch)
-template <int TAPS, bool LN = false>
+// STG: how the 256 threads share the halo's 16-byte pieces.  0: four consecutive lanes = the 64 contiguous bytes of one pixel,
+// LDS slot = kg * npix + pixel — the staging stores of a quad land on ONE 16-byte bank column (4-way conflict on all six
+// ds_write_b128 per tile: the whole of this kernel's SQ_LDS_BANK_CONFLICT, 0.31-0.36 of its LDS cycles).  1: sixteen consecutive
+// lanes still cover the 256 contiguous bytes of four pixels, but as (kg 0 | kg 2 | kg 1 | kg 3) x four pixels, and the channel
+// groups 2, 3 are rotated by four slots (slot = kg * npix + pixel + 4 * (kg >> 1)): every 8-lane store group then hits eight
+// distinct columns, and the fragment reads stay conflict-free (their 16-lane groups pair kg 0 with 1 and 2 with 3, which keep
+// equal rotations).
+template <int TAPS, bool LN = false, int STG = 0>
 __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, const float* __restrict__ Bw) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem1[];
-    f32x4* lds_a = smem1;   // [4][npix]
+    f32x4* lds_a = smem1;   // [4][npix] (+ 4 slots of rotation slack)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -416,7 +423,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
     const int nslots = 4 * npr;
 
     // weight fragments of all taps in LDS for the block's whole life: slot [tap][lg][li]
-    f32x4* lds_w = lds_a + 4 * p.npix;
+    f32x4* lds_w = lds_a + 4 * p.npix + 4;
     for (int idx = t; idx < TAPS * 64; idx += 256) {
         const int tap = idx >> 6, l = idx & 63;
         const int wli = l & 15, wlg = l >> 4;
@@ -432,14 +439,23 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
     f32x4 rs[NLMAX];
     // slot geometry is tile independent: halo row / column and the in-image element offset of every staging slot
-    int shy[NLMAX], shx[NLMAX], soff[NLMAX];
+    int shy[NLMAX], shx[NLMAX], soff[NLMAX], sslot[NLMAX];
 #pragma unroll
     for (int i = 0; i < NLMAX; ++i) {
         const int idx = t + 256 * i;
-        const int kg = idx & 3, pix = idx >> 2;     // 4 consecutive lanes = the 64 contiguous bytes of one pixel
-        shy[i] = idx < nslots ? pix / p.halo_w : (1 << 28);
+        int kg, pix;
+        if constexpr (STG == 0) {
+            kg = idx & 3; pix = idx >> 2;           // 4 consecutive lanes = the 64 contiguous bytes of one pixel
+        } else {
+            const int j = idx & 15;
+            pix = (idx >> 4) * 4 + (j & 3);
+            kg = ((j >> 2) & 1) * 2 + (j >> 3);
+        }
+        const bool on = STG == 0 ? idx < nslots : (pix < npr && idx < 4 * ((npr + 3) & ~3));
+        shy[i] = on ? pix / p.halo_w : (1 << 28);
         shx[i] = pix - (pix / p.halo_w) * p.halo_w;
         soff[i] = ((pix / p.halo_w) * p.W + shx[i]) * p.ldA + kg * 4;
+        sslot[i] = on ? kg * p.npix + pix + (STG ? (kg >> 1) * 4 : 0) : -1;
     }
     auto load_tile = [&](int tile) {
         const int img = tile / (p.tiles_h * p.tiles_w);
@@ -465,7 +481,8 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
             // slot = kg*npix + pixel (npix = 0 mod 16): conflict-free fragment reads (36 per tile); the 6 staging writes
             // per tile are 4-way conflicted, the price of coalesced 64-byte-per-pixel global loads (an XOR swizzle that
             // fixed the writes made 30 % of the read cycles conflicts: profiles/r01aq_pmc_summary.csv)
-            if (idx < nslots) lds_a[(idx & 3) * p.npix + (idx >> 2)] = rs[i];
+            (void)idx;
+            if (sslot[i] >= 0) lds_a[sslot[i]] = rs[i];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
@@ -473,7 +490,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int pbase = 2 * wave * p.halo_w + li;
-        const f32x4* lds_g = lds_a + lg * p.npix;
+        const f32x4* lds_g = lds_a + lg * p.npix + (STG ? (lg >> 1) * 4 : 0);
         // fragments of tap+1 are read while tap is multiplied; the scheduling barrier per tap keeps the compiler from
         // hoisting all 36 fragment reads (144 registers, 2 waves/SIMD) in front of the MFMAs
         f32x4 af[2][4], bfr[2];
@@ -575,6 +592,8 @@ static int g_halo_max_cin = 64;     // reduction channels above which conv_fwd /
 void wdg_halo_set_max_cin(int v) { g_halo_max_cin = v; }
 static int g_halo1_bpc = 4;         // resident workgroups per CU of the persistent kernel (126 registers -> 4 waves per SIMD; measured 2: 122, 3: 113, 4: 111, 5: 127 us)
 void wdg_halo_set_persistent(int v) { g_halo_persistent = v != 0; if (v > 1) g_halo1_bpc = v; }
+static int g_halo1_stage = 1;       // wdg_set_tuning("halo1_stage", 0/1): staging assignment of the persistent kernel (STG)
+void wdg_halo_set_stage(int v) { g_halo1_stage = v != 0; }
 
 static size_t halo_lds_bytes(int kh, int kw, int nt, int wg = 0, int upsample = 0, int th = HALO_TH) {
     const int hh = th + kh - 1, hw = HALO_TW + kw - 1;
@@ -703,10 +722,14 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     }
     if (persistent1) {
         // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
-        const size_t lds1 = ((size_t)4 * p.npix + 9 * 64) * sizeof(f32x4);
+        const size_t lds1 = ((size_t)4 * p.npix + 4 + 9 * 64) * sizeof(f32x4);
         const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * (ln ? std::min(g_halo1_bpc, 3) : g_halo1_bpc));
-        if (ln)
+        if (ln && g_halo1_stage)
+            hipLaunchKernelGGL((wdg_conv_halo1_kernel<9, true, 1>), dim3(nb), block, lds1, st, p, Bw);
+        else if (ln)
             hipLaunchKernelGGL((wdg_conv_halo1_kernel<9, true>), dim3(nb), block, lds1, st, p, Bw);
+        else if (g_halo1_stage)
+            hipLaunchKernelGGL((wdg_conv_halo1_kernel<9, false, 1>), dim3(nb), block, lds1, st, p, Bw);
         else
             hipLaunchKernelGGL((wdg_conv_halo1_kernel<9>), dim3(nb), block, lds1, st, p, Bw);
         WDG_LAUNCH_CHECK();

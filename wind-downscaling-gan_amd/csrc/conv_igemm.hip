@@ -78,24 +78,30 @@ __device__ __forceinline__ int wdg_xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// row index of a phase -> (image, pa, pb): linear order, or 2-D row tiles (WdgPhase::t2_w)
+// row index of a phase -> (image, pa, pb): linear order, or 2-D row tiles (WdgPhase::t2_w: rows are "virtual", tile * BM + row
+// in tile; rows >= t2_rows of a tile are idle — wdg_row_valid)
 template <int BM>
 __device__ __forceinline__ void wdg_row_to_pixel(const WdgPhase& ph, int PaPb, int m, int& img, int& pa, int& pb) {
     if (ph.t2_w) {
         const int tile = m / BM, ml = m - tile * BM;
         img = (int)wdg_fastdiv_do((unsigned)tile, ph.div_t2_img);
-        const int tr = tile - img * (int)(PaPb / BM);
+        const int tr = tile - img * ph.t2_tpi;
         const int ty = (int)wdg_fastdiv_do((unsigned)tr, ph.div_t2_w);
         const int tx = tr - ty * ph.t2_tiles_w;
-        const int t2h = BM >> ph.t2_wshift;
-        pa = ty * t2h + (ml >> ph.t2_wshift);
-        pb = tx * ph.t2_w + (ml & (ph.t2_w - 1));
+        const int ly = (int)wdg_fastdiv_do((unsigned)ml, ph.div_t2_ml);
+        pa = ty * ph.t2_h + ly;
+        pb = tx * ph.t2_w + (ml - ly * ph.t2_w);
     } else {
         img = (int)wdg_fastdiv_do((unsigned)m, ph.div_papb);
         const int rem = m - img * PaPb;
         pa = (int)wdg_fastdiv_do((unsigned)rem, ph.div_pb);
         pb = rem - pa * ph.Pb;
     }
+}
+
+template <int BM>
+__device__ __forceinline__ bool wdg_row_valid(const WdgPhase& ph, int Mph, int m) {
+    return m < Mph && (!ph.t2_w || (m & (BM - 1)) < ph.t2_rows);
 }
 
 // EPI: 0 plain epilogue, 1 = + BatchNorm batch statistics of the output (training-mode producer), 2 = + inference-mode
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int PaPb = ph.Pa * ph.Pb;
-    const int Mph = p.n_img * PaPb;
+    const int Mph = ph.t2_w ? p.n_img * ph.t2_tpi * BM : p.n_img * PaPb;     // (2-D tiles: virtual rows)
     if (m0 >= Mph) return;
 
     const int k4_begin = (KG > 1 ? kgrp : (int)blockIdx.y) * p.k4_per_split;
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
     // ---- buffer descriptors (wave-uniform: kernel arguments and blockIdx only).  Every operand load is a
     // buffer_load_dwordx4 whose byte offset is pushed out of range for padding / out-of-image / tail lanes,
     // so the hardware range check returns the zeros and the load sequence has no branches.
-    const int img0 = (int)wdg_fastdiv_do((unsigned)m0, ph.div_papb);   // (2-D tiles: PaPb is a multiple of BM, so the tile's image is the same)
+    const int img0 = ph.t2_w ? (int)wdg_fastdiv_do((unsigned)(m0 / BM), ph.div_t2_img) : (int)wdg_fastdiv_do((unsigned)m0, ph.div_papb);
     const wdg_srd srdA = wdg_make_srd(p.A + (long long)img0 * p.imgStrideA);
     const wdg_srd srdB = wdg_make_srd(p.B);
 
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int m = m0 + lrow + 32 * i;
-        if (m < Mph) {
+        if (wdg_row_valid<BM>(ph, Mph, m)) {
             int img, pa, pb;
             wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const int ih0 = pa * p.a_mul + ph.a_off_h;
@@ -486,6 +492,9 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
         // conv -> bias -> LeakyReLU -> LayerNormalization over the channels, the block owning complete rows (tiles_n == 1,
         // no split-K: checked by the host).  A row's channels sit in 4 * WGN lanes (the four lane >> 4 groups of WGN
         // waves): its two reductions (sum, centred sum of squares) go through LDS, the K loop's stage being free.
+        // WGN == 1 (the 128 x 64 tile of the discriminator's first strided layer runs this epilogue as four waves of 32 rows x all
+        // 64 columns): a row's channels sit in the four lane >> 4 groups of ONE wave, so both reductions are two xor-shuffles —
+        // no LDS round trip, no barrier (the LDS form below cost that layer 56 us of its 431: 4 barriers + 16 partial reads)
         float* red = reinterpret_cast<float*>(lds_all);                    // [BM][4 * WGN]
         constexpr int RW = 4 * WGN;
         const int rsub = wn * 4 + (lane >> 4);
@@ -506,17 +515,25 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
                 }
                 acc[a][b] = v;
             }
-            red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + rsub] = s_;
+            if constexpr (WGN == 1) {
+                s_ += __shfl_xor(s_, 16, 64);
+                s_ += __shfl_xor(s_, 32, 64);
+                mean[a] = s_ * invC;
+            } else {
+                red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + rsub] = s_;
+            }
         }
-        __syncthreads();
+        if constexpr (WGN > 1) {
+            __syncthreads();
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            float s_ = 0.f;
+            for (int a = 0; a < MT; ++a) {
+                float s_ = 0.f;
 #pragma unroll
-            for (int k = 0; k < RW; ++k) s_ += red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + k];
-            mean[a] = s_ * invC;
+                for (int k = 0; k < RW; ++k) s_ += red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + k];
+                mean[a] = s_ * invC;
+            }
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             float q_ = 0.f;
@@ -529,20 +546,28 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
                     q_ += n + r < p.Ncols ? d * d : 0.f;
                 }
             }
-            red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + rsub] = q_;
+            if constexpr (WGN == 1) {
+                q_ += __shfl_xor(q_, 16, 64);
+                q_ += __shfl_xor(q_, 32, 64);
+                rstd[a] = 1.f / sqrtf(q_ * invC + p.ln_eps);
+            } else {
+                red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + rsub] = q_;
+            }
         }
-        __syncthreads();
+        if constexpr (WGN > 1) {
+            __syncthreads();
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            float q_ = 0.f;
+            for (int a = 0; a < MT; ++a) {
+                float q_ = 0.f;
 #pragma unroll
-            for (int k = 0; k < RW; ++k) q_ += red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + k];
-            rstd[a] = 1.f / sqrtf(q_ * invC + p.ln_eps);
+                for (int k = 0; k < RW; ++k) q_ += red[(wm * (BM / WGM) + a * 16 + (lane & 15)) * RW + k];
+                rstd[a] = 1.f / sqrtf(q_ * invC + p.ln_eps);
+            }
         }
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
-            if (m >= Mph) continue;
+            if (!wdg_row_valid<BM>(ph, Mph, m)) continue;
             int img, pa, pb;
             wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const int oh = pa * p.o_mul + ph.o_off_h;
@@ -576,7 +601,7 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
-            if (m >= Mph) continue;
+            if (!wdg_row_valid<BM>(ph, Mph, m)) continue;
             int img, pa, pb;
             wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const long long pix = (long long)img * PaPb + (long long)pa * ph.Pb + pb;
@@ -624,7 +649,7 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
-        if (m >= Mph) continue;
+        if (!wdg_row_valid<BM>(ph, Mph, m)) continue;
         if (p.splitk > 1) {
             float* dst = p.partial + (((long long)phase_id * p.splitk + blockIdx.y) * p.Mmax + m) * NcP;
 #pragma unroll
@@ -822,6 +847,8 @@ struct WdgWgrad {
     int splitk;
     long long pix_per_split, Ptot;
     wdg_fastdiv div_howo, div_wo;   // pixel index -> (image, row, column) without integer division
+    int xcd_tiles;      // > 0: 1-D grid of xcd_tiles * splitk workgroups, remapped so that one XCD runs the row / column tiles of a
+                        // pixel split back to back (they stream the same x and dy window through that XCD's L2)
 };
 
 // Fragment layout.  A lane's LDS read is ONE vector of MT (NT) consecutive rows (columns) of one pixel:
@@ -870,8 +897,14 @@ __global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
     const int g4 = t & 31;   // row group (A) / column group (B) handled by this thread
     const int ps = t >> 5;   // pixel slot 0..7
 
-    // (an XCD-aware split -> XCD assignment was measured 3-15 % SLOWER here: profiles/r01t_perf_conv_wgrad_xcd_negative.log)
-    const int bx = blockIdx.x, split_id = blockIdx.y;
+    // (round 1 measured an XCD-aware split -> XCD assignment 3-15 % slower: profiles/r01t_perf_conv_wgrad_xcd_negative.log;
+    // re-measured per layer in round 4 — wdg_set_tuning("wgrad_xcd"))
+    int bx = blockIdx.x, split_id = blockIdx.y;
+    if (p.xcd_tiles) {
+        const int w = wdg_xcd_remap(blockIdx.x, gridDim.x);
+        split_id = w / p.xcd_tiles;
+        bx = w - split_id * p.xcd_tiles;
+    }
     const int tiles_m = (p.K4 * 4 + BM - 1) / BM;
     const int tm = bx % tiles_m;
     const int tn = bx / tiles_m;
@@ -1093,6 +1126,7 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
         if (wdg_round_up(ncols, c.BN) * 100 <= best * 113) return c;
     return cand[3];
 }
+static int g_wgrad_xcd = 0;      // wdg_set_tuning("wgrad_xcd", n): XCD-contiguous order for weight gradients with 2..n tiles per pixel split (0 = off)
 static int g_wgrad_bn160 = 32;   // wdg_set_tuning("wgrad_bn160", 32 | 64 | 128): column tile of 160-column weight gradients
 static int pick_wgrad_bn(int ncols) {
     if (ncols == 160 && g_wgrad_bn160 != 32) return g_wgrad_bn160;
@@ -1299,6 +1333,7 @@ static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase:
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
+static int g_ln_wave = 1;     // wdg_set_tuning("ln_wave", 0/1): the 128 x 64 tile's LayerNorm epilogue on 4 x 1 waves (in-wave reductions)
 static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
 static int g_tuning_epoch = 0;
 extern "C" int wdg_tuning_epoch(void) { return g_tuning_epoch; }
@@ -1311,6 +1346,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "patch_lstm_small")) {
         wdg_patch_h16_set_lstm_small(value);
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "ln_wave")) {
+        g_ln_wave = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "igemm_kg2")) {
@@ -1354,12 +1393,20 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_halo_set_max_cin(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "halo1_stage")) {
+        wdg_halo_set_stage(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "halo_persistent")) {
         wdg_halo_set_persistent(value);
         return WDG_OK;
     }
     if (key && !strcmp(key, "wgrad_thin")) {
         wdg_wgrad_thin_enable(value);
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "wgrad_xcd")) {
+        g_wgrad_xcd = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "wgrad_bn160")) {
@@ -1404,8 +1451,8 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         if (value > 1) wdg_patch_h16_set_budget(value);   // value > 1: LDS bytes of a patch chunk in KiB
         return WDG_OK;
     }
-    if (key && !strcmp(key, "tile2d")) {
-        g_tile2d = value != 0;
+    if (key && !strcmp(key, "tile2d")) {      // 0 off, 1 on, 2 = only the evenly dividing power-of-two patches (A/B of the ragged ones)
+        g_tile2d = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "convlstm1_mfma")) {
@@ -1525,21 +1572,29 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     } else {
         p.partial = nullptr;
     }
+    int tiles_m_launch = tiles_m;
     if (g_tile2d && split == 1) {
-        // rows of a tile = a 2-D patch of output pixels (8 x 16 for 128 rows, 8 x 8 for 64, 16 x 16 for 256) where the
-        // phase's pixel grid divides evenly: a 128-row tile of the 8x8 stride-2 layer then touches 22 x 38 input pixels
-        // instead of 8 x 262.  (Split-K launches keep the linear order: their second stage maps rows linearly.)
-        const int t2w = tc.BM == 64 ? 8 : 16;
-        for (int i = 0; i < nphase; ++i) wdg_phase_tile2d(p.ph[i], tc.BM, t2w);
+        // rows of a tile = a 2-D patch of output pixels (8 x 16 for 128 rows, 8 x 8 for 64, 16 x 16 for 256; 6 x 21 on the
+        // 84 x 84 map of the discriminator's first strided layer) where the phase's pixel grid divides: a 128-row tile of the
+        // 8x8 stride-2 layer then touches 22 x 38 input pixels instead of 8 x 262.  A patch may leave a few rows of its tile
+        // idle, so the launch's row space is per phase (virtual rows = tiles * BM).  (Split-K launches keep the linear
+        // order: their second stage maps rows linearly.)
+        long long rows_max = 0;
+        for (int i = 0; i < nphase; ++i) {
+            const int per_img = g_tile2d >= 2 && !(p.ph[i].Pa % 8 == 0 && p.ph[i].Pb % 16 == 0) ? 0 : wdg_phase_tile2d(p.ph[i], tc.BM);
+            rows_max = std::max(rows_max, per_img ? (long long)p.n_img * per_img : (long long)p.n_img * p.ph[i].Pa * p.ph[i].Pb);
+        }
+        tiles_m_launch = (int)((rows_max + tc.BM - 1) / tc.BM);
+        p.Mmax = (int)rows_max;        // (the kernel derives its row-tile count from it; the split-K slabs that index by it are not in play)
     }
-    dim3 grid(tiles_m * tiles_n, split, nphase), block(256);
+    dim3 grid(tiles_m_launch * tiles_n, split, nphase), block(256);
     // several column tiles over a small B operand (the 400-column GEMM of the column-form upsample-conv: 5 tiles, 256 KB of
     // weights): walk the column tiles of a row tile back to back, so its A rows are fetched from the fabric once, not once
     // per column tile
     p.n_fastest = g_n_fastest && tiles_n > 1 && (long long)p.Ncols * K4max * 16 <= g_n_fastest_bytes;
     p.phase_in_x = 0;
     if (nphase > 1 && g_phase_major) {
-        grid = dim3(tiles_m * tiles_n * nphase, split, 1);
+        grid = dim3(tiles_m_launch * tiles_n * nphase, split, 1);
         p.phase_in_x = nphase;
     }
     p.xcd_swizzle = g_xcd_swizzle && grid.x >= 16;
@@ -1572,7 +1627,12 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         }                                                                                               \
         else if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);           \
         else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \
-        else if (epi == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);           \
+        else if (epi == 3) {                                                                            \
+            if constexpr (BM_ == 128 && BN_ == 64) {                                                    \
+                if (g_ln_wave) rc = launch_variant<128, 64, 4, 1, 3, 3>(grid, block, st, p);            \
+                else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);                 \
+            } else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);                   \
+        }                                                                                               \
         else if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);             \
         else if (pipe == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 1>(grid, block, st, p);             \
         else if (pipe == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3>(grid, block, st, p);             \
@@ -1904,6 +1964,10 @@ extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const flo
     const int tiles_m = (p.K4 * 4 + 127) / 128;
     const int tiles_n = (g.Cout + bn - 1) / bn;
     dim3 grid(tiles_m * tiles_n, split, 1), block(256);
+    if (g_wgrad_xcd && split >= 8 && tiles_m * tiles_n > 1 && tiles_m * tiles_n <= g_wgrad_xcd) {
+        p.xcd_tiles = tiles_m * tiles_n;
+        grid = dim3(tiles_m * tiles_n * split, 1, 1);
+    }
     if (bn == 128)
         hipLaunchKernelGGL((wdg_wgrad_kernel<128, 2, 2>), grid, block, 0, st, p);
     else if (bn == 64)

@@ -10,27 +10,40 @@ struct WdgPhase {
     int K4;                // k4 groups (padded to a multiple of 8 with invalid entries)
     int tab_off;           // first table entry of this phase
     wdg_fastdiv div_papb, div_pb;   // row index -> (image, pa, pb) by multiply-high (wdg_phase_finish fills them)
-    // 2-D row tiles (t2_w > 0): the BM rows of a tile are a (BM / t2_w) x t2_w patch of output pixels instead of BM consecutive
-    // pixels of one output row — fewer distinct input rows per tile, so neighbouring taps hit L1 / L2 instead of the fabric
-    int t2_w, t2_wshift, t2_tiles_w;
-    wdg_fastdiv div_t2_img, div_t2_w;   // tile index -> (image, tile row, tile column)
+    // 2-D row tiles (t2_w > 0): the BM rows of a tile are a t2_h x t2_w patch of output pixels instead of BM consecutive
+    // pixels of one output row — fewer distinct input rows per tile, so neighbouring taps hit L1 / L2 instead of the fabric.
+    // t2_h * t2_w <= BM: a patch that does not fill the tile (6 x 21 = 126 of 128 rows on an 84 x 84 map) leaves idle rows,
+    // the row space of the launch is then tiles * BM ("virtual" rows), not the pixel count
+    int t2_w, t2_h, t2_rows, t2_tiles_w, t2_tpi;
+    wdg_fastdiv div_t2_img, div_t2_w, div_t2_ml;   // tile index -> (image, tile row, tile column); row in tile -> (ly, lx)
 };
 static inline void wdg_phase_finish(WdgPhase& ph) {
     ph.div_papb = wdg_fastdiv_make((unsigned)(ph.Pa * ph.Pb > 0 ? ph.Pa * ph.Pb : 1));
     ph.div_pb = wdg_fastdiv_make((unsigned)(ph.Pb > 0 ? ph.Pb : 1));
-    ph.t2_w = ph.t2_wshift = ph.t2_tiles_w = 0;
-    ph.div_t2_img = ph.div_t2_w = wdg_fastdiv_make(1u);
+    ph.t2_w = ph.t2_h = ph.t2_rows = ph.t2_tiles_w = ph.t2_tpi = 0;
+    ph.div_t2_img = ph.div_t2_w = ph.div_t2_ml = wdg_fastdiv_make(1u);
 }
-// enable 2-D row tiles of bm rows (bm, t2w powers of two) when the phase's pixel grid divides evenly
-static inline bool wdg_phase_tile2d(WdgPhase& ph, int bm, int t2w) {
-    const int t2h = bm / t2w;
-    if (t2w <= 0 || t2h <= 0 || t2w * t2h != bm || ph.Pa % t2h || ph.Pb % t2w) return false;
-    int sh = 0;
-    while ((1 << sh) < t2w) ++sh;
-    ph.t2_w = t2w; ph.t2_wshift = sh; ph.t2_tiles_w = ph.Pb / t2w;
-    ph.div_t2_img = wdg_fastdiv_make((unsigned)((ph.Pa / t2h) * (ph.Pb / t2w)));
-    ph.div_t2_w = wdg_fastdiv_make((unsigned)(ph.Pb / t2w));
-    return true;
+// enable 2-D row tiles for tiles of bm rows: the t2_h x t2_w patch (t2_h | Pa, t2_w | Pb) with the most pixels that fits bm
+// rows, if it fills at least 97 % of them; among equals the one with the smallest perimeter, wider than tall (a pixel row of a
+// patch is one contiguous run of the output).  Returns the virtual row count of the phase per image (tiles * bm), 0 = linear.
+static inline int wdg_phase_tile2d(WdgPhase& ph, int bm) {
+    int best_h = 0, best_w = 0;
+    for (int h = 1; h <= ph.Pa && h <= bm; ++h) {
+        if (ph.Pa % h) continue;
+        for (int w = 1; w <= ph.Pb && h * w <= bm; ++w) {
+            if (ph.Pb % w) continue;
+            const int a = h * w, b = best_h * best_w;
+            if (a > b || (a == b && (h + w < best_h + best_w || (h + w == best_h + best_w && w > best_w)))) { best_h = h; best_w = w; }
+        }
+    }
+    if (best_h * best_w * 100 < bm * 97 || best_h < 2) return 0;
+    ph.t2_h = best_h; ph.t2_w = best_w; ph.t2_rows = best_h * best_w;
+    ph.t2_tiles_w = ph.Pb / best_w;
+    ph.t2_tpi = (ph.Pa / best_h) * (ph.Pb / best_w);
+    ph.div_t2_img = wdg_fastdiv_make((unsigned)ph.t2_tpi);
+    ph.div_t2_w = wdg_fastdiv_make((unsigned)ph.t2_tiles_w);
+    ph.div_t2_ml = wdg_fastdiv_make((unsigned)best_w);
+    return ph.t2_tpi * bm;
 }
 
 struct wdg_conv_plan {
@@ -62,6 +75,7 @@ int wdg_halo_plan_init(wdg_conv_plan* pl);
 void wdg_halo_plan_free(wdg_conv_plan* pl);
 void wdg_halo_set_wg(int v);
 void wdg_halo_set_persistent(int v);
+void wdg_halo_set_stage(int v);
 void wdg_halo_set_th4(int v);
 void wdg_halo_set_max_cin(int v);
 void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip

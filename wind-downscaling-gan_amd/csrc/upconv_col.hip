@@ -126,7 +126,11 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
     constexpr int ZW = TS + 4;                       // low-res window edge (12)
     constexpr int PX = 5 * CQ;                       // float4 per window pixel and tap row
     __shared__ f32x4 Z[ZW * ZW * PX];
-    __shared__ f32x4 Hs[ZW * 2 * TS * CQ];
+    // pixel pitch CQ + 1 slots: in the vertical pass a lane reads the CQ slots of ITS output pixel, consecutive lanes consecutive
+    // pixels — at a pitch of CQ = 4 slots every lane of a ds_read_b128 group fell on the same four bank columns (4-way conflict
+    // on all eight reads per tap row: SQ_LDS_BANK_CONFLICT 0.26 of the kernel's LDS cycles); 5 is coprime to the 16 columns
+    constexpr int HP = CQ + (CQ % 2 == 0 ? 1 : 0);
+    __shared__ f32x4 Hs[ZW * 2 * TS * HP];
     const int tiles_x = (Wl + TS - 1) / TS;
     const int i0 = (blockIdx.x / tiles_x) * TS, j0 = (blockIdx.x % tiles_x) * TS;
     const long long n = blockIdx.y;
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
                         h += up_adj_coef(rx, b, Wl) * Z[(ryl * ZW + rxl) * PX + tx * CQ + o4];
                 }
             }
-            Hs[i] = h;
+            Hs[(i / CQ) * HP + o4] = h;
         }
         __syncthreads();
         // 3. vertical pass: the two (ry, a) pairs of this tap row
@@ -214,7 +218,7 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
                 if ((unsigned)ryl < (unsigned)ZW) {
                     const float c = up_adj_coef(ry, a, Hl);
 #pragma unroll
-                    for (int o4 = 0; o4 < CQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * TS + qxl) * CQ + o4];
+                    for (int o4 = 0; o4 < CQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * TS + qxl) * HP + o4];
                 }
             }
         }

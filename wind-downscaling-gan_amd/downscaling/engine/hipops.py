@@ -358,6 +358,59 @@ class HipOps:
             ws = self._ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
         return ws
 
+    def concurrent_streams(self, n):
+        """`n` HIP streams that PROVABLY run beside torch's current stream and beside each other — chosen by measurement.
+
+        Why not just torch.cuda.Stream(): HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default
+        4) in creation order, torch hands out streams of a 32-entry pool round-robin to every caller, and two streams that
+        land on one hardware queue run one after the other.  Whether the trainer's generator / twin-discriminator streams
+        overlap with the main stream therefore depended on who had taken pool entries before — e.g. creating an RCCL process
+        group shifted the assignment and cost the data-parallel step its overlap (70.9 vs 67.9 ms at the headline shape with
+        the group merely initialised, profiles/r04c_dp.txt; raising the queue count instead made cross-queue waits expensive:
+        profiles/r04d_queues.txt, r04e_queues.txt).  The probe: a single-workgroup spin kernel on every stream of the
+        candidate set at once takes one spin time when they sit on different hardware queues and one per stream when they
+        share one.  Falls back to plain pool streams when no concurrent set exists (one hardware queue)."""
+        cached = self.__dict__.setdefault("_cstreams", [])
+        if len(cached) >= n:
+            return cached[:n]
+        main = torch.cuda.current_stream(self.device)
+        cycles = 400_000
+
+        def spin_ms(streams):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(self.device)
+            e0.record(main)
+            for st in streams:                # every stream starts behind e0 ... (all waits BEFORE any spin is enqueued)
+                if st is not main:
+                    st.wait_stream(main)
+            for st in streams:                # ... and spins once
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
+            for st in streams:
+                if st is not main:
+                    main.wait_stream(st)
+            e1.record(main)
+            torch.cuda.synchronize(self.device)
+            return e0.elapsed_time(e1)
+
+        spin_ms([main])
+        t1 = min(spin_ms([main]) for _ in range(3))
+        chosen = list(cached)
+        tried = 0
+        while len(chosen) < n and tried < 24:
+            cand = torch.cuda.Stream(device=self.device)
+            tried += 1
+            group = [main] + chosen + [cand]
+            t = min(spin_ms(group) for _ in range(2))
+            if t < 1.5 * t1:                  # all of them side by side (a shared queue costs at least 2 x t1)
+                chosen.append(cand)
+        found = len(chosen)
+        while len(chosen) < n:                # no concurrent set (e.g. one hardware queue): still correct, just serial
+            chosen.append(torch.cuda.Stream(device=self.device))
+        self._cstreams = chosen
+        self._cstreams_probe = {"spin_ms": t1, "candidates_tried": tried, "concurrent_found": found}
+        return chosen[:n]
+
     def fork(self, name="side"):
         """Context manager: run the enclosed launches on the side stream `name` that starts after everything enqueued so far
         on the current stream; `join()` on the returned object makes the current stream wait for them.  Used for chains of

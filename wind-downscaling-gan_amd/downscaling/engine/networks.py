@@ -49,7 +49,11 @@ class _Net:
         self._packed_version = self.params.version
 
     # ---- weight gradients off the critical path ---------------------------------------------------
-    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "1") != "0"
+    # OFF by default since round 4 (WDG_WGRAD_STREAM=1 enables): with the generator and the twin discriminator on streams of
+    # their own the chip is already shared three ways, and a fourth stream of big weight-gradient kernels beside the data
+    # gradients costs more than its tails save — 66.1-66.7 ms per headline step without it against 66.9 with it at four
+    # hardware queues and 73-81 ms at eight (profiles/r04e_queues.txt, r04f_sched.txt)
+    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "0") != "0"
 
     def _wgrad(self, fn, joins):
         """Runs `fn` (the weight-gradient launches of one layer) on the "wgrad" side stream, after everything enqueued so far
@@ -416,7 +420,9 @@ class DiscriminatorNet(_Net):
         # 70.35 ms, same box).  T > 1: two chains of small DEPENDENT launches side by side are slower than one after the other
         # (two 16-feature step chains: 75 us per step pair on two streams, 52 us on one — every kernel boundary of one chain
         # writes back / invalidates the per-XCD L2s under the other's running kernel); 91.6 -> 88.4 ms per T = 24 step without it
-        mode = os.environ.get("WDG_OVERLAP_BRANCHES", "1")
+        # Round 4: OFF by default at every T — beside the generator / twin streams the branch overlap loses (68.9 vs 67.2 ms at eight
+        # hardware queues, neutral at four: profiles/r04f_sched.txt)
+        mode = os.environ.get("WDG_OVERLAP_BRANCHES", "0")
         self.overlap_branches = mode != "0"
         self.overlap_branches_t1 = mode in ("1", "2")
         self.overlap_branches_tn = mode in ("2", "3")

@@ -81,11 +81,16 @@ class DistSync:
         # gloo has no device collectives in every build: stage device tensors through the host there (tests that
         # run two ranks on one GPU; the production backend is "nccl" = RCCL, which reduces in place on the device)
         self._stage = self.dist.get_backend(group) == "gloo"
+        # measurement switch (bench A/B only): keep the whole exchange code path (deferred Adam, SyncBN bookkeeping, metric
+        # reduce) but issue no collective — separates the cost of the schedule from the cost of the RCCL calls
+        self._noop = os.environ.get("WDG_DIST_NOOP", "0") == "1"
 
     def all_reduce_sum_async(self, t):
         """Start the all-reduce and return a zero-argument `finish()`; the collective runs on RCCL's own stream, so
         kernels enqueued on the compute stream before `finish()` overlap with it (`finish` makes the compute stream
         wait for the result)."""
+        if self._noop:
+            return lambda: None
         if self._stage and t.is_cuda:
             self.all_reduce_sum(t)          # host-staged test path: nothing to overlap
             return lambda: None
@@ -93,6 +98,8 @@ class DistSync:
         return work.wait
 
     def all_reduce_sum(self, t):
+        if self._noop:
+            return
         if self._stage and t.is_cuda:
             h = t.cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -235,7 +242,8 @@ class GanEngine:
         o_gstep = noise.reserve(n_g)                                              # the generator step's noise (:51) comes next
         nf = self._buf("noisy_fake", *noisy.shape)
         if self._gen_stream is None:
-            self._gen_stream = torch.cuda.Stream(device=ops.device)
+            # (streams chosen by a measured concurrency probe: on distinct hardware queues whatever else holds pool streams)
+            self._gen_stream, self._disc_stream = ops.concurrent_streams(2)
         gs, main = self._gen_stream, torch.cuda.current_stream(ops.device)
         noise.normal_at(nview, self.noise_std, offs[0][0])                        # :28
         fake = gen.forward(B, training=True, need_backward=False)                 # :29
@@ -268,7 +276,7 @@ class GanEngine:
                 twin = disc.twin()
                 ds = self._disc_stream
                 if ds is None:
-                    ds = self._disc_stream = torch.cuda.Stream(device=ops.device)
+                    ds = self._disc_stream = ops.concurrent_streams(2)[1]
                 disc._prepare(True)                                               # W0 -> W1 (SN of the gradient-penalty pass)
                 ds.wait_stream(main)
                 with torch.cuda.stream(ds):
