@@ -47,6 +47,8 @@ def build_cases(ops, want):
         if ln:
             cases[tag + "_fwd_ln"] = (lambda: ops.conv_fwd_ln(x, pk, bias, y, z, g, gamma, beta, 1e-3, mr), fl)
         cases[tag + "_fwd"] = (lambda: ops.conv_fwd(x, pk, bias, y, g, act=True), fl)
+        stats = torch.zeros(512, 2 * coutp, dtype=torch.float64, device=dev)
+        cases[tag + "_fwd_bn"] = (lambda: ops.conv_fwd(x, pk, bias, y, g, act=True, bn_stats=stats), fl)    # training-mode BatchNorm producer
         cases[tag + "_dgrad"] = (lambda: ops.conv_dgrad(dy, pk, dx, g), fl)
         cases[tag + "_wgrad"] = (lambda: ops.conv_wgrad(x, dy, pk, dw, g, accumulate=True), fl)
 

@@ -564,32 +564,46 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
                 rstd[a] = 1.f / sqrtf(q_ * invC + p.ln_eps);
             }
         }
+        // stores: pixel offsets once per row, gamma / beta once per column tile (column tile outermost)
+        long long off[MT];
+        bool rv[MT];
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
-            if (!wdg_row_valid<BM>(ph, Mph, m)) continue;
+            rv[a] = wdg_row_valid<BM>(ph, Mph, m);
+            off[a] = 0;
+            if (!rv[a]) continue;
             int img, pa, pb;
             wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
             const int oh = pa * p.o_mul + ph.o_off_h;
             const int ow = pb * p.o_mul + ph.o_off_w;
-            const long long off = (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
-                if (n >= NcP) continue;
-                const f32x4 v = acc[a][b];
-                f32x4 z;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    z[r] = n + r < p.Ncols ? (v[r] - mean[a]) * rstd[a] * p.ln_gamma[n + r] + p.ln_beta[n + r] : 0.f;
-                *reinterpret_cast<f32x4*>(p.Out + off + n) = v;
-                *reinterpret_cast<f32x4*>(p.Out2 + off + n) = z;
-            }
+            off[a] = (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
             if (p.mean_rstd && rsub == 0) {
                 // (forward launches only: one phase, so the output pixel index is img * PaPb + pa * Pb + pb)
                 const long long pixi = (long long)img * PaPb + pa * ph.Pb + pb;
                 p.mean_rstd[2 * pixi] = mean[a];
                 p.mean_rstd[2 * pixi + 1] = rstd[a];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+            if (n >= NcP) continue;
+            f32x4 gm, bt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gm[r] = n + r < p.Ncols ? p.ln_gamma[n + r] : 0.f;
+                bt[r] = n + r < p.Ncols ? p.ln_beta[n + r] : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                if (!rv[a]) continue;
+                const f32x4 v = acc[a][b];
+                f32x4 z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = (v[r] - mean[a]) * rstd[a] * gm[r] + bt[r];
+                *reinterpret_cast<f32x4*>(p.Out + off[a] + n) = v;
+                *reinterpret_cast<f32x4*>(p.Out2 + off[a] + n) = z;
             }
         }
         return;
@@ -639,84 +653,96 @@ __global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
         }
         return;
     }
-    float st1[EPI == 1 ? NT : 1][4], st2[EPI == 1 ? NT : 1][4];
-    if constexpr (EPI == 1) {
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st1[b][r] = st2[b][r] = 0.f;
-    }
+    // Column tile outermost, the MT pixels of a lane innermost: the per-pixel output offsets are formed once (MT values), the
+    // bias / affine vectors of a column tile are loaded once, and the BatchNorm statistics need 8 accumulator registers at a
+    // time instead of 8 * NT — with all NT tiles' sums live the EPI 1 variant of the 128 x 128 tile took 188 registers (two
+    // waves per SIMD) against 168 (three) of the plain one.
+    long long doff[MT];
+    bool rv[MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
-        if (!wdg_row_valid<BM>(ph, Mph, m)) continue;
-        if (p.splitk > 1) {
-            float* dst = p.partial + (((long long)phase_id * p.splitk + blockIdx.y) * p.Mmax + m) * NcP;
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
-                if (n < NcP) *reinterpret_cast<f32x4*>(dst + n) = acc[a][b];
+        rv[a] = wdg_row_valid<BM>(ph, Mph, m);
+        doff[a] = 0;
+        if (rv[a]) {
+            if (p.splitk > 1) {
+                doff[a] = (((long long)phase_id * p.splitk + blockIdx.y) * p.Mmax + m) * NcP;
+            } else {
+                int img, pa, pb;
+                wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
+                const int oh = pa * p.o_mul + ph.o_off_h;
+                const int ow = pb * p.o_mul + ph.o_off_w;
+                doff[a] = (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
             }
-        } else {
-            int img, pa, pb;
-            wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb);
-            const int oh = pa * p.o_mul + ph.o_off_h;
-            const int ow = pb * p.o_mul + ph.o_off_w;
-            float* dst = p.Out + (long long)img * p.imgStrideO + ((long long)oh * p.Wo + ow) * p.ldO;
+        }
+    }
+    float* red = reinterpret_cast<float*>(lds_all);          // EPI 1: [WGM][BN][2] (the K loop has ended behind a barrier, its stages are free)
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
-                if (n >= NcP) continue;
-                f32x4 v = acc[a][b];
-                if (p.bias) {
+    for (int b = 0; b < NT; ++b) {
+        const int n = n0 + wn * (BN / WGN) + b * 16 + q4;
+        if (n >= NcP) continue;
+        if (p.splitk > 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += n + r < p.Ncols ? p.bias[n + r] : 0.f;
+            for (int a = 0; a < MT; ++a)
+                if (rv[a]) *reinterpret_cast<f32x4*>(p.partial + doff[a] + n) = acc[a][b];
+            continue;
+        }
+        f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4 = bias4, sh4 = bias4;
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = n + r < p.Ncols ? p.bias[n + r] : 0.f;
+        }
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc4[r] = n + r < p.Ncols ? p.affine[n + r] : 1.f;
+                sh4[r] = n + r < p.Ncols ? p.affine[p.affine_ld + n + r] : 0.f;
+            }
+        }
+        f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            if (!rv[a]) continue;
+            float* dst = p.Out + doff[a] + n;
+            f32x4 v = acc[a][b] + bias4;
+            if (p.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
+            }
+            if constexpr (EPI == 1) {
+                // (pad channels Ncols..NcP-1 carry zeros: zero weights, no bias)
+                s1 += v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s2[r] = fmaf(v[r], v[r], s2[r]);
+            }
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], sc4[r], sh4[r]);
+            }
+            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;   // channels Ncols .. round4(Ncols)-1 receive zeros (padding)
+        }
+        if constexpr (EPI == 1) {
+            // per-channel partial sums of this block -> one replica slab.  Lanes that share lane >> 4 hold the same four
+            // channels of 16 different pixels: butterfly over lane & 15, then the WGM row-waves meet in LDS
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[r] = wdg_row16_sum(s1[r]);
+                s2[r] = wdg_row16_sum(s2[r]);
+            }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = wn * (BN / WGN) + b * 16 + q4 + r;
+                    red[(wm * BN + col) * 2 + 0] = s1[r];
+                    red[(wm * BN + col) * 2 + 1] = s2[r];
                 }
-                if (p.act) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
-                }
-                if constexpr (EPI == 1) {
-                    // (pad channels Ncols..NcP-1 carry zeros: zero weights, no bias)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        st1[b][r] += v[r];
-                        st2[b][r] = fmaf(v[r], v[r], st2[b][r]);
-                    }
-                }
-                if constexpr (EPI == 2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.Ncols) v[r] = fmaf(v[r], p.affine[n + r], p.affine[p.affine_ld + n + r]);
-                }
-                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst + n);
-                *reinterpret_cast<f32x4*>(dst + n) = v;   // channels Ncols .. round4(Ncols)-1 receive zeros (padding)
             }
         }
     }
     if constexpr (EPI == 1) {
-        // per-channel partial sums of this block -> one replica slab.  Lanes that share lane >> 4 hold the same four
-        // channels of 16 different pixels: butterfly over lane & 15, then the WGM row-waves meet in LDS (the K loop has
-        // ended behind a barrier, its stages are free), one fp64 atomic pair per channel and block.
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                st1[b][r] = wdg_row16_sum(st1[b][r]);
-                st2[b][r] = wdg_row16_sum(st2[b][r]);
-            }
-        float* red = reinterpret_cast<float*>(lds_all);          // [WGM][BN][2]
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int col = wn * (BN / WGN) + b * 16 + q4 + r;
-                    red[(wm * BN + col) * 2 + 0] = st1[b][r];
-                    red[(wm * BN + col) * 2 + 1] = st2[b][r];
-                }
-        }
+        if (p.splitk > 1) return;      // (never launched: the host keeps the statistics hook off split-K launches)
+        // column tiles past the padded channel count wrote nothing: their slots are not read below (n < Ncols)
         __syncthreads();
         double* slab = p.stats + (size_t)((blockIdx.x + blockIdx.z) % (unsigned)p.stats_rep) * 2 * p.stats_C;
         for (int c = t; c < BN; c += 256) {

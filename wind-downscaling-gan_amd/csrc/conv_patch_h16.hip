@@ -52,7 +52,7 @@ struct WdgPatchH16 {
     int CK8, nchunk, kcn;      // channel groups per chunk, chunks, K-steps per tap and chunk
     int flat, nent;            // flat: one chunk whose group count is not a multiple of 4 (24 or 40 channels) — the K-steps walk the
                                // flattened (tap, channel group) list, 4 entries each, instead of padding every tap to 4 groups
-    wdg_fastdiv div_kw;
+    wdg_fastdiv div_kw, div_kcn;
     int tiles_x, tiles_y, tiles_n, ntn_blk;   // tiles_n counts workgroups along the channels, each doing ntn_blk channel tiles
     wdg_fastdiv div_tn, div_tx, div_ty, div_ck, div_pw;
 };
@@ -65,12 +65,15 @@ struct WdgPatchH16 {
 #ifndef WDG_PATCH_HG
 #define WDG_PATCH_HG ((MT * NT <= 16) ? 2 : 1)
 #endif
+#ifndef WDG_PATCH_DEPTH
+#define WDG_PATCH_DEPTH ((LSTM == 2) ? 3 : 2)      // weight stages in flight (register sets): deep for the latency-bound recurrent step (LSTM == 2)
+#endif
 #if WDG_PATCH_LB2
 #define WDG_PATCH_BOUNDS __launch_bounds__(256, 2)
 #else
 #define WDG_PATCH_BOUNDS __launch_bounds__(256)
 #endif
-template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, bool LSTM = false>
+template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, int LSTM = 0>
 __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) {
     typedef wdg_h16x8<FMT> h16x8;
     constexpr int BN = 2 * NT * 16;
@@ -102,6 +105,8 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
 
     const wdg_srd srdA = wdg_make_srd(p.A + (long long)img * p.imgStrideA);
     const wdg_srd srdB = wdg_make_srd(p.B);
+    // (LSTM == 2) the weight tensor exactly: requests past its end return zeros by the hardware's range check, no select
+    const wdg_srd srdBx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.Ncols * p.ldB * 2, 0x00020000);
 
     // ---- per-lane fragment bases (LDS slots) and output pixels
     const int FW = 1 << p.fw_shift, FH = 16 >> p.fw_shift;
@@ -146,10 +151,33 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         b_slot[r] = bj * BN + (n ^ bj);
     }
 
+    // LSTM step: the epilogue's inputs (input part of the gates, previous cell state), requested in ONE batch
+    f32x4 gx[LSTM ? NT : 1][LSTM ? MT : 1];
+    float cp[LSTM ? NT : 1][LSTM ? MT : 1];
+    bool gx_loaded = false;
+    auto load_cell_inputs = [&]() {
+        if constexpr (LSTM) {
+            const int nw0_ = n0 + wn * (BN / 2);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = nw0_ + b * 16 + 4 * lq;
+                const int f = n >> 2;
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
+                    if constexpr (DBG & 64) { gx[b][a] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f}; cp[b][a] = 0.5f; continue; }
+                    const bool on = n < p.Ncols;
+                    gx[b][a] = on ? *reinterpret_cast<const f32x4*>(p.gates_x + pix * (4 * p.gate_F) + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    cp[b][a] = (on && p.c_prev) ? p.c_prev[pix * p.ldc + f] : 0.f;
+                }
+            }
+            gx_loaded = true;
+        }
+    };
     for (int ck = 0; ck < p.nchunk; ++ck) {
         __syncthreads();                             // every wave is done with the previous chunk's patch, weight stages and epilogue tiles
         // ---- patch chunk: global fp32 -> 16-bit -> LDS, PU slots (2 x 16-byte loads each) per thread in flight
-        constexpr int PU = (MT * NT >= 24) ? 8 : 10;   // (the 6 x 4 tile has no registers to spare)
+        constexpr int PU = (MT * NT >= 24) ? 8 : (WDG_PATCH_DEPTH > 2) ? 6 : 10;   // (the 6 x 4 tile has no registers to spare; nor a deep weight pipeline)
         for (int base = (!NLOOP || tni == 0) ? 0 : npatch; base < npatch; base += PU * 256) {
             f32x4 v[PU][2];
             int slot[PU];
@@ -174,20 +202,34 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         // ---- weight stages.  Stage st+2 is fetched into registers while stage st is computed from LDS and stage st+1
         // (fetched one iteration earlier) is written to the other LDS buffer behind the MFMAs: one barrier per stage, two
         // stages of load latency budget.  (tap, kc) counters: f* of the stage being fetched, c* of the one being computed.
+        // (requesting them HERE, in front of the weight stream, spills: 48 + 12 more live registers across the reduction loop
+        // put the 3 x 4 tile at 256 registers + 292 bytes of scratch; they are requested in one batch behind the loop instead)
         int f_kc = 0, f_kx = 0, f_ky = 0;
         int c_kc = 0, c_kx = 0, c_ky = 0;
-        u32x4 rb[2][B_LOADS];
+        constexpr int D = WDG_PATCH_DEPTH;
+        u32x4 rb[D][B_LOADS];
         auto advance = [&](int& kc, int& kx, int& ky) {
             if (++kc == p.kcn) {
                 kc = 0;
                 if (++kx == p.kw) { kx = 0; ++ky; }
             }
         };
+        int f_ks = 0, c_ks = 0;                       // D > 2: K-step counters of the branch-free forms
         auto fetch_stage = [&](u32x4 (&r_)[B_LOADS]) {
             // the two K-steps of the stage; this thread serves K-step bh, channel group bq
             bool kok;
             int koff;
-            if (p.flat) {
+            if constexpr (D > 2) {
+                // LSTM == 2: 3 x 3 taps, stride 1, ONE chunk of 16 channel groups (kcn = 4), whole column tiles — every shape
+                // parameter a constant, so a trip of the stage loop is straight-line code: no counters with carries, no
+                // flat / tap-major fork, no validity selects (the compiler turns those into exec-masked branches, and at every
+                // join its wait-count bookkeeping gives up the exact number of outstanding requests).  Requests past the last
+                // stage stay inside the buffer descriptor's range or read zeros; their stages are never multiplied.
+                const int ks = f_ks + bh;
+                f_ks += 2;
+                kok = true;
+                koff = (ks >> 2) * p.Cin_p + ((ks & 3) * 4 + bq) * 8;
+            } else if (p.flat) {
                 // (f_kc counts K-steps) entry j = (tap, group) = 4 * K-step + bq; the weights' reduction index of entry j is 8 * j
                 const int j = 4 * (f_kc + bh) + bq;
                 f_kc += 2;
@@ -203,6 +245,12 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 kok = ky < p.kh && g8 < p.CK8 && !(DBG & 1);
                 koff = (ky * p.kw + kx) * p.Cin_p + (ck * p.CK8 + g8) * 8;
             }
+            if constexpr (D > 2) {
+#pragma unroll
+                for (int r = 0; r < B_LOADS; ++r)
+                    r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdBx, (int)((unsigned)(b_row[r] + koff) << 1), 0, 0);
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < B_LOADS; ++r)
                 r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB, (kok && b_row[r] >= 0) ? (int)((unsigned)(b_row[r] + koff) << 1) : (int)WDG_SRD_OOB, 0, 0);
@@ -215,6 +263,12 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         // the slot offset of a K-step's tap and channel group for this lane (K-steps past the end: offset 0, their weights are zero;
         // lanes whose channel group is past the chunk read group 0 for the same reason)
         auto tap_offset = [&]() {
+            if constexpr (D > 2) {
+                const int ks = c_ks++;
+                const int tap = ks >> 2, g8 = (ks & 3) * 4 + lq;
+                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;            // tap / 3 for tap < 9
+                return ky * p.PWs + kx + g8 * p.pitch;
+            }
             if (p.flat) {
                 // this lane group's own (tap, channel group) entry; entries past the end read slot 0 (their weights are zero)
                 const int j = 4 * c_kc + lq;
@@ -248,6 +302,11 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
 #pragma unroll
                         for (int a = 0; a < MT; ++a) af[hh][a] = ldsP[fbase[a] + (h ? off1 : off0)];
                     }
+                    // every fragment read of the group stands BEFORE its first MFMA: left to itself the compiler sinks the pixel
+                    // fragments to their uses through one register quad (read, s_waitcnt lgkmcnt(0), four MFMAs, read, ...), six
+                    // exposed LDS round trips per stage with one wave per SIMD to hide them — the recurrent step spent ~0.9 us per
+                    // stage on 0.16 us of matrix work (profiles/r04l_step16_skeletons.txt, r04m_chain_floor.txt)
+                    __builtin_amdgcn_sched_barrier(0);
                 } else {
 #pragma unroll
                     for (int hh = 0; hh < HG; ++hh) {
@@ -274,21 +333,47 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 }
             }
         };
-        fetch_stage(rb[0]);
-        if (nstage > 1) fetch_stage(rb[1]);
-        store_stage(rb[0], 0);
-        __syncthreads();
+        // Weight pipeline, D register sets deep: stage s + D is requested while stage s is computed, and stage s + 1 — requested
+        // D - 1 compute stages ago — moves from its registers into the other LDS buffer behind the MFMAs; one barrier per stage.
+        // D = 2 (rounds 2-3) left ONE compute stage (~0.2 us of MFMAs at one or two waves per SIMD) between a request and its
+        // use against an L2 round trip of ~0.8 us: the stage loop of the recurrent step ran at the round trip, ~0.9 us per stage
+        // whatever the memory traffic (profiles/r04l_step16_skeletons.txt, r04m_chain_floor.txt)
         const bool bar = !(DBG & 32);
-        for (int st = 0; st < nstage; st += 2) {
-            if (st + 2 < nstage) fetch_stage(rb[0]);
-            compute_stage(0);
-            if (st + 1 < nstage) store_stage(rb[1], 1);
-            if (bar) __syncthreads();
-            if (st + 1 < nstage) {
-                if (st + 3 < nstage) fetch_stage(rb[1]);
-                compute_stage(1);
-                if (st + 2 < nstage) store_stage(rb[0], 0);
+        if constexpr (D == 2) {
+            fetch_stage(rb[0]);
+            if (nstage > 1) fetch_stage(rb[1]);
+            store_stage(rb[0], 0);
+            __syncthreads();
+            for (int st = 0; st < nstage; st += 2) {
+                if (st + 2 < nstage) fetch_stage(rb[0]);
+                compute_stage(0);
+                if (st + 1 < nstage) store_stage(rb[1], 1);
                 if (bar) __syncthreads();
+                if (st + 1 < nstage) {
+                    if (st + 3 < nstage) fetch_stage(rb[1]);
+                    compute_stage(1);
+                    if (st + 2 < nstage) store_stage(rb[0], 0);
+                    if (bar) __syncthreads();
+                }
+            }
+        } else {
+            // branch-free body, D stages per trip: with the requests behind `if`s the compiler's wait-count bookkeeping loses the
+            // exact number of outstanding loads at every join and waits for (nearly) all of them — including the requests it has
+            // just issued.  The stage count is rounded up to a multiple of D instead: requests past the end are out of range
+            // (zeros, no memory traffic), their stages multiply the patch's slot 0 by zero weights.
+            const int npad = (nstage + D - 1) / D * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) fetch_stage(rb[i]);
+            store_stage(rb[0], 0);
+            __syncthreads();
+            for (int st = 0; st < npad; st += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    fetch_stage(rb[u]);                                     // stage st + u + D (rb[u]'s stage st + u is in LDS already)
+                    compute_stage((st + u) & 1);
+                    store_stage(rb[(u + 1) % D], (st + u + 1) & 1);
+                    if (bar) __syncthreads();
+                }
             }
         }
     }
@@ -301,30 +386,26 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         // ConvLSTM2D cell (gan/models.py:45; Keras hard_sigmoid / tanh, gate order i, f, c, o) on the accumulators: register r of
         // a lane is gate r of feature (n >> 2) of its pixel.  z = recurrent conv + input part; c = f * c_prev + i * tanh(c~);
         // h = o * tanh(c).  Same arithmetic as wdg_lstm_fwd (pointwise.hip) behind an accumulating convolution.
+        // EVERY input of the wave's tiles (input part of the gates, previous cell state: MT * NT 16-byte + 4-byte loads) in one
+        // memory round trip, then the arithmetic and the stores.  Read per column tile, each tile's loads waited behind
+        // the previous tile's stores (possible aliases): NT dependent round trips — 12 of the step's 35 us on their own
+        // (profiles/r04m_chain_floor.txt: 14.7 us for a step without its K loop against 3.1 us without the epilogue's memory traffic)
+        if (!gx_loaded) load_cell_inputs();
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
             const int n = nw0 + b * 16 + 4 * lq;
             if (n >= p.Ncols) continue;
             const int f = n >> 2;
-            // all of this column tile's inputs first (one memory round trip), then the arithmetic and the stores: read one by
-            // one, every load waits behind the previous pixel's stores (possible aliases) — 12 exposed round trips per wave
-            f32x4 gx[MT];
-            float cp[MT];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
-                gx[a] = *reinterpret_cast<const f32x4*>(p.gates_x + pix * (4 * p.gate_F) + n);
-                cp[a] = p.c_prev ? p.c_prev[pix * p.ldc + f] : 0.f;
-            }
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
-                const f32x4 z = acc[a][b] + gx[a];
+                const f32x4 z = acc[a][b] + gx[b][a];
                 const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
                 const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
                 const float gc = wdg_tanh(z[2]);
                 const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
-                const float cn = gi * gc + gf * cp[a];
+                const float cn = gi * gc + gf * cp[b][a];
+                if constexpr (DBG & 16) { if (cn == 123.456f) p.c_out[pix * p.ldc + f] = cn; continue; }
                 p.c_out[pix * p.ldc + f] = cn;
                 outImg[(long long)opix[a] * p.ldO + f] = go * wdg_tanh(cn);
             }
@@ -440,7 +521,13 @@ static int patch_shapes(const WdgPatchView& g, WdgPatchCfg* c) {
 }
 
 static int g_patch_lstm_small = 1;       // the recurrent step on the smallest tile shape (tuning key patch_lstm_small)
-void wdg_patch_h16_set_lstm_small(int v) { g_patch_lstm_small = v != 0; }
+static int g_patch_lstm_deep = 1;        // recurrent step: the specialised deep-pipeline instantiation (patch_lstm_small value 4 clears, 8 sets)
+static int g_patch_lstm_bn = 0;          // recurrent step: channel tile forced to 64 / 128 (0 = the general rule); patch_lstm_small values >= 64
+void wdg_patch_h16_set_lstm_small(int v) {
+    if (v >= 64) g_patch_lstm_bn = v;
+    else if (v == 4 || v == 8) g_patch_lstm_deep = v == 8;
+    else { g_patch_lstm_small = (v & 1) != 0; if (v & 2) g_patch_lstm_bn = 0; }
+}
 // small_first: the candidate shapes from the smallest — the per-timestep recurrent convolution has few pixel tiles (48 of 8 x 24 on
 // the shipped 24 x 24 map x 16 tiles -> 384 workgroups, 1.5 per CU: half the CUs carry two); 4 x 24 gives every CU three
 static bool patch_plan(const WdgPatchView& g, WdgPatchH16& p, bool small_first = false) {
@@ -486,7 +573,7 @@ int wdg_patch_h16_eligible_t(const wdg_conv_plan* pl) {
     return patch_plan(patch_view(pl, true), p) ? 1 : 0;
 }
 
-template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, bool LSTM = false>
+template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, int LSTM = 0>
 static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_t st) {
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -533,7 +620,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     // 64-channel tiles when the map is small (the per-timestep recurrent convolution) or the layer is narrow
     const long long tiles_px = (long long)g.n_img * p.tiles_x * p.tiles_y;
     const bool narrow = g.Ncols <= 64 || tiles_px * ((g.Ncols + 127) / 128) < (long long)g.cus * 3 / 2;
-    const int BN = narrow ? 64 : 128;
+    const int BN = (lstm && g_patch_lstm_bn) ? g_patch_lstm_bn : narrow ? 64 : 128;
     p.tiles_n = (g.Ncols + BN - 1) / BN;
     p.ntn_blk = 1;
     if (g_patch_nloop && !lstm && p.nchunk == 1 && p.tiles_n > 1 && tiles_px >= 4LL * g.cus) { p.ntn_blk = p.tiles_n; p.tiles_n = 1; }
@@ -542,6 +629,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     p.div_ty = wdg_fastdiv_make((unsigned)p.tiles_y);
     p.div_ck = wdg_fastdiv_make((unsigned)p.CK8);
     p.div_kw = wdg_fastdiv_make((unsigned)g.kw);
+    p.div_kcn = wdg_fastdiv_make((unsigned)p.kcn);
     p.nent = g.kh * g.kw * p.CK8;
     p.flat = g_patch_flat && p.nchunk == 1 && (p.CK8 & 3) != 0 && p.Cin_p == p.CK8 * 8;
     p.div_pw = wdg_fastdiv_make((unsigned)p.PW);
@@ -554,10 +642,21 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     WDG_PATCH_DBG_CASE(1); WDG_PATCH_DBG_CASE(2); WDG_PATCH_DBG_CASE(4); WDG_PATCH_DBG_CASE(8); WDG_PATCH_DBG_CASE(12);
     WDG_PATCH_DBG_CASE(16); WDG_PATCH_DBG_CASE(32); WDG_PATCH_DBG_CASE(3); WDG_PATCH_DBG_CASE(15);
 #undef WDG_PATCH_DBG_CASE
+    // ... and of the recurrent step (bf16, 4 x 24 tiles, 128 channels per tile); bit 6: no gate / cell-state loads in the epilogue
+#define WDG_PATCH_DBG_LSTM(D) if (lstm && g_patch_dbg == D && fmt == 0 && MT == 3 && BN == 128) return patch_launch<0, 3, 4, false, D, 1>(p, (int)blocks, lds, st)
+    WDG_PATCH_DBG_LSTM(1); WDG_PATCH_DBG_LSTM(2); WDG_PATCH_DBG_LSTM(4); WDG_PATCH_DBG_LSTM(16); WDG_PATCH_DBG_LSTM(32); WDG_PATCH_DBG_LSTM(64);
+    WDG_PATCH_DBG_LSTM(3); WDG_PATCH_DBG_LSTM(80); WDG_PATCH_DBG_LSTM(83); WDG_PATCH_DBG_LSTM(87); WDG_PATCH_DBG_LSTM(119);
+#undef WDG_PATCH_DBG_LSTM
 #endif
+    // the recurrent step's deep-pipeline instantiation: 3 x 3, stride 1, one chunk of 16 channel groups, whole column tiles, and a
+    // stage count that is a multiple of its pipeline depth (18 stages, depth 3)
+    const bool lstm_deep = lstm && g_patch_lstm_deep && MT == 3 && BN == 128 && g.kh == 3 && g.kw == 3 && g.stride == 1 && p.CK8 == 16 &&
+                           p.nchunk == 1 && !p.flat && g.Ncols % BN == 0;
+    if (lstm_deep && fmt == 0) return patch_launch<0, 3, 4, false, 0, 2>(p, (int)blocks, lds, st);
+    if (lstm_deep && fmt == 1) return patch_launch<1, 3, 4, false, 0, 2>(p, (int)blocks, lds, st);
 #define WDG_PATCH_CASE(F, M, N)                                                                        \
     if (fmt == F && MT == M && BN == 32 * N)                                                           \
-        return lstm ? patch_launch<F, M, N, false, 0, true>(p, (int)blocks, lds, st)                  \
+        return lstm ? patch_launch<F, M, N, false, 0, 1>(p, (int)blocks, lds, st)                     \
                     : p.ntn_blk > 1 ? patch_launch<F, M, N, true>(p, (int)blocks, lds, st) : patch_launch<F, M, N, false>(p, (int)blocks, lds, st)
     WDG_PATCH_CASE(0, 4, 4); WDG_PATCH_CASE(0, 4, 2); WDG_PATCH_CASE(0, 6, 4); WDG_PATCH_CASE(0, 6, 2); WDG_PATCH_CASE(0, 3, 4); WDG_PATCH_CASE(0, 3, 2);
     WDG_PATCH_CASE(1, 4, 4); WDG_PATCH_CASE(1, 4, 2); WDG_PATCH_CASE(1, 6, 4); WDG_PATCH_CASE(1, 6, 2); WDG_PATCH_CASE(1, 3, 4); WDG_PATCH_CASE(1, 3, 2);

@@ -162,11 +162,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not _LIB_PATH.exists():
+    path = Path(os.environ["WDG_LIB"]) if os.environ.get("WDG_LIB") else _LIB_PATH     # (WDG_LIB: measurement builds of the same ABI)
+    if not path.exists():
         raise NativeError(
-            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C wind-downscaling-gan_amd/csrc`. The HIP library is required; there is no CPU path.")
-    lib = C.CDLL(os.fspath(_LIB_PATH))
+    lib = C.CDLL(os.fspath(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = symbol missing = broken build
         fn.restype = res
