@@ -110,8 +110,9 @@ __device__ __forceinline__ bool wdg_row_valid(const WdgPhase& ph, int Mph, int m
 // on its half with its own LDS stage, the second hands its accumulators to the first through LDS, the first owns the epilogue).
 // For launches with fewer tiles than CUs and a deep reduction whose epilogue needs the complete sums (the generator's recurrent
 // step at batch 8: 144 tiles of 128 x 128, K = 1152): twice the waves on the tile's MFMAs, no workspace, no second kernel.
+// (256 x 32 tile, default loop: 132 registers sat four above the four-waves-per-SIMD line — the bound makes the compiler fit 128)
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
-__global__ void __launch_bounds__(256 * KG) wdg_igemm_kernel(const WdgIgemm p) {
+__global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 && KG == 1) ? 4 : 1) wdg_igemm_kernel(const WdgIgemm p) {
     static_assert(KG == 1 || (KG == 2 && PIPE == 3 && (EPI == 0 || EPI == 4)), "in-workgroup split: rotated loop, barrier-free epilogues");
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;

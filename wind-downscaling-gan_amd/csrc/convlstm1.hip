@@ -184,8 +184,9 @@ constexpr int CLF_TH = 8, CLF_TW = 32;           // 256 pixels = 16 fragments pe
 // (conv(x, kernel) + bias, [pixel][i | f | c~ | o]) for the recurrent steps (convlstm16.hip) instead of running the cell — the
 // T-batched producer of a tensor of 64 floats per pixel (453 MB at batch 8, T = 24); the general kernels wrote it at 1.2-1.4 TB/s
 // (halo tile 395 us, implicit GEMM 324 us), padding the 45-row reduction to 72 / 80.
+// (launch bound: four persistent workgroups per CU are launched — at 132 registers only three were resident)
 template <int CIN, int F, bool PRE = false>
-__global__ void __launch_bounds__(256) wdg_convlstm1_fwd_mfma_kernel(const WdgCl1 p, const float* __restrict__ Wx,
+__global__ void __launch_bounds__(256, PRE ? 1 : 4) wdg_convlstm1_fwd_mfma_kernel(const WdgCl1 p, const float* __restrict__ Wx,
                                                                      const float* __restrict__ bias) {
     static_assert(F == 16, "one 16-feature MFMA tile per gate");
     constexpr int NG = PRE ? 4 : 3;

@@ -46,6 +46,7 @@ class Conv:
         self.b = store.add(bname, (cin if transposed else cout,), P.zeros_init)
         self.u = store.add(f"{name}/{prefix}/sn_u", (1, cout), P.sn_u_init, trainable=False) if sn else None
         self.pk = None
+        self.w.lazy_ok = not transposed          # (backward_weights below is this kernel gradient's only writer)
 
     def build(self):
         self.pk = self.ops.pack_weights(self.w.value)
@@ -79,10 +80,13 @@ class Conv:
             self.ops.conv_fwd_bf16(x, self.pk, self.b.value, y, self.g, act=self.act, affine=affine, slope=LRELU, fmt=fmt)
 
     def backward_weights(self, x, dpre):
+        # (a gradient slot left unfilled by ParamStore.zero_grad(lazy=True) is stored to, not accumulated into)
+        acc = not self.w.fresh
+        self.w.fresh = False
         if self.transposed:
-            self.ops.conv_wgrad(dpre, x, self.pk, self.w.grad, self.g, accumulate=True)
+            self.ops.conv_wgrad(dpre, x, self.pk, self.w.grad, self.g, accumulate=acc)
         else:
-            self.ops.conv_wgrad(x, dpre, self.pk, self.w.grad, self.g, accumulate=True)
+            self.ops.conv_wgrad(x, dpre, self.pk, self.w.grad, self.g, accumulate=acc)
 
     def backward_input(self, dpre, dx, accumulate=False):
         if self.transposed:

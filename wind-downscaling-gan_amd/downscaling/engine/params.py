@@ -19,7 +19,7 @@ class Var:
     update).  Used for the kernel of a layer that reads a channel concatenation whose second segment starts at a padded,
     16-byte aligned channel (GeneratorNet: feature_channels % 16 == 8)."""
     __slots__ = ("name", "shape", "tf_shape", "gap", "trainable", "init", "offset", "size", "tf_size", "value", "grad",
-                 "value_pad", "grad_pad")
+                 "value_pad", "grad_pad", "fresh", "lazy_ok")
 
     def __init__(self, name, shape, trainable, init, gap=None):
         self.name, self.tf_shape, self.trainable, self.init = name, tuple(shape), trainable, init
@@ -34,6 +34,8 @@ class Var:
         self.value = None
         self.grad = None
         self.value_pad = self.grad_pad = None    # flat views up to the 4-element alignment slot (zeros beyond `size`)
+        self.fresh = False                       # ParamStore.zero_grad(lazy=True): the gradient slot is UNDEFINED until first written
+        self.lazy_ok = False                     # ... only for variables whose gradient writer honours `fresh` (layers.Conv kernels)
 
 
 class ParamStore:
@@ -109,8 +111,40 @@ class ParamStore:
         self.seg_scale = self.ops.from_host(np.array([v.size / v.tf_size for v in train], dtype=np.float64)) if any(
             v.gap is not None for v in train) else None
 
-    def zero_grad(self):
-        self.grads.zero_()
+    LAZY_MIN = 1 << 18      # variables of >= 1 MiB take part in lazy zeroing
+
+    def zero_grad(self, lazy=False):
+        """grads <- 0.  lazy=True (the trainer's critic / generator updates, whose next backward pass writes every kernel
+        gradient): the big convolution kernels — 94 % of the discriminator's 34 MB — are not filled but marked `fresh`; the first
+        weight-gradient launch of such a variable then STORES instead of accumulating (layers.Conv.backward_weights), and
+        `settle()` zero-fills whatever is still fresh before anything reads the buffer as a whole."""
+        if not lazy:
+            self.grads.zero_()
+            for v in self.trainable:
+                v.fresh = False
+            return
+        if getattr(self, "_lazy_ranges", None) is None:
+            big = [v for v in self.trainable if v.lazy_ok and v.size >= self.LAZY_MIN]
+            ranges, pos = [], 0
+            for v in big:
+                if v.offset > pos:
+                    ranges.append((pos, v.offset))
+                pos = v.offset + (v.size + 3) // 4 * 4
+            if pos < self.n_train:
+                ranges.append((pos, self.n_train))
+            self._lazy_big, self._lazy_ranges = big, ranges
+        for a, b in self._lazy_ranges:
+            self.grads[a:b].zero_()
+        for v in self._lazy_big:
+            v.fresh = True
+
+    def settle(self):
+        """Zero-fills every gradient slot still marked fresh (a pass that did not form that weight gradient): call before the
+        flat gradient buffer is read as a whole (optimizer step, all-reduce, gradient-norm metric, sums of two networks)."""
+        for v in getattr(self, "_lazy_big", None) or ():
+            if v.fresh:
+                v.grad.zero_()
+                v.fresh = False
 
     def num_trainable(self):
         return sum(v.tf_size for v in self.trainable)

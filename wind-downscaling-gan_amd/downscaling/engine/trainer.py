@@ -27,6 +27,7 @@ class AdamTF:
         self.iterations += 1
         t = self.iterations
         lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        store.settle()
         ops.adam_tf(store.flat, store.grads, self.m, self.v, lr_t, self.beta_1, self.beta_2, self.epsilon, grad_scale)
         store.version += 1
 
@@ -145,6 +146,7 @@ class GanEngine:
         next critic iteration does not depend on the discriminator's weights (and the discriminator pass that opens the
         metrics recompute not on the generator's), so that compute hides the exchange."""
         scale = 1.0
+        net.params.settle()
         if self.sync is not None and self.sync.active:
             scale = 1.0 / self.sync.world_size
             finish = self.sync.all_reduce_sum_async(net.params.grads)
@@ -283,7 +285,7 @@ class GanEngine:
                     twin.params.flat.copy_(disc.params.flat)
                     twin.params.state.copy_(disc.params.state)
                     twin.params.version += 1
-                    twin.params.zero_grad()
+                    twin.params.zero_grad(lazy=True)
                     twin._prepare(True)                                           # W1 -> W2 (SN of the real pass)
                     w2_ready = torch.cuda.Event()
                     w2_ready.record(ds)
@@ -300,7 +302,7 @@ class GanEngine:
                 ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                     # :36
                 gnorm = torch.sqrt(gsq[:, :ch])
                 gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()           # :37
-                disc.params.zero_grad()
+                disc.params.zero_grad(lazy=True)
                 main.wait_event(w2_ready)
                 disc.params.flat.copy_(twin.params.flat)                          # W2 (the twin only reads it from here on)
                 disc.params.state.copy_(twin.params.state)
@@ -310,6 +312,8 @@ class GanEngine:
                 dscore.fill_(sw_mean / B)
                 disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
                 main.wait_stream(ds)
+                disc.params.settle()
+                twin.params.settle()
                 disc.params.grads.add_(twin.params.grads)
             else:
                 disc.set_high_tm(comb, B)
