@@ -885,6 +885,9 @@ struct WdgWgrad {
 // ds_read_b128/b64 per operand.  Pixel-row strides are chosen per read width so that the reads are
 // bank-conflict free (MI355X_MICROARCH.md, LDS: b128 -> stride = 0 mod 64 words, b64 -> 32 mod 64,
 // b32 -> 16 mod 32).  The fragments of pixel group s+1 are read before the MFMAs of group s.
+#ifndef WDG_WGRAD_LB
+#define WDG_WGRAD_LB 1
+#endif
 template <int W>
 struct WdgFrag {
     float v[W];
@@ -906,7 +909,7 @@ __device__ __forceinline__ WdgFrag<W> wdg_lds_frag(const float* q) {
 }
 
 template <int BN, int WGM, int WGN>
-__global__ void __launch_bounds__(256) wdg_wgrad_kernel(const WdgWgrad p) {
+__global__ void __launch_bounds__(256, WDG_WGRAD_LB) wdg_wgrad_kernel(const WdgWgrad p) {
     constexpr int BM = 128;
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;

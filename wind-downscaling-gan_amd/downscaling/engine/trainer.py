@@ -131,6 +131,7 @@ class GanEngine:
         # the discriminator's gradient-penalty pass beside its real pass on a twin network (WDG_OVERLAP_DISC=0 disables):
         # 69.0 -> 68.6 ms at the headline shape, +0.8 % at T = 24 (same-box A/B) — see _critic_pipelined
         self.overlap_discriminator = os.environ.get("WDG_OVERLAP_DISC", "1") != "0"
+        self.hoist_first_real_pass = os.environ.get("WDG_HOIST_REAL", "0") != "0"      # measured: 66.45 vs 66.25 ms with it (profiles/r04s_hoist.txt) - big kernels of two networks side by side gain nothing
         self._disc_stream = None
 
     def _buf(self, key, *shape):
@@ -243,10 +244,47 @@ class GanEngine:
         offs = [(noise.reserve(n_g), noise.reserve(B), noise.reserve(n_i), noise.reserve(n_i)) for _ in range(self.n_critic)]
         o_gstep = noise.reserve(n_g)                                              # the generator step's noise (:51) comes next
         nf = self._buf("noisy_fake", *noisy.shape)
-        if self._gen_stream is None:
+        if self._gen_stream is None or self._disc_stream is None:
             # (streams chosen by a measured concurrency probe: on distinct hardware queues whatever else holds pool streams)
             self._gen_stream, self._disc_stream = ops.concurrent_streams(2)
         gs, main = self._gen_stream, torch.cuda.current_stream(ops.device)
+        twin = disc.twin() if self.overlap_discriminator else None
+        ds = self._disc_stream
+
+        def start_real_pass(o_r):
+            """The three discriminator passes of an iteration on TWO networks (this one and its twin: own variables and
+            activations) and two streams.  What orders the passes in the reference is the spectral-norm chain of the weights —
+            pass k + 1 reads SN(weights of pass k) — not the passes' results: the real pass' weights are ready as soon as the
+            gradient-penalty pass' weights exist.  So: prepare W1 here; the twin takes a copy, prepares W2 = SN(W1) and runs
+            the real pass (forward + weights-only backward) on its own stream while the gradient-penalty pass (forward + input
+            gradient, W1) runs on the main stream; then this network takes W2 from the twin, prepares W3 and runs the generated
+            pass beside the tail of the real one.  The weight gradients of the two passes are summed before the optimizer
+            step (R + F, the same sum the single-network form accumulates)."""
+            self._flush(disc)
+            disc._prepare(True)                                                   # W0 -> W1 (SN of the gradient-penalty pass)
+            ds.wait_stream(main)
+            with torch.cuda.stream(ds):
+                twin.params.flat.copy_(disc.params.flat)
+                twin.params.state.copy_(disc.params.state)
+                twin.params.version += 1
+                twin.params.zero_grad(lazy=True)
+                twin._prepare(True)                                               # W1 -> W2 (SN of the real pass)
+                w2_ready = torch.cuda.Event()
+                w2_ready.record(ds)
+                noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
+                twin.set_high_tm(noisy, B)
+                real_mean = twin.forward(B, training=True, prepared=True).mean()                    # :41
+                real_mean.record_stream(main)                                     # (allocated on `ds`, consumed on the main stream)
+                dsc2 = self._buf("dscore2", B)
+                dsc2.fill_(-sw_mean / B)
+                twin.backward(B, dsc2, need_wgrad=True, need_input_grad=False)
+            return w2_ready, real_mean
+
+        # The real pass of iteration 0 needs neither fake_0 nor anything the generator writes: it starts BEFORE the first
+        # generator forward and runs under it (the only stretch of the critic loop that had one stream busy)
+        hoisted = None
+        if twin is not None and self.hoist_first_real_pass:
+            hoisted = start_real_pass(offs[0][2])
         noise.normal_at(nview, self.noise_std, offs[0][0])                        # :28
         fake = gen.forward(B, training=True, need_backward=False)                 # :29
         for i in range(self.n_critic):
@@ -265,37 +303,11 @@ class GanEngine:
                     gen.params.zero_grad()
                     noise.normal_at(nview, self.noise_std, o_gstep)
                     fake = gen.forward(B, training=True, need_backward=True)
-            self._flush(disc)
-            if self.overlap_discriminator:
-                # The three discriminator passes of an iteration on TWO networks (this one and its twin: own variables and
-                # activations) and two streams.  What orders the passes in the reference is the spectral-norm chain of the
-                # weights — pass k + 1 reads SN(weights of pass k) — not the passes' results: the real pass' weights are ready
-                # as soon as the gradient-penalty pass' weights exist.  So: prepare W1 here; the twin takes a copy, prepares
-                # W2 = SN(W1) and runs the real pass (forward + weights-only backward) on its own stream while the
-                # gradient-penalty pass (forward + input gradient, W1) runs here; then this network takes W2 from the twin,
-                # prepares W3 and runs the generated pass beside the tail of the real one.  The weight gradients of the two
-                # passes are summed before the optimizer step (R + F, the same sum the single-network form accumulates).
-                twin = disc.twin()
-                ds = self._disc_stream
-                if ds is None:
-                    ds = self._disc_stream = ops.concurrent_streams(2)[1]
-                disc._prepare(True)                                               # W0 -> W1 (SN of the gradient-penalty pass)
-                ds.wait_stream(main)
-                with torch.cuda.stream(ds):
-                    twin.params.flat.copy_(disc.params.flat)
-                    twin.params.state.copy_(disc.params.state)
-                    twin.params.version += 1
-                    twin.params.zero_grad(lazy=True)
-                    twin._prepare(True)                                           # W1 -> W2 (SN of the real pass)
-                    w2_ready = torch.cuda.Event()
-                    w2_ready.record(ds)
-                    noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
-                    twin.set_high_tm(noisy, B)
-                    real_mean = twin.forward(B, training=True, prepared=True).mean()                    # :41
-                    real_mean.record_stream(main)                                 # (allocated on `ds`, consumed on the main stream)
-                    dsc2 = self._buf("dscore2", B)
-                    dsc2.fill_(-sw_mean / B)
-                    twin.backward(B, dsc2, need_wgrad=True, need_input_grad=False)
+            if twin is not None:
+                if i == 0 and hoisted is not None:
+                    w2_ready, real_mean = hoisted
+                else:
+                    w2_ready, real_mean = start_real_pass(o_r)
                 disc.set_high_tm(comb, B)
                 disc.forward(B, training=True, prepared=True)                     # :32-34 (W1)
                 dcomb = disc.backward(B, ones, need_wgrad=False)                  # :35
@@ -316,6 +328,7 @@ class GanEngine:
                 twin.params.settle()
                 disc.params.grads.add_(twin.params.grads)
             else:
+                self._flush(disc)
                 disc.set_high_tm(comb, B)
                 disc.forward(B, training=True)                                    # :32-34
                 dcomb = disc.backward(B, ones, need_wgrad=False)                  # :35
