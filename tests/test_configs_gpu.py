@@ -122,10 +122,48 @@ def test_config2_rccl_collectives_single_rank():
     assert a["config"]["parallelism"] == "dp1+syncbn"
     assert a["rccl"]["backend"].startswith("nccl") and a["rccl"]["world_size"] == 1 and a["rccl"]["distinct_devices"] == 1
     assert a["rccl"]["devices"][0]["name"] and a["rccl"]["grad_allreduce_bytes_per_step"] > a["rccl"]["d_grad_allreduce_bytes"]
+    # the data-parallel step runs the headline's multi-stream schedule on streams placed by the probe (trainer.py, hipops.py)
+    assert a["stream_placement"]["concurrent_found"] == 2
     b = _torchrun_bench({}, 1, common)
     assert b["config"]["parallelism"] == "dp1"
     for k, v in b["losses"].items():
         assert abs(a["losses"][k] - v) <= 1e-4 * max(1.0, abs(v)), (k, a["losses"][k], v)
+
+
+def test_stream_placement_is_measured(hip_ops):
+    """HipOps.concurrent_streams: the trainer's generator / twin-discriminator streams are chosen by a concurrency probe, not
+    by pool order (HIP multiplexes streams onto a few hardware queues; an RCCL process group shifts the assignment and the
+    data-parallel step lost its overlap that way).  Independent check of what the probe returns: a spin on the main stream
+    and on both chosen streams at once must take about ONE spin time; and the one-rank RCCL bench above reports the same
+    placement record in its line."""
+    import os
+    if os.environ.get("GPU_MAX_HW_QUEUES", "4") in ("1", "2"):
+        pytest.skip("fewer than three hardware queues by configuration")
+    streams = hip_ops.concurrent_streams(2)
+    main = torch.cuda.current_stream(hip_ops.device)
+    assert len({s.cuda_stream for s in streams} | {main.cuda_stream}) == 3
+    assert hip_ops._cstreams_probe["concurrent_found"] == 2
+
+    def spin(group, cycles=400_000):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(main)
+        for s in group:
+            if s is not main:
+                s.wait_stream(main)
+        for s in group:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+        for s in group:
+            if s is not main:
+                main.wait_stream(s)
+        e1.record(main)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    spin([main])
+    one = min(spin([main]) for _ in range(3))
+    three = min(spin([main] + streams) for _ in range(3))
+    assert three < 1.6 * one, (one, three)               # (serialised on one queue it would be 3 x)
 
 
 def _reset_noise(network, seed):

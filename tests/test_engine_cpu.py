@@ -223,3 +223,36 @@ def test_encoder_forward_and_input_gradient(ops, S, T, latent):
     g = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
     (gref,) = torch.autograd.grad((ref * g).sum(), xr)
     assert rel_err(net.backward_input(g), gref) < 1e-9
+
+
+def test_lazy_zero_grad_equals_eager(ops, monkeypatch):
+    """ParamStore.zero_grad(lazy=True) (the trainer's critic updates): big convolution kernels are not zero-filled but
+    marked fresh, their first weight-gradient launch stores instead of accumulating, a second pass accumulates, and
+    settle() zero-fills what no pass wrote — the gradient buffer must equal the eagerly zeroed one in every case."""
+    from downscaling.engine.params import ParamStore
+    monkeypatch.setattr(ParamStore, "LAZY_MIN", 1)          # (every Conv kernel of the small test network takes part)
+    B, S, T, cl, ch = 2, 20, 1, 3, 2
+    net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=8, seed=4)
+    randomize(net, 12)
+    low, _, high = _inputs(B, T, S, cl, 1, ch, seed=1)
+    net.set_low(low)
+    high_tm = ops.zeros(T * B, S, S, 4)
+    net.to_time_major(high, high_tm)
+    net.set_high_tm(high_tm, B)
+    dscore = torch.randn(B, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+
+    def passes(lazy, n):
+        net.params.grads.fill_(123.0)                       # garbage a lazy zeroing must never let through
+        net.params.zero_grad(lazy=lazy)
+        assert any(v.fresh for v in net.params.trainable) == lazy
+        for _ in range(n):
+            net.forward(B, training=False)
+            net.backward(B, dscore.clone(), need_wgrad=True, need_input_grad=False)
+        net.params.settle()
+        assert not any(v.fresh for v in net.params.trainable)
+        return net.params.grads.clone()
+
+    for n in (0, 1, 2):      # 0: nothing written -> settle() zero-fills; 1: stored; 2: stored, then accumulated
+        eager, lazy = passes(False, n), passes(True, n)
+        assert float((eager - lazy).abs().max()) == 0.0, n
+    assert float(passes(True, 1).abs().max()) > 0.0

@@ -317,8 +317,27 @@ def predict_ensemble(tiles, draws, network=None, sync=None, precision=None, seed
     out = torch.zeros(draws, n, SEQUENCE_LENGTH, IMG_SIZE, IMG_SIZE, NB_OUTPUTS, dtype=ops.dtype, device=dev)
     group_size = BATCH_SIZE * 2
     kwargs = {} if precision is None else {'precision': precision}
+    # Few tiles, many realisations (configs[4]: 8 tiles x 64): a forward of 8 tiles is a chain of latency-bound launches (24
+    # recurrent steps, ~330 kernels), so several MEMBERS share one forward — batch slots [j n, (j + 1) n) hold the tiles with
+    # member j's noise (LazyMemberNoise: each member's own stream from offset 0, exactly as alone).  Every forward runs at the
+    # same batch size (a short last chunk repeats its last member), so a member's values depend neither on the other members
+    # of its launch nor on the number of ranks.
+    per = max(1, int(os.environ.get('WDG_ENSEMBLE_TILES', '64')) // n) if n <= group_size else 1
+    mine = list(range(rank, draws, world))
+    if per > 1 and mine:
+        from .data.data_generator import LazyMemberNoise
+        stacked = tiles.repeat(per, 1, 1, 1, 1)
+        with torch.no_grad():
+            for c0 in range(0, len(mine), per):
+                chunk = mine[c0:c0 + per]
+                members = [FlexibleNoiseGenerator(noise_gen.noise_shape, std=noise_gen.std, random_seed=seed, rank=m)
+                           for m in chunk + [chunk[-1]] * (per - len(chunk))]
+                y = gen([stacked, LazyMemberNoise(members, n, noise_gen.noise_shape, NOISE_CHANNELS, noise_gen.std)], **kwargs)
+                for j, m in enumerate(chunk):
+                    out[m] = y[j * n:(j + 1) * n]
+        mine = []
     with torch.no_grad():
-        for m in range(rank, draws, world):
+        for m in mine:
             member = FlexibleNoiseGenerator(noise_gen.noise_shape, std=noise_gen.std, random_seed=seed, rank=m)
             for g0 in range(0, n, group_size):
                 group = tiles[g0:g0 + group_size]

@@ -25,6 +25,29 @@ class LazyNoise(object):
         self.generator.prng.normal_into(view2d, self.std)
 
 
+class LazyMemberNoise(object):
+    """Pending draws of SEVERAL FlexibleNoiseGenerators for one forward pass of batch len(generators) * tiles: batch slots
+    [j * tiles, (j + 1) * tiles) take generator j's stream exactly as a forward of those `tiles` alone would — element order
+    (time, tile, x, y, channel) from Philox offset 0 — so a member's noise does not depend on which other members share its
+    launch (api.predict_ensemble batches ensemble members this way)."""
+
+    is_lazy_noise = True
+
+    def __init__(self, generators, tiles, noise_shape, channels, std):
+        self.generators, self.tiles, self.std = list(generators), int(tiles), std
+        self.shape = (len(self.generators) * self.tiles, noise_shape[1], noise_shape[2], noise_shape[3], channels)
+
+    def fill(self, view2d):
+        B, T, X, Y, C = self.shape
+        assert view2d.shape[0] == T * B * X * Y and view2d.shape[1] == C
+        rows = self.tiles * X * Y                       # one timestep of one member: a contiguous row block of the time-major view
+        assert (rows * C) % 4 == 0                      # whole Philox blocks per timestep
+        for j, g in enumerate(self.generators):
+            for t in range(T):
+                r0 = (t * B + j * self.tiles) * X * Y
+                g.prng.normal_at(view2d[r0:r0 + rows], self.std, t * (rows * C // 4))
+
+
 class FlexibleNoiseGenerator(object):
     def __init__(self, noise_shape, std=1, random_seed=None, rank=0):
         self.noise_shape = noise_shape

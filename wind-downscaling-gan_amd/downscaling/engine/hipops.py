@@ -225,12 +225,15 @@ class _PrepBatch:
 
 
 class _Fork:
-    def __init__(self, ops, name="side"):
+    def __init__(self, ops, name="side", stream=None):
         self.ops = ops
-        streams = ops.__dict__.setdefault("_side_streams", {})
-        if name not in streams:
-            streams[name] = torch.cuda.Stream(device=ops.device)
-        self.side = streams[name]
+        if stream is not None:
+            self.side = stream          # (a stream the caller placed: HipOps.concurrent_streams)
+        else:
+            streams = ops.__dict__.setdefault("_side_streams", {})
+            if name not in streams:
+                streams[name] = torch.cuda.Stream(device=ops.device)
+            self.side = streams[name]
         self.ctx = None
 
     def __enter__(self):
@@ -411,12 +414,12 @@ class HipOps:
         self._cstreams_probe = {"spin_ms": t1, "candidates_tried": tried, "concurrent_found": found}
         return chosen[:n]
 
-    def fork(self, name="side"):
+    def fork(self, name="side", stream=None):
         """Context manager: run the enclosed launches on the side stream `name` that starts after everything enqueued so far
         on the current stream; `join()` on the returned object makes the current stream wait for them.  Used for chains of
         small launches (the per-timestep recurrent kernels at T > 1) and for work off the critical path of a pass (the
-        weight gradients of a backward pass: name "wgrad")."""
-        return _Fork(self, name)
+        weight gradients of a backward pass: name "wgrad").  stream: run on THIS stream instead of the named pool stream."""
+        return _Fork(self, name, stream)
 
     def set_split_mode(self, on):
         self.split_mode = bool(on)

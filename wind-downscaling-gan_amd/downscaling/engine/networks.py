@@ -65,7 +65,7 @@ class _Net:
         if not self.wgrad_stream:
             fn()
             return
-        with self.ops.fork("wgrad") as side:
+        with self.ops.fork("wgrad", stream=getattr(self, "wgrad_side", None)) as side:
             fn()
         joins.append(side)
 

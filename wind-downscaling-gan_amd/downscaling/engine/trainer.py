@@ -433,6 +433,9 @@ class GanEngine:
                 disc.set_high_tm(real, B)
                 real_mean = disc.forward(B, training=False).mean()
                 real_mean.record_stream(main)
+        if pipelined and os.environ.get("WDG_WGRAD_STREAM_G", "0") == "1" and self._disc_stream is not None:
+            # A/B switch: the generator backward's weight gradients on the (idle here) twin-discriminator stream
+            gen.wgrad_stream, gen.wgrad_side = True, self._disc_stream
         gen.backward(B, dfake)
         gscale = self._reduce_and_step(gen, g_opt)
         if pipelined:
