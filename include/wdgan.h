@@ -459,6 +459,15 @@ int wdg_upconv_colgemm_h16_supported(const wdg_conv_plan* plan);   /* 1 when the
 int wdg_upconv_colgemm_h16(const wdg_conv_plan* plan, const float* x_low, const void* wD16, void* z16, int fmt, wdg_stream stream);
 int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias, const float* affine, float* y, int ldy, int64_t img_stride_y,
                           int n_img, int Hl, int Wl, int C, int act, float slope, wdg_stream stream);
+/* Both stages in ONE launch (inference precision; models.py:62-64 behind api.py:130-138): a workgroup stages the 12 x 12 window of
+ * x_low of its 8 x 8 low-resolution tile once (rounded to the operand format), forms the window's z slice per tap row on the
+ * 16-bit MFMA in LDS and runs the gather passes on it — the column tensor (400 floats per low-resolution pixel) never reaches
+ * memory.  x_low [n, Hl, Wl, ldx >= Cin] fp32; w16: the layer's weight tensor [25 * C][Cin] in the operand format (fmt 0 bf16,
+ * 1 fp16); y [n, 2 Hl, 2 Wl, ldy >= C] fp32 = affine(act(bias + ...)).  Supported: Cin 160, C 16 (the shipped generator). */
+int wdg_upconv_fused_h16_supported(int Cin, int C);
+int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
+                         const float* affine, float* y, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin, int C,
+                         int act, float slope, wdg_stream stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -175,6 +175,27 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
             }
         }
     };
+    // horizontal-pass operands of this thread (see the pass): slot offset inside a window row and coefficient, 0 * slot 0 outside
+    int hz[10];
+    float hc[10];
+    {
+        static_assert(256 % (2 * TS * CQ) == 0 || (2 * TS * CQ) % 256 == 0, "a thread's horizontal-pass outputs share (column, group)");
+        const int o4 = t % CQ, hq = (t / CQ) % (2 * TS);
+        const int gq = 2 * j0 + hq;
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+            const int sx = gq + 3 - tx;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int b = (sx & 1) + 2 * e;
+                const int rx = (sx - b) >> 1;
+                const int rxl = rx - (j0 - 2);
+                const bool on = (unsigned)rxl < (unsigned)ZW;
+                hz[2 * tx + e] = on ? rxl * PX + tx * CQ + o4 : 0;
+                hc[2 * tx + e] = on ? up_adj_coef(rx, b, Wl) : 0.f;
+            }
+        }
+    }
     load_slice(0);
     for (int ty = 0; ty < 5; ++ty) {
         // 1. window of z for this tap row (zeros outside the low-res image): staged from the registers that were
@@ -187,24 +208,18 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
             }
         __syncthreads();
         if (ty + 1 < 5) load_slice(ty + 1);
-        // 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
-        for (int i = t; i < ZW * 2 * TS * CQ; i += 256) {
-            const int o4 = i % CQ, hq = (i / CQ) % (2 * TS), ryl = i / (CQ * 2 * TS);
-            const int gq = 2 * j0 + hq;
-            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        // 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4].  A thread's outputs
+        // i = t + 256 k share the channel group and the output column (256 = 16 window rows' worth of (column, group) pairs), so its
+        // ten (window column, coefficient) pairs are tap-row- and row-independent: formed once per workgroup (hz / hc above)
+        if constexpr ((2 * TS * CQ) % 256 == 0 || 256 % (2 * TS * CQ) == 0) {
+            for (int i = t; i < ZW * 2 * TS * CQ; i += 256) {
+                const int ryl = i / (CQ * 2 * TS);
+                const f32x4* zr = Z + ryl * ZW * PX;
+                f32x4 h = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tx = 0; tx < 5; ++tx) {
-                const int sx = gq + 3 - tx;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int b = (sx & 1) + 2 * e;
-                    const int rx = (sx - b) >> 1;
-                    const int rxl = rx - (j0 - 2);
-                    if ((unsigned)rxl < (unsigned)ZW)
-                        h += up_adj_coef(rx, b, Wl) * Z[(ryl * ZW + rxl) * PX + tx * CQ + o4];
-                }
+                for (int j = 0; j < 10; ++j) h += hc[j] * zr[hz[j]];
+                Hs[(i / CQ) * HP + (i % CQ)] = h;
             }
-            Hs[(i / CQ) * HP + o4] = h;
         }
         __syncthreads();
         // 3. vertical pass: the two (ry, a) pairs of this tap row

@@ -275,6 +275,7 @@ class HipOps:
         self.upconv_col = True   # its backward in column form on the low-res grid
         self.z16 = os.environ.get("WDG_Z16", "0") == "1"   # 16-bit inference: the column GEMM's result z in the operand format
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
+        self.upconv_fused16 = os.environ.get("WDG_UPCONV_FUSED16", "1") != "0"   # 16-bit inference: column GEMM + gather in one launch
         self._scratch_bufs = {}
         # per-timestep launch chains (the ConvLSTM time loops at n_timesteps > 1) replayed from captured HIP graphs: see chain()
         self.gates_x = os.environ.get("WDG_GATES_X", "1") != "0"      # T > 1: the 5 -> 16 ConvLSTM's input convolution in its own kernel
@@ -650,6 +651,13 @@ class HipOps:
             # four values (16-tile group 3.78 -> 4.23 ms) and with 16-byte accesses of eight (lane-pair exchange in the GEMM's
             # epilogue, eight-value slots in the gather: 3.82 -> 3.97 ms) — neither kernel is bound by z's bytes: the 400-column
             # GEMM has a reduction of only 160 (five MFMA K-steps per 16 stores) and the gather is bound by its LDS passes
+            if self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk.cout, pk.cin) and ldl % 4 == 0:
+                # both stages in one launch, z never leaves the CU (csrc/upconv_fused_h16.hip): 0.48 + 0.54 ms -> one launch per
+                # 16-tile group of the shipped generator
+                native.check(self.lib.wdg_upconv_fused_h16(px, ldl, isl, pk.half(fmt)[1].data_ptr(), 0 if fmt == "bf16" else 1, _ptr(bias),
+                                                           _ptr(affine), py, ldy, isy, n, H // 2, W // 2, pk.cout, pk.cin, int(act), slope,
+                                                           self.stream), "upconv_fused_h16")
+                return
             plan16 = None
             if self.z16 and pk.cin % 8 == 0:
                 plan16, _, _ = self._plan_dims(n, H // 2, W // 2, 25 * pk.cin, 25 * pk.cin, (H // 2) * (W // 2) * 25 * pk.cin,
