@@ -97,6 +97,25 @@ def test_bf16_halo_kernels(fmt, hip_ops, ref_ops):
                             affine=aff.float().to(dev), fmt=fmt)
     assert rel_err(y_g2, y_r2) < 1e-4
     assert rel_err(y_g2, y_g) < 1e-2    # both are 16-bit approximations of the same layer
+    # the column form as ONE launch (csrc/upconv_fused_h16.hip, default for 160 -> 16) against its two-launch route: same rounding
+    # points, fp32 sums in another order; on a map smaller than a tile row / column multiple and with pixel strides beyond C
+    assert hip_ops.upconv_fused16 and hip_ops.lib.wdg_upconv_fused_h16_supported(160, 16)
+    xr = torch.randn(2, 13, 21, 160, generator=gen, dtype=torch.float64).float()
+    both = {}
+    for fused in (True, False):
+        hip_ops.upconv_fused16 = fused
+        try:
+            yb = hip_ops.zeros(2, 26, 42, 24)
+            hip_ops.upconv_fwd_bf16(xr.to(dev), pk_g, b.float().to(dev), yb, ConvGeom(5, 5, 1, 2), act=True,
+                                    affine=aff.float().to(dev), fmt=fmt)
+        finally:
+            hip_ops.upconv_fused16 = True
+        assert float(yb[..., 16:].abs().max()) == 0.0
+        both[fused] = yb
+    y_rr = torch.zeros(2, 26, 42, 16, dtype=torch.float64)
+    ref_ops.upconv_fwd_bf16(xr.double(), ref_ops.pack_weights(w), b, y_rr, RG(5, 5, 1, 2), act=True, affine=aff, fmt=fmt)
+    assert rel_err(both[True][..., :16], y_rr) < 1e-4 and rel_err(both[False][..., :16], y_rr) < 1e-4
+    assert rel_err(both[True], both[False]) < 1e-5
     # opt-in (WDG_Z16=1 / ops.z16): z itself stored in the 16-bit format.  The fp32 (HIP) and fp64 (oracle) sums can round to
     # different 16-bit neighbours: one 16-bit ulp of a few of the 100 terms of an output.  The 60 x 68 map above is outside the
     # patch kernel's tile shapes -> the switch must fall back to the fp32-z route bit-identically; 64 x 48 takes the 16-bit route

@@ -6,44 +6,66 @@
 // 2 r - 1 + (a, b) + t - 2 = p.  As two launches, z — 400 floats per low-resolution pixel, 1.4 GB for a 16-tile group of the
 // shipped generator — is written once and read once with a 2.25 x halo: both launches run at the memory system's rate
 // (0.48 + 0.54 ms of the group's 3.5 ms; the 16-bit MFMA work of the GEMM is ~0.1 ms).  A 16-bit z was tried twice in
-// round 3 and lost to its access granularity.  Here a workgroup owns an 8 x 8 low-resolution tile (16 x 16 output pixels):
-//   * the 12 x 12 window of x (K = 160 channels) is staged ONCE, rounded to the operand format, as [k-octet][pixel] 16-byte
-//     slots (pixel index XOR-swizzled by the octet: conflict-free staging stores and fragment reads);
+// round 3 and lost to its access granularity.  Here a PERSISTENT workgroup (one per CU: 135 KB of LDS; eight waves) walks over
+// 8 x 8 low-resolution tiles (16 x 16 output pixels); per tile
+//   * the 12 x 12 window of x (K = 160 channels) is loaded in one round trip of branch-free buffer loads and staged ONCE,
+//     rounded to the operand format, as [k-octet][pixel] 16-byte slots (pixel index XOR-swizzled by the octet: conflict-free
+//     staging stores and fragment reads); every wave then takes the pixel fragments it needs into registers for the whole tile
+//     (they do not depend on the tap row);
 //   * per tap row ty the weights' 80 x K slice streams into LDS (a straight copy of the layer's weight tensor viewed as
-//     [25 * C][K]), the 144 x 80 slice of z is formed by 45 MFMA tiles dealt round-robin to the four waves and written to the
-//     LDS window the gather passes of upconv_col.hip read (horizontal pass -> H, vertical pass -> the thread's output pixel);
+//     [25 * C][K], requested a tap row ahead), the 144 x 80 slice of z is formed by 45 MFMA tiles — six waves own 3 pixel tiles
+//     x 2 column tiles, two waves the fifth column tile — and written to the LDS window the gather passes of upconv_col.hip read
+//     (horizontal pass -> H, vertical pass -> the thread's output pixel);
 //   * bias, LeakyReLU and the inference BatchNorm affine in the epilogue, as in wdg_upconv_gather.
 // Same rounding points as the two-launch route (x and W rounded to nearest even, fp32 accumulation, fp32 z and interpolation);
 // the GEMM is computed on the window, i.e. 2.25 x the multiply-adds — at 16-bit MFMA rates that is cheaper than z's traffic.
+// Measured (16-tile group of the shipped generator, same box): 0.94 ms for the two launches, 0.83 ms fused (DESIGN 10.4 has the
+// steps: what decided it were registers — the compiler hoisted ~130 registers of thread-index arithmetic out of the tile loop
+// until that arithmetic was re-derived per iteration from an opaque value — and LDS operand re-reads, not HBM latency).
+// -DFV_PROF=1 / -DFV_SKIP=bits are measurement builds (tools/prof_fused.py).
 #include "common.h"
 #include "h16.h"
 #include <algorithm>
+#include <type_traits>
 
+#ifndef FV_SKIP
+#define FV_SKIP 0                     // measurement builds: 1 no MFMA phase, 2 no horizontal pass, 4 no vertical pass, 8 no window loads
+#endif
+#ifndef FV_PROF
+#define FV_PROF 0                     // measurement builds: per-phase shader-clock totals of workgroup 0 / wave 0 (wdg_fv_prof)
+#endif
+#if FV_PROF
+__device__ unsigned long long fv_prof[8];
+#define FV_MARK(k) do { const long long now_ = clock64(); pr[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define FV_MARK(k) do {} while (0)
+#endif
 namespace {
 constexpr int F_TS = 8;                      // tile edge on the low-res grid
 constexpr int F_ZW = F_TS + 4;               // window edge (12)
 constexpr int F_NPX = F_ZW * F_ZW;           // 144 window pixels = 9 MFMA pixel tiles
 constexpr int F_CQ = 4;                      // output channels / 4 (C = 16)
-constexpr int F_PX = 5 * F_CQ;               // float4 per window pixel and tap row
+constexpr int F_PX = 5 * F_CQ + 1;           // float4 pitch of a window pixel's tap-row slice of z (20 used; 21: the MFMA epilogue's
+                                             // 16 lanes of one register quad land in 16 different bank quads, at 20 only four)
 constexpr int F_HP = F_CQ + 1;               // H pixel pitch (see wdg_upconv_gather_kernel)
 constexpr int F_NCOL = 5 * 4 * F_CQ;         // 80 columns of z per tap row
 constexpr int F_NT = 512;                    // threads: 133 KB of LDS leave ONE workgroup per CU — eight waves (two per SIMD) give its phases
                                              // (staging, MFMA tiles, the two gather passes, four barriers per tap row) something to overlap with
 constexpr int F_NW = F_NT / 64;
+constexpr int F_SP = 24;                     // pixels / weight columns per staging pass
 
 __device__ __forceinline__ float f_coef(int r, int a, int Hl) {
-    const int q = 2 * r - 1 + a;
-    if ((unsigned)q >= (unsigned)(2 * Hl)) return 0.f;
+    const int q = 2 * r - 1 + a;                      // (selects, no early return: the callers sit in straight-line code)
     float c = (a == 0 || a == 3) ? 0.25f : 0.75f;
-    if (q == 0 || q == 2 * Hl - 1) c += 0.25f;
-    return c;
+    c += (q == 0 || q == 2 * Hl - 1) ? 0.25f : 0.f;
+    return (unsigned)q < (unsigned)(2 * Hl) ? c : 0.f;
 }
 
 template <int FMT, int K>
 __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float* __restrict__ x, int ldx, long long isx,
                                                                    const wdg_h16<FMT>* __restrict__ w16, const float* __restrict__ bias,
                                                                    const float* __restrict__ affine, float* __restrict__ y, int ldy,
-                                                                   long long isy, int Hl, int Wl, int act, float slope) {
+                                                                   long long isy, int Hl, int Wl, int tiles, int total, int act, float slope) {
     typedef wdg_h16x8<FMT> h16x8;
     static_assert(K % 32 == 0, "whole MFMA K-steps");
     constexpr int KO = K / 8, KS = K / 32;
@@ -53,182 +75,286 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
     f32x4* Z = reinterpret_cast<f32x4*>(Ws + KO * F_NCOL);            // [144][20]
     f32x4* Hs = Z + F_NPX * F_PX;                                     // [12 * 16][5]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
+    // Everything derived from the thread index is RE-derived at the top of each tile and each tap row from a value the compiler
+    // cannot see through: left alone it hoists ~130 registers of loop-invariant addresses out of the two loops (the blocks
+    // themselves use < 100), which is what stood between this kernel and keeping more operands in registers.
+    int t = threadIdx.x, li, lq, wave, s_oct, s_p0, s_wy0, s_wx, qyl, qxl, og0, h_hq;
+    bool s_on;
     const int tiles_x = (Wl + F_TS - 1) / F_TS;
-    const int i0 = (blockIdx.x / tiles_x) * F_TS, j0 = (blockIdx.x % tiles_x) * F_TS;
-    const long long n = blockIdx.y;
-    const float* ximg = x + n * isx;
     const wdg_srd srdW = wdg_make_srd(w16);
 
-    // ---- weights of tap row 0 requested first, then the window of x
-    constexpr int W_CH = KO * F_NCOL;                // 16-byte chunks of a tap row's weights
-    constexpr int W_LD = (W_CH + F_NT - 1) / F_NT;
+    // ---- staging geometry: F_SP = 24 pixels (or weight columns) x KO octets per pass over the first 480 threads — a thread keeps
+    // ONE octet and ONE window column, pass u moves it two window rows down (24 = 2 x 12): nothing per-slot to keep in registers
+    static_assert(KO * F_SP <= F_NT && F_NPX % F_SP == 0 && F_SP == 2 * F_ZW, "staging pattern");
+    constexpr int OQ = F_CQ * 256 / F_NT;            // channel groups per thread (the threads beyond 256 take the upper groups)
+    auto derive = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+v"(t));
+        li = t & 15, lq = (t >> 4) & 3, wave = t >> 6;
+        s_oct = t % KO, s_p0 = t / KO;               // (s_p0 < F_SP for the staging threads)
+        s_on = t < KO * F_SP;
+        s_wy0 = s_p0 / F_ZW, s_wx = s_p0 - s_wy0 * F_ZW;
+        qyl = (t & 255) >> 4, qxl = t & 15, og0 = (t >> 8) * OQ;      // this thread's output pixel within the 16 x 16 tile
+        h_hq = (t / F_CQ) % (2 * F_TS);              // its output column in the horizontal pass
+    };
+    derive();
+    // weights of a tap row: registers -> LDS one phase later
+    constexpr int W_LD = (F_NCOL + F_SP - 1) / F_SP;
     u32x4 wr[W_LD];
-    auto fetch_w = [&](int ty) {
+    auto fetch_w = [&](int ty) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
-            const int q = t + F_NT * i;
-            const int c = q / KO, oct = q - c * KO;
-            wr[i] = __builtin_amdgcn_raw_buffer_load_b128(srdW, q < W_CH ? (int)((((unsigned)(ty * F_NCOL + c) * K) + oct * 8) << 1) : (int)WDG_SRD_OOB, 0, 0);
+            const int c = s_p0 + F_SP * i;
+            const unsigned bad = (unsigned)((KO * F_SP - 1 - t) | (F_NCOL - 1 - c)) & 0x80000000u;   // (arithmetic, see fetch_x)
+            wr[i] = __builtin_amdgcn_raw_buffer_load_b128(srdW, (int)((((unsigned)(ty * F_NCOL + c) * K + s_oct * 8) << 1) | bad), 0, 0);
         }
     };
-    auto store_w = [&]() {
+    auto store_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
-            const int q = t + F_NT * i;
-            const int c = q / KO, oct = q - c * KO;
-            if (q < W_CH) Ws[oct * F_NCOL + (c ^ (oct & 7))] = __builtin_bit_cast(h16x8, wr[i]);
+            const int c = s_p0 + F_SP * i;
+            if (s_on && c < F_NCOL) Ws[s_oct * F_NCOL + (c ^ (s_oct & 7))] = __builtin_bit_cast(h16x8, wr[i]);
         }
     };
-    fetch_w(0);
-    constexpr int X_SL = KO * F_NPX;                 // slots of the window
-    constexpr int X_B = 12 * 256 / F_NT;                        // slots per thread and batch: the whole window in ONE round trip (133 KB of LDS
-                                                     // leave one workgroup per CU = one wave per SIMD: registers are not the limit)
-    for (int base = 0; base < X_SL; base += F_NT * X_B) {
-        f32x4 v[X_B][2];
-        int slot[X_B];
+    // window of x: the whole window in ONE round trip of X_B slots per thread
+    constexpr int X_B = F_NPX / F_SP;
+    f32x4 xv[X_B][2];
+    auto fetch_x = [&](int work) __attribute__((always_inline)) {
+        const int n = work / tiles, tile = work - n * tiles;
+        const int i0 = (tile / tiles_x) * F_TS, j0 = (tile % tiles_x) * F_TS;
+        const int gx = j0 - 2 + s_wx, gy0 = i0 - 2 + s_wy0;
+        // (descriptor per image; the padding gets bit 31 of its offset set ARITHMETICALLY — any of the range checks negative -> out
+        // of the descriptor's range -> zeros.  Loads under `if (inside)`, and `inside ? off : OOB` selects alike, come out as
+        // exec-masked blocks with an s_waitcnt each; this way the twelve loads are in flight together)
+        const wdg_srd srdX = wdg_make_srd(x + (long long)n * isx);
+        const int colbad = gx | (Wl - 1 - gx) | (KO * F_SP - 1 - t);
+        const int off0 = ((gy0 * Wl + gx) * ldx + s_oct * 8) * 4, rs = 2 * Wl * ldx * 4;
 #pragma unroll
         for (int u = 0; u < X_B; ++u) {
-            const int s = base + u * F_NT + t;
-            const int pix = s / KO, oct = s - pix * KO;          // consecutive lanes: consecutive octets of one pixel (contiguous bytes)
-            const int wy = pix / F_ZW, wx = pix - wy * F_ZW;
-            const int gy = i0 - 2 + wy, gx = j0 - 2 + wx;
-            const bool ok = s < X_SL && (unsigned)gy < (unsigned)Hl && (unsigned)gx < (unsigned)Wl;
-            v[u][0] = v[u][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const float* src = ximg + ((long long)gy * Wl + gx) * ldx + oct * 8;
-                v[u][0] = *reinterpret_cast<const f32x4*>(src);
-                v[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
-            }
-            slot[u] = s < X_SL ? oct * F_NPX + (pix ^ (oct & 7)) : -1;
+            const int gy = gy0 + 2 * u;
+            const unsigned off = (unsigned)(off0 + u * rs) | ((unsigned)(colbad | gy | (Hl - 1 - gy)) & 0x80000000u);
+            xv[u][0] = wdg_buffer_load_f32x4(srdX, off);
+            xv[u][1] = wdg_buffer_load_f32x4(srdX, off + 16);
         }
+    };
+    auto store_x = [&]() __attribute__((always_inline)) {
+        if (s_on) {
 #pragma unroll
-        for (int u = 0; u < X_B; ++u)
-            if (slot[u] >= 0) Xs[slot[u]] = wdg_pack_h16<FMT>(v[u][0], v[u][1]);
-    }
-
-    // horizontal-pass operands of this thread: its outputs i = t + 256 k share channel group and output column, so the ten
-    // (window column, coefficient) pairs do not depend on the tap row or the window row
-    int hz[10];
-    float hc[10];
-    {
-        const int o4 = t % F_CQ, hq = (t / F_CQ) % (2 * F_TS);
-        const int gq = 2 * j0 + hq;
+            for (int u = 0; u < X_B; ++u) Xs[s_oct * F_NPX + ((s_p0 + F_SP * u) ^ (s_oct & 7))] = wdg_pack_h16<FMT>(xv[u][0], xv[u][1]);
+        }
+    };
+    static_assert(F_NW == 8 && F_NPX == 9 * 16, "3 groups of 3 pixel tiles x (2 + 2 + 1) column tiles over 6 + 2 waves");
+    h16x8 bfr[5][KS];                                // the fragments of this wave's three (waves 0..5) or five (6, 7) pixel tiles, loaded once per tile
+#if FV_PROF
+    long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
+    int work = blockIdx.x;
+    if (work >= total) return;
+    fetch_w(0);
+    for (; work < total; work += gridDim.x) {
+        const int n = work / tiles, tile = work - n * tiles;
+        const int i0 = (tile / tiles_x) * F_TS, j0 = (tile % tiles_x) * F_TS;
+        const int next = work + gridDim.x;
+        derive();
+        // (the window is requested where it is needed: requesting it a tile ahead — 48 registers across the whole tile — was
+        // measured neutral: the kernel's phases are latency chains between barriers, not this round trip)
+        if (!(FV_SKIP & 8)) fetch_x(work);
+        store_x();                                   // (Xs is free: the previous tile's last MFMA phase ended behind a barrier)
+        // horizontal-pass coefficients of this thread for this tile.  Its outputs i = t + F_NT k share channel group and output
+        // column hq; tap column tx reads upsampled column q = 2 j0 + hq + 2 - tx, i.e. low-res columns rx = (q + 1 - b) / 2 for
+        // the two b of q's parity, window column rx - (j0 - 2) (hz below: independent of the tile); the image border doubles /
+        // drops taps
+        float hc[10];
 #pragma unroll
         for (int tx = 0; tx < 5; ++tx) {
-            const int sx = gq + 3 - tx;
+            const int sx = h_hq + 3 - tx, q = 2 * j0 + sx - 1;
+            const float edge = (q == 0 || q == 2 * Wl - 1) ? 0.25f : 0.f;
+            const bool in = (unsigned)q < (unsigned)(2 * Wl);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int b = (sx & 1) + 2 * e;
-                const int rx = (sx - b) >> 1;
-                const int rxl = rx - (j0 - 2);
-                const bool on = (unsigned)rxl < (unsigned)F_ZW;
-                hz[2 * tx + e] = on ? rxl * F_PX + tx * F_CQ + o4 : 0;
-                hc[2 * tx + e] = on ? f_coef(rx, b, Wl) : 0.f;
+                const bool on = (unsigned)(((sx - b) >> 1) + 2) < (unsigned)F_ZW;
+                hc[2 * tx + e] = in && on ? ((b == 0 || b == 3) ? 0.25f : 0.75f) + edge : 0.f;
             }
         }
-    }
-    // this thread's output pixel within the 16 x 16 tile
-    constexpr int OQ = F_CQ * 256 / F_NT;            // channel groups per thread (the threads beyond 256 take the upper groups)
-    const int tp = t & 255, og0 = (t >> 8) * OQ;
-    const int qyl = tp >> 4, qxl = tp & 15;
-    const int qy = 2 * i0 + qyl, qx = 2 * j0 + qxl;
-    f32x4 acc[OQ];
+        FV_MARK(0);                                  // tile prologue: window load + staging, coefficients
+        const int qy = 2 * i0 + qyl, qx = 2 * j0 + qxl;
+        f32x4 acc[OQ];
 #pragma unroll
-    for (int o4 = 0; o4 < OQ; ++o4) acc[o4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int o4 = 0; o4 < OQ; ++o4) acc[o4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int ty = 0; ty < 5; ++ty) {
-        store_w();                                   // (Ws is free: the previous tap row's MFMA phase ended behind a barrier)
-        __syncthreads();
-        if (ty + 1 < 5) fetch_w(ty + 1);
-        // ---- 1. z slice of this tap row: 9 pixel tiles x 5 column tiles (= tx), dealt round-robin to the waves
-        // (two tiles at a time: their five-MFMA chains are independent, one hides the other's dependent-accumulator latency)
-#pragma unroll
-        for (int i = 0; i < (45 + F_NW - 1) / F_NW + 1; i += 2) {
-            const int id0 = wave + F_NW * i, id1 = id0 + F_NW;
-            if (id0 < 45) {
-                const int pt0 = id0 / 5, ct0 = id0 - pt0 * 5;
-                const bool two = id1 < 45;
-                const int pt1 = two ? id1 / 5 : pt0, ct1 = two ? id1 - (id1 / 5) * 5 : ct0;
-                f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
-                h16x8 a0[KS], b0[KS], a1[KS], b1[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int oct = ks * 4 + lq;
-                    a0[ks] = Ws[oct * F_NCOL + ((ct0 * 16 + li) ^ (oct & 7))];
-                    b0[ks] = Xs[oct * F_NPX + ((pt0 * 16 + li) ^ (oct & 7))];
-                    a1[ks] = Ws[oct * F_NCOL + ((ct1 * 16 + li) ^ (oct & 7))];
-                    b1[ks] = Xs[oct * F_NPX + ((pt1 * 16 + li) ^ (oct & 7))];
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    c0 = wdg_mfma16<FMT>(a0[ks], b0[ks], c0);
-                    c1 = wdg_mfma16<FMT>(a1[ks], b1[ks], c1);
-                }
+#pragma unroll 1
+        for (int ty = 0; ty < 5; ++ty) {
+            derive();
+            store_w();                               // (Ws is free: the previous tap row's MFMA phase ended behind a barrier)
+            FV_MARK(1);                              // weights: wait + staging
+            __syncthreads();
+            FV_MARK(2);                              // barrier A
+            if (ty + 1 < 5) fetch_w(ty + 1);         // (the next tap row's weights travel during this one's three phases)
+            else if (next < total) fetch_w(0);
+            // ---- 1. z slice of this tap row: 9 pixel tiles x 5 column tiles (= tx).  The kernel is LDS-bandwidth bound (operand
+            // fragment reads were 2.3 of its 3.3 MB of LDS traffic per tile), so the tiles are blocked for register reuse: waves
+            // 0..5 own THREE pixel tiles (group g = wave % 3) x TWO column tiles (pair wave / 3) and keep the pixel fragments —
+            // which do not depend on the tap row — in registers for the whole tile: per tap row they read two column tiles'
+            // weights for six MFMA tiles.  The fifth column tile goes to waves 6 (pixel tiles 0..4) and 7 (5..8), organised the same
+            // way.  Per tap row 14 fragment sets are read instead of 90, and every wave's phase is one read - MFMA - store sequence.
+            // fragment of k-step ks: octet 4 ks + lq, swizzle (4 ks + lq) & 7 = lq (even ks) or lq + 4 (odd ks)
+            auto xfrag = [&](int pt, int ks) __attribute__((always_inline)) {
+                return Xs[(ks * 4 + lq) * F_NPX + ((pt * 16 + li) ^ ((ks & 1) * 4 + lq))];
+            };
+            auto wfrag = [&](int ct, int ks) __attribute__((always_inline)) {
+                return Ws[(ks * 4 + lq) * F_NCOL + ((ct * 16 + li) ^ ((ks & 1) * 4 + lq))];
+            };
+            auto zstore = [&](int pt, int ct, f32x4 c) __attribute__((always_inline)) {
                 // register r of lane (li, lq): column ct * 16 + 4 lq + r (= output channel 4 lq + r of tap column tx = ct) of pixel li
-                Z[(pt0 * 16 + li) * F_PX + ct0 * F_CQ + lq] = c0;
-                if (two) Z[(pt1 * 16 + li) * F_PX + ct1 * F_CQ + lq] = c1;
-            }
-        }
-        __syncthreads();
-        // ---- 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
-        for (int i = t; i < F_ZW * 2 * F_TS * F_CQ; i += F_NT) {
-            const f32x4* zr = Z + (i / (F_CQ * 2 * F_TS)) * F_ZW * F_PX;
-            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                Z[(pt * 16 + li) * F_PX + ct * F_CQ + lq] = c;
+            };
+            if (!(FV_SKIP & 1)) {
+                if (wave < 6) {
+                    const int g = wave % 3, ct0 = 2 * (wave / 3);
+                    if (ty == 0) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) h += hc[j] * zr[hz[j]];
-            Hs[(i / F_CQ) * F_HP + (i % F_CQ)] = h;
-        }
-        __syncthreads();
-        // ---- 3. vertical pass: the two (ry, a) pairs of this tap row
-        {
-            const int sy = qy + 3 - ty;
+                        for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int a = (sy & 1) + 2 * e;
-                const int ry = (sy - a) >> 1;
-                const int ryl = ry - (i0 - 2);
-                if ((unsigned)ryl < (unsigned)F_ZW) {
-                    const float c = f_coef(ry, a, Hl);
+                            for (int ks = 0; ks < KS; ++ks) bfr[j][ks] = xfrag(3 * g + j, ks);
+                    }
+                    f32x4 c[2][3];
 #pragma unroll
-                    for (int o4 = 0; o4 < OQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * F_TS + qxl) * F_HP + og0 + o4];
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) c[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    h16x8 a[2][KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) a[0][ks] = wfrag(ct0, ks), a[1][ks] = wfrag(ct0 + 1, ks);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) c[i][j] = wdg_mfma16<FMT>(a[i][ks], bfr[j][ks], c[i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) zstore(3 * g + j, ct0 + i, c[i][j]);
+                } else {
+                    // fifth column tile: wave 6 pixel tiles 0..4, wave 7 pixel tiles 5..8 (five accumulators; wave 7's fifth is idle)
+                    const int p0 = wave == 6 ? 0 : 5;
+                    if (ty == 0) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j)
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) bfr[j][ks] = xfrag(p0 + j < 9 ? p0 + j : 8, ks);
+                    }
+                    h16x8 a[KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) a[ks] = wfrag(4, ks);
+                    f32x4 c[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) c[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) c[j] = wdg_mfma16<FMT>(a[ks], bfr[j][ks], c[j]);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                        if (p0 + j < 9) zstore(p0 + j, 4, c[j]);
                 }
             }
-        }
-        __syncthreads();
-    }
-    if (qy < 2 * Hl && qx < 2 * Wl) {
-        float* dst = y + n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+            FV_MARK(3);                              // MFMA phase of this wave
+            __syncthreads();
+            FV_MARK(4);                              // barrier B (= the slowest wave's MFMA phase)
+            // ---- 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
+            int hz[10];
 #pragma unroll
-        for (int o = 0; o < OQ; ++o) {
-            const int o4 = og0 + o;
-            f32x4 v = acc[o];
-            if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
-            if (act) {
+            for (int tx = 0; tx < 5; ++tx) {
+                const int sx = h_hq + 3 - tx;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
+                for (int e = 0; e < 2; ++e) {
+                    const int rxl = ((sx - (sx & 1) - 2 * e) >> 1) + 2;
+                    hz[2 * tx + e] = (unsigned)rxl < (unsigned)F_ZW ? rxl * F_PX + tx * F_CQ + (t % F_CQ) : 0;
+                }
             }
-            if (affine) v = v * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * F_CQ + 4 * o4);
-            *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
+            for (int i = t; i < ((FV_SKIP & 2) ? 0 : F_ZW * 2 * F_TS * F_CQ); i += F_NT) {
+                const f32x4* zr = Z + (i / (F_CQ * 2 * F_TS)) * F_ZW * F_PX;
+                f32x4 h = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 10; ++j) h += hc[j] * zr[hz[j]];
+                Hs[(i / F_CQ) * F_HP + (i % F_CQ)] = h;
+            }
+            __syncthreads();
+            FV_MARK(5);                              // horizontal pass + barrier C
+            // ---- 3. vertical pass: the two (ry, a) pairs of this tap row
+            {
+                const int sy = qy + 3 - ty;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int a = (sy & 1) + 2 * e;
+                    const int ry = (sy - a) >> 1;
+                    const int ryl = ry - (i0 - 2);
+                    if (!(FV_SKIP & 4) && (unsigned)ryl < (unsigned)F_ZW) {
+                        const float c = f_coef(ry, a, Hl);
+#pragma unroll
+                        for (int o4 = 0; o4 < OQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * F_TS + qxl) * F_HP + og0 + o4];
+                    }
+                }
+            }
+            FV_MARK(6);                              // vertical pass
+            // (no barrier: the next phase to write Hs is two barriers away, the next to write Z one — and Z's writers wait for
+            // Ws behind the barrier that follows store_w)
         }
+        if (qy < 2 * Hl && qx < 2 * Wl) {
+            float* dst = y + (long long)n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+#pragma unroll
+            for (int o = 0; o < OQ; ++o) {
+                const int o4 = og0 + o;
+                f32x4 v = acc[o];
+                if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
+                if (act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
+                }
+                if (affine) v = v * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * F_CQ + 4 * o4);
+                *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
+            }
+        }
+        FV_MARK(7);                                  // epilogue
     }
+#if FV_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 8; ++k) fv_prof[k] = pr[k];
+#endif
 }
 
 template <int FMT, int K>
-int fused_launch(dim3 grid, size_t lds, hipStream_t st, const float* x, int ldx, long long isx, const void* w16, const float* bias,
-                 const float* affine, float* y, int ldy, long long isy, int Hl, int Wl, int act, float slope) {
+int fused_launch(int grid, size_t lds, hipStream_t st, const float* x, int ldx, long long isx, const void* w16, const float* bias,
+                 const float* affine, float* y, int ldy, long long isy, int Hl, int Wl, int tiles, int total, int act, float slope) {
     static bool attr = false;
     if (!attr) {
         WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_upconv_fused_h16_kernel<FMT, K>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((wdg_upconv_fused_h16_kernel<FMT, K>), grid, dim3(F_NT), lds, st, x, ldx, isx,
-                       reinterpret_cast<const wdg_h16<FMT>*>(w16), bias, affine, y, ldy, isy, Hl, Wl, act, slope);
+    hipLaunchKernelGGL((wdg_upconv_fused_h16_kernel<FMT, K>), dim3(grid), dim3(F_NT), lds, st, x, ldx, isx,
+                       reinterpret_cast<const wdg_h16<FMT>*>(w16), bias, affine, y, ldy, isy, Hl, Wl, tiles, total, act, slope);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+int fused_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
 }  // namespace
+
+#if FV_PROF
+extern "C" int wdg_fv_prof(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fv_prof), sizeof(fv_prof)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int wdg_upconv_fused_h16_supported(int Cin, int C) { return C == 16 && Cin == 160; }
 
@@ -244,8 +370,13 @@ extern "C" int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_str
                   ((uintptr_t)affine & 15) == 0, "x / w / y / bias / affine must be 16-byte aligned");
     constexpr int K = 160;
     const size_t lds = (size_t)(K / 8) * (F_NPX + F_NCOL) * 16 + (size_t)(F_NPX * F_PX + F_ZW * 2 * F_TS * F_HP) * 16;
-    dim3 grid(((Hl + F_TS - 1) / F_TS) * ((Wl + F_TS - 1) / F_TS), n_img);
+    const int tiles = ((Hl + F_TS - 1) / F_TS) * ((Wl + F_TS - 1) / F_TS);
+    WDG_CHECK_ARG((long long)tiles * n_img < (1ll << 31), "too many tiles");
+    WDG_CHECK_ARG((long long)Hl * Wl * ldx * 4 < (1ll << 31), "an image must stay below 2 GiB (buffer descriptor per image)");
+    const int total = tiles * n_img;
+    const int grid = std::min(total, fused_cus());  // persistent: one workgroup per CU (LDS), each prefetching its next tile's window
     hipStream_t st = (hipStream_t)stream;
-    if (fmt == 0) return fused_launch<0, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, act, slope);
-    return fused_launch<1, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, act, slope);
+    if (fmt == 0)
+        return fused_launch<0, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope);
+    return fused_launch<1, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope);
 }
