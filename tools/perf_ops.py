@@ -83,7 +83,9 @@ def build_cases(ops, want):
         bias, gamma, beta = rnd(16), rnd(16), rnd(16)
         mr = torch.empty(B * 65536, 2, device=dev)
         g = ConvGeom(3, 3, 1, 1)
-        cases["halo16_fwd_lncat"] = (lambda: ops.conv_fwd_ln(x, pk, bias, y, cat[..., 16:], g, gamma, beta, 1e-3, mr), 2.0 * B * 65536 * 16 * 16 * 9)
+        # (default arguments: the names are rebound by the blocks below)
+        cases["halo16_fwd_lncat"] = (lambda x=x, pk=pk, bias=bias, y=y, cat=cat, g=g, gamma=gamma, beta=beta, mr=mr:
+                                     ops.conv_fwd_ln(x, pk, bias, y, cat[..., 16:], g, gamma, beta, 1e-3, mr), 2.0 * B * 65536 * 16 * 16 * 9)
     if need("g11"):
         conv_case("g11", B, 256, 16, 2, 3, 1, 1)
     if need("lstm"):
@@ -107,9 +109,10 @@ def build_cases(ops, want):
         w, bias, gamma, beta = rnd(3, 3, 2, 16, scale=0.3).contiguous(), rnd(16), rnd(16), rnd(16)
         dgm, dbt, dbi, dw = torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.zeros_like(w)
         fl = 2.0 * B * 65536 * 9 * 2 * 16
-        cases["convln_fwd"] = (lambda: ops.convln_fwd(x, w, bias, gamma, beta, 1e-3, 0.2, None, z[..., :16], None), fl)
-        cases["convln_bwd_x"] = (lambda: ops.convln_bwd_x(dz[..., :16], x, w, bias, gamma, 1e-3, 0.2, dx, None, None, None, None), 2 * fl)
-        cases["convln_bwd_xw"] = (lambda: ops.convln_bwd_x(dz[..., :16], x, w, bias, gamma, 1e-3, 0.2, dx, dgm, dbt, dbi, dw), 3 * fl)
+        cases["convln_fwd"] = (lambda x=x, w=w, bias=bias, gamma=gamma, beta=beta, z=z: ops.convln_fwd(x, w, bias, gamma, beta, 1e-3, 0.2, None, z[..., :16], None), fl)
+        cases["convln_bwd_x"] = (lambda x=x, w=w, bias=bias, gamma=gamma, dz=dz, dx=dx: ops.convln_bwd_x(dz[..., :16], x, w, bias, gamma, 1e-3, 0.2, dx, None, None, None, None), 2 * fl)
+        cases["convln_bwd_xw"] = (lambda x=x, w=w, bias=bias, gamma=gamma, dz=dz, dx=dx, dgm=dgm, dbt=dbt, dbi=dbi, dw=dw:
+                                  ops.convln_bwd_x(dz[..., :16], x, w, bias, gamma, 1e-3, 0.2, dx, dgm, dbt, dbi, dw), 3 * fl)
     if need("upconv"):
         xl = rnd(B, 128, 128, 160)
         w = rnd(5, 5, 16, 160, scale=0.05).contiguous()
@@ -120,10 +123,10 @@ def build_cases(ops, want):
         bias = rnd(16)
         pool = {}
         fl = 2.0 * B * 16384 * 160 * 400
-        cases["upconv_fwd"] = (lambda: ops.upconv_fwd(xl, pk, bias, yo, g, act=True, pool=pool), fl)
-        cases["upconv_bwd"] = (lambda: ops.upconv_bwd(xl, dy, pk, dw, dxl, g, pool=pool), 2 * fl)
+        cases["upconv_fwd"] = (lambda xl=xl, pk=pk, bias=bias, yo=yo, g=g, pool=pool: ops.upconv_fwd(xl, pk, bias, yo, g, act=True, pool=pool), fl)
+        cases["upconv_bwd"] = (lambda xl=xl, dy=dy, pk=pk, dw=dw, dxl=dxl, g=g, pool=pool: ops.upconv_bwd(xl, dy, pk, dw, dxl, g, pool=pool), 2 * fl)
         z = torch.empty(B, 128, 128, 400, device=dev)
-        cases["upconv_gemm"] = (lambda: ops.conv_dgrad(xl, pk.as_1x1(), z, ConvGeom(1, 1, 1, 0)), fl)
+        cases["upconv_gemm"] = (lambda xl=xl, pk=pk, z=z: ops.conv_dgrad(xl, pk.as_1x1(), z, ConvGeom(1, 1, 1, 0)), fl)
     if need("ln_bwd"):
         for tag, P, C in (("ln_bwd_c16", B * 65536, 16), ("ln_bwd_c64", B * 84 * 84, 64)):
             dz, y, mr, gm = rnd(P, C), rnd(P, C), torch.rand(P, 2, device=dev) + 0.5, rnd(C)

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
     const int nslots = 4 * npr;
 
     // weight fragments of all taps in LDS for the block's whole life: slot [tap][lg][li]
-    f32x4* lds_w = lds_a + 4 * p.npix + 4;
+    f32x4* lds_w = lds_a + 4 * p.npix + 8;       // (slot 4 npix + 4: where the staging slots beyond the halo are written, never read)
     for (int idx = t; idx < TAPS * 64; idx += 256) {
         const int tap = idx >> 6, l = idx & 63;
         const int wli = l & 15, wlg = l >> 4;
@@ -454,24 +454,39 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
         const bool on = STG == 0 ? idx < nslots : (pix < npr && idx < 4 * ((npr + 3) & ~3));
         shy[i] = on ? pix / p.halo_w : (1 << 28);
         shx[i] = pix - (pix / p.halo_w) * p.halo_w;
-        soff[i] = ((pix / p.halo_w) * p.W + shx[i]) * p.ldA + kg * 4;
-        sslot[i] = on ? kg * p.npix + pix + (STG ? (kg >> 1) * 4 : 0) : -1;
+        soff[i] = (((pix / p.halo_w) * p.W + shx[i]) * p.ldA + kg * 4) * 4;     // bytes
+        sslot[i] = on ? kg * p.npix + pix + (STG ? (kg >> 1) * 4 : 0) : 4 * p.npix + 4;
     }
     auto load_tile = [&](int tile) {
         const int img = tile / (p.tiles_h * p.tiles_w);
         const int rem = tile - img * (p.tiles_h * p.tiles_w);
         const int ty = rem / p.tiles_w, tx = rem - ty * p.tiles_w;
         const int hy0 = ty * HALO_TH + p.dh_min, hx0 = tx * HALO_TW + p.dw_min;
-        const float* Aorg = p.A + (long long)img * p.imgStrideA + ((long long)hy0 * p.W + hx0) * p.ldA;
+        // branch-free: a buffer descriptor per image, padding / unused slots get offset 0x80000000 (beyond it -> zeros) by
+        // arithmetic on the signs of the range checks.  Written as `if (inside) v = load` the six requests became six exec-masked
+        // blocks and the compiler waited for ALL of them at their join — in front of the MFMAs they were meant to travel under
+        const wdg_srd srdA = wdg_make_srd(p.A + (long long)img * p.imgStrideA);
+        const int org = (hy0 * p.W + hx0) * p.ldA * 4;
 #pragma unroll
         for (int i = 0; i < NLMAX; ++i) {
             const int gy = hy0 + shy[i], gx = hx0 + shx[i];
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.Hc && (unsigned)gx < (unsigned)p.Wc)
-                v = *reinterpret_cast<const f32x4*>(Aorg + soff[i]);
-            rs[i] = v;
+            const unsigned neg = (unsigned)((gy | (p.Hc - 1 - gy) | gx | (p.Wc - 1 - gx)) >> 31);
+            rs[i] = wdg_buffer_load_f32x4(srdA, ((unsigned)(org + soff[i]) & ~neg) | (neg & 0x80000000u));
         }
     };
+    // epilogue constants once per workgroup (inside the tile loop they were reloaded per tile under per-element branches, and
+    // their wait also waited for the next tile's halo: the wait counter is in order)
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f}, gm = bv, bt = bv;
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = p.bias[4 * lg + r < p.Ncols ? 4 * lg + r : 0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = 4 * lg + r < p.Ncols ? bv[r] : 0.f;
+    }
+    if constexpr (LN) {
+        gm = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * lg);
+        bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * lg);
+    }
     if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();   // the previous tile's fragment reads are done
@@ -482,7 +497,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
             // per tile are 4-way conflicted, the price of coalesced 64-byte-per-pixel global loads (an XOR swizzle that
             // fixed the writes made 30 % of the read cycles conflicts: profiles/r01aq_pmc_summary.csv)
             (void)idx;
-            if (sslot[i] >= 0) lds_a[sslot[i]] = rs[i];
+            lds_a[sslot[i]] = rs[i];       // (unconditional: under `if (slot >= 0)` the compiler sinks the slot's LOAD into the branch)
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
@@ -518,16 +533,10 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
         const int ty = b % p.tiles_h;
         const int img = b / p.tiles_h;
         if (4 * lg < ((p.Ncols + 3) & ~3)) {
-            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bv[r] = 4 * lg + r < p.Ncols ? p.bias[4 * lg + r] : 0.f;
-            }
             if constexpr (LN) {
                 // conv -> bias -> LeakyReLU -> LayerNormalization over the 16 channels of a pixel: they sit in the four lanes
                 // li, li + 16, li + 32, li + 48 (four registers each), so the two reductions (sum, centred sum of squares — the
                 // two-pass form of wdg_ln_fwd) are two xor-shuffles each; y and z leave as 16-byte stores, no pass re-reads y
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * lg), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * lg);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int oy = ty * HALO_TH + 2 * wave + (a >> 1);
@@ -560,6 +569,19 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
                     }
                 }
             } else {
+            // accumulate: the four previous values requested together (from clamped, always valid addresses — per-element
+            // `if (inside) v += *dst` is four load - wait - store sequences)
+            f32x4 prev[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) prev[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.accumulate) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int oy = min(ty * HALO_TH + 2 * wave + (a >> 1), p.Ho - 1);
+                    const int ox = min(tx * HALO_TW + (a & 1) * 16 + li, p.Wo - 1);
+                    prev[a] = *reinterpret_cast<const f32x4*>(p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO + 4 * lg);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int oy = ty * HALO_TH + 2 * wave + (a >> 1);
@@ -571,8 +593,7 @@ __global__ void __launch_bounds__(256) wdg_conv_halo1_kernel(const WdgHalo p, co
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
                 }
-                if (p.accumulate) v += *dst;
-                *dst = v;
+                *dst = v + prev[a];
             }
             }
         }
@@ -722,7 +743,11 @@ int wdg_halo_launch(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA
     }
     if (persistent1) {
         // latency-bound thin 3x3 layer: persistent blocks with next-tile prefetch (4 resident blocks per CU)
-        const size_t lds1 = ((size_t)4 * p.npix + 4 + 9 * 64) * sizeof(f32x4);
+        const size_t lds1 = ((size_t)4 * p.npix + 8 + 9 * 64) * sizeof(f32x4);
+        if ((long long)p.Hc * p.Wc * p.ldA * 4 >= (1LL << 31)) {
+            wdg_set_error("halo: an image of the input must stay below 2 GiB (buffer descriptor per image)");
+            return WDG_ERR_ARG;
+        }
         const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * (ln ? std::min(g_halo1_bpc, 3) : g_halo1_bpc));
         if (ln && g_halo1_stage)
             hipLaunchKernelGGL((wdg_conv_halo1_kernel<9, true, 1>), dim3(nb), block, lds1, st, p, Bw);

@@ -51,20 +51,35 @@ __global__ void __launch_bounds__(256) wdg_convln_fwd_kernel(const WdgConvLn p, 
     const int img = live ? (int)(pix / ((long long)p.H * p.W)) : 0;
     const int rem = live ? (int)(pix - (long long)img * p.H * p.W) : 0;
     const int oy = rem / p.W, ox = rem - oy * p.W;
-    const float* Ximg = p.X + (long long)img * p.isx;
     float acc[CN_CO];
 #pragma unroll
     for (int o = 0; o < CN_CO; ++o) acc[o] = bias[o];
-    f32x4 xv[9][C4];   // every tap's input first: one exposed load latency instead of nine
+    // every tap's input first: one exposed load latency instead of nine.  Branch-free buffer loads (padding: bit 31 of the
+    // offset set arithmetically -> beyond the descriptor -> zeros): written as `inside ? load : 0` the nine loads compiled to
+    // nine exec-masked blocks, each with its own s_waitcnt vmcnt(0) — nine round trips in sequence after all
+    // (the descriptor must be wave-uniform — a per-lane one is served by a readfirstlane loop: it starts at the image of the
+    // workgroup's first pixel, the offsets carry the (at most few) images a workgroup's 256 pixels run on from there)
+    f32x4 xv[9][C4];
+    const int img0 = (int)(pix0 / ((long long)p.H * p.W));
+    const wdg_srd srdX = wdg_make_srd(p.X + (long long)img0 * p.isx);
+    const int dead = live ? 0 : -1;
+    const int ibase = (img - img0) * (int)p.isx;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int gy = oy + tap / 3 - 1, gx = ox + tap % 3 - 1;
-        const bool ok = live && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const unsigned neg = (unsigned)((dead | gy | (p.H - 1 - gy) | gx | (p.W - 1 - gx)) >> 31);      // all ones outside
+        const unsigned off = ((unsigned)((ibase + (gy * p.W + gx) * p.ldx) * 4) & ~neg) | (neg & 0x80000000u);
 #pragma unroll
-        for (int c4 = 0; c4 < C4; ++c4)
-            xv[tap][c4] = ok ? *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4)
-                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c4 = 0; c4 < C4; ++c4) xv[tap][c4] = wdg_buffer_load_f32x4(srdX, off + 16 * c4);
     }
+    // all nine requested before the first is consumed (the scheduler pairs them with their uses), and every destination kept
+    // whole until here: with two channels in use the allocator recycled the dead half of a 16-byte destination for the next
+    // tap's address arithmetic — and had to wait for the load in between
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) asm volatile("" : "+v"(xv[tap][c4]));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -484,6 +499,8 @@ extern "C" int wdg_convln_fwd(const float* x, int ldx, int64_t isx, const float*
     WDG_CHECK_ARG(x && w_hwio && bias && gamma && beta && z, "null argument");
     WDG_CHECK_ARG((y != nullptr) == (mean_rstd != nullptr), "y and mean_rstd: both (for wdg_convln_bwd) or neither (wdg_convln_bwd_x)");
     WDG_CHECK_ARG(wdg_convln_supported(cin, cout), "unsupported (cin, cout)");
+    WDG_CHECK_ARG(((long long)H * W * ldx + (256 / ((long long)H * W) + 1) * (long long)isx) * 4 < (1LL << 31),
+                  "the images of x a workgroup's 256 pixels touch must stay below 2 GiB (one buffer descriptor)");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ((uintptr_t)y & 15) == 0 && ldy % 4 == 0 &&
                       ((uintptr_t)z & 15) == 0 && ldz % 4 == 0, "alignment");
     WdgConvLn p;

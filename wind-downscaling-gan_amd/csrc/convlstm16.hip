@@ -15,6 +15,7 @@
 // accumulator register r of lane (li = lane & 15, lg = lane >> 4) is output channel 16 b + 4 lg + r of pixel li — in the forward
 // step column tile b is gate b, so a lane holds i, f, c~, o of four features of its pixel and updates the cell in registers.
 #include "conv_plan.h"
+#include <algorithm>
 #include <cstring>
 
 namespace {
@@ -64,10 +65,19 @@ __device__ __forceinline__ HaloSlots l_halo_slots(int t, int hy0, int hx0, int H
         const int hy = pix / L_HW, hx = pix - hy * L_HW;
         const int gy = hy0 + hy, gx = hx0 + hx;
         const bool in = idx < 4 * L_NPR;
-        s.lds[u] = in ? kg * L_NPIX + pix : -1;
+        // (slots beyond the halo go to a padding slot no fragment reads — 204..207 of a plane: an `if (slot >= 0)` around the
+        // LDS store makes the compiler sink the slot's LOAD into that branch, behind everything else and with a full wait)
+        s.lds[u] = in ? kg * L_NPIX + pix : 4 * L_NPIX - 1;
         s.off[u] = (in && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (gy * W + gx) * 4 + kg : -1;   // (pixel, kg) packed
     }
     return s;
+}
+
+// byte offset of a halo slot's 16 bytes within the image, 0x80000000 (beyond the descriptor's 2 GiB) for padding — by arithmetic
+// on the sign, not a select (which comes out as a branch around the load)
+__device__ __forceinline__ unsigned l_halo_byte_off(int off, int ld) {
+    const unsigned neg = (unsigned)(off >> 31);
+    return ((unsigned)(((off >> 2) * ld + (off & 3) * 4) * 4) & ~neg) | (neg & 0x80000000u);
 }
 
 __global__ void __launch_bounds__(256, 3) wdg_lstm16_fwd_kernel(const WdgLstm16 p) {
@@ -82,36 +92,38 @@ __global__ void __launch_bounds__(256, 3) wdg_lstm16_fwd_kernel(const WdgLstm16 
     const int oy0 = ty * L_TH, ox0 = tx * L_TW;
     const float* Aimg = p.A + (long long)img * p.imgStrideA;
 
-    // ---- requests in the order of first use: halo of h_{t-1}, weights, then the tile's own operands
+    // ---- requests in the order of first use: halo of h_{t-1}, weights, then the tile's own operands.  ALL of them branch-free
+    // (buffer loads; padding and the ragged edge get bit 31 of their offset set arithmetically -> out of the descriptor's
+    // range -> zeros): as `if (inside) v = load` / `inside ? load : 0` the compiler emitted exec-masked blocks with two full
+    // s_waitcnt vmcnt(0) between them — three round trips in sequence where this chain of launches can afford one.
     const HaloSlots hs = l_halo_slots(t, oy0 - 1, ox0 - 1, p.H, p.W);
+    const long long pimg = (long long)img * p.H * p.W;
+    const wdg_srd srdA = wdg_make_srd(Aimg), srdG = wdg_make_srd(p.gates + pimg * 64), srdC = wdg_make_srd(p.c_prev + pimg * p.ldc);
     f32x4 hv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        hv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (hs.off[u] >= 0) hv[u] = *reinterpret_cast<const f32x4*>(Aimg + (long long)(hs.off[u] >> 2) * p.ldA + (hs.off[u] & 3) * 4);
-    }
+    for (int u = 0; u < 4; ++u)
+        hv[u] = wdg_buffer_load_f32x4(srdA, l_halo_byte_off(hs.off[u], p.ldA));
     f32x4 wv[9];
 #pragma unroll
     for (int u = 0; u < 9; ++u) wv[u] = p.Wl[u * 256 + t];
     const int oy = oy0 + wave;
-    const long long pimg = (long long)img * p.H * p.W;
     f32x4 old[2][4], cprev[2];
     bool ok[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int ox = ox0 + a * 16 + li;
         ok[a] = oy < p.H && ox < p.W;
-        const long long pix = pimg + (long long)oy * p.W + ox;
+        const unsigned bad = (unsigned)((p.H - 1 - oy) | (p.W - 1 - ox)) & 0x80000000u;
+        const int pl = oy * p.W + ox;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-            old[a][b] = ok[a] ? *reinterpret_cast<const f32x4*>(p.gates + pix * 64 + b * 16 + 4 * lg) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        cprev[a] = ok[a] ? *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.ldc + 4 * lg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) old[a][b] = wdg_buffer_load_f32x4(srdG, (unsigned)((pl * 64 + b * 16 + 4 * lg) * 4) | bad);
+        cprev[a] = wdg_buffer_load_f32x4(srdC, (unsigned)((pl * p.ldc + 4 * lg) * 4) | bad);
     }
 #pragma unroll
     for (int u = 0; u < 9; ++u) lds_w[u * 256 + t] = wv[u];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (hs.lds[u] >= 0) lds_a[hs.lds[u]] = hv[u];
+        lds_a[hs.lds[u]] = hv[u];
     __syncthreads();
 
 #pragma unroll
@@ -167,42 +179,49 @@ __global__ void __launch_bounds__(256, 3) wdg_lstm16_bwd_kernel(const WdgLstm16 
     const int oy0 = ty * L_TH, ox0 = tx * L_TW;
     const float* Aimg = p.A + (long long)img * p.imgStrideA;
 
+    // (every request branch-free, see the forward kernel: here the compiler had put a full wait between the request of the
+    // next dgates slice and the MFMAs that were meant to cover it)
     const HaloSlots hs = l_halo_slots(t, oy0 - 1, ox0 - 1, p.H, p.W);
-    f32x4 hv[4];
-    auto halo_request = [&](int ck) {
+    const long long pimg = (long long)img * p.H * p.W;
+    const wdg_srd srdA = wdg_make_srd(Aimg), srdD = wdg_make_srd(p.dh_prev + (long long)img * p.imgStrideDh),
+                  srdG = wdg_make_srd(p.gates_t + pimg * 64), srdCp = wdg_make_srd((p.c_prev ? p.c_prev : p.c_cur) + pimg * p.ldc),
+                  srdCc = wdg_make_srd(p.c_cur + pimg * p.ldc), srdDc = wdg_make_srd(p.dc_in + pimg * p.ldc);
+    unsigned hoff[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            hv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (hs.off[u] >= 0)
-                hv[u] = *reinterpret_cast<const f32x4*>(Aimg + (long long)(hs.off[u] >> 2) * p.ldA + ck * 16 + (hs.off[u] & 3) * 4);
-        }
+    for (int u = 0; u < 4; ++u)
+        hoff[u] = l_halo_byte_off(hs.off[u], p.ldA);          // (+ 64 ck below: padding stays at 0x80000000 + 64 ck, out of range)
+    f32x4 hv[4];
+    auto halo_request = [&](int ck) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hv[u] = wdg_buffer_load_f32x4(srdA, hoff[u] + ck * 64);
     };
     halo_request(0);
     f32x4 wv[9];
 #pragma unroll
     for (int u = 0; u < 9; ++u) wv[u] = p.Wl[u * 256 + t];
     const int oy = oy0 + wave;
-    const long long pimg = (long long)img * p.H * p.W;
     f32x4 old[2], bin[2][7];
     bool ok[2];
+    const unsigned no_cprev = p.c_prev ? 0u : 0x80000000u;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int ox = ox0 + a * 16 + li;
         ok[a] = oy < p.H && ox < p.W;
-        const long long pl = (long long)oy * p.W + ox, pix = pimg + pl;
-        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        old[a] = ok[a] ? *reinterpret_cast<const f32x4*>(p.dh_prev + (long long)img * p.imgStrideDh + pl * p.ld_dh + 4 * lg) : z4;
+        const unsigned bad = (unsigned)((p.H - 1 - oy) | (p.W - 1 - ox)) & 0x80000000u;
+        const int pl = oy * p.W + ox;
+        old[a] = wdg_buffer_load_f32x4(srdD, (unsigned)((pl * p.ld_dh + 4 * lg) * 4) | bad);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bin[a][q] = ok[a] ? *reinterpret_cast<const f32x4*>(p.gates_t + pix * 64 + q * 16 + 4 * lg) : z4;
-        bin[a][4] = (ok[a] && p.c_prev) ? *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.ldc + 4 * lg) : z4;
-        bin[a][5] = ok[a] ? *reinterpret_cast<const f32x4*>(p.c_cur + pix * p.ldc + 4 * lg) : z4;
-        bin[a][6] = ok[a] ? *reinterpret_cast<const f32x4*>(p.dc_in + pix * p.ldc + 4 * lg) : z4;
+        for (int q = 0; q < 4; ++q) bin[a][q] = wdg_buffer_load_f32x4(srdG, (unsigned)((pl * 64 + q * 16 + 4 * lg) * 4) | bad);
+        const unsigned co = (unsigned)((pl * p.ldc + 4 * lg) * 4) | bad;
+        bin[a][4] = wdg_buffer_load_f32x4(srdCp, co | no_cprev);
+        bin[a][5] = wdg_buffer_load_f32x4(srdCc, co);
+        bin[a][6] = wdg_buffer_load_f32x4(srdDc, co);
     }
 #pragma unroll
     for (int u = 0; u < 9; ++u) lds_w[u * 256 + t] = wv[u];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (hs.lds[u] >= 0) lds_a[hs.lds[u]] = hv[u];
+        lds_a[hs.lds[u]] = hv[u];
     __syncthreads();
 
     f32x4 acc[2];
@@ -210,6 +229,7 @@ __global__ void __launch_bounds__(256, 3) wdg_lstm16_bwd_kernel(const WdgLstm16 
 #pragma unroll
     for (int ck = 0; ck < 4; ++ck) {
         if (ck < 3) halo_request(ck + 1);          // in flight under this slice's MFMAs
+        __builtin_amdgcn_sched_barrier(0);         // (... which the scheduler otherwise moves behind most of them)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // data gradient: tap (th, tw) reads dgates at (y + 1 - th, x + 1 - tw) -> halo row wave + 2 - th, column + 2 - tw
@@ -226,7 +246,7 @@ __global__ void __launch_bounds__(256, 3) wdg_lstm16_bwd_kernel(const WdgLstm16 
             __syncthreads();                       // every wave is done with this slice
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (hs.lds[u] >= 0) lds_a[hs.lds[u]] = hv[u];
+                lds_a[hs.lds[u]] = hv[u];
             __syncthreads();
         }
     }
@@ -281,7 +301,7 @@ bool lstm16_geom(const wdg_conv_plan* pl) {
     const wdg_conv_geom& g = pl->g;
     return g_lstm16_step && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad_h == 1 && g.pad_w == 1 && g.Cin == 16 && g.Cout == 64 &&
            g.H == g.Ho && g.W == g.Wo && g.ldy == 64 && g.img_stride_y == (int64_t)g.H * g.W * 64 && g.ldx % 4 == 0 &&
-           (long long)g.H * g.W * 4 < (1LL << 31);
+           (long long)g.H * g.W * std::max(g.ldx, 64) * 4 < (1LL << 31);      // (per-image buffer descriptors: 2 GiB)
 }
 bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr, const void* e = nullptr,
                const void* f = nullptr, const void* g = nullptr, const void* h = nullptr) {
@@ -314,6 +334,7 @@ extern "C" int wdg_convlstm16_step(const wdg_conv_plan* pl, const float* h_prev,
     WDG_CHECK_ARG(pl && h_prev && wl_fwd && gates && c_prev && c_out && h_out && lstm16_geom(pl), "not supported for this geometry");
     WDG_CHECK_ARG(ldc >= 16 && ldh >= 16 && ldc % 4 == 0 && ldh % 4 == 0 && aligned16(h_prev, wl_fwd, gates, c_prev, c_out, h_out),
                   "bad strides / alignment");
+    WDG_CHECK_ARG((long long)pl->g.H * pl->g.W * ldc * 4 < (1LL << 31), "an image's cell state must stay below 2 GiB");
     if (int rc = lds_opt_in()) return rc;
     const wdg_conv_geom& g = pl->g;
     WdgLstm16 p;
@@ -334,6 +355,7 @@ extern "C" int wdg_convlstm16_bwd_step(const wdg_conv_plan* pl, const float* dga
                   "not supported for this geometry");
     WDG_CHECK_ARG(ldc >= 16 && ldc % 4 == 0 && aligned16(dgates_next, wl_bwd, dh_prev, gates_t, c_prev, c_cur, dc_in, dgates_out) &&
                       aligned16(dc_out), "bad strides / alignment");
+    WDG_CHECK_ARG((long long)pl->g.H * pl->g.W * ldc * 4 < (1LL << 31), "an image's cell state must stay below 2 GiB");
     if (int rc = lds_opt_in()) return rc;
     const wdg_conv_geom& g = pl->g;
     WdgLstm16 p;
