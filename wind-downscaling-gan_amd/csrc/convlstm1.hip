@@ -220,6 +220,38 @@ __global__ void __launch_bounds__(256, PRE ? 1 : 4) wdg_convlstm1_fwd_mfma_kerne
 #pragma unroll
         for (int r = 0; r < 4; ++r) bg[g][r] = bias[(PRE ? g : (g == 0 ? 0 : g + 1)) * F + 4 * lq + r];
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
+    // x halo of the NEXT tile in registers while this one is multiplied, requested branch-free (buffer loads, offset 0x80000000 =
+    // beyond the descriptor for the padding and for slots beyond the halo): `if (inside) load` in the staging loop was two
+    // dependent round trips per tile between two barriers
+    // (exactly CIN values per slot — 16 bytes per full channel group, 4 bytes per leftover channel: the allocator recycles unused
+    // lanes of a 16-byte destination at once and then has to wait for the load before it may overwrite them)
+    constexpr int NXS = (XH * XW + 255) / 256;
+    float xr[NXS][CIN];
+    auto x_request = [&](int tile_) __attribute__((always_inline)) {
+        int b_ = tile_;
+        const int tx_ = b_ % p.tiles_w;
+        b_ /= p.tiles_w;
+        const int ty_ = b_ % p.tiles_h, img_ = b_ / p.tiles_h;
+        const wdg_srd srdX = wdg_make_srd(p.X + (long long)img_ * p.imgStrideX);
+#pragma unroll
+        for (int s_ = 0; s_ < NXS; ++s_) {
+            const int pix = t + 256 * s_;
+            const int hy = pix / XW, hx = pix - hy * XW;
+            const int gy = ty_ * CLF_TH - 1 + hy, gx = tx_ * CLF_TW - 1 + hx;
+            const unsigned neg = (unsigned)((gy | (p.H - 1 - gy) | gx | (p.W - 1 - gx) | (XH * XW - 1 - pix)) >> 31);
+            const unsigned off = ((unsigned)((gy * p.W + gx) * p.ldx * 4) & ~neg) | (neg & 0x80000000u);
+#pragma unroll
+            for (int c4 = 0; c4 < CIN / 4; ++c4) {
+                const f32x4 q = wdg_buffer_load_f32x4(srdX, off + 16 * c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xr[s_][4 * c4 + j] = q[j];
+            }
+#pragma unroll
+            for (int c = CIN / 4 * 4; c < CIN; ++c)
+                xr[s_][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdX, (int)(off + 4 * c), 0, 0));
+        }
+    };
+    if ((int)blockIdx.x < ntiles) x_request(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b = tile;
         const int tx = b % p.tiles_w;
@@ -227,24 +259,16 @@ __global__ void __launch_bounds__(256, PRE ? 1 : 4) wdg_convlstm1_fwd_mfma_kerne
         const int ty = b % p.tiles_h;
         const int img = b / p.tiles_h;
         const int oy0 = ty * CLF_TH, ox0 = tx * CLF_TW;
-        const float* Ximg = p.X + (long long)img * p.imgStrideX;
-        // x halo -> channel planes (zero outside the image = the conv's zero padding)
-        for (int pix = t; pix < XH * XW; pix += 256) {
-            const int hy = pix / XW, hx = pix - hy * XW;
-            const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
-                const float* src = Ximg + ((long long)gy * p.W + gx) * p.ldx;
+        // x halo -> channel planes (zero outside the image = the conv's zero padding; slots beyond the halo land in a plane's
+        // 12 padding floats, which nothing reads)
 #pragma unroll
-                for (int c4 = 0; c4 < (CIN + 3) / 4; ++c4) {
-                    const f32x4 q = *reinterpret_cast<const f32x4*>(src + 4 * c4);
-                    v[4 * c4] = q[0]; v[4 * c4 + 1] = q[1]; v[4 * c4 + 2] = q[2]; v[4 * c4 + 3] = q[3];
-                }
-            }
+        for (int s_ = 0; s_ < NXS; ++s_) {
+            const int pix = min(t + 256 * s_, XH * XW);
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) xs[c * PLANE + pix] = v[c];
+            for (int c = 0; c < CIN; ++c) xs[c * PLANE + pix] = xr[s_][c];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) x_request(tile + gridDim.x);
         // 16 fragments (8 rows x 2 half rows of 16 pixels): wave wv takes rows 2 wv, 2 wv + 1.  Software-pipelined: the 36 MFMAs
         // of fragment fi + 1 stand before the cell arithmetic of fragment fi in program order, so the cell's instructions issue
         // while the matrix instructions drain instead of waiting for their own fragment's last one
@@ -314,11 +338,12 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     constexpr int ROWS = 9 * CIN + 1, RT = (ROWS + 15) / 16, COLS = 3 * F, CT = (COLS + 15) / 16;
     constexpr int WN = RT * CT * 256;                // floats of one wave's accumulator tiles
     constexpr bool RED_IN_DGS = GH * GW * G3 >= 4 * WN;
-    __shared__ __attribute__((aligned(16))) f32x4 xs[XH * XW * C4];
+    __shared__ __attribute__((aligned(16))) f32x4 xs[XH * XW * C4 + 1];     // (+ 1: where staging slots beyond the halo are written)
     __shared__ __attribute__((aligned(16))) float dgs[GH * GW * G3];
     __shared__ float dxp[128 * CIN];
     __shared__ float red_extra[(WG && !RED_IN_DGS) ? 4 * WN : 1];
     constexpr int KP = (9 * CIN + 3) / 4 * 4;        // flattened (tap, channel) rows padded to the MFMA k granule
+    constexpr int NXS = (XH * XW * C4 + 255) / 256;  // x-halo staging slots per thread
 
     const int t = threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(t >> 7);
@@ -365,6 +390,45 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
         }
     }
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
+    // The tile loop is a chain of round trips (x halo, dh, the read-modify-write of dx) with three workgroups per CU to hide them:
+    // every request is branch-free (buffer loads, offset 0x80000000 = beyond the descriptor for padding — `if (inside) v = load`
+    // compiles to an exec-masked block with its own full wait per load), the x halo of the NEXT tile travels during this tile's
+    // arithmetic (so does its dh), the previous dx values are requested together.
+    f32x4 xr[NXS];
+    constexpr bool DHPRE = !MF && FH % 4 == 0;       // dh of this thread's work items of stage 2 (the scalar-gate path) likewise
+    f32x4 dhr[DHPRE ? 2 : 1][DHPRE ? FH / 4 : 1];
+    auto x_request = [&](int tile_) __attribute__((always_inline)) {
+        int b_ = tile_;
+        const int tx_ = b_ % p.tiles_w;
+        b_ /= p.tiles_w;
+        const int ty_ = b_ % p.tiles_h, img_ = b_ / p.tiles_h;
+        const wdg_srd srdX = wdg_make_srd(p.X + (long long)img_ * p.imgStrideX);
+        if constexpr (DHPRE) {
+            const wdg_srd srdDH = wdg_make_srd(p.dH + (long long)img_ * p.imgStrideDH);
+            const int n_items_ = p.dX ? GH * GW : CL_TH * CL_TW;
+#pragma unroll
+            for (int r_ = 0; r_ < 2; ++r_) {
+                const int item = r_ * 128 + (t & 127);
+                const int hy_ = p.dX ? item / GW : 1 + item / CL_TW;
+                const int hx_ = p.dX ? item - (item / GW) * GW : 1 + item % CL_TW;
+                const int gy = ty_ * CL_TH - 1 + hy_, gx = tx_ * CL_TW - 1 + hx_;
+                const unsigned neg = (unsigned)((gy | (p.H - 1 - gy) | gx | (p.W - 1 - gx) | (n_items_ - 1 - item)) >> 31);
+                const unsigned off = ((unsigned)(((gy * p.W + gx) * p.lddh + f0) * 4) & ~neg) | (neg & 0x80000000u);
+#pragma unroll
+                for (int q = 0; q < FH / 4; ++q) dhr[r_][q] = wdg_buffer_load_f32x4(srdDH, off + 16 * q);
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < NXS; ++s_) {
+            const int idx = t + 256 * s_;
+            const int c4 = idx % C4, pix = idx / C4;
+            const int hy = pix / XW, hx = pix - hy * XW;
+            const int gy = ty_ * CL_TH - 2 + hy, gx = tx_ * CL_TW - 2 + hx;
+            const unsigned neg = (unsigned)((gy | (p.H - 1 - gy) | gx | (p.W - 1 - gx) | (XH * XW * C4 - 1 - idx)) >> 31);
+            xr[s_] = wdg_buffer_load_f32x4(srdX, ((unsigned)(((gy * p.W + gx) * p.ldx + 4 * c4) * 4) & ~neg) | (neg & 0x80000000u));
+        }
+    };
+    if ((int)blockIdx.x < ntiles) x_request(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int b = tile;
     const int tx = b % p.tiles_w;
@@ -372,19 +436,15 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     const int ty = b % p.tiles_h;
     const int img = b / p.tiles_h;
     const int oy0 = ty * CL_TH, ox0 = tx * CL_TW;
-    const float* Ximg = p.X + (long long)img * p.imgStrideX;
     const float* DHimg = p.dH + (long long)img * p.imgStrideDH;
 
     // 1. x halo -> LDS (zero outside the image = the conv's zero padding)
-    for (int idx = t; idx < XH * XW * C4; idx += 256) {
-        const int c4 = idx % C4;
-        const int pix = idx / C4;
-        const int hy = pix / XW, hx = pix - hy * XW;
-        const int gy = oy0 - 2 + hy, gx = ox0 - 2 + hx;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-            v = *reinterpret_cast<const f32x4*>(Ximg + ((long long)gy * p.W + gx) * p.ldx + 4 * c4);
-        xs[c4 * (XH * XW) + pix] = v;   // channel-group planes: a wave's 16-byte reads of consecutive pixels are contiguous
+#pragma unroll
+    for (int s_ = 0; s_ < NXS; ++s_) {
+        const int idx = t + 256 * s_;
+        const int c4 = idx % C4, pix = idx / C4;
+        // channel-group planes: a wave's 16-byte reads of consecutive pixels are contiguous
+        xs[idx < XH * XW * C4 ? c4 * (XH * XW) + pix : XH * XW * C4] = xr[s_];
     }
     __syncthreads();
     if constexpr (MF) {
@@ -449,12 +509,15 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
                 __attribute__((aligned(8))) float gi[FH], gc[FH], go[FH];
                 cl_gates<CIN, F, FH, false>(Wx, bias, f0, load, gi, gc, go);
                 const float* dhp = DHimg + ((long long)gy * p.W + gx) * p.lddh + f0;
+                (void)dhp;
 #pragma unroll
                 for (int f = 0; f < FH; ++f) {
                     const float si = cl_hsig(gi[f]), tc_ = cl_tanh(gc[f]), so = cl_hsig(go[f]);
                     const float c = si * tc_;
                     const float th = cl_tanh(c);
-                    const float dh = dhp[f];
+                    float dh;
+                    if constexpr (DHPRE) dh = dhr[base ? 1 : 0][f / 4][f % 4];
+                    else dh = dhp[f];
                     const float dc = dh * so * (1.f - th * th);
                     dgi[f] = dc * tc_ * cl_hsig_grad(gi[f]);
                     dgc[f] = dc * si * (1.f - tc_ * tc_);
@@ -483,6 +546,9 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     }
     }
     __syncthreads();
+    // (x halo and dh of the next tile: under the weight-gradient MFMAs and the dx stage — requested before stage 2 they would be
+    // waited for at its first branch, the wait counter being in order)
+    if (tile + (int)gridDim.x < ntiles) x_request(tile + gridDim.x);
     if constexpr (WG) {
         // 2b. weight / bias gradient of this tile: wave wv = centre row wv, 8 steps of 4 pixels
         const float* xsf = reinterpret_cast<const float*>(xs);
@@ -556,14 +622,18 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     __syncthreads();
     if (half == 0) {
         const int gy = oy0 + py, gx = ox0 + px;
+        float prev[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) prev[c] = 0.f;
+        if (p.accumulate_dx) {          // (the previous values together, from a clamped = always valid address)
+            const float* src = p.dX + (long long)img * p.imgStrideDX + ((long long)min(gy, p.H - 1) * p.W + min(gx, p.W - 1)) * p.lddx;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) prev[c] = src[c];
+        }
         if (gy < p.H && gx < p.W) {
             float* dst = p.dX + (long long)img * p.imgStrideDX + ((long long)gy * p.W + gx) * p.lddx;
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                float v = dx[c] + (F >= 2 ? dxp[cp * CIN + c] : 0.f);
-                if (p.accumulate_dx) v += dst[c];
-                dst[c] = v;
-            }
+            for (int c = 0; c < CIN; ++c) dst[c] = dx[c] + (F >= 2 ? dxp[cp * CIN + c] : 0.f) + prev[c];
         }
     }
     }   // if (p.dX)
