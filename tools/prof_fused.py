@@ -10,8 +10,10 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "wind-downscaling-gan_amd")]
 import torch  # noqa: E402
 
-NAMES = ["tile prologue (window load, staging)", "weights wait + staging", "barrier A", "MFMA phase (wave 0)",
-         "barrier B (slowest wave)", "horizontal pass + barrier C", "vertical pass", "epilogue"]
+NAMES = ["tile prologue (window load, staging, coefficients)", "weights of row 0: wait + staging", "barrier",
+         "fragments to registers + MFMA phase of row 0", "rows 1 staged, MFMA row 1 + horizontal gather row 0",
+         "barrier Z (H complete, next z complete)", "vertical gather + weights + barrier Y + MFMA / horizontal gather",
+         "epilogue"]
 
 
 def main():

@@ -19,7 +19,7 @@
 //   * bias, LeakyReLU and the inference BatchNorm affine in the epilogue, as in wdg_upconv_gather.
 // Same rounding points as the two-launch route (x and W rounded to nearest even, fp32 accumulation, fp32 z and interpolation);
 // the GEMM is computed on the window, i.e. 2.25 x the multiply-adds — at 16-bit MFMA rates that is cheaper than z's traffic.
-// Measured (16-tile group of the shipped generator, same box): 0.94 ms for the two launches, 0.83 ms fused (DESIGN 10.4 has the
+// Measured (16-tile group of the shipped generator, same box): 0.94 ms for the two launches, 0.74 ms fused (DESIGN 10.4 has the
 // steps: what decided it were registers — the compiler hoisted ~130 registers of thread-index arithmetic out of the tile loop
 // until that arithmetic was re-derived per iteration from an opaque value — and LDS operand re-reads, not HBM latency).
 // -DFV_PROF=1 / -DFV_SKIP=bits are measurement builds (tools/prof_fused.py).
@@ -52,6 +52,7 @@ constexpr int F_NCOL = 5 * 4 * F_CQ;         // 80 columns of z per tap row
 constexpr int F_NT = 512;                    // threads: 133 KB of LDS leave ONE workgroup per CU — eight waves (two per SIMD) give its phases
                                              // (staging, MFMA tiles, the two gather passes, four barriers per tap row) something to overlap with
 constexpr int F_NW = F_NT / 64;
+constexpr int F_ZSLOTS = F_NPX * (5 * F_CQ + 1);   // 16-byte slots of a z buffer (144 pixels x pitch 21)
 constexpr int F_SP = 24;                     // pixels / weight columns per staging pass
 
 __device__ __forceinline__ float f_coef(int r, int a, int Hl) {
@@ -70,10 +71,14 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
     static_assert(K % 32 == 0, "whole MFMA K-steps");
     constexpr int KO = K / 8, KS = K / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [x window / second z buffer | weights of a tap row | z | H]: once every wave holds its pixel fragments in registers the
+    // window is dead, and its LDS becomes the buffer the MFMA phase of tap row ty + 1 writes while the gather of ty reads the other
     h16x8* Xs = reinterpret_cast<h16x8*>(smem);                       // [KO][144]
-    h16x8* Ws = Xs + KO * F_NPX;                                      // [KO][80]
-    f32x4* Z = reinterpret_cast<f32x4*>(Ws + KO * F_NCOL);            // [144][20]
-    f32x4* Hs = Z + F_NPX * F_PX;                                     // [12 * 16][5]
+    f32x4* Zb = reinterpret_cast<f32x4*>(smem);                       // [144][21] (z of odd tap rows; aliases Xs)
+    h16x8* Ws = Xs + F_ZSLOTS;                                        // [KO][80]
+    f32x4* Za = reinterpret_cast<f32x4*>(Ws + KO * F_NCOL);           // [144][21] (z of even tap rows)
+    f32x4* Hs = Za + F_ZSLOTS;                                        // [12 * 16][5]
+    static_assert(KO * F_NPX <= F_ZSLOTS, "the window fits the z buffer it becomes");
 
     // Everything derived from the thread index is RE-derived at the top of each tile and each tap row from a value the compiler
     // cannot see through: left alone it hoists ~130 registers of loop-invariant addresses out of the two loops (the blocks
@@ -182,87 +187,65 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
 #pragma unroll
         for (int o4 = 0; o4 < OQ; ++o4) acc[o4] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-        for (int ty = 0; ty < 5; ++ty) {
-            derive();
-            store_w();                               // (Ws is free: the previous tap row's MFMA phase ended behind a barrier)
-            FV_MARK(1);                              // weights: wait + staging
-            __syncthreads();
-            FV_MARK(2);                              // barrier A
-            if (ty + 1 < 5) fetch_w(ty + 1);         // (the next tap row's weights travel during this one's three phases)
-            else if (next < total) fetch_w(0);
-            // ---- 1. z slice of this tap row: 9 pixel tiles x 5 column tiles (= tx).  The kernel is LDS-bandwidth bound (operand
-            // fragment reads were 2.3 of its 3.3 MB of LDS traffic per tile), so the tiles are blocked for register reuse: waves
-            // 0..5 own THREE pixel tiles (group g = wave % 3) x TWO column tiles (pair wave / 3) and keep the pixel fragments —
-            // which do not depend on the tap row — in registers for the whole tile: per tap row they read two column tiles'
-            // weights for six MFMA tiles.  The fifth column tile goes to waves 6 (pixel tiles 0..4) and 7 (5..8), organised the same
-            // way.  Per tap row 14 fragment sets are read instead of 90, and every wave's phase is one read - MFMA - store sequence.
-            // fragment of k-step ks: octet 4 ks + lq, swizzle (4 ks + lq) & 7 = lq (even ks) or lq + 4 (odd ks)
-            auto xfrag = [&](int pt, int ks) __attribute__((always_inline)) {
-                return Xs[(ks * 4 + lq) * F_NPX + ((pt * 16 + li) ^ ((ks & 1) * 4 + lq))];
-            };
-            auto wfrag = [&](int ct, int ks) __attribute__((always_inline)) {
-                return Ws[(ks * 4 + lq) * F_NCOL + ((ct * 16 + li) ^ ((ks & 1) * 4 + lq))];
-            };
+        // fragment of k-step ks: octet 4 ks + lq, swizzle (4 ks + lq) & 7 = lq (even ks) or lq + 4 (odd ks)
+        auto xfrag = [&](int pt, int ks) __attribute__((always_inline)) {
+            return Xs[(ks * 4 + lq) * F_NPX + ((pt * 16 + li) ^ ((ks & 1) * 4 + lq))];
+        };
+        auto wfrag = [&](int ct, int ks) __attribute__((always_inline)) {
+            return Ws[(ks * 4 + lq) * F_NCOL + ((ct * 16 + li) ^ ((ks & 1) * 4 + lq))];
+        };
+        // ---- 1. z slice of a tap row: 9 pixel tiles x 5 column tiles (= tx).  Operand fragment reads were 2.3 of the kernel's
+        // 3.3 MB of LDS traffic per tile, so the tiles are blocked for register reuse: waves 0..5 own THREE pixel tiles (group
+        // g = wave % 3) x TWO column tiles (pair wave / 3) and keep the pixel fragments — which do not depend on the tap row — in
+        // registers for the whole tile: per tap row they read two column tiles' weights for six MFMA tiles.  The fifth column tile
+        // goes to waves 6 (pixel tiles 0..4) and 7 (5..8), organised the same way.  Per tap row 14 fragment sets are read
+        // instead of 90, and every wave's phase is one read - MFMA - store sequence.
+        auto mfma_phase = [&](f32x4* Z) __attribute__((always_inline)) {
             auto zstore = [&](int pt, int ct, f32x4 c) __attribute__((always_inline)) {
                 // register r of lane (li, lq): column ct * 16 + 4 lq + r (= output channel 4 lq + r of tap column tx = ct) of pixel li
                 Z[(pt * 16 + li) * F_PX + ct * F_CQ + lq] = c;
             };
-            if (!(FV_SKIP & 1)) {
-                if (wave < 6) {
-                    const int g = wave % 3, ct0 = 2 * (wave / 3);
-                    if (ty == 0) {
+            if (FV_SKIP & 1) return;
+            if (wave < 6) {
+                const int g = wave % 3, ct0 = 2 * (wave / 3);
+                f32x4 c[2][3];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int ks = 0; ks < KS; ++ks) bfr[j][ks] = xfrag(3 * g + j, ks);
-                    }
-                    f32x4 c[2][3];
+                    for (int j = 0; j < 3; ++j) c[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                h16x8 a[2][KS];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int ks = 0; ks < KS; ++ks) a[0][ks] = wfrag(ct0, ks), a[1][ks] = wfrag(ct0 + 1, ks);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) c[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    h16x8 a[2][KS];
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) a[0][ks] = wfrag(ct0, ks), a[1][ks] = wfrag(ct0 + 1, ks);
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) c[i][j] = wdg_mfma16<FMT>(a[i][ks], bfr[j][ks], c[i][j]);
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) zstore(3 * g + j, ct0 + i, c[i][j]);
-                } else {
-                    // fifth column tile: wave 6 pixel tiles 0..4, wave 7 pixel tiles 5..8 (five accumulators; wave 7's fifth is idle)
-                    const int p0 = wave == 6 ? 0 : 5;
-                    if (ty == 0) {
+                        for (int j = 0; j < 3; ++j) c[i][j] = wdg_mfma16<FMT>(a[i][ks], bfr[j][ks], c[i][j]);
 #pragma unroll
-                        for (int j = 0; j < 5; ++j)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int ks = 0; ks < KS; ++ks) bfr[j][ks] = xfrag(p0 + j < 9 ? p0 + j : 8, ks);
-                    }
-                    h16x8 a[KS];
+                    for (int j = 0; j < 3; ++j) zstore(3 * g + j, ct0 + i, c[i][j]);
+            } else {
+                // fifth column tile: wave 6 pixel tiles 0..4, wave 7 pixel tiles 5..8 (five accumulators; wave 7's fifth is idle)
+                const int p0 = wave == 6 ? 0 : 5;
+                h16x8 a[KS];
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) a[ks] = wfrag(4, ks);
-                    f32x4 c[5];
+                for (int ks = 0; ks < KS; ++ks) a[ks] = wfrag(4, ks);
+                f32x4 c[5];
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) c[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 5; ++j) c[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) c[j] = wdg_mfma16<FMT>(a[ks], bfr[j][ks], c[j]);
+                    for (int j = 0; j < 5; ++j) c[j] = wdg_mfma16<FMT>(a[ks], bfr[j][ks], c[j]);
 #pragma unroll
-                    for (int j = 0; j < 5; ++j)
-                        if (p0 + j < 9) zstore(p0 + j, 4, c[j]);
-                }
+                for (int j = 0; j < 5; ++j)
+                    if (p0 + j < 9) zstore(p0 + j, 4, c[j]);
             }
-            FV_MARK(3);                              // MFMA phase of this wave
-            __syncthreads();
-            FV_MARK(4);                              // barrier B (= the slowest wave's MFMA phase)
-            // ---- 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
+        };
+        // ---- 2. horizontal pass: H[ryl][qxl][o4] = sum_tx sum_{two (rx, b)} k_rx(b) z[ry, rx][(ty, tx), o4]
+        auto h_pass = [&](const f32x4* Z) __attribute__((always_inline)) {
             int hz[10];
 #pragma unroll
             for (int tx = 0; tx < 5; ++tx) {
@@ -280,26 +263,73 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
                 for (int j = 0; j < 10; ++j) h += hc[j] * zr[hz[j]];
                 Hs[(i / F_CQ) * F_HP + (i % F_CQ)] = h;
             }
-            __syncthreads();
-            FV_MARK(5);                              // horizontal pass + barrier C
-            // ---- 3. vertical pass: the two (ry, a) pairs of this tap row
-            {
-                const int sy = qy + 3 - ty;
+        };
+        // ---- 3. vertical pass: the two (ry, a) pairs of a tap row
+        auto v_pass = [&](int ty) __attribute__((always_inline)) {
+            const int sy = qy + 3 - ty;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int a = (sy & 1) + 2 * e;
-                    const int ry = (sy - a) >> 1;
-                    const int ryl = ry - (i0 - 2);
-                    if (!(FV_SKIP & 4) && (unsigned)ryl < (unsigned)F_ZW) {
-                        const float c = f_coef(ry, a, Hl);
+            for (int e = 0; e < 2; ++e) {
+                const int a = (sy & 1) + 2 * e;
+                const int ry = (sy - a) >> 1;
+                const int ryl = ry - (i0 - 2);
+                if (!(FV_SKIP & 4) && (unsigned)ryl < (unsigned)F_ZW) {
+                    const float c = f_coef(ry, a, Hl);
 #pragma unroll
-                        for (int o4 = 0; o4 < OQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * F_TS + qxl) * F_HP + og0 + o4];
-                    }
+                    for (int o4 = 0; o4 < OQ; ++o4) acc[o4] += c * Hs[(ryl * 2 * F_TS + qxl) * F_HP + og0 + o4];
                 }
             }
-            FV_MARK(6);                              // vertical pass
-            // (no barrier: the next phase to write Hs is two barriers away, the next to write Z one — and Z's writers wait for
-            // Ws behind the barrier that follows store_w)
+        };
+
+        // Software pipeline over the tap rows: the MFMA phase of row ty + 2 and the horizontal gather of row ty + 1 are
+        // independent (two z buffers) and share one phase, the vertical gather of row ty shares the other with the staging of
+        // the next weights — as five phases in sequence each was a latency chain between barriers at two waves per SIMD (MFMA
+        // 27 %, horizontal gather 27 %, barriers 16 % of the kernel's clocks).  Two barriers per tap row:
+        //   Z(ty): H of row ty complete; z of row ty + 1 complete; the weights' LDS free
+        //   Y(ty): weights of row ty + 2 staged; every wave done with H (vertical gather of row ty)
+        store_w();                                   // weights of tap row 0 (requested a tile ahead)
+        FV_MARK(1);
+        __syncthreads();
+        FV_MARK(2);
+        fetch_w(1);
+        if (wave < 6) {
+            const int g = wave % 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bfr[j][ks] = xfrag(3 * g + j, ks);
+        } else {
+            const int p0 = wave == 6 ? 0 : 5;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bfr[j][ks] = xfrag(p0 + j < 9 ? p0 + j : 8, ks);
+        }
+        mfma_phase(Za);                              // row 0
+        FV_MARK(3);
+        __syncthreads();                             // (every wave holds its fragments: the window's LDS is the second z buffer now)
+        store_w();                                   // weights of row 1
+        __syncthreads();
+        fetch_w(2);
+        mfma_phase(Zb);                              // row 1
+        h_pass(Za);                                  // row 0
+        FV_MARK(4);
+#pragma unroll 1
+        for (int ty = 0; ty < 5; ++ty) {
+            __syncthreads();                         // Z(ty)
+            FV_MARK(5);
+            derive();
+            v_pass(ty);
+            if (ty < 3) store_w();                   // weights of row ty + 2
+            if (ty < 4) {
+                __syncthreads();                     // Y(ty)
+                if (ty < 3) {
+                    if (ty + 3 < 5) fetch_w(ty + 3);
+                    else if (next < total) fetch_w(0);
+                    mfma_phase((ty & 1) ? Zb : Za);  // row ty + 2
+                }
+                h_pass((ty & 1) ? Za : Zb);          // row ty + 1
+            }
+            FV_MARK(6);
         }
         if (qy < 2 * Hl && qx < 2 * Wl) {
             float* dst = y + (long long)n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
@@ -369,7 +399,7 @@ extern "C" int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_str
     WDG_CHECK_ARG(((uintptr_t)x_low & 15) == 0 && ((uintptr_t)w16 & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 &&
                   ((uintptr_t)affine & 15) == 0, "x / w / y / bias / affine must be 16-byte aligned");
     constexpr int K = 160;
-    const size_t lds = (size_t)(K / 8) * (F_NPX + F_NCOL) * 16 + (size_t)(F_NPX * F_PX + F_ZW * 2 * F_TS * F_HP) * 16;
+    const size_t lds = ((size_t)2 * F_ZSLOTS + (size_t)(K / 8) * F_NCOL + (size_t)F_ZW * 2 * F_TS * F_HP) * 16;   // 137,728 B
     const int tiles = ((Hl + F_TS - 1) / F_TS) * ((Wl + F_TS - 1) / F_TS);
     WDG_CHECK_ARG((long long)tiles * n_img < (1ll << 31), "too many tiles");
     WDG_CHECK_ARG((long long)Hl * Wl * ldx * 4 < (1ll << 31), "an image must stay below 2 GiB (buffer descriptor per image)");
