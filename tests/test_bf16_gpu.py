@@ -16,6 +16,10 @@ CASES = [
     ("gates_128to512", 2, 16, 16, 128, 512, 3, 1, 1),
     ("c5_128to64", 2, 16, 16, 128, 64, 3, 1, 1),
     ("convT2x2_as_conv", 2, 16, 16, 32, 192, 2, 2, 0),
+    # ... on a map the patch kernel tiles: its transposed direction (the generator's 2 x 2 stride-2 Conv2DTranspose) runs as ONE
+    # GEMM with 4 * 32 columns and a scattering epilogue (WdgPatchH16::shufC)
+    ("convT2x2_shuffle", 2, 48, 48, 32, 192, 2, 2, 0),
+    ("convT2x2_shuffle_c20", 3, 32, 96, 20, 64, 2, 2, 0),
     ("odd_sizes", 3, 21, 19, 40, 72, 3, 1, 1),
     # conv_patch_h16.hip (input patch in LDS): 1 x 16 fragments (map width % 16) and 4 x 4 fragments (map width % 24)
     ("patchA_c0_96", 2, 96, 96, 23, 128, 8, 2, 3),

@@ -297,6 +297,12 @@ static int conv_dgrad_h16(const wdg_conv_plan* pl, const float* dy, const void* 
     // side -> the patch kernel's full-line stores (conv_patch_h16.hip)
     const int prc = wdg_patch_h16_launch(pl, 1, dy, wD16, bias, affine, dx, act, slope, accumulate, fmt, (hipStream_t)stream);
     if (prc != 1) return prc;
+    // transposed k x k stride-k layer (the generator's 2 x 2 stride-2 Conv2DTranspose, models.py:58): taps do not overlap, so it is
+    // the same GEMM with k * k * Cin columns and a scattering epilogue — 197 -> ~60 us on the shipped shape against the phase form below
+    if (g.kh == g.kw && g.stride == g.kh && g.kh >= 2 && !g.pad_h && !g.pad_w) {
+        const int src = wdg_patch_h16_launch(pl, 2, dy, wD16, bias, affine, dx, act, slope, accumulate, fmt, (hipStream_t)stream);
+        if (src != 1) return src;
+    }
     WdgIgemmBf16 p;
     memset(&p, 0, sizeof(p));
     p.A = dy; p.B = wD16; p.Out = dx; p.bias = bias; p.affine = affine; p.ktab = pl->d_tab_dgrad;

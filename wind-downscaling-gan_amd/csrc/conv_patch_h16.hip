@@ -40,6 +40,10 @@ struct WdgPatchH16 {
     float slope;
     int out16;                 // the output is stored in the 16-bit operand format (Out points to 16-bit elements; ldO / imgStrideO in
                                // elements): the column GEMM of the upsample layer, whose only reader is the bilinear gather
+    int shufC;                 // > 0: transposed k x k stride-k convolution as a 1 x 1 GEMM with k * k * shufC columns — column n is tap
+                               // n / shufC (ky = tap / shufK, kx = tap % shufK), channel n % shufC of output pixel (k y + ky, k x + kx): the
+                               // epilogue scatters ("pixel shuffle"); bias / affine are indexed by the channel.  Wo here = low-res width
+    int shufK;
     int gate_F;                // > 0: ConvLSTM gate columns interleaved — column n is gate n & 3 of feature n >> 2, i.e. weight row
                                // and bias index (n & 3) * gate_F + (n >> 2); a lane's 4 accumulator registers are then i, f, c~, o
     const float* gates_x;      // LSTM step (template LSTM): input part of the gates, interleaved columns [pixel][4 * gate_F]
@@ -118,7 +122,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         const int fr = f / p.tfx, fc = f - fr * p.tfx;
         const int oyl = fr * FH + fy, oxl = fc * FW + fx;
         fbase[a] = (oyl << (2 * p.sshift)) * p.PWs + oxl;
-        opix[a] = (oy0 + oyl) * p.Wo + ox0 + oxl;
+        opix[a] = p.shufC ? ((oy0 + oyl) * p.shufK) * (p.Wo * p.shufK) + (ox0 + oxl) * p.shufK : (oy0 + oyl) * p.Wo + ox0 + oxl;
     }
 
     const int nks = p.flat ? (p.nent + 3) >> 2 : p.kh * p.kw * p.kcn;            // K-steps per chunk
@@ -416,13 +420,18 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             const int n = nw0 + b * 16 + 4 * lq;
             if (n >= p.Ncols || (DBG & 16)) continue;
             const bool full = n + 3 < p.Ncols;
+            // scattered output (transposed k x k stride-k layer): this quad's tap -> pixel offset, channel
+            const int stap = p.shufC ? n / p.shufC : 0;
+            const int nch = p.shufC ? n - stap * p.shufC : n;                       // (shufC % 4 == 0: a quad stays inside one tap)
+            const int spix = p.shufC ? (stap / p.shufK) * (p.Wo * p.shufK) + stap % p.shufK : 0;
+            const int naff = p.shufC ? p.shufC : p.Ncols;
             f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = bias4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (n + r < p.Ncols) {
-                    const int nb = p.gate_F ? r * p.gate_F + (n >> 2) : n + r;      // (interleaved gate columns: n % 4 == 0)
+                    const int nb = p.gate_F ? r * p.gate_F + (n >> 2) : nch + r;    // (interleaved gate columns: n % 4 == 0)
                     if (p.bias) bias4[r] = p.bias[nb];
-                    if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[p.Ncols + nb]; }
+                    if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[naff + nb]; }
                 }
             if (p.out16) {
                 // 16-bit result (no bias / activation / accumulate on this route; column count a multiple of 16).  A lane's four
@@ -453,7 +462,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                float* dst = outImg + (long long)opix[a] * p.ldO + n;
+                float* dst = outImg + (long long)(opix[a] + spix) * p.ldO + nch;
                 f32x4 v = acc[a][b] + bias4;
                 if (p.act) {
 #pragma unroll
@@ -508,6 +517,14 @@ static WdgPatchView patch_view(const wdg_conv_plan* pl, bool transposed1x1) {
     else
         v = {g.n_img, g.Ho, g.Wo, g.ldy, g.H, g.W, g.ldx, g.img_stride_y, g.img_stride_x, pl->Cout_p, g.Cin,
              1, 1, 1, 0, 0, pl->cus};
+    return v;
+}
+// ... of a transposed k x k stride-k (non-overlapping) layer: a 1 x 1 GEMM on the low-resolution grid with k * k * Cin columns,
+// scattered by the epilogue (WdgPatchH16::shufC)
+static WdgPatchView patch_view_shuffle(const wdg_conv_plan* pl) {
+    const wdg_conv_geom& g = pl->g;
+    WdgPatchView v = {g.n_img, g.Ho, g.Wo, g.ldy, g.Ho, g.Wo, g.ldx, g.img_stride_y, g.img_stride_x, pl->Cout_p, g.kh * g.kw * g.Cin,
+                      1, 1, 1, 0, 0, pl->cus};
     return v;
 }
 
@@ -593,8 +610,12 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
                          const WdgPatchGates* gx, int out16) {
     if (out16 && (gx || bias || affine || act || accumulate)) return 1;
     if (out16 && (pl->g.Cin % 16 || pl->g.ldx % 8)) return 1;       // (transposed 1 x 1 view: the x side is the result — whole 16-column tiles)
-    if (transposed1x1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
-    const WdgPatchView g = patch_view(pl, transposed1x1 != 0);
+    const bool shuffle = transposed1x1 == 2;
+    if (transposed1x1 == 1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
+    if (shuffle && (pl->g.kh != pl->g.kw || pl->g.stride != pl->g.kh || pl->g.kh < 2 || pl->g.pad_h || pl->g.pad_w || pl->g.Cin % 4 ||
+                    pl->g.H != pl->g.Ho * pl->g.kh || pl->g.W != pl->g.Wo * pl->g.kw || gx || out16))
+        return 1;
+    const WdgPatchView g = shuffle ? patch_view_shuffle(pl) : patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;
     memset(&p, 0, sizeof(p));
     if (!patch_plan(g, p, g_patch_lstm_small && gx && gx->c_out)) return 1;
@@ -604,6 +625,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     p.Ncols = g.Ncols; p.ldB = g.kh * g.kw * g.K_p; p.Cin_p = g.K_p;
     p.kh = g.kh; p.kw = g.kw; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
+    if (shuffle) { p.shufC = pl->g.Cin; p.shufK = pl->g.kh; }
     const bool lstm = gx && gx->c_out;
     if (gx) {
         // ConvLSTM gate columns interleaved (x-part: plain epilogue, columns written interleaved; step: cell update in the epilogue)
