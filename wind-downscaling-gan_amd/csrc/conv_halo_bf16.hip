@@ -185,6 +185,114 @@ __global__ void __launch_bounds__(256) wdg_conv_halo_bf16_kernel(const WdgHaloBf
     }
 }
 
+// ---- 3 x 3, 16 input channels, <= 4 output channels (the generator's 16 -> 2 output conv, models.py:70) -------------------
+// The general kernel above spends this layer's time outside the matrix pipe: its staging loop is one dependent load per
+// iteration, its weight fragments come from global memory inside the tap loop, and with 2 live output columns of a 16-column
+// tile its epilogue is sixteen predicated 4-byte stores per thread.  Here: persistent workgroups (the next tile's halo is
+// requested branch-free under this tile's MFMAs), the nine taps' weight fragments in registers for the workgroup's life,
+// operands swapped (A = weights, B = pixels) so that a lane holds the four (padded) output channels of ONE pixel and stores
+// them as 16 bytes, and two taps per MFMA (k = 32 = 2 taps x 16 channels: five MFMAs per 16-pixel fragment).
+template <int FMT>
+__global__ void __launch_bounds__(256) wdg_conv_thin16_h16_kernel(const WdgHaloBf16 p, const wdg_h16<FMT>* __restrict__ Bw) {
+    typedef wdg_h16x8<FMT> bf16x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16x8* lds_a = reinterpret_cast<bf16x8*>(smem_raw);           // [2 kg][npix] (+ 1 slot for the staging slots beyond the halo)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int npr = p.halo_h * p.halo_w;
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weight fragments: MFMA i multiplies taps 2 i and 2 i + 1; this lane's k-octet lg is channel group lg & 1 of tap 2 i + (lg >> 1)
+    bf16x8 wf[5];
+    int poff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int tap = 2 * i + (lg >> 1), kg = lg & 1;
+        const int4 e = p.taps[tap < p.ntaps ? tap : 0];
+        wf[i] = hb_pack_t<FMT>(z4, z4);
+        if (tap < p.ntaps && li < p.Ncols) wf[i] = *reinterpret_cast<const bf16x8*>(Bw + (long long)li * p.ldB + e.z + kg * 8);
+        poff[i] = kg * p.npix + (e.x - p.dh_min) * p.halo_w + (e.y - p.dw_min);     // (tap 9: any slot, its weights are zero)
+    }
+    // epilogue constants of this lane's four channels (lanes lg > 0 hold padding columns)
+    f32x4 bias4 = z4, sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = z4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool on = lg == 0 && r < p.Ncols;
+        if (p.bias && on) bias4[r] = p.bias[r];
+        if (p.affine) { sc4[r] = on ? p.affine[r] : 0.f; sh4[r] = on ? p.affine[p.Ncols + r] : 0.f; }
+    }
+    // staging slots (tile independent): slot = (pixel, channel group), two consecutive lanes = the 64 contiguous bytes of a pixel
+    constexpr int NSL = 3;                                         // 2 * 10 * 34 = 680 slots over 256 threads
+    int shy[NSL], shx[NSL], sslot[NSL], soff[NSL];
+#pragma unroll
+    for (int s_ = 0; s_ < NSL; ++s_) {
+        const int idx = t + 256 * s_;
+        const int pix = idx >> 1, kg = idx & 1;
+        const bool on = pix < npr;
+        shy[s_] = on ? pix / p.halo_w : (1 << 28);
+        shx[s_] = pix - (pix / p.halo_w) * p.halo_w;
+        soff[s_] = (((pix / p.halo_w) * p.W + shx[s_]) * p.ldA + kg * 8) * 4;
+        sslot[s_] = on ? kg * p.npix + pix : 2 * p.npix;
+    }
+    const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
+    f32x4 rs[NSL][2];
+    auto request = [&](int tile) __attribute__((always_inline)) {
+        const int img = tile / (p.tiles_h * p.tiles_w);
+        const int rem = tile - img * (p.tiles_h * p.tiles_w);
+        const int ty = rem / p.tiles_w, tx = rem - ty * p.tiles_w;
+        const int hy0 = ty * HB_TH + p.dh_min, hx0 = tx * HB_TW + p.dw_min;
+        const wdg_srd srdA = wdg_make_srd(p.A + (long long)img * p.imgStrideA);
+        const int org = (hy0 * p.W + hx0) * p.ldA * 4;
+#pragma unroll
+        for (int s_ = 0; s_ < NSL; ++s_) {
+            const int gy = hy0 + shy[s_], gx = hx0 + shx[s_];
+            const unsigned neg = (unsigned)((gy | (p.Hc - 1 - gy) | gx | (p.Wc - 1 - gx)) >> 31);
+            const unsigned off = ((unsigned)(org + soff[s_]) & ~neg) | (neg & 0x80000000u);
+            rs[s_][0] = wdg_buffer_load_f32x4(srdA, off);
+            rs[s_][1] = wdg_buffer_load_f32x4(srdA, off + 16);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) request(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                           // the previous tile's fragment reads are done
+#pragma unroll
+        for (int s_ = 0; s_ < NSL; ++s_) lds_a[sslot[s_]] = hb_pack_t<FMT>(rs[s_][0], rs[s_][1]);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
+        const int img = tile / (p.tiles_h * p.tiles_w);
+        const int rem = tile - img * (p.tiles_h * p.tiles_w);
+        const int ty = rem / p.tiles_w, tx = rem - ty * p.tiles_w;
+        f32x4 acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int pb = (2 * wave + (f >> 1)) * p.halo_w + (f & 1) * 16 + li;
+            bf16x8 b[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) b[i] = lds_a[poff[i] + pb];
+            acc[f] = z4;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc[f] = wdg_mfma16<FMT>(wf[i], b[i], acc[f]);
+        }
+        // register r of lane (li, lg): output channel 4 lg + r of pixel li of the fragment
+        if (lg == 0) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int oy = ty * HB_TH + 2 * wave + (f >> 1), ox = tx * HB_TW + (f & 1) * 16 + li;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                f32x4 v = acc[f] + bias4;
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
+                }
+                if (p.affine) v = v * sc4 + sh4;
+                *reinterpret_cast<f32x4*>(p.Out + (long long)img * p.imgStrideO + ((long long)oy * p.Wo + ox) * p.ldO) = v;
+            }
+        }
+    }
+}
+
+static int g_thin16 = 1;     // wdg_set_tuning("halo16_thin", 0/1)
+void wdg_halo_bf16_set_thin(int v) { g_thin16 = v != 0; }
+
 static int launch_halo_bf16(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA,
                             int upsample, const void* B16, const float* bias, const float* affine, float* Out, int act,
                             float slope, int accumulate, int fmt, hipStream_t st) {
@@ -230,6 +338,16 @@ static int launch_halo_bf16(const wdg_conv_plan* pl, bool dgrad, const float* A,
     p.lr_h = p.halo_h / 2 + 3; p.lr_w = p.halo_w / 2 + 3;
     const size_t lds = (size_t)4 * p.npix * 16 + (upsample ? (size_t)p.lr_h * p.lr_w * 8 * 16 : 0);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
+    // the 16 -> 2 output conv (3 x 3, 16 padded input channels, <= 4 output channels whose padded pixel stride is 4 floats)
+    if (g_thin16 && !upsample && !accumulate && p.ntaps == 9 && g.kh == 3 && g.kw == 3 && p.C8 == 2 && p.Ncols <= 4 && p.ldO == 4 &&
+        ldA % 4 == 0 && ((uintptr_t)Out & 15) == 0 && ((uintptr_t)A & 15) == 0 && (long long)p.Hc * p.Wc * ldA * 4 < (1LL << 31)) {
+        const size_t lds1 = ((size_t)2 * p.npix + 1) * 16;
+        const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * 8);
+        if (fmt == 0) hipLaunchKernelGGL((wdg_conv_thin16_h16_kernel<0>), dim3(nb), block, lds1, st, p, (const __bf16*)B16);
+        else hipLaunchKernelGGL((wdg_conv_thin16_h16_kernel<1>), dim3(nb), block, lds1, st, p, (const _Float16*)B16);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
 #define WDG_HB_CASE(NT_)                                                                                              \
     if (nt == NT_) {                                                                                              \
         if (fmt == 0) hipLaunchKernelGGL((wdg_conv_halo_bf16_kernel<NT_, 0>), grid, block, lds, st, p, (const __bf16*)B16);   \

@@ -1423,6 +1423,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         wdg_halo_set_max_cin(value);
         return WDG_OK;
     }
+    if (key && !strcmp(key, "halo16_thin")) {
+        wdg_halo_bf16_set_thin(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "halo1_stage")) {
         wdg_halo_set_stage(value);
         return WDG_OK;

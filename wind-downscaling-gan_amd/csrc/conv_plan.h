@@ -76,6 +76,7 @@ void wdg_halo_plan_free(wdg_conv_plan* pl);
 void wdg_halo_set_wg(int v);
 void wdg_halo_set_persistent(int v);
 void wdg_halo_set_stage(int v);
+void wdg_halo_bf16_set_thin(int v);   // conv_halo_bf16.hip: the specialised 16 -> (<= 4) output-conv kernel on / off
 void wdg_halo_set_th4(int v);
 void wdg_halo_set_max_cin(int v);
 void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
