@@ -466,8 +466,15 @@ int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias, const flo
  * 1 fp16); y [n, 2 Hl, 2 Wl, ldy >= C] fp32 = affine(act(bias + ...)).  Supported: Cin 160, C 16 (the shipped generator). */
 int wdg_upconv_fused_h16_supported(int Cin, int C);
 int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
-                         const float* affine, float* y, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin, int C,
-                         int act, float slope, wdg_stream stream);
+                         const float* affine, void* y, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin, int C,
+                         int act, float slope, int out16, wdg_stream stream);
+/* out16 != 0: y holds 16-bit elements of the operand format (ldy / img_stride_y in elements, ldy % 8 == 0) — for the reader below,
+ * which rounds to that format anyway: the same values, half the bytes.
+ * wdg_conv_thin16_fwd_h16: the generator's output conv (models.py:70: 3 x 3, stride 1, 16 (padded) input channels, <= 4 output
+ * channels at a pixel stride of 4 floats) reading x16 [n, H, W, ldx16] in the operand format — bit for bit the result of
+ * wdg_conv_halo_fwd_bf16 / _f16 on the fp32 tensor x16 was rounded from.  `plan`: the layer's forward plan. */
+int wdg_conv_thin16_fwd_h16(const wdg_conv_plan* plan, const void* x16, int ldx16, int64_t img_stride_x16, const void* wF16, int fmt,
+                            const float* bias, const float* affine, float* y, int act, float slope, wdg_stream stream);
 
 
 /* ------------------------------------------------------------------------------------------

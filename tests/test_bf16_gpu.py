@@ -175,6 +175,16 @@ def test_bf16_generator_forward(hip_ops, S, T, F, fmt):
     assert rel_err(out32, ref) < 1e-4
     err = rel_err(out16, ref)
     assert 1e-6 < err < (3e-2 if fmt == "bf16" else 4e-3), err   # a different precision, within the stated tolerance
+    # the activation between the last two layers handed over in the operand format (WDG_ACT16, default) or in fp32: the reader
+    # rounds to the operand format either way — the outputs are the same bits
+    if F == 128 and hip_ops.act16_output_conv_ok(net.c9.pk, net.c11.pk, net.c11.g):
+        hip_ops.act16 = False
+        try:
+            out16b = torch.zeros(B, T, S, S, ch, device=dev)
+            net.from_time_major(net.forward(B, False, precision=fmt), out16b)
+        finally:
+            hip_ops.act16 = True
+        assert torch.equal(out16, out16b)
     with pytest.raises(ValueError):
         net.forward(B, True, precision=fmt)
 

@@ -31,6 +31,7 @@ struct WdgHaloBf16 {
     float slope;
     int tiles_h, tiles_w;
     int lr_h, lr_w;         // low-res staging tile (upsample mode)
+    int in16;               // (thin kernel) A holds 16-bit elements of the operand format; ldA / imgStrideA in elements
 };
 
 template <int FMT>
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(256) wdg_conv_thin16_h16_kernel(const WdgHaloB
         const bool on = pix < npr;
         shy[s_] = on ? pix / p.halo_w : (1 << 28);
         shx[s_] = pix - (pix / p.halo_w) * p.halo_w;
-        soff[s_] = (((pix / p.halo_w) * p.W + shx[s_]) * p.ldA + kg * 8) * 4;
+        soff[s_] = ((pix / p.halo_w) * p.W + shx[s_]) * p.ldA + kg * 8;       // elements
         sslot[s_] = on ? kg * p.npix + pix : 2 * p.npix;
     }
     const int ntiles = p.n_img * p.tiles_h * p.tiles_w;
@@ -240,13 +241,25 @@ __global__ void __launch_bounds__(256) wdg_conv_thin16_h16_kernel(const WdgHaloB
         const int rem = tile - img * (p.tiles_h * p.tiles_w);
         const int ty = rem / p.tiles_w, tx = rem - ty * p.tiles_w;
         const int hy0 = ty * HB_TH + p.dh_min, hx0 = tx * HB_TW + p.dw_min;
+        const int org = (hy0 * p.W + hx0) * p.ldA;
+        if (p.in16) {
+            // the producer stored the activations in the operand format already (the same rounding, one step earlier): eight
+            // channels are one 16-byte request, no conversion
+            const wdg_srd srdA = wdg_make_srd(reinterpret_cast<const wdg_h16<FMT>*>(p.A) + (long long)img * p.imgStrideA);
+#pragma unroll
+            for (int s_ = 0; s_ < NSL; ++s_) {
+                const int gy = hy0 + shy[s_], gx = hx0 + shx[s_];
+                const unsigned neg = (unsigned)((gy | (p.Hc - 1 - gy) | gx | (p.Wc - 1 - gx)) >> 31);
+                rs[s_][0] = wdg_buffer_load_f32x4(srdA, ((unsigned)((org + soff[s_]) * 2) & ~neg) | (neg & 0x80000000u));
+            }
+            return;
+        }
         const wdg_srd srdA = wdg_make_srd(p.A + (long long)img * p.imgStrideA);
-        const int org = (hy0 * p.W + hx0) * p.ldA * 4;
 #pragma unroll
         for (int s_ = 0; s_ < NSL; ++s_) {
             const int gy = hy0 + shy[s_], gx = hx0 + shx[s_];
             const unsigned neg = (unsigned)((gy | (p.Hc - 1 - gy) | gx | (p.Wc - 1 - gx)) >> 31);
-            const unsigned off = ((unsigned)(org + soff[s_]) & ~neg) | (neg & 0x80000000u);
+            const unsigned off = ((unsigned)((org + soff[s_]) * 4) & ~neg) | (neg & 0x80000000u);
             rs[s_][0] = wdg_buffer_load_f32x4(srdA, off);
             rs[s_][1] = wdg_buffer_load_f32x4(srdA, off + 16);
         }
@@ -255,7 +268,8 @@ __global__ void __launch_bounds__(256) wdg_conv_thin16_h16_kernel(const WdgHaloB
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                                           // the previous tile's fragment reads are done
 #pragma unroll
-        for (int s_ = 0; s_ < NSL; ++s_) lds_a[sslot[s_]] = hb_pack_t<FMT>(rs[s_][0], rs[s_][1]);
+        for (int s_ = 0; s_ < NSL; ++s_)
+            lds_a[sslot[s_]] = p.in16 ? __builtin_bit_cast(bf16x8, rs[s_][0]) : hb_pack_t<FMT>(rs[s_][0], rs[s_][1]);
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);
         const int img = tile / (p.tiles_h * p.tiles_w);
@@ -295,7 +309,7 @@ void wdg_halo_bf16_set_thin(int v) { g_thin16 = v != 0; }
 
 static int launch_halo_bf16(const wdg_conv_plan* pl, bool dgrad, const float* A, int ldA, long long imgStrideA,
                             int upsample, const void* B16, const float* bias, const float* affine, float* Out, int act,
-                            float slope, int accumulate, int fmt, hipStream_t st) {
+                            float slope, int accumulate, int fmt, hipStream_t st, int in16 = 0) {
     const wdg_conv_geom& g = pl->g;
     WdgHaloBf16 p;
     memset(&p, 0, sizeof(p));
@@ -339,8 +353,15 @@ static int launch_halo_bf16(const wdg_conv_plan* pl, bool dgrad, const float* A,
     const size_t lds = (size_t)4 * p.npix * 16 + (upsample ? (size_t)p.lr_h * p.lr_w * 8 * 16 : 0);
     dim3 grid((unsigned)((long long)g.n_img * p.tiles_h * p.tiles_w)), block(256);
     // the 16 -> 2 output conv (3 x 3, 16 padded input channels, <= 4 output channels whose padded pixel stride is 4 floats)
-    if (g_thin16 && !upsample && !accumulate && p.ntaps == 9 && g.kh == 3 && g.kw == 3 && p.C8 == 2 && p.Ncols <= 4 && p.ldO == 4 &&
-        ldA % 4 == 0 && ((uintptr_t)Out & 15) == 0 && ((uintptr_t)A & 15) == 0 && (long long)p.Hc * p.Wc * ldA * 4 < (1LL << 31)) {
+    p.in16 = in16;
+    const bool thin = !upsample && !accumulate && p.ntaps == 9 && g.kh == 3 && g.kw == 3 && p.C8 == 2 && p.Ncols <= 4 && p.ldO == 4 &&
+                      ldA % (in16 ? 8 : 4) == 0 && ((uintptr_t)Out & 15) == 0 && ((uintptr_t)A & 15) == 0 &&
+                      (long long)p.Hc * p.Wc * ldA * 4 < (1LL << 31);
+    if (in16 && !thin) {
+        wdg_set_error("halo_bf16: 16-bit activations are read by the 3 x 3, 16 -> (<= 4) channel kernel only");
+        return WDG_ERR_ARG;
+    }
+    if ((g_thin16 || in16) && thin) {
         const size_t lds1 = ((size_t)2 * p.npix + 1) * 16;
         const unsigned nb = (unsigned)std::min<long long>((long long)grid.x, (long long)pl->cus * 8);
         if (fmt == 0) hipLaunchKernelGGL((wdg_conv_thin16_h16_kernel<0>), dim3(nb), block, lds1, st, p, (const __bf16*)B16);
@@ -392,4 +413,16 @@ extern "C" int wdg_upconv_fwd_f16(const wdg_conv_plan* pl, const float* x_low, i
                                   const void* wD16, const float* bias, const float* affine, float* y, int act,
                                   float slope, wdg_stream stream) {
     return upconv_fwd_h16(pl, x_low, ld_low, img_stride_low, wD16, bias, affine, y, act, slope, 1, stream);
+}
+
+// The same convolution reading its input in the 16-BIT operand format (x16 [n, H, W, ldx16 >= 16] bf16 (fmt 0) / fp16 (fmt 1),
+// strides in elements): for the generator's output conv (models.py:70) behind wdg_upconv_fused_h16(out16 = 1) — the value the
+// kernel multiplies is the rounded one either way, so the result is the one of wdg_conv_halo_fwd_bf16 / _f16 bit for bit.
+// 3 x 3, stride 1, 16 (padded) input channels, <= 4 output channels with a pixel stride of 4 floats.
+extern "C" int wdg_conv_thin16_fwd_h16(const wdg_conv_plan* pl, const void* x16, int ldx16, int64_t img_stride_x16, const void* wF16,
+                                       int fmt, const float* bias, const float* affine, float* y, int act, float slope,
+                                       wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x16 && wF16 && y && (fmt == 0 || fmt == 1), "bad argument");
+    return launch_halo_bf16(pl, false, reinterpret_cast<const float*>(x16), ldx16, img_stride_x16, 0, wF16, bias, affine, y, act, slope, 0,
+                            fmt, (hipStream_t)stream, 1);
 }

@@ -66,7 +66,7 @@ template <int FMT, int K>
 __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float* __restrict__ x, int ldx, long long isx,
                                                                    const wdg_h16<FMT>* __restrict__ w16, const float* __restrict__ bias,
                                                                    const float* __restrict__ affine, float* __restrict__ y, int ldy,
-                                                                   long long isy, int Hl, int Wl, int tiles, int total, int act, float slope) {
+                                                                   long long isy, int Hl, int Wl, int tiles, int total, int act, float slope, int out16) {
     typedef wdg_h16x8<FMT> h16x8;
     static_assert(K % 32 == 0, "whole MFMA K-steps");
     constexpr int KO = K / 8, KS = K / 32;
@@ -332,18 +332,27 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
             FV_MARK(6);
         }
         if (qy < 2 * Hl && qx < 2 * Wl) {
-            float* dst = y + (long long)n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+            f32x4 v[OQ];
 #pragma unroll
             for (int o = 0; o < OQ; ++o) {
                 const int o4 = og0 + o;
-                f32x4 v = acc[o];
-                if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
+                v[o] = acc[o];
+                if (bias) v[o] += *reinterpret_cast<const f32x4*>(bias + 4 * o4);
                 if (act) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], slope);
+                    for (int r = 0; r < 4; ++r) v[o][r] = wdg_lrelu(v[o][r], slope);
                 }
-                if (affine) v = v * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * F_CQ + 4 * o4);
-                *reinterpret_cast<f32x4*>(dst + 4 * o4) = v;
+                if (affine) v[o] = v[o] * *reinterpret_cast<const f32x4*>(affine + 4 * o4) + *reinterpret_cast<const f32x4*>(affine + 4 * F_CQ + 4 * o4);
+            }
+            if (out16) {
+                // the thread's eight consecutive channels in the operand format (the only reader rounds to it anyway): 16 bytes
+                static_assert(OQ == 2, "eight channels per thread");
+                wdg_h16<FMT>* dst = reinterpret_cast<wdg_h16<FMT>*>(y) + (long long)n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+                *reinterpret_cast<h16x8*>(dst + 4 * og0) = wdg_pack_h16<FMT>(v[0], v[1]);
+            } else {
+                float* dst = y + (long long)n * isy + ((long long)qy * (2 * Wl) + qx) * ldy;
+#pragma unroll
+                for (int o = 0; o < OQ; ++o) *reinterpret_cast<f32x4*>(dst + 4 * (og0 + o)) = v[o];
             }
         }
         FV_MARK(7);                                  // epilogue
@@ -356,7 +365,7 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
 
 template <int FMT, int K>
 int fused_launch(int grid, size_t lds, hipStream_t st, const float* x, int ldx, long long isx, const void* w16, const float* bias,
-                 const float* affine, float* y, int ldy, long long isy, int Hl, int Wl, int tiles, int total, int act, float slope) {
+                 const float* affine, float* y, int ldy, long long isy, int Hl, int Wl, int tiles, int total, int act, float slope, int out16) {
     static bool attr = false;
     if (!attr) {
         WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_upconv_fused_h16_kernel<FMT, K>),
@@ -364,7 +373,7 @@ int fused_launch(int grid, size_t lds, hipStream_t st, const float* x, int ldx, 
         attr = true;
     }
     hipLaunchKernelGGL((wdg_upconv_fused_h16_kernel<FMT, K>), dim3(grid), dim3(F_NT), lds, st, x, ldx, isx,
-                       reinterpret_cast<const wdg_h16<FMT>*>(w16), bias, affine, y, ldy, isy, Hl, Wl, tiles, total, act, slope);
+                       reinterpret_cast<const wdg_h16<FMT>*>(w16), bias, affine, y, ldy, isy, Hl, Wl, tiles, total, act, slope, out16);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
@@ -390,9 +399,13 @@ extern "C" int wdg_upconv_fused_h16_supported(int Cin, int C) { return C == 16 &
 
 // y [n, 2 Hl, 2 Wl, >= C] = affine(act(bias + convT5x5(bilinear_x2(x_low)))), x_low [n, Hl, Wl, ldx >= Cin] fp32 (rounded to the
 // operand format while staged), w16 = the layer's weight tensor [25 * C][Cin] in bf16 (fmt 0) / fp16 (fmt 1).
+// out16 != 0: y holds 16-bit elements of the operand format (ldy / img_stride_y in elements, ldy % 8 == 0) — for a reader that
+// rounds to that format anyway (wdg_conv_thin16_fwd_h16): the same values, half the bytes.
 extern "C" int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
-                                    const float* affine, float* y, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin,
-                                    int C, int act, float slope, wdg_stream stream) {
+                                    const float* affine, void* y_, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin,
+                                    int C, int act, float slope, int out16, wdg_stream stream) {
+    float* y = reinterpret_cast<float*>(y_);
+    WDG_CHECK_ARG(!out16 || ldy % 8 == 0, "16-bit output: pixel stride a multiple of 8 elements");
     WDG_CHECK_ARG(x_low && w16 && y && (fmt == 0 || fmt == 1) && n_img > 0 && n_img < 65536 && Hl > 0 && Wl > 0, "bad argument");
     WDG_CHECK_ARG(wdg_upconv_fused_h16_supported(Cin, C), "unsupported channel counts (Cin 160, C 16)");
     WDG_CHECK_ARG(ldx % 4 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= C, "pixel strides");
@@ -407,6 +420,6 @@ extern "C" int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_str
     const int grid = std::min(total, fused_cus());  // persistent: one workgroup per CU (LDS), each prefetching its next tile's window
     hipStream_t st = (hipStream_t)stream;
     if (fmt == 0)
-        return fused_launch<0, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope);
-    return fused_launch<1, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope);
+        return fused_launch<0, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope, out16);
+    return fused_launch<1, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope, out16);
 }

@@ -276,6 +276,8 @@ class HipOps:
         self.z16 = os.environ.get("WDG_Z16", "0") == "1"   # 16-bit inference: the column GEMM's result z in the operand format
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
         self.upconv_fused16 = os.environ.get("WDG_UPCONV_FUSED16", "1") != "0"   # 16-bit inference: column GEMM + gather in one launch
+        # the 16-channel activation between the generator's last two layers in the 16-bit operand format (inference precision)
+        self.act16 = os.environ.get("WDG_ACT16", "1") != "0"
         self._scratch_bufs = {}
         # per-timestep launch chains (the ConvLSTM time loops at n_timesteps > 1) replayed from captured HIP graphs: see chain()
         self.gates_x = os.environ.get("WDG_GATES_X", "1") != "0"      # T > 1: the 5 -> 16 ConvLSTM's input convolution in its own kernel
@@ -631,8 +633,29 @@ class HipOps:
         native.check(fn(plan, dy.data_ptr(), pk.half(fmt)[1].data_ptr(), _ptr(bias), _ptr(affine),
                         dx.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_dgrad_16")
 
+    H16_DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+    def act16_output_conv_ok(self, pk_up, pk_out, g_out):
+        """True when the generator's last two layers can pass their 16-channel activation in the 16-bit operand format: the fused
+        upsample kernel writes it (out16), the 16 -> (<= 4) output conv reads it (wdg_conv_thin16_fwd_h16).  Same values as the
+        fp32 hand-over (the reader rounds to the operand format either way), half the bytes."""
+        return bool(self.act16 and self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk_up.cout, pk_up.cin)
+                    and g_out.kh == 3 and g_out.kw == 3 and g_out.stride == 1 and g_out.pad == 1 and pk_out.cin == 16 and pk_out.cout <= 4)
+
     def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2, fmt="bf16"):
-        """16-bit thin stride-1 conv (<= 64 output channels) through the halo-tile kernel."""
+        """16-bit thin stride-1 conv (<= 64 output channels) through the halo-tile kernel.  x may be a tensor in the 16-bit operand
+        format (3 x 3, 16 -> (<= 4) channels only: csrc/conv_halo_bf16.hip, wdg_conv_thin16_fwd_h16)."""
+        if x.dtype in (torch.bfloat16, torch.float16):
+            if x.dtype != self.H16_DTYPES[fmt]:
+                raise ValueError(f"conv_halo_fwd_bf16: x is {x.dtype}, the operand format is {fmt}")
+            n, H, W, _ = x.shape
+            cp = (pk.cin + 3) // 4 * 4
+            plan, _, _ = self._plan_dims(n, H, W, pk.cin, cp, H * W * cp, H, W, pk.cout, *_v4(y)[1:], g)
+            px, ldx, isx = _v4(x)
+            native.check(self.lib.wdg_conv_thin16_fwd_h16(plan, px, ldx, isx, pk.half(fmt)[0].data_ptr(), 0 if fmt == "bf16" else 1,
+                                                          _ptr(bias), _ptr(affine), y.data_ptr(), int(act), slope, self.stream),
+                         "conv_thin16_fwd_h16")
+            return
         plan, _, _ = self._plan(x, y, pk.cin, pk.cout, g)
         fn = self.lib.wdg_conv_halo_fwd_bf16 if fmt == "bf16" else self.lib.wdg_conv_halo_fwd_f16
         native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
@@ -651,13 +674,18 @@ class HipOps:
             # four values (16-tile group 3.78 -> 4.23 ms) and with 16-byte accesses of eight (lane-pair exchange in the GEMM's
             # epilogue, eight-value slots in the gather: 3.82 -> 3.97 ms) — neither kernel is bound by z's bytes: the 400-column
             # GEMM has a reduction of only 160 (five MFMA K-steps per 16 stores) and the gather is bound by its LDS passes
+            y16 = y.dtype in (torch.bfloat16, torch.float16)
             if self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk.cout, pk.cin) and ldl % 4 == 0:
                 # both stages in one launch, z never leaves the CU (csrc/upconv_fused_h16.hip): 0.48 + 0.54 ms -> one launch per
-                # 16-tile group of the shipped generator
+                # 16-tile group of the shipped generator.  y in the operand format: for a reader that rounds to it anyway
+                if y16 and y.dtype != self.H16_DTYPES[fmt]:
+                    raise ValueError(f"upconv_fwd_bf16: y is {y.dtype}, the operand format is {fmt}")
                 native.check(self.lib.wdg_upconv_fused_h16(px, ldl, isl, pk.half(fmt)[1].data_ptr(), 0 if fmt == "bf16" else 1, _ptr(bias),
                                                            _ptr(affine), py, ldy, isy, n, H // 2, W // 2, pk.cout, pk.cin, int(act), slope,
-                                                           self.stream), "upconv_fused_h16")
+                                                           int(y16), self.stream), "upconv_fused_h16")
                 return
+            if y16:
+                raise ValueError("upconv_fwd_bf16: a 16-bit y needs the fused kernel (act16_output_conv_ok)")
             plan16 = None
             if self.z16 and pk.cin % 8 == 0:
                 plan16, _, _ = self._plan_dims(n, H // 2, W // 2, 25 * pk.cin, 25 * pk.cin, (H // 2) * (W // 2) * 25 * pk.cin,

@@ -245,23 +245,32 @@ class GeneratorNet(_Net):
         more (the backward of the upsample + transposed-conv block works on the low-res grid, ops.upconv_bwd)."""
         if need_backward is None:
             need_backward = training
+        if precision in ("bf16", "fp16") and training:       # (before anything is prepared: a refused call leaves no trace)
+            raise ValueError("the 16-bit operand path is inference-only")
         b = self.buffers(B)
         F, IF, T = self.F, self.IF, self.T
         self._prepare(training)
         res2 = b["cat2"][..., self.F4p:]
         res4 = b["cat4"][..., F // 2:]
         if precision in ("bf16", "fp16"):
-            if training:
-                raise ValueError("the 16-bit operand path is inference-only")
             f = precision
             self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine(), fmt=f)
             self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine(), fmt=f)
             self.lstm.forward(res4, b["h"], B, T, bf16=True, fmt=f)
             self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
             self.c7.forward_bf16(b["cat4"], b["cat2"][..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
-            self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, b["z9"], self.c9.g, act=True,
+            z9 = b["z9"]
+            ok16 = getattr(self.ops, "act16_output_conv_ok", None)
+            if ok16 is not None and z9.shape[3] == 16 and ok16(self.c9.pk, self.c11.pk, self.c11.g):
+                # the 16-channel activation between the last two layers in the operand format: its only reader rounds to that
+                # format anyway — the same values, half the bytes of the largest-by-pixels tensor of the forward
+                key = "z9_" + f
+                if key not in b or b[key].shape != z9.shape:
+                    b[key] = self.ops.zeros(*z9.shape, dtype=self.ops.H16_DTYPES[f])
+                z9 = b[key]
+            self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, z9, self.c9.g, act=True,
                                      affine=self.bn10.infer_affine(), fmt=f, pool=self._scratch_pool(b))
-            self.ops.conv_halo_fwd_bf16(b["z9"], self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
+            self.ops.conv_halo_fwd_bf16(z9, self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
             return b["out"]
         if precision != "fp32":
             raise ValueError(f"unknown precision {precision!r}")
