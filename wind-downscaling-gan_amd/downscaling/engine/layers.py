@@ -146,6 +146,8 @@ class BatchNorm:
         self.ss = o.empty(2 * C)
         self.saved = o.empty(2 * C)
         self.count = 1.0
+        self._epoch = 0                 # training-mode passes seen (each rewrites ss and the moving statistics)
+        self._infer_key = None          # (params.version, _epoch) self.ss holds the inference affine of
         if self.Cp != self.C:
             self.mvar.value_pad[self.C:] = 0.0     # (alignment slots: keep the pad channels' variance at 0, not the init 1)
 
@@ -169,15 +171,21 @@ class BatchNorm:
                 sync.all_reduce_sum(stats)
                 count *= sync.world_size
             self.count = count
+            self._epoch += 1
             o.bn_finalize_train(stats, count, self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad,
                                 self.mvar.value_pad, BN_MOMENTUM, BN_EPS, self.ss, self.saved)
         else:
-            o.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS, self.ss)
+            self.infer_affine()
         o.bn_apply(y, self.ss, z)
 
     def infer_affine(self):
-        """[scale | shift] of the inference-mode normalisation (moving statistics), for epilogue fusion."""
-        self.ops.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS, self.ss)
+        """[scale | shift] of the inference-mode normalisation (moving statistics), for epilogue fusion.  Recomputed only when
+        the parameters (ParamStore.version: optimizer step, load, set_weights) or the moving statistics (a training-mode pass)
+        changed: five launches per generator forward otherwise — inside the replayed inference graph as well."""
+        key = (self.net.params.version, self._epoch)
+        if self._infer_key != key:
+            self.ops.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS, self.ss)
+            self._infer_key = key
         return self.ss
 
     def backward(self, dz, y, dpre, dbias, act_slope=LRELU):
