@@ -465,16 +465,28 @@ int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias, const flo
  * memory.  x_low [n, Hl, Wl, ldx >= Cin] fp32; w16: the layer's weight tensor [25 * C][Cin] in the operand format (fmt 0 bf16,
  * 1 fp16); y [n, 2 Hl, 2 Wl, ldy >= C] fp32 = affine(act(bias + ...)).  Supported: Cin 160, C 16 (the shipped generator). */
 int wdg_upconv_fused_h16_supported(int Cin, int C);
-int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
+int wdg_upconv_fused_h16(const void* x_low, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
                          const float* affine, void* y, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin, int C,
-                         int act, float slope, int out16, wdg_stream stream);
+                         int act, float slope, int out16, int in16, wdg_stream stream);
 /* out16 != 0: y holds 16-bit elements of the operand format (ldy / img_stride_y in elements, ldy % 8 == 0) — for the reader below,
- * which rounds to that format anyway: the same values, half the bytes.
+ * which rounds to that format anyway: the same values, half the bytes.  in16 != 0: x_low likewise (ldx % 8 == 0).
  * wdg_conv_thin16_fwd_h16: the generator's output conv (models.py:70: 3 x 3, stride 1, 16 (padded) input channels, <= 4 output
  * channels at a pixel stride of 4 floats) reading x16 [n, H, W, ldx16] in the operand format — bit for bit the result of
  * wdg_conv_halo_fwd_bf16 / _f16 on the fp32 tensor x16 was rounded from.  `plan`: the layer's forward plan. */
 int wdg_conv_thin16_fwd_h16(const wdg_conv_plan* plan, const void* x16, int ldx16, int64_t img_stride_x16, const void* wF16, int fmt,
                             const float* bias, const float* affine, float* y, int act, float slope, wdg_stream stream);
+
+/* Activations in the 16-bit operand format between two layers of the inference-precision forward.  Every such layer rounds its
+ * input to the operand format while staging it; when all readers of a tensor are such layers the producer can store it rounded —
+ * the values multiplied are the same bits, the tensor has half the bytes.  in16 / out16: x / y hold 16-bit elements (bf16 for
+ * fmt 0, IEEE fp16 for fmt 1) and the plan's ldx / ldy / image strides count elements of the tensors as stored.  Only the
+ * input-patch kernel takes this route; wdg_conv_h16_act16_supported says whether it would (transposed 0: the plan's forward conv
+ * = wdg_conv_fwd_bf16 / _f16; 1: its transposed direction = wdg_conv_dgrad_bf16 / _f16: 1 x 1, or k x k stride-k). */
+int wdg_conv_h16_act16_supported(const wdg_conv_plan* plan, int transposed, int in16, int out16);
+int wdg_conv_fwd_h16_act16(const wdg_conv_plan* plan, const void* x, int in16, const void* wF16, int fmt, const float* bias,
+                           const float* affine, void* y, int out16, int act, float slope, wdg_stream stream);
+int wdg_conv_dgrad_h16_act16(const wdg_conv_plan* plan, const void* dy, int in16, const void* wD16, int fmt, const float* bias,
+                             const float* affine, void* dx, int out16, int act, float slope, wdg_stream stream);
 
 
 /* ------------------------------------------------------------------------------------------

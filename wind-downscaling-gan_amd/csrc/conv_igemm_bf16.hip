@@ -389,3 +389,47 @@ extern "C" int wdg_convlstm_step_h16(const wdg_conv_plan* pl, const float* h_pre
     WDG_CHECK_ARG(rc != 1, "patch kernel refused the geometry");
     return rc;
 }
+
+// ---- activations in the 16-bit operand format between two 16-bit layers --------------------------------------------------
+// A layer of the inference-precision forward rounds its input to the operand format while staging it.  When every reader of a
+// tensor is such a layer, the PRODUCER can store it rounded: the values multiplied are the same bits, the tensor has half the
+// bytes.  in16: x holds 16-bit elements (the plan's ldx / image stride are in elements of x as it is stored), out16: y likewise.
+// Only the input-patch kernel (conv_patch_h16.hip) takes this route: `transposed` 0 = the forward conv of the plan, 1 = its
+// transposed direction (1 x 1, or k x k stride-k as one GEMM with a scattering epilogue).  The query says whether it would.
+extern "C" int wdg_conv_h16_act16_supported(const wdg_conv_plan* pl, int transposed, int in16, int out16) {
+    if (!pl) return 0;
+    const wdg_conv_geom& g = pl->g;
+    if (!transposed) {
+        if (pl->Cin_p % 8 || (in16 && g.ldx % 8) || (out16 && (g.Cout % 16 || g.ldy % 8))) return 0;
+        return wdg_patch_h16_eligible(pl);
+    }
+    if (pl->Cout_p % 8 || (in16 && g.ldy % 8) || (out16 && g.ldx % 8)) return 0;
+    if (g.kh == 1 && g.kw == 1) return (!out16 || g.Cin % 16 == 0) && wdg_patch_h16_eligible_t(pl);
+    return (!out16 || g.Cin % 32 == 0) && wdg_patch_h16_eligible_s(pl);
+}
+extern "C" int wdg_conv_fwd_h16_act16(const wdg_conv_plan* pl, const void* x, int in16, const void* wF16, int fmt, const float* bias,
+                                      const float* affine, void* y, int out16, int act, float slope, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && wF16 && y && (fmt == 0 || fmt == 1), "bad argument");
+    WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wF16 & 15) == 0 && ((uintptr_t)y & 15) == 0, "alignment");
+    const int rc = wdg_patch_h16_launch(pl, 0, reinterpret_cast<const float*>(x), wF16, bias, affine, reinterpret_cast<float*>(y), act, slope,
+                                        0, fmt, (hipStream_t)stream, nullptr, out16, in16);
+    if (rc == 1) {
+        wdg_set_error("wdg_conv_fwd_h16_act16: geometry outside the patch kernel (wdg_conv_h16_act16_supported)");
+        return WDG_ERR_ARG;
+    }
+    return rc;
+}
+extern "C" int wdg_conv_dgrad_h16_act16(const wdg_conv_plan* pl, const void* dy, int in16, const void* wD16, int fmt, const float* bias,
+                                        const float* affine, void* dx, int out16, int act, float slope, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && dy && wD16 && dx && (fmt == 0 || fmt == 1), "bad argument");
+    WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD16 & 15) == 0 && ((uintptr_t)dx & 15) == 0, "alignment");
+    const wdg_conv_geom& g = pl->g;
+    const int mode = (g.kh == 1 && g.kw == 1) ? 1 : 2;
+    const int rc = wdg_patch_h16_launch(pl, mode, reinterpret_cast<const float*>(dy), wD16, bias, affine, reinterpret_cast<float*>(dx), act,
+                                        slope, 0, fmt, (hipStream_t)stream, nullptr, out16, in16);
+    if (rc == 1) {
+        wdg_set_error("wdg_conv_dgrad_h16_act16: geometry outside the patch kernel (wdg_conv_h16_act16_supported)");
+        return WDG_ERR_ARG;
+    }
+    return rc;
+}

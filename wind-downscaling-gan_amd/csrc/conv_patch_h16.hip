@@ -38,6 +38,8 @@ struct WdgPatchH16 {
     int pad_h, pad_w;
     int act, accumulate;
     float slope;
+    int in16;                  // the input is stored in the 16-bit operand format (A points to 16-bit elements; ldA / imgStrideA in
+                               // elements): the producer rounded the activation where this kernel would have — same bits, half the bytes
     int out16;                 // the output is stored in the 16-bit operand format (Out points to 16-bit elements; ldO / imgStrideO in
                                // elements): the column GEMM of the upsample layer, whose only reader is the bilinear gather
     int shufC;                 // > 0: transposed k x k stride-k convolution as a 1 x 1 GEMM with k * k * shufC columns — column n is tap
@@ -107,7 +109,8 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     const int oy0 = ty * p.TH, ox0 = tx * p.TW;
     const int iy0 = oy0 * s - p.pad_h, ix0 = ox0 * s - p.pad_w;
 
-    const wdg_srd srdA = wdg_make_srd(p.A + (long long)img * p.imgStrideA);
+    const wdg_srd srdA = p.in16 ? wdg_make_srd(reinterpret_cast<const wdg_h16<FMT>*>(p.A) + (long long)img * p.imgStrideA)
+                                : wdg_make_srd(p.A + (long long)img * p.imgStrideA);
     const wdg_srd srdB = wdg_make_srd(p.B);
     // (LSTM == 2) the weight tensor exactly: requests past its end return zeros by the hardware's range check, no select
     const wdg_srd srdBx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.Ncols * p.ldB * 2, 0x00020000);
@@ -182,6 +185,27 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         __syncthreads();                             // every wave is done with the previous chunk's patch, weight stages and epilogue tiles
         // ---- patch chunk: global fp32 -> 16-bit -> LDS, PU slots (2 x 16-byte loads each) per thread in flight
         constexpr int PU = (MT * NT >= 24) ? 8 : (WDG_PATCH_DEPTH > 2) ? 6 : 10;   // (the 6 x 4 tile has no registers to spare; nor a deep weight pipeline)
+        if (p.in16) {
+            // 16-bit activations: a slot is ONE 16-byte request and goes to LDS as it is
+            for (int base = (!NLOOP || tni == 0) ? 0 : npatch; base < npatch; base += PU * 256) {
+                f32x4 v[PU];
+                int slot[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int idx = base + u * 256 + t;
+                    const int pix = (int)wdg_fastdiv_do((unsigned)idx, p.div_ck);
+                    const int c = idx - pix * p.CK8;
+                    const int y = (int)wdg_fastdiv_do((unsigned)pix, p.div_pw);
+                    const int x = pix - y * p.PW;
+                    const int gy = iy0 + y, gx = ix0 + x;
+                    const bool ok = idx < npatch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W && !(DBG & 2);
+                    v[u] = wdg_buffer_load_f32x4(srdA, ok ? (unsigned)((gy * p.W + gx) * p.ldA + (ck * p.CK8 + c) * 8) << 1 : WDG_SRD_OOB);
+                    slot[u] = idx < npatch ? c * p.pitch + (((y << p.sshift) + (x & (s - 1))) * p.PWs) + (x >> p.sshift) : dummy_slot;
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u) ldsP[slot[u]] = __builtin_bit_cast(h16x8, v[u]);
+            }
+        } else
         for (int base = (!NLOOP || tni == 0) ? 0 : npatch; base < npatch; base += PU * 256) {
             f32x4 v[PU][2];
             int slot[PU];
@@ -434,10 +458,12 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                     if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[naff + nb]; }
                 }
             if (p.out16) {
-                // 16-bit result (no bias / activation / accumulate on this route; column count a multiple of 16).  A lane's four
-                // channels are 8 bytes — stores of that width ran at 0.6x the rate and made the 16-bit z slower than the fp32 one.
-                // So the column tiles go in pairs: the two lanes that share a pixel's eight consecutive channels (lq even / odd)
-                // swap one quad each, the even one stores tile b, the odd one tile b + 1, 16 bytes per lane.
+                // 16-bit result (column count a multiple of 16; no accumulate).  A lane's four channels are 8 bytes — stores of
+                // that width ran at 0.6x the rate and made the 16-bit z slower than the fp32 one.  So the column tiles go in pairs:
+                // the two lanes that share a pixel's eight consecutive channels (lq even / odd) swap one quad each, the even one
+                // stores tile b, the odd one tile b + 1, 16 bytes per lane.  Bias / activation / affine as on the fp32 route (the
+                // constants of tile b + 1 are loaded here as well); with a scattering epilogue (shufC % 32 == 0) a pair stays
+                // inside one tap.
                 static_assert(NT % 2 == 0, "column tiles in pairs");
                 if (b & 1) continue;
                 typedef wdg_h16<FMT> h16x4 __attribute__((ext_vector_type(4)));
@@ -446,9 +472,23 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 wdg_h16<FMT>* out16 = reinterpret_cast<wdg_h16<FMT>*>(p.Out) + (long long)img * p.imgStrideO;
                 const bool odd = lq & 1;
                 const int nst = nw0 + (b + (odd ? 1 : 0)) * 16 + 8 * (lq >> 1);
+                const int nst_ch = p.shufC ? nst - stap * p.shufC : nst;
+                f32x4 bias4b = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4b = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4b = bias4b;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + 16 + r < p.Ncols) {
+                        const int nb = nch + 16 + r;
+                        if (p.bias) bias4b[r] = p.bias[nb];
+                        if (p.affine) { sc4b[r] = p.affine[nb]; sh4b[r] = p.affine[naff + nb]; }
+                    }
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
-                    const f32x4 v0 = acc[a][b], v1 = acc[a][b + 1];
+                    f32x4 v0 = acc[a][b] + bias4, v1 = acc[a][b + 1] + bias4b;
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v0[r] = wdg_lrelu(v0[r], p.slope); v1[r] = wdg_lrelu(v1[r], p.slope); }
+                    }
+                    if (p.affine) { v0 = v0 * sc4 + sh4; v1 = v1 * sc4b + sh4b; }
                     const u32x2 t0 = __builtin_bit_cast(u32x2, (h16x4){(wdg_h16<FMT>)v0[0], (wdg_h16<FMT>)v0[1], (wdg_h16<FMT>)v0[2], (wdg_h16<FMT>)v0[3]});
                     const u32x2 t1 = __builtin_bit_cast(u32x2, (h16x4){(wdg_h16<FMT>)v1[0], (wdg_h16<FMT>)v1[1], (wdg_h16<FMT>)v1[2], (wdg_h16<FMT>)v1[3]});
                     const u32x2 mine = odd ? t1 : t0, give = odd ? t0 : t1;
@@ -456,7 +496,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                     got[0] = (unsigned)__shfl_xor((int)give[0], 16, 64);
                     got[1] = (unsigned)__shfl_xor((int)give[1], 16, 64);
                     const u32x4 o = odd ? (u32x4){got[0], got[1], mine[0], mine[1]} : (u32x4){mine[0], mine[1], got[0], got[1]};
-                    if (nst < p.Ncols) *reinterpret_cast<u32x4*>(out16 + (long long)opix[a] * p.ldO + nst) = o;
+                    if (nst < p.Ncols) *reinterpret_cast<u32x4*>(out16 + (long long)(opix[a] + spix) * p.ldO + nst_ch) = o;
                 }
                 continue;
             }
@@ -590,6 +630,15 @@ int wdg_patch_h16_eligible_t(const wdg_conv_plan* pl) {
     return patch_plan(patch_view(pl, true), p) ? 1 : 0;
 }
 
+// ... of a transposed k x k stride-k layer as one scattering GEMM
+int wdg_patch_h16_eligible_s(const wdg_conv_plan* pl) {
+    const wdg_conv_geom& g = pl->g;
+    if (g.kh != g.kw || g.stride != g.kh || g.kh < 2 || g.pad_h || g.pad_w || g.Cin % 4 || g.H != g.Ho * g.kh || g.W != g.Wo * g.kw) return 0;
+    WdgPatchH16 p;
+    memset(&p, 0, sizeof(p));
+    return patch_plan(patch_view_shuffle(pl), p) ? 1 : 0;
+}
+
 template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, int LSTM = 0>
 static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_t st) {
     static size_t lds_set = 0;
@@ -607,19 +656,22 @@ static int patch_launch(const WdgPatchH16& p, int blocks, size_t lds, hipStream_
 // transposed1x1: x is dy, y is dx and w16 the data-gradient packing [Cin][Cout_p] of a 1 x 1, stride-1 plan.
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
                          const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
-                         const WdgPatchGates* gx, int out16) {
-    if (out16 && (gx || bias || affine || act || accumulate)) return 1;
-    if (out16 && (pl->g.Cin % 16 || pl->g.ldx % 8)) return 1;       // (transposed 1 x 1 view: the x side is the result — whole 16-column tiles)
+                         const WdgPatchGates* gx, int out16, int in16) {
+    if (out16 && (gx || accumulate)) return 1;
+    if (in16 && gx && gx->c_out) return 1;           // (the recurrent step keeps its fp32 hidden state)
     const bool shuffle = transposed1x1 == 2;
     if (transposed1x1 == 1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
     if (shuffle && (pl->g.kh != pl->g.kw || pl->g.stride != pl->g.kh || pl->g.kh < 2 || pl->g.pad_h || pl->g.pad_w || pl->g.Cin % 4 ||
-                    pl->g.H != pl->g.Ho * pl->g.kh || pl->g.W != pl->g.Wo * pl->g.kw || gx || out16))
+                    pl->g.H != pl->g.Ho * pl->g.kh || pl->g.W != pl->g.Wo * pl->g.kw || gx))
         return 1;
     const WdgPatchView g = shuffle ? patch_view_shuffle(pl) : patch_view(pl, transposed1x1 != 0);
     WdgPatchH16 p;
     memset(&p, 0, sizeof(p));
     if (!patch_plan(g, p, g_patch_lstm_small && gx && gx->c_out)) return 1;
-    p.A = x; p.B = w16; p.Out = y; p.bias = bias; p.affine = affine; p.out16 = out16;
+    if (out16 && (g.Ncols % 16 || g.ldO % 8)) return 1;              // whole 16-column tiles in pairs of lanes, 16-byte stores
+    if (out16 && shuffle && pl->g.Cin % 32) return 1;                // ... a pair inside one tap
+    if (in16 && g.ldA % 8) return 1;
+    p.A = x; p.B = w16; p.Out = y; p.bias = bias; p.affine = affine; p.out16 = out16; p.in16 = in16;
     p.imgStrideA = g.imgStrideA; p.imgStrideO = g.imgStrideO;
     p.H = g.H; p.W = g.W; p.ldA = g.ldA; p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldO;
     p.Ncols = g.Ncols; p.ldB = g.kh * g.kw * g.K_p; p.Cin_p = g.K_p;

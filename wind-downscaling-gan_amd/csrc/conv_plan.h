@@ -131,9 +131,10 @@ struct WdgPatchGates {
     int ldh;
     int skip_k;
 };
+int wdg_patch_h16_eligible_s(const wdg_conv_plan* pl);
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,
                          const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
-                         const WdgPatchGates* gx = nullptr, int out16 = 0);
+                         const WdgPatchGates* gx = nullptr, int out16 = 0, int in16 = 0);
 
 // convlstm1.hip
 void wdg_convlstm1_set_mfma(int v);

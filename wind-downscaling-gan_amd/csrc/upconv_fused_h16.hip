@@ -66,7 +66,7 @@ template <int FMT, int K>
 __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float* __restrict__ x, int ldx, long long isx,
                                                                    const wdg_h16<FMT>* __restrict__ w16, const float* __restrict__ bias,
                                                                    const float* __restrict__ affine, float* __restrict__ y, int ldy,
-                                                                   long long isy, int Hl, int Wl, int tiles, int total, int act, float slope, int out16) {
+                                                                   long long isy, int Hl, int Wl, int tiles, int total, int act, float slope, int out16, int in16) {
     typedef wdg_h16x8<FMT> h16x8;
     static_assert(K % 32 == 0, "whole MFMA K-steps");
     constexpr int KO = K / 8, KS = K / 32;
@@ -130,8 +130,19 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
         // (descriptor per image; the padding gets bit 31 of its offset set ARITHMETICALLY — any of the range checks negative -> out
         // of the descriptor's range -> zeros.  Loads under `if (inside)`, and `inside ? off : OOB` selects alike, come out as
         // exec-masked blocks with an s_waitcnt each; this way the twelve loads are in flight together)
-        const wdg_srd srdX = wdg_make_srd(x + (long long)n * isx);
         const int colbad = gx | (Wl - 1 - gx) | (KO * F_SP - 1 - t);
+        if (in16) {
+            // x in the operand format already (rounded by its producers where this kernel would have): one request per slot
+            const wdg_srd srdX = wdg_make_srd(reinterpret_cast<const wdg_h16<FMT>*>(x) + (long long)n * isx);
+            const int off0 = ((gy0 * Wl + gx) * ldx + s_oct * 8) * 2, rs = 2 * Wl * ldx * 2;
+#pragma unroll
+            for (int u = 0; u < X_B; ++u) {
+                const int gy = gy0 + 2 * u;
+                xv[u][0] = wdg_buffer_load_f32x4(srdX, (unsigned)(off0 + u * rs) | ((unsigned)(colbad | gy | (Hl - 1 - gy)) & 0x80000000u));
+            }
+            return;
+        }
+        const wdg_srd srdX = wdg_make_srd(x + (long long)n * isx);
         const int off0 = ((gy0 * Wl + gx) * ldx + s_oct * 8) * 4, rs = 2 * Wl * ldx * 4;
 #pragma unroll
         for (int u = 0; u < X_B; ++u) {
@@ -144,7 +155,8 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
     auto store_x = [&]() __attribute__((always_inline)) {
         if (s_on) {
 #pragma unroll
-            for (int u = 0; u < X_B; ++u) Xs[s_oct * F_NPX + ((s_p0 + F_SP * u) ^ (s_oct & 7))] = wdg_pack_h16<FMT>(xv[u][0], xv[u][1]);
+            for (int u = 0; u < X_B; ++u)
+                Xs[s_oct * F_NPX + ((s_p0 + F_SP * u) ^ (s_oct & 7))] = in16 ? __builtin_bit_cast(h16x8, xv[u][0]) : wdg_pack_h16<FMT>(xv[u][0], xv[u][1]);
         }
     };
     static_assert(F_NW == 8 && F_NPX == 9 * 16, "3 groups of 3 pixel tiles x (2 + 2 + 1) column tiles over 6 + 2 waves");
@@ -365,7 +377,7 @@ __global__ void __launch_bounds__(F_NT) wdg_upconv_fused_h16_kernel(const float*
 
 template <int FMT, int K>
 int fused_launch(int grid, size_t lds, hipStream_t st, const float* x, int ldx, long long isx, const void* w16, const float* bias,
-                 const float* affine, float* y, int ldy, long long isy, int Hl, int Wl, int tiles, int total, int act, float slope, int out16) {
+                 const float* affine, float* y, int ldy, long long isy, int Hl, int Wl, int tiles, int total, int act, float slope, int out16, int in16) {
     static bool attr = false;
     if (!attr) {
         WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_upconv_fused_h16_kernel<FMT, K>),
@@ -373,7 +385,7 @@ int fused_launch(int grid, size_t lds, hipStream_t st, const float* x, int ldx, 
         attr = true;
     }
     hipLaunchKernelGGL((wdg_upconv_fused_h16_kernel<FMT, K>), dim3(grid), dim3(F_NT), lds, st, x, ldx, isx,
-                       reinterpret_cast<const wdg_h16<FMT>*>(w16), bias, affine, y, ldy, isy, Hl, Wl, tiles, total, act, slope, out16);
+                       reinterpret_cast<const wdg_h16<FMT>*>(w16), bias, affine, y, ldy, isy, Hl, Wl, tiles, total, act, slope, out16, in16);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
@@ -400,11 +412,14 @@ extern "C" int wdg_upconv_fused_h16_supported(int Cin, int C) { return C == 16 &
 // y [n, 2 Hl, 2 Wl, >= C] = affine(act(bias + convT5x5(bilinear_x2(x_low)))), x_low [n, Hl, Wl, ldx >= Cin] fp32 (rounded to the
 // operand format while staged), w16 = the layer's weight tensor [25 * C][Cin] in bf16 (fmt 0) / fp16 (fmt 1).
 // out16 != 0: y holds 16-bit elements of the operand format (ldy / img_stride_y in elements, ldy % 8 == 0) — for a reader that
-// rounds to that format anyway (wdg_conv_thin16_fwd_h16): the same values, half the bytes.
-extern "C" int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
+// rounds to that format anyway (wdg_conv_thin16_fwd_h16): the same values, half the bytes.  in16 != 0: x_low likewise (written by
+// wdg_conv_fwd_h16_act16 / wdg_conv_dgrad_h16_act16 with out16).
+extern "C" int wdg_upconv_fused_h16(const void* x_low_, int ldx, int64_t img_stride_x, const void* w16, int fmt, const float* bias,
                                     const float* affine, void* y_, int ldy, int64_t img_stride_y, int n_img, int Hl, int Wl, int Cin,
-                                    int C, int act, float slope, int out16, wdg_stream stream) {
+                                    int C, int act, float slope, int out16, int in16, wdg_stream stream) {
     float* y = reinterpret_cast<float*>(y_);
+    const float* x_low = reinterpret_cast<const float*>(x_low_);
+    WDG_CHECK_ARG(!in16 || ldx % 8 == 0, "16-bit input: pixel stride a multiple of 8 elements");
     WDG_CHECK_ARG(!out16 || ldy % 8 == 0, "16-bit output: pixel stride a multiple of 8 elements");
     WDG_CHECK_ARG(x_low && w16 && y && (fmt == 0 || fmt == 1) && n_img > 0 && n_img < 65536 && Hl > 0 && Wl > 0, "bad argument");
     WDG_CHECK_ARG(wdg_upconv_fused_h16_supported(Cin, C), "unsupported channel counts (Cin 160, C 16)");
@@ -420,6 +435,6 @@ extern "C" int wdg_upconv_fused_h16(const float* x_low, int ldx, int64_t img_str
     const int grid = std::min(total, fused_cus());  // persistent: one workgroup per CU (LDS), each prefetching its next tile's window
     hipStream_t st = (hipStream_t)stream;
     if (fmt == 0)
-        return fused_launch<0, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope, out16);
-    return fused_launch<1, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope, out16);
+        return fused_launch<0, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope, out16, in16);
+    return fused_launch<1, K>(grid, lds, st, x_low, ldx, img_stride_x, w16, bias, affine, y, ldy, img_stride_y, Hl, Wl, tiles, total, act, slope, out16, in16);
 }

@@ -513,9 +513,24 @@ class HipOps:
                                              int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                              self.stream), "conv_dgrad")
 
+    def _is16(self, t, fmt):
+        if t.dtype in (torch.bfloat16, torch.float16):
+            if t.dtype != self.H16_DTYPES[fmt]:
+                raise ValueError(f"tensor is {t.dtype}, the operand format is {fmt}")
+            return 1
+        return 0
+
     def conv_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
-        """Inference precision: y = affine(act(conv(r16(x), r16(W)) + bias)), fp32 accumulation; fmt "bf16" | "fp16"."""
+        """Inference precision: y = affine(act(conv(r16(x), r16(W)) + bias)), fp32 accumulation; fmt "bf16" | "fp16".
+        x and / or y may be tensors in the 16-bit operand format (wdg_conv_fwd_h16_act16: the patch kernel only)."""
         plan, _, _ = self._plan(x, y, pk.cin, pk.cout, g)
+        in16, out16 = self._is16(x, fmt), self._is16(y, fmt)
+        if in16 or out16:
+            assert not accumulate
+            native.check(self.lib.wdg_conv_fwd_h16_act16(plan, x.data_ptr(), in16, pk.half(fmt)[0].data_ptr(), 0 if fmt == "bf16" else 1,
+                                                         _ptr(bias), _ptr(affine), y.data_ptr(), out16, int(act), slope, self.stream),
+                         "conv_fwd_h16_act16")
+            return
         fn = self.lib.wdg_conv_fwd_bf16 if fmt == "bf16" else self.lib.wdg_conv_fwd_f16
         native.check(fn(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), _ptr(affine),
                         y.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_fwd_16")
@@ -629,6 +644,13 @@ class HipOps:
 
     def conv_dgrad_bf16(self, dy, pk, dx, g, bias=None, act=False, affine=None, accumulate=False, slope=0.2, fmt="bf16"):
         plan, _, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
+        in16, out16 = self._is16(dy, fmt), self._is16(dx, fmt)
+        if in16 or out16:
+            assert not accumulate
+            native.check(self.lib.wdg_conv_dgrad_h16_act16(plan, dy.data_ptr(), in16, pk.half(fmt)[1].data_ptr(), 0 if fmt == "bf16" else 1,
+                                                           _ptr(bias), _ptr(affine), dx.data_ptr(), out16, int(act), slope, self.stream),
+                         "conv_dgrad_h16_act16")
+            return
         fn = self.lib.wdg_conv_dgrad_bf16 if fmt == "bf16" else self.lib.wdg_conv_dgrad_f16
         native.check(fn(plan, dy.data_ptr(), pk.half(fmt)[1].data_ptr(), _ptr(bias), _ptr(affine),
                         dx.data_ptr(), int(act), slope, int(accumulate), self.stream), "conv_dgrad_16")
@@ -641,6 +663,19 @@ class HipOps:
         fp32 hand-over (the reader rounds to the operand format either way), half the bytes."""
         return bool(self.act16 and self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk_up.cout, pk_up.cin)
                     and g_out.kh == 3 and g_out.kw == 3 and g_out.stride == 1 and g_out.pad == 1 and pk_out.cin == 16 and pk_out.cout <= 4)
+
+    def act16_upconv_in_ok(self, x_low, pk_up):
+        """The fused upsample kernel reads x_low in the 16-bit operand format."""
+        return bool(self.act16 and self.upconv_fused16 and not self.z16 and self.upconv_colfwd and
+                    self.lib.wdg_upconv_fused_h16_supported(pk_up.cout, pk_up.cin) and _v4(x_low)[1] % 8 == 0)
+
+    def act16_conv_ok(self, x, y, pk, g, transposed, in16, out16):
+        """Would conv_fwd_bf16 (transposed False) / conv_dgrad_bf16 (True) take x / y in the 16-bit operand format?  x, y: tensors
+        of the final shapes and strides (any dtype: only the geometry is read)."""
+        if not self.act16:
+            return False
+        plan, _, _ = self._plan(y, x, pk.cin, pk.cout, g) if transposed else self._plan(x, y, pk.cin, pk.cout, g)
+        return bool(self.lib.wdg_conv_h16_act16_supported(plan, int(transposed), int(in16), int(out16)))
 
     def conv_halo_fwd_bf16(self, x, pk, bias, y, g, act=False, affine=None, slope=0.2, fmt="bf16"):
         """16-bit thin stride-1 conv (<= 64 output channels) through the halo-tile kernel.  x may be a tensor in the 16-bit operand
@@ -675,17 +710,18 @@ class HipOps:
             # epilogue, eight-value slots in the gather: 3.82 -> 3.97 ms) — neither kernel is bound by z's bytes: the 400-column
             # GEMM has a reduction of only 160 (five MFMA K-steps per 16 stores) and the gather is bound by its LDS passes
             y16 = y.dtype in (torch.bfloat16, torch.float16)
-            if self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk.cout, pk.cin) and ldl % 4 == 0:
+            x16 = self._is16(x_low, fmt)
+            if self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk.cout, pk.cin) and ldl % (8 if x16 else 4) == 0:
                 # both stages in one launch, z never leaves the CU (csrc/upconv_fused_h16.hip): 0.48 + 0.54 ms -> one launch per
                 # 16-tile group of the shipped generator.  y in the operand format: for a reader that rounds to it anyway
                 if y16 and y.dtype != self.H16_DTYPES[fmt]:
                     raise ValueError(f"upconv_fwd_bf16: y is {y.dtype}, the operand format is {fmt}")
                 native.check(self.lib.wdg_upconv_fused_h16(px, ldl, isl, pk.half(fmt)[1].data_ptr(), 0 if fmt == "bf16" else 1, _ptr(bias),
                                                            _ptr(affine), py, ldy, isy, n, H // 2, W // 2, pk.cout, pk.cin, int(act), slope,
-                                                           int(y16), self.stream), "upconv_fused_h16")
+                                                           int(y16), x16, self.stream), "upconv_fused_h16")
                 return
-            if y16:
-                raise ValueError("upconv_fwd_bf16: a 16-bit y needs the fused kernel (act16_output_conv_ok)")
+            if y16 or x16:
+                raise ValueError("upconv_fwd_bf16: 16-bit activations need the fused kernel (act16_output_conv_ok)")
             plan16 = None
             if self.z16 and pk.cin % 8 == 0:
                 plan16, _, _ = self._plan_dims(n, H // 2, W // 2, 25 * pk.cin, 25 * pk.cin, (H // 2) * (W // 2) * 25 * pk.cin,

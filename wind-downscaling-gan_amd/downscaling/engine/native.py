@@ -128,7 +128,10 @@ SIGNATURES = {
     "wdg_upconv_colgemm_h16": (i32, [C.c_void_p, c_fp, C.c_void_p, C.c_void_p, i32, c_fp]),
     "wdg_upconv_gather_h16": (i32, [C.c_void_p, i32, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, f32, c_fp]),
     "wdg_upconv_fused_h16_supported": (i32, [i32, i32]),
-    "wdg_upconv_fused_h16": (i32, [c_fp, i32, i64, C.c_void_p, i32, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_fp]),
+    "wdg_upconv_fused_h16": (i32, [c_fp, i32, i64, C.c_void_p, i32, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, f32, i32, i32, c_fp]),
+    "wdg_conv_h16_act16_supported": (i32, [C.c_void_p, i32, i32, i32]),
+    "wdg_conv_fwd_h16_act16": (i32, [C.c_void_p, c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, f32, c_fp]),
+    "wdg_conv_dgrad_h16_act16": (i32, [C.c_void_p, c_fp, i32, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, f32, c_fp]),
     "wdg_conv_thin16_fwd_h16": (i32, [C.c_void_p, c_fp, i32, i64, c_fp, i32, c_fp, c_fp, c_fp, i32, f32, c_fp]),
     "wdg_patch_gather": (i32, [c_fp, i32, i64, c_fp, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_patch_scatter": (i32, [c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),

@@ -254,11 +254,29 @@ class GeneratorNet(_Net):
         res4 = b["cat4"][..., F // 2:]
         if precision in ("bf16", "fp16"):
             f = precision
+            # Activations whose every reader is a 16-bit layer are stored in the operand format by their producers (the readers
+            # would round them to it while staging: the same bits, half the bytes): the [c7 | c0] concatenation that feeds c2 and
+            # the upsample block — the largest tensor of the forward — and (below) the 16 channels between the last two layers.
+            cat2 = b["cat2"]
+            key = "cat2_" + f
+            if key not in b:
+                b[key] = None
+                ok = getattr(self.ops, "act16_conv_ok", None)
+                if ok is not None and self.ops.act16 and cat2.shape[3] % 8 == 0 and self.F4p % 8 == 0:
+                    c16 = self.ops.zeros(*cat2.shape, dtype=self.ops.H16_DTYPES[f])
+                    if ok(b["x0"], c16[..., self.F4p:], self.c0.pk, self.c0.g, False, 0, 1) and \
+                            ok(c16[..., self.F4p:], res4, self.c2.pk, self.c2.g, False, 1, 0) and \
+                            ok(b["cat4"], c16[..., :self.F4p], self.c7.pk, self.c7.g, True, 0, 1) and \
+                            self.ops.act16_upconv_in_ok(c16, self.c9.pk):
+                        b[key] = c16
+            if b[key] is not None and self.ops.act16:
+                cat2 = b[key]
+                res2 = cat2[..., self.F4p:]
             self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine(), fmt=f)
             self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine(), fmt=f)
             self.lstm.forward(res4, b["h"], B, T, bf16=True, fmt=f)
             self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
-            self.c7.forward_bf16(b["cat4"], b["cat2"][..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
+            self.c7.forward_bf16(b["cat4"], cat2[..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
             z9 = b["z9"]
             ok16 = getattr(self.ops, "act16_output_conv_ok", None)
             if ok16 is not None and z9.shape[3] == 16 and ok16(self.c9.pk, self.c11.pk, self.c11.g):
@@ -268,7 +286,7 @@ class GeneratorNet(_Net):
                 if key not in b or b[key].shape != z9.shape:
                     b[key] = self.ops.zeros(*z9.shape, dtype=self.ops.H16_DTYPES[f])
                 z9 = b[key]
-            self.ops.upconv_fwd_bf16(b["cat2"], self.c9.pk, self.c9.b.value, z9, self.c9.g, act=True,
+            self.ops.upconv_fwd_bf16(cat2, self.c9.pk, self.c9.b.value, z9, self.c9.g, act=True,
                                      affine=self.bn10.infer_affine(), fmt=f, pool=self._scratch_pool(b))
             self.ops.conv_halo_fwd_bf16(z9, self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
             return b["out"]
