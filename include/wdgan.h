@@ -580,6 +580,14 @@ int wdg_spatial_ks(const float* real, const float* fake, int B, int T, int H, in
  * ------------------------------------------------------------------------------------------ */
 int wdg_philox_normal(float* out, int ldo, const float* add, int lda, int64_t P, int C,
                       uint64_t seed, uint64_t offset, float std, wdg_stream stream);
+
+/* Generator input in one pass (models.py:28: concatenate([low-res image, noise])): out [rows, ld] with rows = T' * B * XY in
+ * time-major order (row = (t * B + b) * XY + r) receives [image[b, t, r, 0:CI] | std * N(0, 1) x CN | zeros]; image element
+ * (b, t, r, c) sits at image[b * img_stride_b + t * img_stride_t + r * CI + c].  The noise is exactly the stream
+ * wdg_philox_normal(out + CI, ld, NULL, 0, rows, CN, seed, offset, std) writes.  Supported: CI 3, CN 20, ld 24. */
+int wdg_input_assemble_supported(int CI, int CN, int ld);
+int wdg_input_assemble(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, float* out, int ld, int64_t rows,
+                       int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, wdg_stream stream);
 /* U[0,1) for the interpolation coefficients eps (ganbase.py:30). */
 int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, wdg_stream stream);
 

@@ -291,3 +291,34 @@ def test_generator_inference_graph_replay(hip_ops, precision):
     g.graph_inference = False
     y_eager = g([image, noise], training=False, precision=precision)
     assert torch.equal(y_graph, y_eager) and not torch.equal(y_graph, outs[True][0])
+
+
+@pytest.mark.parametrize("T", [1, 3])
+def test_generator_input_assembled_in_one_pass(hip_ops, T):
+    """Generator.__call__ with a LazyNoise: [image | noise | 0] written by ONE kernel (wdg_input_assemble, csrc/pointwise.hip)
+    against the channel copy + wdg_philox_normal pair — the same Philox counters and arithmetic, so the input buffer and the
+    output are the same bits; also for the per-member draws of api.predict_ensemble (LazyMemberNoise)."""
+    from downscaling.data.data_generator import FlexibleNoiseGenerator, LazyMemberNoise
+    from downscaling.gan.models import make_generator
+    S, B = 32, 4
+    g = make_generator(S, 3, 20, 2, T, feature_channels=16)
+    g.graph_inference = False
+    dev = hip_ops.device
+    image = torch.randn(B, T, S, S, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    assert hip_ops.input_assemble_ok(3, 20, g.net.buffers(B)["x0"].shape[-1])
+    res = {}
+    for fused in (True, False):
+        hip_ops.input_fused = fused
+        try:
+            ng = FlexibleNoiseGenerator((B, T, S, S, 20), std=0.1, random_seed=7)
+            out = g([image, ng.lazy(bs=B)]).clone()
+            x0 = g.net.buffers(B)["x0"].clone()
+            gens = [FlexibleNoiseGenerator((2, T, S, S, 20), std=0.1, random_seed=100 + j) for j in range(2)]
+            out_m = g([image, LazyMemberNoise(gens, 2, (2, T, S, S, 20), 20, 0.1)]).clone()
+            x0_m = g.net.buffers(B)["x0"].clone()
+        finally:
+            hip_ops.input_fused = True
+        res[fused] = (out, x0, out_m, x0_m)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert float(res[True][1][..., 23:].abs().max()) == 0.0 and float(res[True][1][..., 3:23].abs().max()) > 0.0

@@ -24,6 +24,14 @@ class LazyNoise(object):
         assert view2d.shape[0] * view2d.shape[1] == int(np.prod(self.shape))
         self.generator.prng.normal_into(view2d, self.std)
 
+    def fill_with_image(self, rows, image):
+        """The same draw, written together with the image into whole rows [time * batch * x * y, ld] of the generator's input
+        buffer ([image | noise | zero alignment channels]; one kernel instead of a channel copy and a noise pass)."""
+        B, T, X, Y, C = self.shape
+        assert rows.shape[0] == T * B * X * Y and tuple(image.shape[:4]) == (B, T, X, Y)
+        prng = self.generator.prng
+        prng.assemble_at(image, rows, B, X * Y, C, self.std, prng.reserve(rows.shape[0] * C))
+
 
 class LazyMemberNoise(object):
     """Pending draws of SEVERAL FlexibleNoiseGenerators for one forward pass of batch len(generators) * tiles: batch slots
@@ -46,6 +54,18 @@ class LazyMemberNoise(object):
             for t in range(T):
                 r0 = (t * B + j * self.tiles) * X * Y
                 g.prng.normal_at(view2d[r0:r0 + rows], self.std, t * (rows * C // 4))
+
+    def fill_with_image(self, rows_all, image):
+        """As fill, with the image written in the same pass (see LazyNoise.fill_with_image)."""
+        B, T, X, Y, C = self.shape
+        assert rows_all.shape[0] == T * B * X * Y and tuple(image.shape[:4]) == (B, T, X, Y)
+        rows = self.tiles * X * Y
+        assert (rows * C) % 4 == 0
+        for j, g in enumerate(self.generators):
+            img_j = image[j * self.tiles:(j + 1) * self.tiles]
+            for t in range(T):
+                r0 = (t * B + j * self.tiles) * X * Y
+                g.prng.assemble_at(img_j[:, t:t + 1], rows_all[r0:r0 + rows], self.tiles, X * Y, C, self.std, t * (rows * C // 4))
 
 
 class FlexibleNoiseGenerator(object):

@@ -278,6 +278,8 @@ class HipOps:
         self.upconv_fused16 = os.environ.get("WDG_UPCONV_FUSED16", "1") != "0"   # 16-bit inference: column GEMM + gather in one launch
         # the 16-channel activation between the generator's last two layers in the 16-bit operand format (inference precision)
         self.act16 = os.environ.get("WDG_ACT16", "1") != "0"
+        # generator input ([image | noise]) assembled by one kernel when the noise is drawn on the device (LazyNoise)
+        self.input_fused = os.environ.get("WDG_INPUT_FUSED", "1") != "0"
         self._scratch_bufs = {}
         # per-timestep launch chains (the ConvLSTM time loops at n_timesteps > 1) replayed from captured HIP graphs: see chain()
         self.gates_x = os.environ.get("WDG_GATES_X", "1") != "0"      # T > 1: the 5 -> 16 ConvLSTM's input convolution in its own kernel
@@ -1139,6 +1141,17 @@ class HipOps:
         pa, lda = _v2(add) if add is not None else (0, 0)
         native.check(self.lib.wdg_philox_normal(po, ldo, pa, lda, out.shape[0], out.shape[1], seed & (2**64 - 1),
                                                 offset, std, self.stream), "philox_normal")
+
+    def input_assemble_ok(self, ci, cn, ld):
+        return bool(self.input_fused and self.lib.wdg_input_assemble_supported(ci, cn, ld))
+
+    def input_assemble(self, image, rows_out, B, XY, cn, seed, offset, std):
+        """rows_out [T' * B * XY, ld] (time-major rows of the generator's input buffer) <- [image | noise | 0]: image [B, T', XY.., CI]
+        (any batch / time strides, pixels dense), the noise = philox_normal(rows_out[:, CI:CI + cn], seed, offset, std)'s stream."""
+        assert image.dim() == 5 and image.stride(4) == 1 and image.stride(3) == image.shape[4] and image.stride(2) == image.shape[3] * image.shape[4]
+        po, ldo = _v2(rows_out)
+        native.check(self.lib.wdg_input_assemble(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo, rows_out.shape[0],
+                                                 B, XY, cn, seed & (2**64 - 1), offset, std, self.stream), "input_assemble")
 
     def philox_uniform(self, out, seed, offset):
         native.check(self.lib.wdg_philox_uniform(out.data_ptr(), out.numel(), seed & (2**64 - 1), offset, self.stream), "philox_uniform")

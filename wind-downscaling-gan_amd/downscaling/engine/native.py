@@ -148,6 +148,8 @@ SIGNATURES = {
     "wdg_spatial_ks_scratch_bytes": (szt, [i32, i32, i32, i32, i32]),
     "wdg_spatial_ks": (i32, [c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, c_fp]),
     "wdg_philox_normal": (i32, [c_fp, i32, c_fp, i32, i64, i32, u64, u64, f32, c_fp]),
+    "wdg_input_assemble_supported": (i32, [i32, i32, i32]),
+    "wdg_input_assemble": (i32, [c_fp, i64, i64, i32, c_fp, i32, i64, i32, i32, i32, u64, u64, f32, c_fp]),
     "wdg_philox_uniform": (i32, [c_fp, i64, u64, u64, c_fp]),
     "wdg_adam_tf": (i32, [c_fp, c_fp, c_fp, c_fp, i64, f32, f32, f32, f32, f32, c_fp]),
 }

@@ -189,6 +189,10 @@ class GeneratorNet(_Net):
         else:
             self.ops.permute_bt(noise, b["x0"].view(T, B, *b["x0"].shape[1:])[..., self.in_channels:self.cin])
 
+    def input_rows(self, B):
+        """[T*B*S*S, ld] view of the whole input buffer ([image | noise | zero alignment channels] per pixel, time-major rows)."""
+        return v2(self.buffers(B)["x0"])
+
     def noise_view(self, B):
         """[T*B*S*S, noise_channels] view of the input buffer: noise can be generated in place."""
         return v2(self.buffers(B)["x0"][..., self.in_channels:self.cin])

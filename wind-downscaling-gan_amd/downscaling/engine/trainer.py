@@ -53,6 +53,10 @@ class PhiloxSource:
     def normal_at(self, view2d, std, offset, add=None):
         self.ops.philox_normal(view2d, self.seed, offset, float(std), add)
 
+    def assemble_at(self, image, rows_out, B, XY, cn, std, offset):
+        """[image | noise | 0] into whole rows of the generator's input buffer; the noise is normal_at's stream at `offset`."""
+        self.ops.input_assemble(image, rows_out, B, XY, cn, self.seed, offset, float(std))
+
     def uniform_at(self, vec, offset):
         self.ops.philox_uniform(vec, self.seed, offset)
 

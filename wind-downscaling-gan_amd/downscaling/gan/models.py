@@ -152,11 +152,16 @@ class Generator(_Model):
         B, T = image.shape[0], image.shape[1]
         assert tuple(image.shape[1:]) == (net.T, net.S, net.S, net.in_channels), image.shape
         assert tuple(noise.shape) == (B, net.T, net.S, net.S, net.noise_channels), noise.shape
-        net.set_image(image)
-        if lazy:
-            noise.fill(net.noise_view(B))
+        ok = getattr(ops, "input_assemble_ok", None)
+        if lazy and hasattr(noise, "fill_with_image") and image.is_contiguous() and image.dtype == ops.dtype and ok is not None and \
+                ok(net.in_channels, net.noise_channels, net.buffers(B)["x0"].shape[-1]):
+            noise.fill_with_image(net.input_rows(B), image)      # [image | noise | 0] in one pass, the same Philox stream
         else:
-            net.set_noise(noise)
+            net.set_image(image)
+            if lazy:
+                noise.fill(net.noise_view(B))
+            else:
+                net.set_noise(noise)
         precision = precision or ("fp32" if training else self.inference_precision)
         if training or not self.graph_inference:
             out_tm = net.forward(B, bool(training), precision=precision)
