@@ -297,6 +297,13 @@ def generator_activation_elements(size):
     return 309 * size * size
 
 
+def generator_activation_bytes(size, act16):
+    """Bytes behind generator_activation_elements on the 16-bit path: every tensor is stored in fp32 except — with the
+    activation hand-over in the operand format (WDG_ACT16) — the layer-0 output (written once, read twice: 96
+    elements per output pixel), the 32 @ (S/2)^2 tensor (16) and the 16 @ S^2 tensor (32): 144 of the 309 elements at 2 bytes."""
+    return (309 * 4 - (144 * 2 if act16 else 0)) * size * size
+
+
 def other_config_legs(dev, ops):
     """Driver-timed figures for BASELINE configs[0], [3], [4] inside the default bench line (N = 1 only; one small network
     build + a few hundred ms of GPU time).  All inputs resident in HBM before the timed regions except the end-to-end
@@ -341,17 +348,19 @@ def other_config_legs(dev, ops):
     tts = 16 * api.SEQUENCE_LENGTH
     gf_tt = generator_flops(gen.net)                         # 3.799 GFLOP per tile-timestep (S = 96, T = 24)
     fl = tts * gf_tt
-    act_bytes = int(getattr(gen.net, "activation_bytes_16", 4))      # bytes per stored activation element on the 16-bit path
-    by = tts * generator_activation_elements(api.IMG_SIZE) * act_bytes
+    act16 = gen.net.buffers(16).get("cat2_bf16") is not None and bool(getattr(ops, "act16", False))
+    by = tts * generator_activation_bytes(api.IMG_SIZE, act16)
     out["config3_bf16_group16_T24"] = {
         "ms": med, "ms_min": best, "tile_timesteps_per_s": tts / med * 1e3, "dtype": "bf16 operands, f32 accumulate",
         "roofline": {"bound": "mfma", "achieved": fl / med * 1e-9, "peak": PEAK_16BIT_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl / med * 1e-9 / PEAK_16BIT_MFMA_TFLOPS},
-        "hbm": {"algorithmic_bytes": by, "bytes_per_activation_element": act_bytes, "achieved_gbps": by / med * 1e-6, "peak_gbps": PEAK_HBM_GBPS,
+        "hbm": {"algorithmic_bytes": by, "activations_in_operand_format": act16, "achieved_gbps": by / med * 1e-6, "peak_gbps": PEAK_HBM_GBPS,
                 "frac": by / med * 1e-6 / PEAK_HBM_GBPS,
-                "note": "309 activation elements per output pixel and tile-timestep (bench.generator_activation_elements) x the stored "
-                        "element size; weights (7.2 MB) excluded"},
-        "note": "16 tiles x 24 h through G(96,3,20,2,T=24) incl. noise generation, graph replay; parity bound 3e-2 vs the fp64 oracle"}
+                "note": "309 activation elements per output pixel and tile-timestep (bench.generator_activation_elements), 4 bytes "
+                        "each except the 144 handed over in the 16-bit operand format (bench.generator_activation_bytes); weights "
+                        "(7.2 MB) excluded"},
+        "note": "16 tiles x 24 h through G(96,3,20,2,T=24): input assembly (image + noise drawn on the device), forward replayed from "
+                "its HIP graph, output permutation; parity bound 3e-2 vs the fp64 oracle"}
     # end to end: 1200 x 1200 x 24 h field -> 225 tiles -> blended field (upload and download included)
     fields = np.random.default_rng(3).standard_normal((24, 1200, 1200, 3)).astype(np.float32)
     fields[..., 2] = fields[..., 2] * 500 + 1200
