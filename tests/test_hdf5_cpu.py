@@ -85,3 +85,31 @@ def test_unsupported_features_are_named(tmp_path):
     with pytest.raises(NotImplementedError, match="superblock version 9"):
         hdf5.File(p)
     assert hdf5.is_hdf5(GOLD / "h5_plain.h5") and not hdf5.is_hdf5(GOLD / "nc4_expected.npz")
+
+
+def test_fill_value_of_unwritten_storage():
+    """Storage that was never written (a contiguous dataset without an address, a missing chunk) reads as the dataset's FILL VALUE,
+    as with libhdf5 — zeros would decode to add_offset, a plausible wind, where xarray gives NaN.  The Fill Value message (0x05,
+    all three versions) is parsed; netCDF-4's `_FillValue` attribute is the fallback."""
+    import struct
+    from downscaling.io import hdf5
+    val = struct.pack("<h", -32767)
+    assert hdf5.File._fill_value(bytes([1, 2, 2, 1]) + struct.pack("<I", 2) + val) == val          # version 1
+    assert hdf5.File._fill_value(bytes([2, 2, 2, 1]) + struct.pack("<I", 2) + val) == val          # version 2, defined
+    assert hdf5.File._fill_value(bytes([2, 2, 2, 0])) is None                                      # version 2, undefined
+    assert hdf5.File._fill_value(bytes([3, 0x20 | 0x09]) + struct.pack("<I", 2) + val) == val      # version 3, value follows
+    assert hdf5.File._fill_value(bytes([3, 0x10 | 0x09])) is None                                  # version 3, explicitly undefined
+    f = hdf5.File(GOLD / "nc4_era5_like.nc")
+    packed = [d for d in f.root.datasets().values() if "_FillValue" in d.attrs and d.type.dtype.kind in "iu"]
+    assert packed, "the fixture has packed variables"
+    for d in packed:
+        want = np.asarray(d.attrs["_FillValue"]).reshape(-1)[0]
+        # (this fixture's Fill Value message is "defined, size 0" = the library default: the attribute decides; netCDF-C writes
+        # the value into the message as well, and then the message decides)
+        assert d._fill is None
+        filled = f._filled(d, (2, 3), d.type.dtype.newbyteorder("="))
+        assert filled.shape == (2, 3) and (filled == want).all()
+        d._fill = struct.pack("<h", -5)
+        assert (f._filled(d, (4,), d.type.dtype.newbyteorder("=")) == -5).all()
+    plain = [d for d in f.root.datasets().values() if "_FillValue" not in d.attrs and d.type.dtype.kind in "iuf"]
+    assert plain and (f._filled(plain[0], (3,), plain[0].type.dtype.newbyteorder("=")) == 0).all()

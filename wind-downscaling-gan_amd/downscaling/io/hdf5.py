@@ -48,6 +48,7 @@ class Dataset:
         self.attrs = {}
         self._layout = None
         self._filters = []
+        self._fill = None          # raw bytes of the fill value (messages 0x05 / 0x04), None when undefined
 
     @property
     def dtype(self):
@@ -81,8 +82,13 @@ class Group:
 
 class File:
     def __init__(self, path):
+        # the file is MAPPED, not read: a multi-GB CDS download is touched page by page as datasets are decoded
+        import mmap
         with open(str(path), "rb") as fh:
-            self.buf = fh.read()
+            try:
+                self.buf = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            except (ValueError, OSError):              # empty file / no mmap on this filesystem
+                self.buf = fh.read()
         self.path = str(path)
         base = 0
         while self.buf[base:base + 8] != SIGNATURE:          # (a user block: the superblock sits at 512, 1024, ...)
@@ -427,7 +433,7 @@ class File:
                 p = a + 8
                 for _ in range(n):
                     noff, oaddr = _u(b, p, O), self._a(p + O)
-                    end = b.index(b"\x00", data + noff)
+                    end = b.find(b"\x00", data + noff)           # (find: bytes and mmap both have it)
                     links.append((b[data + noff:end].decode("utf-8", "replace"), oaddr))
                     p += 2 * O + 24
                 return
@@ -459,6 +465,11 @@ class File:
                     ds._layout = d
                 elif mtype == 0x0B:
                     ds._filters = self._filter_pipeline(d)
+                elif mtype == 0x05:
+                    ds._fill = self._fill_value(d) or ds._fill
+                elif mtype == 0x04 and ds._fill is None and len(d) >= 4:      # "fill value (old)": size, value
+                    n_ = _u(d, 0, 4)
+                    ds._fill = bytes(d[4:4 + n_]) if 0 < n_ <= len(d) - 4 else None
             ds.attrs = self._attributes(msgs)
             return ds
         g = Group(self, name, addr)
@@ -552,6 +563,46 @@ class File:
         node(addr)
         return out
 
+    @staticmethod
+    def _fill_value(d):
+        """Raw bytes of the value in a Fill Value message (0x05), or None when it is undefined / the library default (zeros).
+        Versions 1 and 2: alloc time, write time, `defined` flag, then (v1 always, v2 when defined) size + value; version 3: one
+        flags byte (bit 5: a value follows, bit 4: explicitly undefined)."""
+        if len(d) < 2:
+            return None
+        ver = d[0]
+        if ver in (1, 2):
+            if len(d) < 4 or (ver == 2 and not d[3]):
+                return None
+            if len(d) < 8:
+                return None
+            n_ = _u(d, 4, 4)
+            return bytes(d[8:8 + n_]) if 0 < n_ <= len(d) - 8 else None
+        if ver == 3:
+            if not (d[1] & 0x20) or len(d) < 6:
+                return None
+            n_ = _u(d, 2, 4)
+            return bytes(d[6:6 + n_]) if 0 < n_ <= len(d) - 6 else None
+        return None
+
+    def _filled(self, ds, shape, native):
+        """An array of the dataset's fill value: what libhdf5 returns for storage that was never written (a contiguous dataset
+        without an address, a missing chunk).  The HDF5 message first; netCDF-4 repeats it as the `_FillValue` attribute.  For
+        packed variables this is what decodes to NaN — zeros would decode to add_offset, a plausible value."""
+        t = ds.type
+        fv = None
+        if ds._fill is not None and len(ds._fill) == t.size and t.dtype.kind in "iuf":
+            fv = np.frombuffer(ds._fill, t.dtype, 1)[0]
+        elif "_FillValue" in ds.attrs and t.dtype.kind in "iuf":
+            try:
+                fv = np.asarray(ds.attrs["_FillValue"]).reshape(-1)[0]
+            except (IndexError, TypeError, ValueError):
+                fv = None
+        out = np.zeros(shape, native)
+        if fv is not None:
+            out[...] = np.asarray(fv).astype(native)
+        return out
+
     def _read_dataset(self, ds):
         t = ds.type
         if t is None or ds._layout is None:
@@ -571,7 +622,7 @@ class File:
         if cls == 1:
             addr = self._a_bytes(d, 2)
             if addr is None:
-                return np.zeros(shape, native)             # never written: fill value (0 / netCDF's _FillValue is applied by the caller)
+                return self._filled(ds, shape, native)     # never written
             return np.frombuffer(self.buf, t.dtype, n, addr).astype(native).reshape(shape)
         if cls != 2:
             raise NotImplementedError(f"{ds.name}: data layout class {cls}")
@@ -607,7 +658,10 @@ class File:
             else:
                 raise NotImplementedError(f"{ds.name}: chunk index type {itype} (B-tree v2: written with libver='latest' on "
                                           f"several unlimited dimensions) — repack with `h5repack --low=0`")
-        out = np.zeros(shape, native)
+        # (missing chunks keep the fill value; when every chunk is there the initial value is never seen)
+        complete = len(chunks) > 0 and all(c[1] is not None for c in chunks) and \
+            len(chunks) >= int(np.prod([-(-s_ // c_) for s_, c_ in zip(shape, cdims)])) if rank else True
+        out = np.empty(shape, native) if complete else self._filled(ds, shape, native)
         for offs, addr, size, mask in chunks:
             if addr is None:
                 continue
