@@ -277,6 +277,8 @@ class HipOps:
         self.upconv_colfwd = os.environ.get("WDG_UPCONV_COLFWD", "1") != "0"   # forward in column form (1x1 GEMM + bilinear gather): 1.22 vs 1.6 ms
         self.upconv_fused16 = os.environ.get("WDG_UPCONV_FUSED16", "1") != "0"   # 16-bit inference: column GEMM + gather in one launch
         # the 16-channel activation between the generator's last two layers in the 16-bit operand format (inference precision)
+        # WDG_CHAIN_TIMING=1: [count, seconds] of the host inside HipOps.chain's graph replays (tools: who keeps the streams waiting)
+        self.chain_timing = [0, 0.0] if os.environ.get("WDG_CHAIN_TIMING", "0") != "0" else None
         self.act16 = os.environ.get("WDG_ACT16", "1") != "0"
         # generator input ([image | noise]) assembled by one kernel when the noise is drawn on the device (LazyNoise)
         self.input_fused = os.environ.get("WDG_INPUT_FUSED", "1") != "0"
@@ -329,7 +331,14 @@ class HipOps:
                     del graphs[k]
             seen.pop(key, None)
             entry = graphs[key] = (graph, own_ws)  # (the graph's private scratch lives exactly as long as the graph)
+        if self.chain_timing is None:
+            entry[0].replay()
+            return
+        import time
+        t0 = time.perf_counter()
         entry[0].replay()
+        self.chain_timing[0] += 1
+        self.chain_timing[1] += time.perf_counter() - t0
 
     # ---- plumbing ---------------------------------------------------------------------------
     @property
