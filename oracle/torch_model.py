@@ -7,8 +7,11 @@ differentiable torch-CPU functions in float64, gradients by torch.autograd.  It 
   /root/reference/src/downscaling/gan/models.py:9-73    make_generator
   /root/reference/src/downscaling/gan/models.py:76-142  make_discriminator
   /root/reference/src/downscaling/tf_utils.py:7-12      img_size / channels
-  /root/reference/src/downscaling/gan/ganbase.py:21-94  GAN.train_step
-  /root/reference/src/downscaling/gan/train.py:11-12,34-35,57-58   losses, Adam hyper-parameters
+  /root/reference/src/downscaling/gan/ganbase.py:21-94  GAN.train_step (incl. sample_weight :23,44,67 and the
+                                                         reconstruction-loss slot :57-59)
+  /root/reference/src/downscaling/gan/ganbase.py:96-113 GAN.test_step
+  /root/reference/src/downscaling/gan/train.py:11-12,19-26,34-35,57-58   losses, reconstruction_loss, Adam hyper-parameters
+  /root/reference/src/downscaling/gan/metrics.py:32-45  wind_speed_weighted_rmse (usable as content loss)
 
 with the TensorFlow 2.4.3 / tensorflow-addons 0.14.0 layer semantics restated from their published
 definitions (those packages are third-party dependencies pinned in requirements.txt:2-3, absent from
@@ -282,19 +285,64 @@ def _grads(loss, w, keys):
     return {k: (g if g is not None else torch.zeros_like(w[k])) for k, g in zip(keys, gs)}
 
 
-def train_step(gw, dw, low, high, draws, g_opt, d_opt, n_critic=3, gamma=100.0, d_loss_fn=None):
+def weighted_loss(value, sample_weight):
+    """What Keras' `compiled_loss(y_true, y_pred, sample_weight)` makes of a plain-function loss (TF 2.4.3
+    `LossesContainer` -> `LossFunctionWrapper(fn, reduction=AUTO)` -> `compute_weighted_loss`): the function's value
+    (a scalar for train.py:11-12) times the per-sample weights, reduced SUM_OVER_BATCH_SIZE — sum(value * sw) / numel.
+    No weights: the value itself.  ganbase.py:44,67."""
+    if sample_weight is None:
+        return value
+    sw = torch.as_tensor(sample_weight, dtype=value.dtype).reshape(-1)
+    w = value * sw
+    return w.sum() / w.numel()
+
+
+def wind_speed_weighted_rmse(real_output, fake_output):
+    """gan/metrics.py:32-45 -> [B]."""
+    u, v = real_output[..., 0], real_output[..., 1]
+    u_hat, v_hat = fake_output[..., 0], fake_output[..., 1]
+    est = torch.sqrt(u_hat ** 2 + v_hat ** 2)
+    rea = torch.sqrt(u ** 2 + v ** 2)
+    epsilon, t = 4, 0.425
+    beta = (epsilon + rea) / (epsilon + est)
+    tau = torch.where(est >= rea, torch.full_like(est, t), torch.full_like(est, 1 - t))
+    result = tau * ((u_hat - beta * u) ** 2 + (v_hat - beta * v) ** 2)
+    result = torch.where(torch.isnan(result), torch.zeros_like(result), result)
+    return torch.sqrt(result.mean(dim=(1, 2, 3)))
+
+
+class reconstruction_loss:
+    """gan/train.py:19-26."""
+
+    def __init__(self, feature_extractor, coefficient=1.0):
+        self.feature_extractor, self.coefficient = feature_extractor, coefficient
+
+    def __call__(self, low_res, high_res):
+        delta = self.feature_extractor(low_res) - self.feature_extractor(high_res)
+        return self.coefficient * torch.mean(torch.sqrt(torch.sum(delta ** 2, dim=-1)))
+
+
+def train_step(gw, dw, low, high, draws, g_opt, d_opt, n_critic=3, gamma=100.0, d_loss_fn=None, sample_weight=None,
+               reconstruction_loss=None, shortcut_variant=False):
     """GAN.train_step, ganbase.py:21-94.  `draws` supplies the random tensors in call order:
     draws.noise() [B,T,S,S,nz], draws.eps() [B], draws.inst() [B,T,S,S,ch].  Mutates gw/dw in place.
     d_loss_fn(real_output [B,1], fake_output [B,1]) -> scalar: the discriminator's compiled loss
-    (ganbase.py:44-45; default the Wasserstein form of train.py:11-12)."""
+    (ganbase.py:44-45; default the Wasserstein form of train.py:11-12).
+    sample_weight [B] (ganbase.py:23): third element of the data tuple, weights the compiled discriminator loss (:44, :67).
+    reconstruction_loss(low_res[..., :2], fake_high_res) (ganbase.py:57-59): added to the generator's loss; a non-scalar
+    value makes gen_loss non-scalar and `tape.gradient` differentiates the SUM of its elements (TF semantics).
+    shortcut_variant: the discriminator graph of the shipped checkpoint (discriminator_layout)."""
     S = high.shape[2]
     gk, dk = trainable_keys(gw), trainable_keys(dw)
     for k in gk:
         gw[k].requires_grad_(True)
     for k in dk:
         dw[k].requires_grad_(True)
-    g_sn, d_sn = generator_sn_keys(), discriminator_sn_keys(S)
+    g_sn, d_sn = generator_sn_keys(), discriminator_sn_keys(S, shortcut_variant)
+    sv = shortcut_variant
     B = low.shape[0]
+    wasserstein = (lambda r, f: -(r.mean() - f.mean()))                                # train.py:11-12
+    loss_fn = wasserstein if d_loss_fn is None else d_loss_fn
     for _ in range(n_critic):                                                          # :26
         noise = draws.noise()                                                          # :28
         apply_sn(gw, g_sn, True)
@@ -306,57 +354,68 @@ def train_step(gw, dw, low, high, draws, g_opt, d_opt, n_critic=3, gamma=100.0, 
         eps = draws.eps().reshape(B, 1, 1, 1, 1)                                       # :30
         combined = (eps * high + (1 - eps) * fake).requires_grad_(True)                # :31
         apply_sn(dw, d_sn, True)
-        out = discriminator_forward(dw, low, combined)                                 # :32-34
+        out = discriminator_forward(dw, low, combined, sv)                             # :32-34
         (gimg,) = torch.autograd.grad(out.sum(), combined)                             # :35
         gnorm = torch.sqrt((gimg ** 2).sum((1, 2, 3)))                                 # :36
         gradient_reg = gamma * ((gnorm - 1) ** 2).mean()                               # :37
         hr = high + draws.inst()                                                       # :40
         apply_sn(dw, d_sn, True)
-        if d_loss_fn is None:
-            real_s = discriminator_forward(dw, low, hr)                                # :41
-            g_real = _grads(-real_s.mean(), dw, dk)     # weights as they were for this call (TF reads the
-            fhr = fake + draws.inst()                   # variable value at forward time)          :42
-            apply_sn(dw, d_sn, True)
-            fake_s = discriminator_forward(dw, low, fhr)                               # :43
-            g_fake = _grads(fake_s.mean(), dw, dk)
-            disc_loss = (fake_s.mean() - real_s.mean()).detach() + gradient_reg.detach()   # :44-45
-            d_grads = {k: g_real[k] + g_fake[k] for k in dk}                           # :46
-        else:
-            # a loss that couples the two outputs: the real pass keeps the variable values it read (a copy: the fake
-            # pass' SN update overwrites them in place), the tape sums both passes' partial derivatives per variable
-            w_real = {k: (v.detach().clone().requires_grad_(True) if k in dk else v.detach().clone()) for k, v in dw.items()}
-            real_s = discriminator_forward(w_real, low, hr)                            # :41
-            fhr = fake + draws.inst()                                                  # :42
-            apply_sn(dw, d_sn, True)
-            fake_s = discriminator_forward(dw, low, fhr)                               # :43
-            loss = d_loss_fn(real_s, fake_s)                                           # :44 compiled_loss(real, fake)
-            both = torch.autograd.grad(loss, [w_real[k] for k in dk] + [dw[k] for k in dk], allow_unused=True)
-            zero = lambda g, k: g if g is not None else torch.zeros_like(dw[k])   # noqa: E731
-            g_real = {k: zero(g, k) for k, g in zip(dk, both[:len(dk)])}
-            g_fake = {k: zero(g, k) for k, g in zip(dk, both[len(dk):])}
-            disc_loss = loss.detach() + gradient_reg.detach()
-            d_grads = {k: g_real[k] + g_fake[k] for k in dk}
+        # the real pass keeps the variable values it read (a copy: the generated pass' SN update overwrites them in place;
+        # TF reads the variable value at forward time), the tape sums both passes' partial derivatives per variable
+        w_real = {k: (v.detach().clone().requires_grad_(True) if k in dk else v.detach().clone()) for k, v in dw.items()}
+        real_s = discriminator_forward(w_real, low, hr, sv)                            # :41
+        fhr = fake + draws.inst()                                                      # :42
+        apply_sn(dw, d_sn, True)
+        fake_s = discriminator_forward(dw, low, fhr, sv)                               # :43
+        loss = weighted_loss(loss_fn(real_s, fake_s), sample_weight)                   # :44 compiled_loss(real, fake, sw, ...)
+        both = torch.autograd.grad(loss, [w_real[k] for k in dk] + [dw[k] for k in dk], allow_unused=True)
+        zero = lambda g, k: g if g is not None else torch.zeros_like(dw[k])   # noqa: E731
+        g_real = {k: zero(g, k) for k, g in zip(dk, both[:len(dk)])}
+        g_fake = {k: zero(g, k) for k, g in zip(dk, both[len(dk):])}
+        disc_loss = loss.detach() + gradient_reg.detach()                              # :45 regularization_losses
+        d_grads = {k: g_real[k] + g_fake[k] for k in dk}                               # :46
         d_opt.step(dw, d_grads)                                                        # :47
     noise = draws.noise()                                                              # :51
     apply_sn(gw, g_sn, True)
     st = {}
     fake = generator_forward(gw, low, noise, True, st)                                 # :52
     apply_sn(dw, d_sn, True)
-    score = discriminator_forward(dw, low, fake)                                       # :53
+    score = discriminator_forward(dw, low, fake, sv)                                   # :53
     gen_disc_loss = -score.mean()                                                      # :54
-    g_grads = _grads(gen_disc_loss, gw, gk)                                            # :60
+    gen_loss, reco_loss = gen_disc_loss, None                                          # :55-56
+    if reconstruction_loss is not None:                                                # :57-59
+        reco_loss = reconstruction_loss(low[..., :2], fake)
+        gen_loss = gen_loss + reco_loss
+    g_grads = _grads(gen_loss.sum(), gw, gk)                                           # :60 (non-scalar target: summed)
     with torch.no_grad():
         for k, v in st.items():
             gw[k].copy_(v)
     g_opt.step(gw, g_grads)                                                            # :61
     with torch.no_grad():                                                              # :63-68
-        real_s = discriminator_forward(dw, low, high)
+        real_s = discriminator_forward(dw, low, high, sv)
         fake = generator_forward(gw, low, draws.noise(), False)
-        fake_s = discriminator_forward(dw, low, fake)
+        fake_s = discriminator_forward(dw, low, fake, sv)
+        d_loss = weighted_loss(loss_fn(real_s, fake_s), sample_weight)                 # :67
     return {
-        "g_loss": -fake_s.mean(), "g_disc_loss": gen_disc_loss.detach(), "d_loss": fake_s.mean() - real_s.mean(),
+        "g_loss": -fake_s.mean(), "g_disc_loss": gen_disc_loss.detach(), "d_loss": d_loss,
+        "g_reco_loss": None if reco_loss is None else reco_loss.detach(),
         "d_gradient_pen": gnorm.mean().detach(),
         "g_gradient_param": torch.stack([(g ** 2).mean() for g in g_grads.values()]).mean(),
         "d_gradient_param": torch.stack([(g ** 2).mean() for g in d_grads.values()]).mean(),
         "_d_loss_train": disc_loss, "fake": fake,
     }
+
+
+def test_step(gw, dw, low, high, draws, d_loss_fn=None, shortcut_variant=False):
+    """GAN.test_step, ganbase.py:96-113 (inference mode: no SN update, BatchNorm on moving statistics; the compiled loss is
+    called WITHOUT the sample weights, :103).  Draw order: the generator noise first (:99)."""
+    loss_fn = (lambda r, f: -(r.mean() - f.mean())) if d_loss_fn is None else d_loss_fn
+    with torch.no_grad():
+        noise = draws.noise()                                                          # :99
+        true_predictions = discriminator_forward(dw, low, high, shortcut_variant)      # :100
+        generated = generator_forward(gw, low, noise, False)                           # :101
+        fake_predictions = discriminator_forward(dw, low, generated, shortcut_variant)  # :102
+        return {"loss": loss_fn(true_predictions, fake_predictions), "generated": generated}   # :103
+
+
+test_step.__test__ = False      # (not a pytest test)

@@ -189,6 +189,39 @@ def test_bf16_generator_forward(hip_ops, S, T, F, fmt):
         net.forward(B, True, precision=fmt)
 
 
+@pytest.mark.parametrize("switch", ["upconv_colfwd", "upconv_fused16"])
+def test_act16_buffers_follow_the_upsample_route(hip_ops, switch):
+    """with the documented switches WDG_UPCONV_COLFWD=0 / WDG_UPCONV_FUSED16=0 the fused upsample kernel
+    — the only route of upconv_fwd_bf16 that takes activations in the 16-bit operand format — is not taken, so the generator
+    must not allocate 16-bit hand-over buffers (a 16-bit z9 in front of an fp32-writing route was a device out-of-bounds
+    write), the forward must stay inside the stated tolerance, and a direct call with a 16-bit y must be refused."""
+    from downscaling.engine.networks import GeneratorNet
+    B, T, S, cin, nz, ch, F, fmt = 2, 1, 32, 3, 20, 2, 128, "bf16"
+    dev = hip_ops.device
+    saved = getattr(hip_ops, switch)
+    setattr(hip_ops, switch, False)
+    try:
+        net = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
+        w = randomize(net, 11)
+        g = torch.Generator().manual_seed(0)
+        low = torch.randn(B, T, S, S, cin, generator=g, dtype=torch.float64)
+        noise = torch.randn(B, T, S, S, nz, generator=g, dtype=torch.float64) * 0.1
+        net.set_image(low.float().to(dev))
+        net.set_noise(noise.float().to(dev))
+        assert not hip_ops.act16_output_conv_ok(net.c9.pk, net.c11.pk, net.c11.g)
+        out16 = torch.zeros(B, T, S, S, ch, device=dev)
+        net.from_time_major(net.forward(B, False, precision=fmt), out16)
+        b = net.buffers(B)
+        assert "z9_" + fmt not in b and b.get("cat2_" + fmt) is None
+        ref = TM.generator_forward(w, low, noise, False)
+        assert 1e-6 < rel_err(out16, ref) < 3e-2
+        y16 = torch.zeros(*b["z9"].shape, dtype=torch.bfloat16, device=dev)
+        with pytest.raises(ValueError):
+            hip_ops.upconv_fwd_bf16(b["cat2"], net.c9.pk, net.c9.b.value, y16, net.c9.g, act=True, fmt=fmt)
+    finally:
+        setattr(hip_ops, switch, saved)
+
+
 @pytest.mark.parametrize("fmt", ["bf16", "fp16"])
 @pytest.mark.parametrize("S,T,F", [(96, 3, 128), (64, 2, 64)])
 def test_convlstm16_fused_step_matches_unfused(hip_ops, S, T, F, fmt):

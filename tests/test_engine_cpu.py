@@ -206,6 +206,69 @@ def test_train_step_with_custom_discriminator_loss(ops, loss):
             assert rel_err(a[k], b[k]) < 1e-12, k
 
 
+def _ws_rmse_engine(real_output, fake_output):
+    """The package's metrics.wind_speed_weighted_rmse (metrics.py:32-45) in the reconstruction-loss slot: differentiable
+    when its second argument requires a gradient."""
+    from downscaling.gan.metrics import wind_speed_weighted_rmse
+    return wind_speed_weighted_rmse(real_output, fake_output)
+
+
+@pytest.mark.parametrize("case", ["encoder", "ws_rmse_vector", "sample_weight", "shortcut"])
+def test_train_step_remaining_branches(ops, case):
+    """The branches of GAN.train_step the default call does not take (VERDICT r4 missing #2), engine vs the autograd
+    restatement, two steps each:
+      encoder         reconstruction_loss(encoder, 0.5) in the generator step (ganbase.py:57-59, train.py:19-26) with the
+                      reference's own feature extractor (EncoderNet, autoencoder.py:23-36);
+      ws_rmse_vector  wind_speed_weighted_rmse (metrics.py:32-45) as content loss: a per-sample VECTOR, so gen_loss is a
+                      vector and the tape differentiates its sum;
+      sample_weight   the third element of the data tuple (ganbase.py:23,44,67);
+      shortcut        the discriminator graph of the shipped checkpoint inside a train step (lazily zeroed gradients)."""
+    B, cin, nz, ch, S, T = 2, 3, 2, 2, 24 if case == "encoder" else 12, 2
+    variant = case == "shortcut"
+    gen = GeneratorNet(ops, S, cin, nz, ch, T, feature_channels=32, seed=5)
+    disc = DiscriminatorNet(ops, S, S, cin, ch, T, feature_channels=8, seed=6, shortcut_variant=variant)
+    gw, dw = randomize(gen, 21), randomize(disc, 22)
+    eng = GanEngine(gen, disc, PhiloxSource(ops, seed=99), noise_std=0.1, n_critic=2)
+    g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
+    og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
+    draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
+    kw_e, kw_r = {}, {}
+    if case == "encoder":
+        from downscaling.engine.networks import EncoderNet
+        from downscaling.gan.train import reconstruction_loss
+        from downscaling.autoencoder.autoencoder import Encoder
+        enc = EncoderNet(ops, S, T, 4, seed=7)
+        ew = randomize(enc, 31)
+        kw_e["reconstruction_loss"] = reconstruction_loss(Encoder(enc), 0.5)
+        kw_r["reconstruction_loss"] = TM.reconstruction_loss(lambda x: TM.encoder_forward(ew, x, 4), 0.5)
+    elif case == "ws_rmse_vector":
+        kw_e["reconstruction_loss"] = _ws_rmse_engine
+        kw_r["reconstruction_loss"] = TM.wind_speed_weighted_rmse
+    elif case == "sample_weight":
+        kw_e["sample_weight"] = kw_r["sample_weight"] = torch.tensor([0.25, 1.75], dtype=torch.float64) * 0.8
+    for step in range(2):
+        low, _, high = _inputs(B, T, S, cin, nz, ch, seed=60 + step)
+        res = eng.train_step(low, high, g_opt, d_opt, **kw_e)
+        ref = TM.train_step(gw, dw, low, high, draws, og, od, n_critic=2, shortcut_variant=variant, **kw_r)
+        keys = ["g_loss", "g_disc_loss", "d_loss", "d_gradient_pen", "g_gradient_param", "d_gradient_param", "_d_loss_train"]
+        if "reconstruction_loss" in kw_e:
+            keys.append("g_reco_loss")
+        for k in keys:
+            assert rel_err(res[k], ref[k]) < 1e-7, (step, k)
+        for net, w in ((gen, gw), (disc, dw)):
+            got = weights64(net)
+            for k in w:
+                assert rel_err(got[k], w[k]) < 1e-7, (step, k)
+    # test_step (ganbase.py:96-113) on the trained pair
+    low, _, high = _inputs(B, T, S, cin, nz, ch, seed=69)
+    t = eng.test_step(low, high)
+    tr = TM.test_step(gw, dw, low, high, draws, shortcut_variant=variant)
+    assert rel_err(t["loss"], tr["loss"]) < 1e-7
+    fake = torch.zeros(B, T, S, S, ch, dtype=torch.float64)
+    gen.from_time_major(eng.last_fake_tm, fake)
+    assert rel_err(fake, tr["generated"]) < 1e-7
+
+
 @pytest.mark.parametrize("S,T,latent", [(96, 2, 96), (24, 1, 4), (40, 2, 8)])
 def test_encoder_forward_and_input_gradient(ops, S, T, latent):
     """AutoEncoder.make_encoder (autoencoder/autoencoder.py:23-36), the reconstruction-loss feature extractor: forward
@@ -225,14 +288,18 @@ def test_encoder_forward_and_input_gradient(ops, S, T, latent):
     assert rel_err(net.backward_input(g), gref) < 1e-9
 
 
-def test_lazy_zero_grad_equals_eager(ops, monkeypatch):
-    """ParamStore.zero_grad(lazy=True) (the trainer's critic updates): big convolution kernels are not zero-filled but
+@pytest.mark.parametrize("variant", [False, True])
+def test_lazy_zero_grad_equals_eager(ops, monkeypatch, variant):
+    """variant=True: the shortcut kernel of the shipped checkpoint's graph, whose gradient is written by _shortcut_bwd and not
+    by Conv.backward_weights (it accumulated onto the stale slot and settle() then zeroed it).
+    ParamStore.zero_grad(lazy=True) (the trainer's critic updates): big convolution kernels are not zero-filled but
     marked fresh, their first weight-gradient launch stores instead of accumulating, a second pass accumulates, and
     settle() zero-fills what no pass wrote — the gradient buffer must equal the eagerly zeroed one in every case."""
     from downscaling.engine.params import ParamStore
     monkeypatch.setattr(ParamStore, "LAZY_MIN", 1)          # (every Conv kernel of the small test network takes part)
     B, S, T, cl, ch = 2, 20, 1, 3, 2
-    net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=8, seed=4)
+    net = DiscriminatorNet(ops, S, S, cl, ch, T, feature_channels=8, seed=4, shortcut_variant=variant)
+    assert (net.shortcut is not None) == variant
     randomize(net, 12)
     low, _, high = _inputs(B, T, S, cl, 1, ch, seed=1)
     net.set_low(low)
@@ -256,3 +323,10 @@ def test_lazy_zero_grad_equals_eager(ops, monkeypatch):
         eager, lazy = passes(False, n), passes(True, n)
         assert float((eager - lazy).abs().max()) == 0.0, n
     assert float(passes(True, 1).abs().max()) > 0.0
+    if variant:
+        net.params.zero_grad(lazy=True)
+        assert net.shortcut["conv"].w.fresh
+        net.forward(B, training=False)
+        net.backward(B, dscore.clone(), need_wgrad=True, need_input_grad=False)
+        net.params.settle()
+        assert float(net.shortcut["conv"].w.grad.abs().max()) > 0.0

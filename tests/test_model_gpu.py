@@ -231,6 +231,79 @@ def test_train_step_custom_discriminator_loss(hip_ops, S, T):
                 assert rel_err(got[k], w[k]) < TOL, (step, k)
 
 
+@pytest.mark.parametrize("case,S,T", [("encoder", 40, 1), ("encoder", 96, 2), ("ws_rmse_vector", 32, 2), ("ws_rmse_scalar", 20, 1),
+                                      ("sample_weight", 32, 2), ("shortcut", 32, 2), ("shortcut", 20, 1)])
+def test_train_step_remaining_branches(hip_ops, monkeypatch, case, S, T):
+    """The branches of GAN.train_step the default call does not take (VERDICT r4 missing #2) on the HIP kernels, default
+    (pipelined, two-network) schedule, against the fp64 restatement — two steps, every weight and log at 1e-4, then
+    GAN.test_step (ganbase.py:96-113) on the trained pair:
+      encoder          train.reconstruction_loss(encoder, 0.5) (ganbase.py:57-59, train.py:19-26) on EncoderNet: the loss
+                       gradient joins the discriminator's input gradient by a strided-slice accumulate (GanEngine._reco_grad);
+      ws_rmse_vector   metrics.wind_speed_weighted_rmse (metrics.py:32-45) as content loss — a per-sample vector: the tape
+                       differentiates the sum of gen_loss' elements;   ws_rmse_scalar: its mean;
+      sample_weight    the third element of the data tuple (ganbase.py:23,44,67);
+      shortcut         the shipped checkpoint's discriminator graph with EVERY kernel gradient lazily zeroed (LAZY_MIN = 1):
+                       the shortcut kernel's gradient is written by _shortcut_bwd."""
+    from downscaling.engine.networks import DiscriminatorNet, EncoderNet, GeneratorNet
+    from downscaling.engine.params import ParamStore
+    from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
+    from downscaling.gan import metrics as M
+    from downscaling.gan.train import reconstruction_loss
+    B, cin, nz, ch = 2, 3, 4, 2
+    dev = hip_ops.device
+    variant = case == "shortcut"
+    if variant:
+        monkeypatch.setattr(ParamStore, "LAZY_MIN", 1)
+    gen = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=32, seed=5)
+    disc = DiscriminatorNet(hip_ops, S, S, cin, ch, T, feature_channels=8, seed=6, shortcut_variant=variant)
+    assert (disc.shortcut is not None) == variant
+    gw, dw = randomize(gen, 21), randomize(disc, 22)
+    eng = GanEngine(gen, disc, PhiloxSource(hip_ops, seed=99), noise_std=0.1, n_critic=2)
+    g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
+    og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
+    draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
+    kw_e, kw_r = {}, {}
+    if case == "encoder":
+        from downscaling.autoencoder.autoencoder import Encoder
+        latent = 8 if S == 40 else 96
+        enc = EncoderNet(hip_ops, S, T, latent, seed=7)
+        ew = randomize(enc, 31)
+        kw_e["reconstruction_loss"] = reconstruction_loss(Encoder(enc), 0.5)
+        kw_r["reconstruction_loss"] = TM.reconstruction_loss(lambda x: TM.encoder_forward(ew, x, latent), 0.5)
+    elif case == "ws_rmse_vector":
+        kw_e["reconstruction_loss"] = M.wind_speed_weighted_rmse
+        kw_r["reconstruction_loss"] = TM.wind_speed_weighted_rmse
+    elif case == "ws_rmse_scalar":
+        kw_e["reconstruction_loss"] = lambda a, b: M.wind_speed_weighted_rmse(a, b).mean()
+        kw_r["reconstruction_loss"] = lambda a, b: TM.wind_speed_weighted_rmse(a, b).mean()
+    elif case == "sample_weight":
+        kw_e["sample_weight"] = kw_r["sample_weight"] = torch.tensor([0.2, 1.4], dtype=torch.float64)
+    keys = ["g_loss", "g_disc_loss", "d_loss", "d_gradient_pen", "g_gradient_param", "d_gradient_param", "_d_loss_train"]
+    for step in range(2):
+        low, _, high = _inputs(B, T, S, cin, nz, ch, seed=80 + step)
+        res = eng.train_step(low.float().to(dev), high.float().to(dev), g_opt, d_opt, **kw_e)
+        ref = TM.train_step(gw, dw, low, high, draws, og, od, n_critic=2, shortcut_variant=variant, **kw_r)
+        for k in keys:
+            a, b = float(res[k]), float(ref[k])
+            assert abs(a - b) < 2e-4 * max(1.0, abs(b)), (step, k, a, b)
+        if "reconstruction_loss" in kw_e:
+            assert rel_err(res["g_reco_loss"], ref["g_reco_loss"]) < TOL
+            assert float(torch.as_tensor(ref["g_reco_loss"]).abs().max()) > 1e-3       # (the content term is not negligible)
+        for net, w in ((gen, gw), (disc, dw)):
+            got = weights64(net)
+            for k in w:
+                assert rel_err(got[k], w[k]) < TOL, (step, k)
+    if variant:
+        assert float(disc.shortcut["conv"].w.grad.abs().max()) > 0.0          # the shortcut kernel did receive a gradient
+    low, _, high = _inputs(B, T, S, cin, nz, ch, seed=89)
+    t = eng.test_step(low.float().to(dev), high.float().to(dev))
+    tr = TM.test_step(gw, dw, low, high, draws, shortcut_variant=variant)
+    assert abs(float(t["loss"]) - float(tr["loss"])) < 2e-4 * max(1.0, abs(float(tr["loss"])))
+    fake = torch.zeros(B, T, S, S, ch, device=dev)
+    gen.from_time_major(eng.last_fake_tm, fake)
+    assert rel_err(fake, tr["generated"]) < TOL
+
+
 @pytest.mark.parametrize("S,T,latent", [(96, 2, 96), (40, 1, 8)])
 def test_encoder_feature_extractor(hip_ops, S, T, latent):
     """The reconstruction-loss feature extractor (autoencoder/autoencoder.py:23-36) on the HIP kernels: forward and
@@ -291,6 +364,73 @@ def test_generator_inference_graph_replay(hip_ops, precision):
     g.graph_inference = False
     y_eager = g([image, noise], training=False, precision=precision)
     assert torch.equal(y_graph, y_eager) and not torch.equal(y_graph, outs[True][0])
+
+
+@pytest.mark.parametrize("shortcut_variant", [False, True])
+def test_checkpoint_round_trip_through_hip_networks(hip_ops, tmp_path, shortcut_variant):
+    """GAN.save_weights / load_weights (ganbase.py:132-140, api.py:21,85) THROUGH the HIP networks (VERDICT r4 missing #3): a
+    trained pair (SN-updated kernels, BatchNorm moving statistics, Adam-moved weights) is saved as TF tensor bundles and
+    loaded into fresh networks whose inference graphs were ALREADY captured on other weights.  Everything that hangs off
+    the parameter version — repacked kernel layouts, 16-bit weight copies, cached inference BatchNorm affines, captured HIP
+    graphs — must follow the load: the restored generator's output is bit-identical in fp32 and in bf16 (graph replay and
+    eager), differs from what the stale graph produced, and the restored discriminator scores identically."""
+    from downscaling.data.data_generator import FlexibleNoiseGenerator
+    from downscaling.engine import runtime
+    from downscaling.engine.tf_bundle import read_bundle
+    from downscaling.gan import train
+    from downscaling.gan.ganbase import GAN
+    from downscaling.gan.models import make_discriminator, make_generator
+    runtime.set_ops(hip_ops)
+    dev = hip_ops.device
+    S, T, B, nz = 32, 3, 2, 4
+
+    def build():
+        g = make_generator(S, 3, nz, 2, T, feature_channels=64)
+        d = make_discriminator(S, S, 3, 2, T, feature_channels=8, shortcut_variant=shortcut_variant)
+        gan = GAN(g, d, FlexibleNoiseGenerator((B, T, S, S, nz), std=0.1, random_seed=3), n_critic=1)
+        gan.compile(train.generator_optimizer(), train.discriminator_optimizer(), discriminator_loss=train.discriminator_loss)
+        return gan
+
+    gen_ = torch.Generator().manual_seed(5)
+    low = torch.randn(B, T, S, S, 3, generator=gen_).to(dev)
+    high = torch.randn(B, T, S, S, 2, generator=gen_).to(dev)
+    noise = (torch.randn(B, T, S, S, nz, generator=gen_) * 0.1).to(dev)
+
+    def infer(gan, precision):
+        gan.generator.graph_inference = True
+        for _ in range(4):                                   # calls 1-2 eager, 3 captures, 4 replays
+            y = gan.generator([low, noise], training=False, precision=precision).clone()
+        assert any(isinstance(k, tuple) for k in gan.generator.net._graphs)
+        gan.generator.graph_inference = False
+        y_eager = gan.generator([low, noise], training=False, precision=precision).clone()
+        assert torch.equal(y, y_eager)
+        return y
+
+    a = build()
+    randomize(a.generator.net, 41), randomize(a.discriminator.net, 42)
+    for _ in range(2):
+        logs = a.train_step((low, high))
+    assert all(torch.isfinite(torch.as_tensor(float(v))) for v in logs.values() if v is not None)
+    ya = {p: infer(a, p) for p in ("fp32", "bf16")}
+    sa = a.discriminator([low, high], training=False).clone()
+    a.save_weights(str(tmp_path / "ckpt"))
+    saved = read_bundle(str(tmp_path / "ckpt" / "generator"))
+    assert any(k.endswith("moving_variance") or "moving_variance" in k for k in saved)
+
+    b = build()
+    randomize(b.generator.net, 51), randomize(b.discriminator.net, 52)
+    stale = {p: infer(b, p) for p in ("fp32", "bf16")}        # graphs (and 16-bit copies / BN affines) of OTHER weights exist now
+    assert not torch.equal(stale["fp32"], ya["fp32"])
+    b.load_weights(str(tmp_path / "ckpt"))
+    for p in ("fp32", "bf16"):
+        b.generator.graph_inference = True
+        y_first = b.generator([low, noise], training=False, precision=p).clone()     # the stale graph must not be replayed
+        assert torch.equal(y_first, ya[p]), p
+        assert torch.equal(infer(b, p), ya[p]), p
+    assert torch.equal(b.discriminator([low, high], training=False), sa)
+    # every variable (trainable and not: sn_u, moving statistics) came back bit for bit
+    for net_a, net_b in ((a.generator.net, b.generator.net), (a.discriminator.net, b.discriminator.net)):
+        assert torch.equal(net_a.params.flat, net_b.params.flat) and torch.equal(net_a.params.state, net_b.params.state)
 
 
 @pytest.mark.parametrize("T", [1, 3])

@@ -668,17 +668,29 @@ class HipOps:
 
     H16_DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
-    def act16_output_conv_ok(self, pk_up, pk_out, g_out):
+    def act16_output_conv_ok(self, pk_up, pk_out, g_out, x_low=None, bias=None, affine=None):
         """True when the generator's last two layers can pass their 16-channel activation in the 16-bit operand format: the fused
         upsample kernel writes it (out16), the 16 -> (<= 4) output conv reads it (wdg_conv_thin16_fwd_h16).  Same values as the
         fp32 hand-over (the reader rounds to the operand format either way), half the bytes."""
-        return bool(self.act16 and self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk_up.cout, pk_up.cin)
+        if x_low is not None and (x_low.shape[3] != pk_up.cout or _v4(x_low)[1] % (8 if x_low.dtype != torch.float32 else 4)):
+            return False
+        if any(t is not None and t.data_ptr() % 16 for t in (bias, affine)):
+            return False
+        return bool(self.act16 and self._upconv_fused16_layer_ok(pk_up)
                     and g_out.kh == 3 and g_out.kw == 3 and g_out.stride == 1 and g_out.pad == 1 and pk_out.cin == 16 and pk_out.cout <= 4)
+
+    def _upconv_fused16_layer_ok(self, pk):
+        """The layer-level preconditions of the ONE route of upconv_fwd_bf16 that accepts activations in the 16-bit operand
+        format (the fused kernel, csrc/upconv_fused_h16.hip).  Shared by the act16_* predicates the networks use to ALLOCATE
+        16-bit buffers and by upconv_fwd_bf16 itself, so that a switch such as WDG_UPCONV_COLFWD=0 cannot leave a 16-bit buffer
+        in front of a route that would treat it as fp32."""
+        return bool(self.upconv_colfwd and self.upconv_fused16 and not self.z16 and pk.w is not None and pk.cout % 8 == 0 and
+                    pk.wD is pk.w and self.lib.wdg_upconv_col_supported(pk.cin) and
+                    self.lib.wdg_upconv_fused_h16_supported(pk.cout, pk.cin))
 
     def act16_upconv_in_ok(self, x_low, pk_up):
         """The fused upsample kernel reads x_low in the 16-bit operand format."""
-        return bool(self.act16 and self.upconv_fused16 and not self.z16 and self.upconv_colfwd and
-                    self.lib.wdg_upconv_fused_h16_supported(pk_up.cout, pk_up.cin) and _v4(x_low)[1] % 8 == 0)
+        return bool(self.act16 and self._upconv_fused16_layer_ok(pk_up) and x_low.shape[3] == pk_up.cout and _v4(x_low)[1] % 8 == 0)
 
     def act16_conv_ok(self, x, y, pk, g, transposed, in16, out16):
         """Would conv_fwd_bf16 (transposed False) / conv_dgrad_bf16 (True) take x / y in the 16-bit operand format?  x, y: tensors
@@ -711,18 +723,24 @@ class HipOps:
         px, ldl, isl = _v4(x_low)
         py, ldy, isy = _v4(y)
         n, H, W, _ = y.shape
-        if self.upconv_colfwd and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
-                x_low.shape[3] == pk.cout and pk.cout % 8 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
-                pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (affine is None or affine.data_ptr() % 16 == 0):
+        y16 = y.dtype in (torch.bfloat16, torch.float16)
+        x16 = self._is16(x_low, fmt)
+        col = self.upconv_colfwd and g.kh == 5 and g.kw == 5 and g.stride == 1 and g.pad == 2 and pk.w is not None and \
+            x_low.shape[3] == pk.cout and pk.cout % 8 == 0 and self.lib.wdg_upconv_col_supported(pk.cin) and \
+            pk.wD is pk.w and (bias is None or bias.data_ptr() % 16 == 0) and (affine is None or affine.data_ptr() % 16 == 0)
+        fused = col and self._upconv_fused16_layer_ok(pk) and ldl % (8 if x16 else 4) == 0
+        if (y16 or x16) and not fused:
+            # every other route below reads x_low / writes y as fp32: refuse BEFORE anything is launched
+            raise ValueError("upconv_fwd_bf16: activations in the 16-bit operand format need the fused kernel "
+                             "(act16_output_conv_ok / act16_upconv_in_ok), which this layer / switch setting does not take")
+        if col:
             # column form with 16-bit GEMM operands: z = x * W, then the fp32 bilinear gather.  z16 (WDG_Z16=1, opt-in): z itself is
             # stored in the operand format — 400 columns per low-resolution pixel make it the largest tensor of the forward (1.4 GB
             # per 16-tile group in fp32), written once and read once.  Measured SLOWER than fp32 z twice: with 8-byte accesses of
             # four values (16-tile group 3.78 -> 4.23 ms) and with 16-byte accesses of eight (lane-pair exchange in the GEMM's
             # epilogue, eight-value slots in the gather: 3.82 -> 3.97 ms) — neither kernel is bound by z's bytes: the 400-column
             # GEMM has a reduction of only 160 (five MFMA K-steps per 16 stores) and the gather is bound by its LDS passes
-            y16 = y.dtype in (torch.bfloat16, torch.float16)
-            x16 = self._is16(x_low, fmt)
-            if self.upconv_fused16 and not self.z16 and self.lib.wdg_upconv_fused_h16_supported(pk.cout, pk.cin) and ldl % (8 if x16 else 4) == 0:
+            if fused:
                 # both stages in one launch, z never leaves the CU (csrc/upconv_fused_h16.hip): 0.48 + 0.54 ms -> one launch per
                 # 16-tile group of the shipped generator.  y in the operand format: for a reader that rounds to it anyway
                 if y16 and y.dtype != self.H16_DTYPES[fmt]:
@@ -731,8 +749,6 @@ class HipOps:
                                                            _ptr(affine), py, ldy, isy, n, H // 2, W // 2, pk.cout, pk.cin, int(act), slope,
                                                            int(y16), x16, self.stream), "upconv_fused_h16")
                 return
-            if y16 or x16:
-                raise ValueError("upconv_fwd_bf16: 16-bit activations need the fused kernel (act16_output_conv_ok)")
             plan16 = None
             if self.z16 and pk.cin % 8 == 0:
                 plan16, _, _ = self._plan_dims(n, H // 2, W // 2, 25 * pk.cin, 25 * pk.cin, (H // 2) * (W // 2) * 25 * pk.cin,

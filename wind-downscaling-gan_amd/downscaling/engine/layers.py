@@ -143,11 +143,13 @@ class BatchNorm:
         self.stats = o.zeros(self.REPLICAS, 2 * C, dtype=torch.float64)
         self.red = o.zeros(2 * C, dtype=torch.float64)
         self.red_local = o.zeros(2 * C, dtype=torch.float64)
-        self.ss = o.empty(2 * C)
+        self.ss = o.empty(2 * C)                 # training-mode [scale | shift] of the current pass
+        self.ss_infer = o.empty(2 * C)           # inference-mode affine (moving statistics): its own buffer, so a training
+                                                 # pass cannot clobber what a captured inference graph reads
         self.saved = o.empty(2 * C)
         self.count = 1.0
         self._epoch = 0                 # training-mode passes seen (each rewrites ss and the moving statistics)
-        self._infer_key = None          # (params.version, _epoch) self.ss holds the inference affine of
+        self._infer_key = None          # (params.version, _epoch) self.ss_infer holds the inference affine of
         if self.Cp != self.C:
             self.mvar.value_pad[self.C:] = 0.0     # (alignment slots: keep the pad channels' variance at 0, not the init 1)
 
@@ -174,19 +176,21 @@ class BatchNorm:
             self._epoch += 1
             o.bn_finalize_train(stats, count, self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad,
                                 self.mvar.value_pad, BN_MOMENTUM, BN_EPS, self.ss, self.saved)
+            o.bn_apply(y, self.ss, z)
         else:
-            self.infer_affine()
-        o.bn_apply(y, self.ss, z)
+            o.bn_apply(y, self.infer_affine(), z)
 
     def infer_affine(self):
         """[scale | shift] of the inference-mode normalisation (moving statistics), for epilogue fusion.  Recomputed only when
         the parameters (ParamStore.version: optimizer step, load, set_weights) or the moving statistics (a training-mode pass)
-        changed: five launches per generator forward otherwise — inside the replayed inference graph as well."""
+        changed: five launches per generator forward otherwise — inside the replayed inference graph as well.  Anything that
+        writes gamma / beta / the moving statistics in place by another road must call ParamStore.touch()."""
         key = (self.net.params.version, self._epoch)
         if self._infer_key != key:
-            self.ops.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS, self.ss)
+            self.ops.bn_finalize_infer(self.gamma.value_pad, self.beta.value_pad, self.mmean.value_pad, self.mvar.value_pad, BN_EPS,
+                                       self.ss_infer)
             self._infer_key = key
-        return self.ss
+        return self.ss_infer
 
     def backward(self, dz, y, dpre, dbias, act_slope=LRELU):
         """dpre = BN-backward(dz) * lrelu'(y); accumulates dgamma, dbeta and (fused) the conv bias grad."""

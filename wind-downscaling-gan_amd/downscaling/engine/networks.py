@@ -283,7 +283,9 @@ class GeneratorNet(_Net):
             self.c7.forward_bf16(b["cat4"], cat2[..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
             z9 = b["z9"]
             ok16 = getattr(self.ops, "act16_output_conv_ok", None)
-            if ok16 is not None and z9.shape[3] == 16 and ok16(self.c9.pk, self.c11.pk, self.c11.g):
+            aff10 = self.bn10.infer_affine()
+            if ok16 is not None and z9.shape[3] == 16 and ok16(self.c9.pk, self.c11.pk, self.c11.g, x_low=cat2,
+                                                               bias=self.c9.b.value, affine=aff10):
                 # the 16-channel activation between the last two layers in the operand format: its only reader rounds to that
                 # format anyway — the same values, half the bytes of the largest-by-pixels tensor of the forward
                 key = "z9_" + f
@@ -291,7 +293,7 @@ class GeneratorNet(_Net):
                     b[key] = self.ops.zeros(*z9.shape, dtype=self.ops.H16_DTYPES[f])
                 z9 = b[key]
             self.ops.upconv_fwd_bf16(cat2, self.c9.pk, self.c9.b.value, z9, self.c9.g, act=True,
-                                     affine=self.bn10.infer_affine(), fmt=f, pool=self._scratch_pool(b))
+                                     affine=aff10, fmt=f, pool=self._scratch_pool(b))
             self.ops.conv_halo_fwd_bf16(z9, self.c11.pk, self.c11.b.value, b["out"], self.c11.g, act=False, fmt=f)
             return b["out"]
         if precision != "fp32":
@@ -599,7 +601,11 @@ class DiscriminatorNet(_Net):
         conv, pk1 = sc["conv"], sc["conv"].pk.as_1x1()
         sc["ln"].backward(v2(dsum), v2(b["sc_y"]), v2(dsum), conv.b.grad if need_wgrad else None, need_wgrad)
         if need_wgrad:
-            o.conv_wgrad(b["sc_patch"], dsum, pk1, conv.w.grad.view(1, 1, pk1.cin, pk1.cout), self._G1, accumulate=True)
+            # (the `fresh` protocol of ParamStore.zero_grad(lazy=True), as Conv.backward_weights: a slot left unfilled is
+            # stored to by its first writer — this launch is the shortcut kernel's only one)
+            acc = not conv.w.fresh
+            conv.w.fresh = False
+            o.conv_wgrad(b["sc_patch"], dsum, pk1, conv.w.grad.view(1, 1, pk1.cin, pk1.cout), self._G1, accumulate=acc)
         o.conv_dgrad(dsum, pk1, b["sc_dpatch"], self._G1)
         o.patch_scatter(b["sc_dpatch"], dx_src, sc["k"], sc["stride"], sc["pad"], accumulate=True)
 
@@ -616,6 +622,9 @@ class DiscriminatorNet(_Net):
 
     def _conv_ln_bwd(self, conv, ln, dz, y, x, dx, need_wgrad):
         if self._fused_conv_ln(conv):
+            if need_wgrad and conv.w.fresh:          # (this kernel accumulates: honour a lazily zeroed slot)
+                conv.w.grad.zero_()
+                conv.w.fresh = False
             self.ops.convln_bwd_x(dz, x, conv.w.value, conv.b.value, ln.gamma.value, LN_EPS, LRELU, dx,
                                   ln.gamma.grad if need_wgrad else None, ln.beta.grad if need_wgrad else None,
                                   conv.b.grad if need_wgrad else None, conv.w.grad if need_wgrad else None)

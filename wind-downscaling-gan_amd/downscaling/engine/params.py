@@ -45,6 +45,18 @@ class ParamStore:
         self.version = 0  # bumped whenever values change outside SN (optimizer step, load, set)
         self.flat = self.grads = self.state = None
 
+    def touch(self):
+        """Values (flat / state) were written in place by something other than set_weights / the optimizer: everything derived
+        from them and cached on `version` (packed kernel layouts, 16-bit copies, inference BatchNorm affines, captured inference
+        graphs) is stale."""
+        self.version += 1
+
+    def copy_from(self, other):
+        """This store's variables <- another store of the same graph (the trainer's twin discriminator)."""
+        self.flat.copy_(other.flat)
+        self.state.copy_(other.state)
+        self.touch()
+
     def add(self, name, shape, init, trainable=True, gap=None):
         v = Var(name, shape, trainable, init, gap)
         self.vars.append(v)

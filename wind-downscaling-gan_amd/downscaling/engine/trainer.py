@@ -89,6 +89,14 @@ class DistSync:
         # measurement switch (bench A/B only): keep the whole exchange code path (deferred Adam, SyncBN bookkeeping, metric
         # reduce) but issue no collective — separates the cost of the schedule from the cost of the RCCL calls
         self._noop = os.environ.get("WDG_DIST_NOOP", "0") == "1"
+        if self._noop:
+            if self.world_size > 1 and os.environ.get("WDG_DIST_NOOP_FORCE", "0") != "1":
+                raise RuntimeError("WDG_DIST_NOOP=1 in a multi-rank job: every all-reduce (gradients, SyncBN statistics, metrics) "
+                                   "would be skipped and the replicas would train on rank-local gradients.  It is a one-rank "
+                                   "measurement switch; unset it (or set WDG_DIST_NOOP_FORCE=1 for a timing-only run).")
+            import warnings
+            warnings.warn("WDG_DIST_NOOP=1: collectives are skipped (timing experiment only, results are not a training step)",
+                          RuntimeWarning)
 
     def all_reduce_sum_async(self, t):
         """Start the all-reduce and return a zero-argument `finish()`; the collective runs on RCCL's own stream, so
@@ -144,6 +152,16 @@ class GanEngine:
             t = self.ops.zeros(*shape)
             self._tmp[key] = t
         return t
+
+    def _const(self, key, n, value):
+        """A length-n vector holding `value` (the score gradients +-sw/B, the ones of the gradient-penalty pass): filled when
+        the value changes, not once per use — seven torch fill launches per step less."""
+        ent = self._tmp.get(("const", key))
+        if ent is None or ent[0].shape[0] != n or ent[1] != value:
+            t = ent[0] if ent is not None and ent[0].shape[0] == n else self.ops.zeros(n)
+            t.fill_(value)
+            ent = self._tmp[("const", key)] = (t, value)
+        return ent[0]
 
     def _reduce_and_step(self, net, opt):
         """Gradient all-reduce + optimizer step.  With several ranks the all-reduce is started asynchronously and the
@@ -204,9 +222,7 @@ class GanEngine:
         disc, ops, noise = self.disc, self.ops, self.noise
         ch = disc.ch
         twin = disc.twin()
-        twin.params.flat.copy_(disc.params.flat)
-        twin.params.state.copy_(disc.params.state)
-        twin.params.version += 1
+        twin.params.copy_from(disc.params)
         twin.params.zero_grad()
         twin.set_low(low)
         noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(real[..., :ch]))        # :40
@@ -229,7 +245,7 @@ class GanEngine:
         disc.params.grads.add_(twin.params.grads)
         return loss.detach(), real_scores.mean(), fake_scores.mean()
 
-    def _critic_pipelined(self, B, T, real, comb, noisy, eps, gsq, ones, dscore, sw_mean, d_opt):
+    def _critic_pipelined(self, B, T, real, comb, noisy, eps, gsq, ones, sw_mean, d_opt):
         """The critic iterations (ganbase.py:26-47) with the generator forward of iteration i + 1 on a second HIP stream under
         the three discriminator passes of iteration i.  Within a train step the generator's weights do not depend on the
         discriminator's, so the only ordering the reference imposes between them is the data: fake_i feeds the interpolate and
@@ -268,9 +284,7 @@ class GanEngine:
             disc._prepare(True)                                                   # W0 -> W1 (SN of the gradient-penalty pass)
             ds.wait_stream(main)
             with torch.cuda.stream(ds):
-                twin.params.flat.copy_(disc.params.flat)
-                twin.params.state.copy_(disc.params.state)
-                twin.params.version += 1
+                twin.params.copy_from(disc.params)
                 twin.params.zero_grad(lazy=True)
                 twin._prepare(True)                                               # W1 -> W2 (SN of the real pass)
                 w2_ready = torch.cuda.Event()
@@ -279,9 +293,7 @@ class GanEngine:
                 twin.set_high_tm(noisy, B)
                 real_mean = twin.forward(B, training=True, prepared=True).mean()                    # :41
                 real_mean.record_stream(main)                                     # (allocated on `ds`, consumed on the main stream)
-                dsc2 = self._buf("dscore2", B)
-                dsc2.fill_(-sw_mean / B)
-                twin.backward(B, dsc2, need_wgrad=True, need_input_grad=False)
+                twin.backward(B, self._const("real", B, -sw_mean / B), need_wgrad=True, need_input_grad=False)
             return w2_ready, real_mean
 
         # The real pass of iteration 0 needs neither fake_0 nor anything the generator writes: it starts BEFORE the first
@@ -320,13 +332,10 @@ class GanEngine:
                 gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()           # :37
                 disc.params.zero_grad(lazy=True)
                 main.wait_event(w2_ready)
-                disc.params.flat.copy_(twin.params.flat)                          # W2 (the twin only reads it from here on)
-                disc.params.state.copy_(twin.params.state)
-                disc.params.version += 1
+                disc.params.copy_from(twin.params)                                # W2 (the twin only reads it from here on)
                 disc.set_high_tm(nf, B)
                 fake_mean = disc.forward(B, training=True).mean()                 # :43 (prepares W3 = SN(W2))
-                dscore.fill_(sw_mean / B)
-                disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+                disc.backward(B, self._const("fake", B, sw_mean / B), need_wgrad=True, need_input_grad=False)
                 main.wait_stream(ds)
                 disc.params.settle()
                 twin.params.settle()
@@ -343,12 +352,10 @@ class GanEngine:
                 noise.normal_at(v2(noisy[..., :ch]), self.noise_std, o_r, add=v2(real[..., :ch]))   # :40
                 disc.set_high_tm(noisy, B)
                 real_mean = disc.forward(B, training=True).mean()                 # :41
-                dscore.fill_(-sw_mean / B)
-                disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+                disc.backward(B, self._const("real", B, -sw_mean / B), need_wgrad=True, need_input_grad=False)
                 disc.set_high_tm(nf, B)
                 fake_mean = disc.forward(B, training=True).mean()                 # :43
-                dscore.fill_(sw_mean / B)
-                disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+                disc.backward(B, self._const("fake", B, sw_mean / B), need_wgrad=True, need_input_grad=False)
             disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
             main.wait_stream(gs)
@@ -375,12 +382,10 @@ class GanEngine:
         gen.to_time_major(high, real)
         comb, noisy = self._buf("comb", N, S, S, chp), self._buf("noisy", N, S, S, chp)
         eps, gsq = self._buf("eps", B), self._buf("gsq", B, chp)
-        ones = self._buf("ones", B)
-        ones.fill_(1.0)
-        dscore = self._buf("dscore", B)
+        ones = self._const("ones", B, 1.0)
 
         if pipelined:
-            disc_loss, gnorm, dscale, fake = self._critic_pipelined(B, T, real, comb, noisy, eps, gsq, ones, dscore, sw_mean, d_opt)
+            disc_loss, gnorm, dscale, fake = self._critic_pipelined(B, T, real, comb, noisy, eps, gsq, ones, sw_mean, d_opt)
         for _ in range(0 if pipelined else self.n_critic):                        # ganbase.py:26
             noise.normal_into(gen.noise_view(B), self.noise_std)                   # :28
             fake = gen.forward(B, training=True, need_backward=False)             # :29 (outside any tape)
@@ -402,13 +407,11 @@ class GanEngine:
             noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(real[..., :ch]))   # :40
             disc.set_high_tm(noisy, B)
             real_mean = disc.forward(B, training=True).mean()                     # :41
-            dscore.fill_(-sw_mean / B)
-            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+            disc.backward(B, self._const("real", B, -sw_mean / B), need_wgrad=True, need_input_grad=False)
             noise.normal_into(v2(noisy[..., :ch]), self.noise_std, add=v2(fake[..., :ch]))   # :42
             disc.set_high_tm(noisy, B)
             fake_mean = disc.forward(B, training=True).mean()                     # :43
-            dscore.fill_(sw_mean / B)
-            disc.backward(B, dscore, need_wgrad=True, need_input_grad=False)
+            disc.backward(B, self._const("fake", B, sw_mean / B), need_wgrad=True, need_input_grad=False)
             disc_loss = (fake_mean - real_mean) * sw_mean + gradient_reg          # :44-45, train.py:11-12
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
         if not pipelined:
@@ -420,12 +423,15 @@ class GanEngine:
 
         disc.set_high_tm(fake, B)
         gen_disc_loss = -disc.forward(B, training=True).mean()                    # :54
-        dscore.fill_(-1.0 / B)
-        dfake = disc.backward(B, dscore, need_wgrad=False)
-        gen_loss, reco_loss = gen_disc_loss, None
+        reco_loss, dreco, n_rep = None, None, 1
         if reconstruction_loss is not None:                                       # :57-59
+            # gen_loss = gen_disc_loss + reco_loss; a non-scalar reco_loss (e.g. metrics.wind_speed_weighted_rmse: one value per
+            # sample) makes gen_loss non-scalar and tape.gradient (:60) differentiates the SUM of its elements: the adversarial
+            # term then counts once per element
             reco_loss, dreco = self._reco_grad(reconstruction_loss, low, fake, B, T)
-            gen_loss = gen_loss + reco_loss
+            n_rep = max(1, reco_loss.numel())
+        dfake = disc.backward(B, self._const("gstep", B, -float(n_rep) / B), need_wgrad=False)
+        if dreco is not None:
             ops.copy_channels(dreco, dfake[..., :ch], accumulate=True)
         if pipelined:
             # metrics recompute, :63-65: D(real) in inference mode reads neither the generator nor anything its backward
@@ -446,7 +452,8 @@ class GanEngine:
             main.wait_stream(gs)
         else:
             disc.set_high_tm(real, B)                                             # metrics recompute, :63-68
-            real_mean = disc.forward(B, training=False).mean()                    # overlaps the generator's exchange
+            real_scores = disc.forward(B, training=False).clone()                 # overlaps the generator's exchange
+            real_mean = real_scores.mean()
         self._flush(gen)
         g_gradient_param = self._grad_param_metric(gen, gscale)
         noise.normal_into(gen.noise_view(B), self.noise_std)
@@ -455,11 +462,15 @@ class GanEngine:
         fake_scores = disc.forward(B, training=False)
         fake_mean = fake_scores.mean()
         self.last_fake_tm = fake
+        if d_loss_fn is None:
+            d_loss = (fake_mean - real_mean) * sw_mean                            # :67, train.py:11-12
+        else:
+            d_loss = d_loss_fn(real_scores.view(B, 1), fake_scores.view(B, 1)) * sw_mean    # :67 compiled_loss = the custom callable
         return self._reduce_metrics({
             "g_loss": -fake_mean,
             "g_disc_loss": gen_disc_loss,
             "g_reco_loss": reco_loss,
-            "d_loss": (fake_mean - real_mean) * sw_mean,
+            "d_loss": d_loss,
             "d_gradient_pen": gnorm.mean(),
             "g_gradient_param": g_gradient_param,
             "d_gradient_param": d_gradient_param,
@@ -477,13 +488,14 @@ class GanEngine:
         gen.from_time_major(fake_tm, fake_api)
         leaf = fake_api.detach().requires_grad_(True)
         loss = reconstruction_loss(low[..., :2], leaf)
-        (gapi,) = torch.autograd.grad(loss, leaf)
+        (gapi,) = torch.autograd.grad(loss.sum(), leaf)
         gtm = self._buf("dreco", T * B, gen.S, gen.S, ch)
         gen.to_time_major(gapi, gtm)
         return loss.detach(), gtm
 
-    def test_step(self, low, high):
-        """GAN.test_step (ganbase.py:96-113): discriminator loss on real vs generated, inference mode."""
+    def test_step(self, low, high, d_loss_fn=None):
+        """GAN.test_step (ganbase.py:96-113): the discriminator's compiled loss (no sample weights, :103) on real vs
+        generated, inference mode.  Draw order as the reference: the generator noise first (:99)."""
         gen, disc = self.gen, self.disc
         B, T = low.shape[0], low.shape[1]
         S, chp = gen.S, round4(disc.ch)
@@ -491,10 +503,15 @@ class GanEngine:
         disc.set_low(low)
         real = self._buf("real", T * B, S, S, chp)
         gen.to_time_major(high, real)
-        self.noise.normal_into(gen.noise_view(B), self.noise_std)
+        self.noise.normal_into(gen.noise_view(B), self.noise_std)                 # :99
         disc.set_high_tm(real, B)
-        real_mean = disc.forward(B, training=False).mean()
-        fake = gen.forward(B, training=False)
+        real_scores = disc.forward(B, training=False).clone()                     # :100
+        fake = gen.forward(B, training=False)                                     # :101
         disc.set_high_tm(fake, B)
-        fake_mean = disc.forward(B, training=False).mean()
-        return self._reduce_metrics({"loss": fake_mean - real_mean})
+        fake_scores = disc.forward(B, training=False)                             # :102
+        self.last_fake_tm = fake
+        if d_loss_fn is None:
+            loss = fake_scores.mean() - real_scores.mean()                        # :103, train.py:11-12
+        else:
+            loss = d_loss_fn(real_scores.view(B, 1), fake_scores.view(B, 1))
+        return self._reduce_metrics({"loss": loss})

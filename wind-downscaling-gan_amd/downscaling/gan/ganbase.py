@@ -95,7 +95,7 @@ class GAN:
     def test_step(self, data):
         x, y, sample_weight = unpack_x_y_sample_weight(data)
         ops = self.generator.ops
-        res = self.engine.test_step(_to_dev(x, ops), _to_dev(y, ops))
+        res = self.engine.test_step(_to_dev(x, ops), _to_dev(y, ops), d_loss_fn=getattr(self, "_d_loss_fn", None))
         return_metrics = {'loss': res['loss']}
         for metric in self.metrics:
             return_metrics[metric.name] = metric.result()
