@@ -129,6 +129,24 @@ int wdg_conv_dgrad_bn(const wdg_conv_plan* plan, const float* dy, const float* w
                       float slope, double* stats, int stats_rep, const float* affine, void* ws, size_t ws_bytes,
                       wdg_stream stream);
 
+/* Data gradient of a convolution whose INPUT was produced by conv -> bias -> LeakyReLU -> LayerNormalization (the backward of
+ * models.py:97,105,116,125 chained to the data gradient of the layer that reads the normalised tensor: models.py:113-114,
+ * 122-123; ganbase.py:35,46,60):
+ *   dx = dgrad(dy)                                               (as wdg_conv_dgrad, no bias / activation / accumulate)
+ *   channels [c0, c0 + C) of dx are dz, the gradient w.r.t. the norm's OUTPUT; they are replaced IN PLACE by
+ *   dpre = rstd * (dz g - mean_c(dz g) - xh * mean_c(dz g xh)) * lrelu'(y),   xh = (y - mean) * rstd,
+ *   the gradient w.r.t. the producer's pre-activation (act_slope < 0: no activation derivative), and
+ *   dgamma += sum_p dz xh, dbeta += sum_p dz, dbias += sum_p dpre      (each optional).
+ * y: the norm's input [pixel][ldy_act] (C channels, own pixel / image stride), mean_rstd [pixel][2] as written by the forward.
+ * par_ws: zero-initialised scratch of wdg_conv_dgrad_lnbwd_par_floats(C) floats (needed with parameter gradients; the call
+ * leaves it zeroed).  One launch where an implicit-GEMM tile owns complete pixels — the norm's two reductions then run on the
+ * accumulators and the standalone pass over dz (read dz + y, write dpre) disappears —, wdg_conv_dgrad + wdg_ln_bwd
+ * otherwise: the results do not depend on the route. */
+int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* plan, const float* dy, const float* wD, float* dx, const float* y, int ldy_act,
+                         int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope,
+                         float* dgamma, float* dbeta, float* dbias, float* par_ws, void* ws, size_t ws_bytes, wdg_stream stream);
+int64_t wdg_conv_dgrad_lnbwd_par_floats(int C);
+
 /* conv -> bias -> LeakyReLU -> LayerNormalization in one call (the discriminator's blocks, models.py:113-116, 122-125,
  * 134-136; the shortcut branch, tf_utils.py:29-31; the encoder, autoencoder.py:27-30):
  *   y = act(conv(x) + bias)            (kept: the backward pass needs the pre-norm activation)

@@ -174,6 +174,19 @@ class TorchOps:
             out = out + dx[..., :pk.cin]
         dx[..., :pk.cin] = out
 
+    def conv_dgrad_lnbwd(self, dy, pk, dx, g, y, mean_rstd, gamma, c0, C, act_slope, dgamma, dbeta, dbias, par_ws=None):
+        """The operator interface's fused call (HipOps.conv_dgrad_lnbwd) as the composition it stands for: data gradient, then
+        the LayerNorm + LeakyReLU backward on channels [c0, c0 + C) of it, in place."""
+        self.conv_dgrad(dy, pk, dx, g)
+        grp = dx[..., c0:c0 + C]
+        d2 = grp.reshape(-1, C)
+        out = torch.empty_like(d2)
+        self.ln_bwd(d2, y[..., :C].reshape(-1, C), mean_rstd, gamma, act_slope, out, dgamma, dbeta, dbias)
+        dx[..., c0:c0 + C] = out.reshape(grp.shape)
+
+    def lnbwd_scratch(self, C):
+        return None
+
     # inference precision: operands rounded to a 16-bit format (bf16 or IEEE fp16, round-to-nearest-even), exact accumulation
     @staticmethod
     def _r16(t, fmt="bf16"):

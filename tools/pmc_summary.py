@@ -44,7 +44,9 @@ def read(dirname):
 
 
 def main():
-    dirs, out = sys.argv[1:-1], sys.argv[-1]
+    argv = [a for a in sys.argv[1:] if a != "--no-traffic"]
+    no_traffic = "--no-traffic" in sys.argv          # (operator-level runs, tools/pmc_ops.sh: leave profiles/pmc_traffic.json alone)
+    dirs, out = argv[:-1], argv[-1]
     tot, n, dur = defaultdict(dict), defaultdict(dict), {}
     for d in dirs:
         a, c, du = read(d)
@@ -64,6 +66,10 @@ def main():
             row["fetch_mb_per_launch_x2"] = 2 * per("FETCH_SIZE") * 1024 / 1e6
         if "WRITE_SIZE" in t:
             row["write_mb_per_launch"] = per("WRITE_SIZE") * 1024 / 1e6
+        if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            # fabric-side bytes (L2 misses incl. Infinity-Cache hits) over the launch duration: what the over-fetch of a
+            # gather kernel costs against the ~6.3 TB/s a streaming copy reaches
+            row["fabric_tbps"] = (row["fetch_mb_per_launch_x2"] + row["write_mb_per_launch"]) * 1e6 / max(row["avg_us_under_pmc"] * 1e-6, 1e-12) / 1e12
         if "TCC_HIT_sum" in t:
             row["l2_hit"] = t["TCC_HIT_sum"] / max(t["TCC_HIT_sum"] + t.get("TCC_MISS_sum", 0.0), 1.0)
         if "SQ_WAVE_CYCLES" in t:
@@ -83,7 +89,7 @@ def main():
         rows.append(row)
     rows.sort(key=lambda r: -r["_total_us"])
     cols = ["kernel", "launches", "avg_us_under_pmc", "fetch_kb_per_launch_raw", "fetch_mb_per_launch_x2", "write_mb_per_launch",
-            "l2_hit", "wait_any_frac", "wait_inst_frac", "active_frac", "lds_bank_conflict_frac", "mfma_busy_frac", "clock_ghz_under_pmc"]
+            "fabric_tbps", "l2_hit", "wait_any_frac", "wait_inst_frac", "active_frac", "lds_bank_conflict_frac", "mfma_busy_frac", "clock_ghz_under_pmc"]
     with open(out, "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore")
         w.writeheader()
@@ -98,7 +104,7 @@ def main():
         dom = {"launches": n,
                "fetch_mb_per_launch_x2": sum(r["fetch_mb_per_launch_x2"] * r["launches"] for r in var) / n,
                "write_mb_per_launch": sum(r["write_mb_per_launch"] * r["launches"] for r in var) / n}
-    if dom:
+    if dom and not no_traffic:
         import hashlib
         h = hashlib.sha256()
         for f in sorted((Path(__file__).resolve().parent.parent / "wind-downscaling-gan_amd" / "csrc").glob("*.h*")):

@@ -22,6 +22,13 @@
 #include "conv_plan.h"
 #include <algorithm>
 
+// Timing-only skeletons (measurement builds: -DWDG_KLOOP_EXP=<bits>, tools/build_exp.sh; the shipped library is built without it
+// and the results of such a build are WRONG by construction).  bit 0: operand loads replaced by constants; bit 1: no LDS staging
+// stores; bit 2: fragments not re-read from LDS inside the K loop (read once before it); bit 3: no barriers in the K loop.
+#ifndef WDG_KLOOP_EXP
+#define WDG_KLOOP_EXP 0
+#endif
+
 struct WdgIgemm {
     const float* A;
     const float* B;
@@ -67,6 +74,19 @@ struct WdgIgemm {
     const float* c_prev;
     float* c_out;
     float* h_out;
+    // LayerNormalization BACKWARD on the data gradient being written (EPI 5; models.py:97,105,116,125 differentiated): the output
+    // columns [lnb_c0, lnb_c0 + lnb_C) are the gradient dz w.r.t. the OUTPUT of a LayerNormalization whose input was y = LeakyReLU(conv
+    // + bias).  The epilogue holds dz for all channels of a pixel, so it writes dpre = rstd * (dz g - mean_c(dz g) - xh mean_c(dz g xh))
+    // * lrelu'(y) in their place (what the standalone wdg_ln_bwd pass produced from a re-read of dz) and, when lnb_par is given,
+    // accumulates the block's share of dgamma = sum dz xh, dbeta = sum dz, dbias = sum dpre into one of lnb_rep replica slabs
+    // [3][lnb_C] (float atomics; wdg_ln_param_finish_kernel sums the replicas into the gradient vectors and clears them).
+    const float* lnb_y;
+    const float* lnb_stats;
+    const float* lnb_gamma;
+    float* lnb_par;
+    long long lnb_imgStride;
+    int lnb_ldy, lnb_c0, lnb_C, lnb_rep;
+    float lnb_slope;
     WdgPhase ph[9];
 };
 
@@ -213,6 +233,14 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
     int4 e_cur = nk > 0 ? tab[0] : (int4){0, 0, 0, -1};
     auto load_tile = [&](int kt) {
         const int4 e = e_cur;
+        if constexpr (WDG_KLOOP_EXP & 1) {
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) ra[i] = (f32x4){(float)(e.x + i), 1.f, (float)kt, 2.f};
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) rb[i] = (f32x4){(float)(e.w + i), 1.f, (float)kt, 2.f};
+            e_cur = tab[(kt + 1 < nk ? kt + 1 : kt) * 8];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int ih = a_ih0[i] + e.y, iw = a_iw0[i] + e.z;
@@ -228,6 +256,10 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
     };
 
     auto store_tile = [&](f32x4* ldsA, f32x4* ldsB) {
+        if constexpr (WDG_KLOOP_EXP & 2) {
+            asm volatile("" :: "v"(ra[0][0]), "v"(rb[0][0]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int row = lrow + 32 * i;
@@ -418,6 +450,20 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
             store_tile(ldsA, ldsB);
         }
         __syncthreads();
+        if constexpr ((WDG_KLOOP_EXP & 4) != 0) {
+            f32x4 af[MT], bf[NT];
+            read_frags(ldsA, ldsB, 0, af, bf);
+            for (int kt = 0; kt < nk; ++kt) {
+                load_tile(kt + 1 < nk ? kt + 1 : kt);
+                mfma_block(af, bf);
+                if constexpr (!(WDG_KLOOP_EXP & 8)) __syncthreads();
+                mfma_block(af, bf);
+                store_tile(ldsA, ldsB);
+                if constexpr (!(WDG_KLOOP_EXP & 8)) __syncthreads();
+#pragma unroll
+                for (int a = 0; a < MT; ++a) asm volatile("" : "+v"(af[a]));
+            }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             load_tile(kt + 1 < nk ? kt + 1 : kt);   // unconditional (the last one is redundant)
             {
@@ -428,11 +474,11 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
             {
                 f32x4 af[MT], bf[NT];
                 read_frags(ldsA, ldsB, 1, af, bf);
-                __syncthreads();   // every wave has read this tile: the stage may be overwritten
+                if constexpr (!(WDG_KLOOP_EXP & 8)) __syncthreads();   // every wave has read this tile: the stage may be overwritten
                 mfma_block(af, bf);
             }
             store_tile(ldsA, ldsB);
-            __syncthreads();
+            if constexpr (!(WDG_KLOOP_EXP & 8)) __syncthreads();
         }
     } else {
         // double-buffered LDS: the next tile is written into the other stage right after this wave's own
@@ -654,6 +700,120 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
         }
         return;
     }
+    if constexpr (EPI == 5) {
+        // One wave owns complete rows (WGN == 1: checked at instantiation), a pixel's channels sit in the four lane >> 4 groups
+        // of that wave: both reductions of the LayerNorm backward are in-lane sums + two xor-shuffles.  No bias / activation /
+        // accumulate / split-K on this route (the host falls back to the two-launch form otherwise).
+        static_assert(WGN == 1, "EPI 5: a row's channels in one wave");
+        const int c0 = p.lnb_c0, C = p.lnb_C;
+        const float invC = 1.f / (float)C;
+        const int HoWo = p.Ho * p.Wo;
+        // this lane's share of the parameter gradients, per column tile of the group (summed over its MT pixels)
+        f32x4 pg[NT], pb[NT], pd[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) pg[b] = pb[b] = pd[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 gm[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + b * 16 + q4;
+            const bool in = n >= c0 && n < c0 + C;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gm[b][r] = in ? p.lnb_gamma[n - c0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
+            const bool rv = wdg_row_valid<BM>(ph, Mph, m);
+            int img = 0, pa = 0, pb_ = 0;
+            if (rv) wdg_row_to_pixel<BM>(ph, PaPb, m, img, pa, pb_);
+            const int oh = pa * p.o_mul + ph.o_off_h;
+            const int ow = pb_ * p.o_mul + ph.o_off_w;
+            const long long pix = (long long)oh * p.Wo + ow;
+            const long long off = (long long)img * p.imgStrideO + pix * p.ldO;
+            const float* yrow = p.lnb_y + (long long)img * p.lnb_imgStride + pix * p.lnb_ldy;
+            const float* st = p.lnb_stats + 2 * ((long long)img * HoWo + pix);
+            // every load of the pixel first (one memory round trip), then the arithmetic
+            float mean = 0.f, rstd = 0.f;
+            f32x4 yv[NT];
+            if (rv) {
+                mean = st[0];
+                rstd = st[1];
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + b * 16 + q4;
+                yv[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rv && n >= c0 && n < c0 + C) yv[b] = *reinterpret_cast<const f32x4*>(yrow + (n - c0));
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (yv[b][r] - mean) * rstd;
+                    const float gg = acc[a][b][r] * gm[b][r];       // (gm = 0 outside the group)
+                    s1 += gg;
+                    s2 += gg * xh;
+                }
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            s1 *= invC;
+            s2 *= invC;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int n = n0 + b * 16 + q4;
+                if (n >= NcP) continue;
+                f32x4 v = acc[a][b];
+                if (n >= c0 && n < c0 + C) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (yv[b][r] - mean) * rstd;
+                        float d = rstd * (v[r] * gm[b][r] - s1 - xh * s2);
+                        if (p.lnb_slope >= 0.f) d *= (yv[b][r] > 0.f ? 1.f : p.lnb_slope);
+                        if (rv) {
+                            pg[b][r] = fmaf(v[r], xh, pg[b][r]);
+                            pb[b][r] += v[r];
+                            pd[b][r] += d;
+                        }
+                        v[r] = d;
+                    }
+                }
+                if (rv) *reinterpret_cast<f32x4*>(p.Out + off + n) = v;
+            }
+        }
+        if (!p.lnb_par) return;
+        // parameter gradients: the 16 pixels of a lane group by DPP row sums, the WGM row-waves through LDS (the K loop's stage is
+        // free behind its last barrier), one atomic per (block, channel, quantity) into a replica slab
+        float* red = reinterpret_cast<float*>(lds_all);                    // [WGM][3][BN]
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v0 = wdg_row16_sum(pg[b][r]), v1 = wdg_row16_sum(pb[b][r]), v2 = wdg_row16_sum(pd[b][r]);
+                if ((lane & 15) == 0) {
+                    const int col = b * 16 + q4 + r;
+                    red[(wm * 3 + 0) * BN + col] = v0;
+                    red[(wm * 3 + 1) * BN + col] = v1;
+                    red[(wm * 3 + 2) * BN + col] = v2;
+                }
+            }
+        }
+        __syncthreads();
+        float* slab = p.lnb_par + (size_t)(blockIdx.x % (unsigned)p.lnb_rep) * 3 * C;
+        for (int idx = t; idx < 3 * BN; idx += 256) {
+            const int which = idx / BN, col = idx - which * BN;
+            const int n = n0 + col;
+            if (n < c0 || n >= c0 + C) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) v += red[(w * 3 + which) * BN + col];
+            atomicAdd(slab + which * C + (n - c0), v);
+        }
+        return;
+    }
     // Column tile outermost, the MT pixels of a lane innermost: the per-pixel output offsets are formed once (MT values), the
     // bias / affine vectors of a column tile are loaded once, and the BatchNorm statistics need 8 accumulator registers at a
     // time instead of 8 * NT — with all NT tiles' sums live the EPI 1 variant of the 128 x 128 tile took 188 registers (two
@@ -760,6 +920,21 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
             }
         }
     }
+}
+
+// Replica slabs [rep][3][C] of the LayerNorm-backward epilogue (EPI 5) -> dgamma / dbeta / dbias (accumulated; any may be NULL),
+// and the slabs cleared for the next launch.  One thread per (quantity, channel), replicas summed in order.
+__global__ void __launch_bounds__(256) wdg_ln_param_finish_kernel(float* par, int rep, int C, float* dgamma, float* dbeta, float* dbias) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * C) return;
+    const int which = idx / C, c = idx - which * C;
+    float v = 0.f;
+    for (int r = 0; r < rep; ++r) {
+        v += par[(size_t)r * 3 * C + idx];
+        par[(size_t)r * 3 * C + idx] = 0.f;
+    }
+    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dbias;
+    if (dst) dst[c] += v;
 }
 
 // split-K second stage: sum the slabs, apply the epilogue, scatter to the output view.
@@ -981,6 +1156,11 @@ __global__ void __launch_bounds__(256, WDG_WGRAD_LB) wdg_wgrad_kernel(const WdgW
             const bool okx = in && a_row_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
             const int offx = (int)im * (int)p.imgStrideX + (ih0 * p.W + iw0) * p.ldx + e.x;
             const int offy = (int)im * (int)p.imgStrideY + (int)rem * p.ldy + nb;
+            if constexpr (WDG_KLOOP_EXP & 1) {
+                ra[i] = (f32x4){(float)offx, 1.f, (float)okx, 2.f};
+                rb[i] = (f32x4){(float)offy, 1.f, (float)in, 2.f};
+                continue;
+            }
             ra[i] = wdg_buffer_load_f32x4(srdX, okx ? (unsigned)offx << 2 : WDG_SRD_OOB);
             rb[i] = wdg_buffer_load_f32x4(srdY, (in && b_col_ok) ? (unsigned)offy << 2 : WDG_SRD_OOB);
         }
@@ -994,10 +1174,14 @@ __global__ void __launch_bounds__(256, WDG_WGRAD_LB) wdg_wgrad_kernel(const WdgW
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = ps + 8 * i;
+            if constexpr (WDG_KLOOP_EXP & 2) {
+                asm volatile("" :: "v"(ra[i][0]), "v"(rb[i][0]));
+                continue;
+            }
             *reinterpret_cast<f32x4*>(&ldsA[px * RSA + 4 * g4]) = ra[i];
             if (BN >= 128 || 4 * g4 < BN) *reinterpret_cast<f32x4*>(&ldsB[px * RSB + 4 * g4]) = rb[i];
         }
-        __syncthreads();
+        if constexpr (!(WDG_KLOOP_EXP & 8)) __syncthreads();
         load_tile(kt + 1);   // unconditional (past the end every lane is out of range -> no memory traffic): keeps the
                              // address arithmetic and the loads in the MFMA basic block, where they interleave
         WdgFrag<MT> af[2];
@@ -1007,8 +1191,14 @@ __global__ void __launch_bounds__(256, WDG_WGRAD_LB) wdg_wgrad_kernel(const WdgW
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             if (s + 1 < 8) {
+                if constexpr (WDG_KLOOP_EXP & 4) {
+                    af[(s + 1) & 1] = af[s & 1];
+                    bf[(s + 1) & 1] = bf[s & 1];
+                    asm volatile("" : "+v"(af[(s + 1) & 1].v[0]), "+v"(bf[(s + 1) & 1].v[0]));
+                } else {
                 af[(s + 1) & 1] = wdg_lds_frag<MT>(fragA + 4 * (s + 1) * RSA);
                 bf[(s + 1) & 1] = wdg_lds_frag<NT>(fragB + 4 * (s + 1) * RSB);
+                }
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -1016,7 +1206,7 @@ __global__ void __launch_bounds__(256, WDG_WGRAD_LB) wdg_wgrad_kernel(const WdgW
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1].v[a], bf[s & 1].v[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();
+        if constexpr (!(WDG_KLOOP_EXP & 8)) __syncthreads();
     }
 
     // ---- epilogue.  Accumulator (a, reg r) of lane (i = lane & 15, q = lane >> 4) is logical row 4q + r of
@@ -1156,7 +1346,12 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
         if (wdg_round_up(ncols, c.BN) * 100 <= best * 113) return c;
     return cand[3];
 }
-static int g_wgrad_xcd = 0;      // wdg_set_tuning("wgrad_xcd", n): XCD-contiguous order for weight gradients with 2..n tiles per pixel split (0 = off)
+// wdg_set_tuning("wgrad_xcd", n): XCD-contiguous order for weight gradients with 2..n tiles per pixel split (0 = off).  Round 5: ON — the
+// row / column tiles of one pixel split then run back to back on ONE XCD and share its L2 copy of the x / dy window: fabric fetch of
+// the 7x7 stride-3 32 -> 64 weight gradient 1,726 -> 438 MB per launch, L2 hit 0.16 -> 0.78 (profiles/r05b_*: time in isolation
+// unchanged, 464 vs 467 us — the kernel is not bound by its fetch —, but 1.3 GB less fabric traffic per launch for whatever runs beside it)
+static int g_wgrad_xcd = 16;
+static int g_tap_class_order = 1;   // wdg_set_tuning("tap_class_order", 0/1): forward tables of strided layers in residue-class order (plans created afterwards)
 static int g_wgrad_bn160 = 32;   // wdg_set_tuning("wgrad_bn160", 32 | 64 | 128): column tile of 160-column weight gradients
 static int pick_wgrad_bn(int ncols) {
     if (ncols == 160 && g_wgrad_bn160 != 32) return g_wgrad_bn160;
@@ -1220,8 +1415,21 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     // ---- forward table
     std::vector<int4> tf;
     std::vector<int2> wr;
-    for (int th = 0; th < g->kh; ++th)
-        for (int tw = 0; tw < g->kw; ++tw)
+    // Tap order.  With stride s > 1 the taps fall into s * s residue classes (th mod s, tw mod s): the taps of one class read
+    // the SAME residue grid of input pixels, shifted by whole output pixels, while taps of different classes share no input
+    // pixel at all.  In row-major tap order a class comes back every s-th tap / tap row — for the 7 x 7 stride-3 layer a tile's
+    // input line is re-read after ~21 K-steps, by which time the CU's other workgroups have pushed it out of L1 and L2 (fabric
+    // fetch 4.3 x the input).  Class-major order makes the re-reads consecutive K-steps.  (The table carries the weight offset
+    // of every entry, so the reduction order is free; the weight-gradient rows follow the same order through `wrow`.)
+    std::vector<std::pair<int, int>> tap_order;
+    const int cls = g_tap_class_order ? g->stride : 1;
+    for (int a = 0; a < cls; ++a)
+        for (int b = 0; b < cls; ++b)
+            for (int th = a; th < g->kh; th += cls)
+                for (int tw = b; tw < g->kw; tw += cls) tap_order.push_back(std::make_pair(th, tw));
+    for (auto& tt : tap_order) {
+        const int th = tt.first, tw = tt.second;
+        {
             for (int c4 = 0; c4 < pl->Cin_p / 4; ++c4) {
                 const int tap = th * g->kw + tw;
                 int4 e;
@@ -1235,6 +1443,8 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
                 r.y = std::min(4, g->Cin - 4 * c4);
                 wr.push_back(r);
             }
+        }
+    }
     while (tf.size() % 8) {
         tf.push_back((int4){0, -(1 << 28), -(1 << 28), -1});
         wr.push_back((int2){0, 0});
@@ -1363,6 +1573,7 @@ static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase:
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
+static int g_dgrad_lnbwd = 1;      // wdg_set_tuning("dgrad_lnbwd", 0/1): LayerNorm backward in the data gradient's epilogue (wdg_conv_dgrad_lnbwd)
 static int g_ln_wave = 1;     // wdg_set_tuning("ln_wave", 0/1): the 128 x 64 tile's LayerNorm epilogue on 4 x 1 waves (in-wave reductions)
 static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
 static int g_tuning_epoch = 0;
@@ -1441,6 +1652,14 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "wgrad_xcd")) {
         g_wgrad_xcd = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "dgrad_lnbwd")) {
+        g_dgrad_lnbwd = value != 0;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "tap_class_order")) {
+        g_tap_class_order = value != 0;
         return WDG_OK;
     }
     if (key && !strcmp(key, "wgrad_bn160")) {
@@ -1547,6 +1766,7 @@ static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm&
     static_assert(KG == 1 || lds >= (size_t)BM * BN * sizeof(float), "the second group's accumulators fit the two stages");
     static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
     static_assert(EPI != 3 || lds >= (size_t)BM * 4 * WGN * sizeof(float), "LayerNorm scratch fits the K-loop stage");
+    static_assert(EPI != 5 || lds >= (size_t)WGM * 3 * BN * sizeof(float), "LayerNorm-backward scratch fits the K-loop stage");
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 48 * 1024)
@@ -1570,6 +1790,9 @@ static void set_b3(WdgIgemm& p, int k_per_tap) {
     p.B3 = it->second.first;
     p.B3_slice = it->second.second;
 }
+
+// tiles whose EPI 5 instantiation exists (4 x 1 waves: a row's channels in one wave)
+static bool lnb_tile_ok(const TileCfg& tc) { return (tc.BM == 256 && tc.BN <= 32) || (tc.BM == 128 && tc.BN == 64); }
 
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
                         hipStream_t st, bool* bn_fused = nullptr) {
@@ -1639,7 +1862,11 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     // fused BatchNorm hooks: only without split-K (the reduce kernel owns the epilogue then; callers fall back to the
     // standalone passes — see conv_fused_bn) and only on the default pipeline
     const bool ln_ok = p.ln_gamma && split == 1 && tiles_n == 1 && nphase == 1 && (p.Ncols & 3) == 0;
-    const int epi = p.lstm_F ? 4 : (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
+    const int epi = p.lnb_y ? 5 : p.lstm_F ? 4 : (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
+    if (epi == 5 && !(split == 1 && tiles_n == 1 && pipe == 3 && !p.accumulate && !p.bias && !p.act && lnb_tile_ok(tc))) {
+        wdg_set_error("igemm: the LayerNorm-backward epilogue needs one column tile of a 4 x 1 wave layout, no split-K, the fp32 pipeline");
+        return WDG_ERR_ARG;
+    }
     if (epi == 4 && (split != 1 || nphase != 1 || pipe == 4)) {
         wdg_set_error("igemm: the ConvLSTM step epilogue needs one phase, no split-K and the fp32 pipeline");
         return WDG_ERR_ARG;
@@ -1658,6 +1885,11 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
                     else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p);             \
                 } else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p);               \
             } else rc = WDG_ERR_ARG;                                                                    \
+        }                                                                                               \
+        else if (epi == 5) {                                                                            \
+            if constexpr ((BM_ == 256 && BN_ <= 32) || (BM_ == 128 && BN_ == 64))                       \
+                rc = launch_variant<BM_, BN_, 4, 1, 3, 5>(grid, block, st, p);                          \
+            else rc = WDG_ERR_ARG;                                                                      \
         }                                                                                               \
         else if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);           \
         else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \
@@ -1902,6 +2134,66 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
                               wdg_stream stream) {
     return conv_dgrad_impl(pl, dy, wD, bias, dx, act, slope, accumulate, nullptr, ws, ws_bytes, stream);
 }
+
+#define WDG_LNB_REP 64
+
+// Data gradient of a convolution whose INPUT tensor (channels [c0, c0 + C) of it) was produced by conv -> bias -> LeakyReLU -> LayerNormalization:
+// dx = dgrad(dy), then the LayerNorm + LeakyReLU backward applied to those channels of dx IN PLACE (dx[..., c0:c0+C] becomes the gradient
+// w.r.t. the producer's pre-activation), with dgamma / dbeta / dbias accumulated when given.  One launch where an implicit-GEMM tile owns
+// complete pixels (the norm's two reductions run on the accumulators), dgrad + wdg_ln_bwd otherwise: the results do not depend on the route.
+extern "C" int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* pl, const float* dy, const float* wD, float* dx, const float* y, int ldy_act,
+                                    int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope,
+                                    float* dgamma, float* dbeta, float* dbias, float* par_ws, void* ws, size_t ws_bytes, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && dy && wD && dx && y && mean_rstd && gamma, "null argument");
+    const wdg_conv_geom& g = pl->g;
+    WDG_CHECK_ARG(c0 >= 0 && C > 0 && c0 % 4 == 0 && C % 4 == 0 && c0 + C <= g.Cin, "bad channel group");
+    WDG_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ldy_act % 4 == 0 && ldy_act >= C, "y / gamma alignment");
+    const bool want_par = dgamma || dbeta || dbias;
+    bool fuse = g_dgrad_lnbwd && !(pl->halo_auto_dgrad && pl->halo_dgrad_nt) && g_igemm_pipe == 3 && pl->dgrad_split == 1 && (!want_par || par_ws);
+    if (fuse) {
+        long long Mmax = 0;
+        for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g.n_img * ph.Pa * ph.Pb);
+        const TileCfg tc = pick_tile(g.Cin, true, Mmax);
+        fuse = lnb_tile_ok(tc) && g.Cin <= tc.BN;
+    }
+    if (!fuse) {
+        int rc = conv_dgrad_impl(pl, dy, wD, nullptr, dx, 0, 0.f, 0, nullptr, ws, ws_bytes, stream);
+        if (rc != WDG_OK) return rc;
+        if (g.img_stride_x != (int64_t)g.H * g.W * g.ldx || img_stride_act != (int64_t)g.H * g.W * ldy_act) {
+            wdg_set_error("wdg_conv_dgrad_lnbwd: the unfused path needs contiguous images");
+            return WDG_ERR_ARG;
+        }
+        return wdg_ln_bwd(dx + c0, g.ldx, y, ldy_act, mean_rstd, gamma, act_slope, dx + c0, g.ldx, dgamma, dbeta, dbias,
+                          (int64_t)g.n_img * g.H * g.W, C, stream);
+    }
+    WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0 && ((uintptr_t)dx & 15) == 0, "dy / wD / dx must be 16-byte aligned");
+    WdgIgemm p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.B = wD; p.Out = dx; p.ktab = pl->d_tab_dgrad;
+    p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
+    p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
+    p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
+    p.Ncols = g.Cin; p.ldB = pl->Cout_p;
+    p.a_mul = 1; p.o_mul = g.stride;
+    p.lnb_y = y; p.lnb_ldy = ldy_act; p.lnb_imgStride = img_stride_act; p.lnb_stats = mean_rstd; p.lnb_gamma = gamma;
+    p.lnb_c0 = c0; p.lnb_C = C; p.lnb_slope = act_slope; p.lnb_par = want_par ? par_ws : nullptr; p.lnb_rep = WDG_LNB_REP;
+    int Mmax = 0;
+    const int np = (int)pl->ph_dgrad.size();
+    for (int i = 0; i < np; ++i) {
+        p.ph[i] = pl->ph_dgrad[i];
+        Mmax = std::max(Mmax, g.n_img * p.ph[i].Pa * p.ph[i].Pb);
+    }
+    p.Mmax = Mmax;
+    const int rc = launch_igemm(p, np, pl->K4_dgrad_max, 1, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != WDG_OK || !want_par) return rc;
+    hipLaunchKernelGGL(wdg_ln_param_finish_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, par_ws, WDG_LNB_REP, C,
+                       dgamma, dbeta, dbias);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// floats of the zero-initialised scratch `par_ws` of wdg_conv_dgrad_lnbwd for a group of C channels (the call leaves it zeroed)
+extern "C" int64_t wdg_conv_dgrad_lnbwd_par_floats(int C) { return (int64_t)WDG_LNB_REP * 3 * C; }
 
 static int bn_hook_make(WdgBnHook& h, double* stats, int stats_rep, const float* affine, int C) {
     WDG_CHECK_ARG((stats != nullptr) != (affine != nullptr), "exactly one of stats / affine");

@@ -524,6 +524,22 @@ class HipOps:
                                              int(act), slope, int(accumulate), ws.data_ptr(), ws.numel(),
                                              self.stream), "conv_dgrad")
 
+    def conv_dgrad_lnbwd(self, dy, pk, dx, g, y, mean_rstd, gamma, c0, C, act_slope, dgamma, dbeta, dbias, par_ws=None):
+        """dx = conv_transpose(dy, W), then the LayerNorm + LeakyReLU backward of the layer that PRODUCED channels [c0, c0 + C) of
+        this convolution's input, applied to those channels of dx in place (dx[..., c0:c0+C] becomes the gradient w.r.t. that
+        producer's pre-activation) — wdg_conv_dgrad_lnbwd: in the data gradient's epilogue where a tile owns complete pixels
+        (the standalone wdg_ln_bwd pass over dz disappears), conv_dgrad + ln_bwd otherwise.  y [N,H,W,C]: the norm's input;
+        par_ws: zeroed scratch from lnbwd_scratch(C), needed with parameter gradients (one per concurrent caller)."""
+        plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
+        ws = self._workspace(wsb)
+        py, ldy, isy = _v4(y)
+        native.check(self.lib.wdg_conv_dgrad_lnbwd(plan, dy.data_ptr(), pk.wD.data_ptr(), dx.data_ptr(), py, ldy, isy, mean_rstd.data_ptr(),
+                                                   gamma.data_ptr(), int(c0), int(C), float(act_slope), _ptr(dgamma), _ptr(dbeta), _ptr(dbias),
+                                                   _ptr(par_ws), ws.data_ptr(), ws.numel(), self.stream), "conv_dgrad_lnbwd")
+
+    def lnbwd_scratch(self, C):
+        return self.zeros(int(self.lib.wdg_conv_dgrad_lnbwd_par_floats(int(C))))
+
     def _is16(self, t, fmt):
         if t.dtype in (torch.bfloat16, torch.float16):
             if t.dtype != self.H16_DTYPES[fmt]:

@@ -94,6 +94,19 @@ class Conv:
         else:
             self.ops.conv_dgrad(dpre, self.pk, dx, self.g, accumulate=accumulate)
 
+    def backward_input_through_ln(self, dpre, dx, ln, y, c0, dbias, need_param_grads, act_slope=LRELU):
+        """backward_input, chained with the backward of the LayerNormalization `ln` (+ LeakyReLU) that produced channels
+        [c0, c0 + ln.C) of this layer's input from the pre-norm activation `y`: those channels of dx leave the call as the
+        gradient w.r.t. the producer's pre-activation (what ln.backward would make of them in a pass of its own), and the
+        norm's / the producer's bias gradients are accumulated — HipOps.conv_dgrad_lnbwd."""
+        assert not self.transposed
+        if need_param_grads:
+            self.ops.conv_dgrad_lnbwd(dpre, self.pk, dx, self.g, y, ln.mean_rstd, ln.gamma.value, c0, ln.C, act_slope,
+                                      ln.gamma.grad, ln.beta.grad, dbias, ln.lnbwd_scratch())
+        else:
+            self.ops.conv_dgrad_lnbwd(dpre, self.pk, dx, self.g, y, ln.mean_rstd, ln.gamma.value, c0, ln.C, act_slope,
+                                      None, None, None, None)
+
 
 class Dense:
     """keras.layers.Dense (linear) under TimeDistributed: rows = images, run as a 1x1 convolution on an [N,1,1,K] view
@@ -218,6 +231,13 @@ class LayerNorm:
     def ensure_stats(self, P):
         if self.mean_rstd is None or self.mean_rstd.shape[0] != P:
             self.mean_rstd = self.ops.empty(P, 2)
+
+    def lnbwd_scratch(self):
+        """Zeroed replica slabs for the parameter gradients of the fused data-gradient + LayerNorm-backward launch (owned by the
+        layer: the twin discriminator runs its passes on another stream at the same time)."""
+        if getattr(self, "_lnb_ws", None) is None:
+            self._lnb_ws = self.ops.lnbwd_scratch(self.C)
+        return self._lnb_ws
 
     def forward(self, y, z, keep_stats=True):
         self.ensure_stats(y.shape[0])

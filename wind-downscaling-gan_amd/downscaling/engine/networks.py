@@ -455,6 +455,7 @@ class DiscriminatorNet(_Net):
         # writes back / invalidates the per-XCD L2s under the other's running kernel); 91.6 -> 88.4 ms per T = 24 step without it
         # Round 4: OFF by default at every T — beside the generator / twin streams the branch overlap loses (68.9 vs 67.2 ms at eight
         # hardware queues, neutral at four: profiles/r04f_sched.txt)
+        self.chain_ln_bwd = os.environ.get("WDG_CHAIN_LN_BWD", "1") != "0"       # (A/B switch: LayerNorm backward in the upstream data gradient's epilogue)
         mode = os.environ.get("WDG_OVERLAP_BRANCHES", "0")
         self.overlap_branches = mode != "0"
         self.overlap_branches_t1 = mode in ("1", "2")
@@ -620,7 +621,13 @@ class DiscriminatorNet(_Net):
         else:
             conv.forward_ln(x, y, z, ln)     # (z: a channel slice of the concatenation — wdg_conv_fwd_ln_strided)
 
-    def _conv_ln_bwd(self, conv, ln, dz, y, x, dx, need_wgrad):
+    def _conv_ln_bwd(self, conv, ln, dz, y, x, dx, need_wgrad, ln_done=False):
+        """ln_done: dz has been through the norm's backward already (in the epilogue of the launch that produced it)."""
+        if ln_done:
+            if need_wgrad:
+                self._wgrad(lambda: conv.backward_weights(x, dz), self._bwd_joins)
+            conv.backward_input(dz, dx)
+            return
         if self._fused_conv_ln(conv):
             if need_wgrad and conv.w.fresh:          # (this kernel accumulates: honour a lazily zeroed slot)
                 conv.w.grad.zero_()
@@ -651,18 +658,39 @@ class DiscriminatorNet(_Net):
         o.dense_gap_bwd(x.view(N, self.K), self.dense_w.value.view(-1), dscore, dx.view(N, self.K),
                         self.dense_w.grad.view(-1) if need_wgrad else None,
                         self.dense_b.grad if need_wgrad else None, B, T)
+        # The LayerNormalization backward of a block runs in the epilogue of the data gradient that PRODUCES its dz — the
+        # data gradient of the block above it (Conv.backward_input_through_ln: the epilogue holds dz for all channels of a
+        # pixel, so the norm's two reductions run on the accumulators and the standalone pass over dz disappears) — wherever
+        # nothing else adds to that dz afterwards (the shortcut's share arrives by a later accumulate).  ln_done: the dz this
+        # iteration starts from has been through its norm's backward already.
+        chain = self.chain_ln_bwd and hasattr(o, "conv_dgrad_lnbwd")
+        ln_done = False
+        b_chained = False
         for i in range(len(self.blocks) - 1, -1, -1):
             conv, ln, osz, co = self.blocks[i]
             dz = b["dzs"][i]
             split = self.shortcut is not None and i == self.shortcut["block"]
             if split:
+                assert not ln_done
                 o.copy_channels(dz, b["sc_dz"])                                   # the sum's gradient feeds both branches
-            ln.backward(v2(dz), v2(b["ys"][i]), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
+            if not ln_done:
+                ln.backward(v2(dz), v2(b["ys"][i]), v2(dz), conv.b.grad if need_wgrad else None, need_wgrad)
             xin = b["zs"][i - 1] if i > 0 else b["cat"]
             dxin = b["dzs"][i - 1] if i > 0 else b["dcat"]
             if need_wgrad:
                 self._wgrad(lambda conv=conv, xin=xin, dz=dz: conv.backward_weights(xin, dz), joins)
-            conv.backward_input(dz, dxin)
+            below_split = self.shortcut is not None and i - 1 == self.shortcut["block"]    # (its dz is copied for the shortcut first)
+            ln_done = False
+            if chain and not split and not below_split and i > 0:
+                pconv, pln = self.blocks[i - 1][0], self.blocks[i - 1][1]
+                conv.backward_input_through_ln(dz, dxin, pln, b["ys"][i - 1], 0, pconv.b.grad if need_wgrad else None, need_wgrad)
+                ln_done = True
+            elif chain and not split and i == 0 and not self._fused_conv_ln(self.conv_b):
+                # dcat = [dz of ln_a | dz of ln_b]: the low + high branch's norm (models.py:105) in this launch's epilogue
+                conv.backward_input_through_ln(dz, dxin, self.ln_b, b["yb"], Fd, self.conv_b.b.grad if need_wgrad else None, need_wgrad)
+                b_chained = True
+            else:
+                conv.backward_input(dz, dxin)
             if split:
                 self._shortcut_bwd(b, b["sc_dz"], xin, dxin, need_wgrad)
         def branch_a():   # high-res only
@@ -670,7 +698,7 @@ class DiscriminatorNet(_Net):
             self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None, B, T, need_wgrad)
 
         def branch_b():   # low + high
-            self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad)
+            self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad, ln_done=b_chained)
             self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
 
         if getattr(self, "_overlap_now", False):
