@@ -7,7 +7,11 @@ cd "$(dirname "$0")/../wind-downscaling-gan_amd/csrc"
 OUT=../../gpurun_variants; mkdir -p $OUT
 OBJS=$(ls *.o | grep -v '^conv_igemm.o$')
 for BITS in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DWDG_KLOOP_EXP=$BITS -c conv_igemm.hip -o /tmp/igemm_exp$BITS.o
+  case "$BITS" in
+    early) FLAGS="-DWDG_EARLY_LOADS=1";;     # operand requests pinned in front of the MFMAs on the narrow tiles
+    *) FLAGS="-DWDG_KLOOP_EXP=$BITS";;
+  esac
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $FLAGS -c conv_igemm.hip -o /tmp/igemm_exp$BITS.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libwdgan_exp$BITS.so $OBJS /tmp/igemm_exp$BITS.o
   echo "exp$BITS built"
 done

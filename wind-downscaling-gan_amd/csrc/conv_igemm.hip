@@ -131,9 +131,16 @@ __device__ __forceinline__ bool wdg_row_valid(const WdgPhase& ph, int Mph, int m
 // For launches with fewer tiles than CUs and a deep reduction whose epilogue needs the complete sums (the generator's recurrent
 // step at batch 8: 144 tiles of 128 x 128, K = 1152): twice the waves on the tile's MFMAs, no workspace, no second kernel.
 // (256 x 32 tile, default loop: 132 registers sat four above the four-waves-per-SIMD line — the bound makes the compiler fit 128)
+// measurement builds: -DWDG_EARLY_LOADS=1 pins the next tile's operand requests in front of the K-step's MFMAs on the narrow tiles
+// (BN <= 64) and relaxes the 256 x 32 tile's four-waves-per-SIMD bound (the requests' 24-40 destination registers are then live
+// across the MFMA phase)
+#ifndef WDG_EARLY_LOADS
+#define WDG_EARLY_LOADS 0
+#endif
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
-__global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 && KG == 1) ? 4 : 1) wdg_igemm_kernel(const WdgIgemm p) {
+__global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 && KG == 1 && !WDG_EARLY_LOADS) ? 4 : 1) wdg_igemm_kernel(const WdgIgemm p) {
     static_assert(KG == 1 || (KG == 2 && PIPE == 3 && (EPI == 0 || EPI == 4)), "in-workgroup split: rotated loop, barrier-free epilogues");
+    static_assert(PIPE != 5 || (BN % 16 == 0 && BM % 32 == 0), "LDS-DMA pieces are 8 whole rows");
     constexpr int MT = BM / WGM / 16;
     constexpr int NT = BN / WGN / 16;
     constexpr int A_LOADS = BM / 32;
@@ -423,6 +430,73 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
             store_split();
             __syncthreads();
         }
+    } else if (PIPE == 5) {
+        // ---- operands travel global -> LDS directly (LDS-DMA: buffer_load_dwordx4 ... lds), two LDS stages, ONE barrier per K-step.
+        // No staging registers (the rotated loop keeps 24-40 of them live between the request and the ds_write, which is why the
+        // compiler sinks the requests behind the K-step's MFMAs), no ds_write instructions, and the requests of tile k + 1 are issued
+        // at the top of step k: a whole MFMA phase ahead of the barrier that publishes them.
+        // The DMA's LDS destination is lane-linear (wave base + 16 * lane), so the stage is pixel-major, slot(row, pos) = 8 * row + pos,
+        // and the bank swizzle sits on the SOURCE side: slot (row, pos) holds the row's k4 group  pos ^ ((row >> 1) & 7).  A staging
+        // thread (row = t >> 3, pos = t & 7) therefore owns the k4 group kgl = (t & 7) ^ ((t >> 4) & 7) — for every one of its rows,
+        // 32 apart —, the 8 lanes of a row request a permutation of the row's 128 contiguous bytes (full lines), and a fragment
+        // read (16 consecutive rows of one k4 group) touches 16 slots whose (row & 1, pos) pairs are all different: 64 banks.
+        // Padding / tail lanes: offset beyond the descriptor -> the DMA writes zeros (probed: tools/probes/lds_dma_oob.hip).
+        const int kgl = (t & 7) ^ ((t >> 4) & 7);
+        const int4* tab5 = p.ktab + ph.tab_off + k4_begin + kgl;
+        const int wv_u = __builtin_amdgcn_readfirstlane(wave);
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        int4 e5 = nk > 0 ? tab5[0] : (int4){0, 0, 0, -1};
+        auto issue = [&](int kt, int stage) {
+            const int4 e = e5;
+            f32x4* const sA = lds_all + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const int ih = a_ih0[i] + e.y, iw = a_iw0[i] + e.z;
+                const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (e.w >= 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(sA + 64 * wv_u + 256 * i), 16,
+                                                         ok ? (int)((unsigned)(a_off[i] + e.x) << 2) : (int)WDG_SRD_OOB, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                if (8 * wv_u + 32 * i < BN) {           // (wave-uniform: a wave's piece is 8 rows, BN is a multiple of 16)
+                    const bool ok = b_ok[i] && (e.w >= 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(sA + 8 * BM + 64 * wv_u + 256 * i), 16,
+                                                             ok ? (int)((unsigned)(b_off[i] + e.w) << 2) : (int)WDG_SRD_OOB, 0, 0, 0);
+                }
+            }
+            e5 = tab5[(kt + 1 < nk ? kt + 1 : kt) * 8];
+        };
+        auto read_frags5 = [&](const f32x4* sA, int h, f32x4 (&af)[MT], f32x4 (&bf)[NT]) {
+            const int kgr = 4 * h + (lane >> 4);
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = wm * (BM / WGM) + a * 16 + (lane & 15);
+                af[a] = sA[8 * row + (kgr ^ ((row >> 1) & 7))];
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = wn * (BN / WGN) + b * 16 + (lane & 15);
+                bf[b] = sA[8 * BM + 8 * row + (kgr ^ ((row >> 1) & 7))];
+            }
+        };
+        if (nk > 0) issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                      // s_waitcnt vmcnt(0) + barrier: every wave's pieces of tile kt have landed, and
+                                                  // every wave has finished reading the other stage (its reads of step kt - 1)
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            const f32x4* sA = lds_all + (kt & 1) * STAGE;
+            {
+                f32x4 af[MT], bf[NT];
+                read_frags5(sA, 0, af, bf);
+                mfma_block(af, bf);
+            }
+            {
+                f32x4 af[MT], bf[NT];
+                read_frags5(sA, 1, af, bf);
+                mfma_block(af, bf);
+            }
+        }
+        __syncthreads();                          // (epilogues reuse the stages as scratch)
     } else if (PIPE == 0) {
         f32x4* ldsA = lds_all;
         f32x4* ldsB = lds_all + 8 * BM;
@@ -466,6 +540,7 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
         } else
         for (int kt = 0; kt < nk; ++kt) {
             load_tile(kt + 1 < nk ? kt + 1 : kt);   // unconditional (the last one is redundant)
+            if constexpr (WDG_EARLY_LOADS != 0 && BN <= 64) __builtin_amdgcn_sched_barrier(0);
             {
                 f32x4 af[MT], bf[NT];
                 read_frags(ldsA, ldsB, 0, af, bf);
@@ -1350,7 +1425,7 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
 // row / column tiles of one pixel split then run back to back on ONE XCD and share its L2 copy of the x / dy window: fabric fetch of
 // the 7x7 stride-3 32 -> 64 weight gradient 1,726 -> 438 MB per launch, L2 hit 0.16 -> 0.78 (profiles/r05b_*: time in isolation
 // unchanged, 464 vs 467 us — the kernel is not bound by its fetch —, but 1.3 GB less fabric traffic per launch for whatever runs beside it)
-static int g_wgrad_xcd = 16;
+static int g_wgrad_xcd = 32;
 static int g_tap_class_order = 1;   // wdg_set_tuning("tap_class_order", 0/1): forward tables of strided layers in residue-class order (plans created afterwards)
 static int g_wgrad_bn160 = 32;   // wdg_set_tuning("wgrad_bn160", 32 | 64 | 128): column tile of 160-column weight gradients
 static int pick_wgrad_bn(int ncols) {
@@ -1573,6 +1648,7 @@ static int g_tile2d = 1;        // 2-D row tiles in the implicit GEMM (WdgPhase:
 static int g_phase_major = 1;   // strided data gradients: the s*s phases of an output tile adjacent in the launch order (same XCD)
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
+static int g_igemm_dma = 4;        // wdg_set_tuning("igemm_dma", mask): tiles that run the LDS-DMA K loop (launch_igemm)
 static int g_dgrad_lnbwd = 1;      // wdg_set_tuning("dgrad_lnbwd", 0/1): LayerNorm backward in the data gradient's epilogue (wdg_conv_dgrad_lnbwd)
 static int g_ln_wave = 1;     // wdg_set_tuning("ln_wave", 0/1): the 128 x 64 tile's LayerNorm epilogue on 4 x 1 waves (in-wave reductions)
 static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
@@ -1652,6 +1728,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "wgrad_xcd")) {
         g_wgrad_xcd = value;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "igemm_dma")) {
+        g_igemm_dma = value;
         return WDG_OK;
     }
     if (key && !strcmp(key, "dgrad_lnbwd")) {
@@ -1762,7 +1842,7 @@ static void set_b3(WdgIgemm& p, int k_per_tap);
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
     constexpr size_t lds = PIPE == 4 ? (size_t)12 * (BM + BN) * 16     // three bf16 slices per operand: 1.5x the fp32 stage
-                                     : (size_t)((PIPE == 0 || PIPE == 3) ? KG : 2) * 8 * (BM + BN) * sizeof(f32x4);
+                                     : (size_t)((PIPE == 0 || PIPE == 3) ? KG : 2) * 8 * (BM + BN) * sizeof(f32x4);   // (PIPE 5: two stages)
     static_assert(KG == 1 || lds >= (size_t)BM * BN * sizeof(float), "the second group's accumulators fit the two stages");
     static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
     static_assert(EPI != 3 || lds >= (size_t)BM * 4 * WGN * sizeof(float), "LayerNorm scratch fits the K-loop stage");
@@ -1856,6 +1936,11 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     }
     p.xcd_swizzle = g_xcd_swizzle && grid.x >= 16;
     const int pipe = g_igemm_pipe;
+    // LDS-DMA loop (PIPE 5) on the tiles wdg_set_tuning("igemm_dma", mask) names: bit 0 = 128x64, 1 = 256x32 / 256x16, 2 = 64x64, 3 = 128x128,
+    // 4 = 128x80 / 128x160 / 256x80
+    const int dma_bit = (tc.BM == 128 && tc.BN == 64) ? 1 : (tc.BM == 256 && tc.BN <= 32) ? 2 : (tc.BM == 64 && tc.BN == 64) ? 4
+                        : (tc.BM == 128 && tc.BN == 128) ? 8 : 16;
+    const bool pipe5 = pipe == 3 && (g_igemm_dma & dma_bit) && kg == 1;
     // the pre-split weight copy pays on the wide tiles (measured: profiles/r02t_per_layer_split.txt); elsewhere the kernel slices B itself
     if (!(tc.BM >= 128 && (tc.BN == 64 || tc.BN == 128))) p.B3 = nullptr;
     int rc = WDG_OK;
@@ -1887,18 +1972,21 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
             } else rc = WDG_ERR_ARG;                                                                    \
         }                                                                                               \
         else if (epi == 5) {                                                                            \
-            if constexpr ((BM_ == 256 && BN_ <= 32) || (BM_ == 128 && BN_ == 64))                       \
-                rc = launch_variant<BM_, BN_, 4, 1, 3, 5>(grid, block, st, p);                          \
-            else rc = WDG_ERR_ARG;                                                                      \
+            if constexpr ((BM_ == 256 && BN_ <= 32) || (BM_ == 128 && BN_ == 64)) {                     \
+                if (pipe5) rc = launch_variant<BM_, BN_, 4, 1, 5, 5>(grid, block, st, p);               \
+                else rc = launch_variant<BM_, BN_, 4, 1, 3, 5>(grid, block, st, p);                     \
+            } else rc = WDG_ERR_ARG;                                                                    \
         }                                                                                               \
         else if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);           \
         else if (epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 2>(grid, block, st, p);           \
         else if (epi == 3) {                                                                            \
             if constexpr (BM_ == 128 && BN_ == 64) {                                                    \
-                if (g_ln_wave) rc = launch_variant<128, 64, 4, 1, 3, 3>(grid, block, st, p);            \
+                if (pipe5) rc = launch_variant<128, 64, 4, 1, 5, 3>(grid, block, st, p);                \
+                else if (g_ln_wave) rc = launch_variant<128, 64, 4, 1, 3, 3>(grid, block, st, p);       \
                 else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);                 \
             } else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 3>(grid, block, st, p);                   \
         }                                                                                               \
+        else if (pipe5 && epi == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 5>(grid, block, st, p);     \
         else if (pipe == 0) rc = launch_variant<BM_, BN_, WM_, WN_, 0>(grid, block, st, p);             \
         else if (pipe == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 1>(grid, block, st, p);             \
         else if (pipe == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3>(grid, block, st, p);             \
