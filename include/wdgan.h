@@ -396,6 +396,20 @@ int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, const float
                       float* h, int ldh, int64_t img_stride_h, int n_img, int H, int W, int cin, int F,
                       wdg_stream stream);
 
+/* The same three calls for the ConvLSTM2D that reads the concatenation [low_res | high_res] (models.py:100-101) WITHOUT the
+ * concatenated tensor: the last x2_n (1 or 2) of the cin = 5 input channels are read from a second tensor x2 [n][H][W][ldx2]
+ * (the caller's high-res tensor, in place), the others from x — the low-res part is constant over a train step, the high-res
+ * part changes with every discriminator pass (twelve two-channel copies per step otherwise).  5 -> 16 layer only
+ * (wdg_convlstm1_x2_supported); dw == NULL in the backward: no weight gradient. */
+int wdg_convlstm1_x2_supported(int cin, int F, int x2_n);
+int wdg_convlstm1_fwd_x2(const float* x, int ldx, int64_t img_stride_x, const float* x2, int ldx2, int64_t img_stride_x2,
+                         int x2_n, const float* wx, const float* bias, float* h, int ldh, int64_t img_stride_h, int n_img,
+                         int H, int W, int cin, int F, wdg_stream stream);
+int wdg_convlstm1_bwd_x2(const float* x, int ldx, int64_t img_stride_x, const float* x2, int ldx2, int64_t img_stride_x2, int x2_n,
+                         const float* wx, const float* bias, const float* dh, int lddh, int64_t img_stride_dh, float* dx,
+                         int lddx, int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                         float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream);
+
 /* n_timesteps > 1 (models.py:101): the input part of the 5 -> 16-feature layer's gate pre-activations for ALL timesteps in one
  * launch, gates[n, y, x, i | f | c~ | o] = conv(x, kernel) + bias — the tensor the recurrent steps (wdg_convlstm16_step)
  * accumulate onto.  Same matrix-pipe kernel as wdg_convlstm1_fwd (45-row reduction, weights in registers), storing the four
@@ -517,6 +531,14 @@ int wdg_dense_gap_fwd(const float* x, const float* w, const float* b, float* sco
  * dw/db may be NULL (input-gradient-only pass, ganbase.py:35,60). */
 int wdg_dense_gap_bwd(const float* x, const float* w, const float* dscore, float* dx, float* dw,
                       float* db, int B, int T, int K, wdg_stream stream);
+/* The same head backward chained with the backward of the LayerNormalization (+ LeakyReLU) whose OUTPUT is the head's input x
+ * (models.py:125/136 under :137-140): dx receives dpre, the gradient w.r.t. that norm's producer's pre-activation, instead of
+ * dz = dscore / T * w (which never leaves the registers); y [rows * K / C][C] is the norm's input, mean_rstd as written by the
+ * forward, dgamma / dbeta / dbias accumulate (optional; par_ws: zeroed scratch of wdg_conv_dgrad_lnbwd_par_floats(C) floats).
+ * Equals wdg_dense_gap_bwd followed by wdg_ln_bwd in place. */
+int wdg_dense_gap_bwd_ln(const float* x, const float* w, const float* dscore, float* dx, float* dw, float* db, int B, int T,
+                         int K, const float* y, const float* mean_rstd, const float* gamma, int C, float act_slope,
+                         float* dgamma, float* dbeta, float* dbias, float* par_ws, wdg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise / reductions used by GAN.train_step.

@@ -474,7 +474,21 @@ class TorchOps:
     def convlstm1_supported(self, cin, F_):
         return (cin, F_) in ((2, 2), (5, 16))
 
-    def convlstm1_fwd(self, x, wx, bias, h, cin, F_):
+    def convlstm1_x2_supported(self, cin, F_, n2):
+        return cin == 5 and F_ == 16 and 1 <= n2 <= 2
+
+    @staticmethod
+    def _with_x2(x, cin, x2):
+        """The layer's input with its last n2 channels taken from the second tensor (HipOps.convlstm1_fwd / _bwd, x2=)."""
+        if x2 is None:
+            return x
+        t2, n2 = x2
+        x = x.clone()
+        x[..., cin - n2:cin] = t2[..., :n2]
+        return x
+
+    def convlstm1_fwd(self, x, wx, bias, h, cin, F_, x2=None):
+        x = self._with_x2(x, cin, x2)
         gates = torch.zeros(*x.shape[:3], 4 * F_, dtype=x.dtype)
         self.conv_fwd(x, PackedWeights(self, wx), bias, gates, ConvGeom(3, 3, 1, 1))
         c = torch.zeros(*x.shape[:3], F_, dtype=x.dtype)
@@ -482,7 +496,8 @@ class TorchOps:
         self.lstm_fwd(gates.view(-1, 4 * F_), None, c.view(-1, F_), hh.view(-1, F_), F_)
         h[..., :F_] = hh
 
-    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False, dw=None, dbias=None):
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False, dw=None, dbias=None, x2=None):
+        x = self._with_x2(x, cin, x2)
         pk = PackedWeights(self, wx)
         gates = torch.zeros(*x.shape[:3], 4 * F_, dtype=x.dtype)
         self.conv_fwd(x, pk, bias, gates, ConvGeom(3, 3, 1, 1))
@@ -571,6 +586,14 @@ class TorchOps:
     def dense_gap_fwd(self, x, w, b, score, B, T):
         s = (x @ w + b[0]).reshape(T, B)  # rows are time-major
         score.copy_(s.mean(0))
+
+    def dense_gap_bwd_ln(self, x, w, dscore, dx, dw, db, B, T, y, mean_rstd, gamma, C, act_slope, dgamma, dbeta, dbias, par_ws=None):
+        """HipOps.dense_gap_bwd_ln as the composition it stands for."""
+        self.dense_gap_bwd(x, w, dscore, dx, dw, db, B, T)
+        d2 = dx.reshape(-1, C)
+        out = torch.empty_like(d2)
+        self.ln_bwd(d2, y.reshape(-1, C), mean_rstd, gamma, act_slope, out, dgamma, dbeta, dbias)
+        dx.copy_(out.reshape(dx.shape))
 
     def dense_gap_bwd(self, x, w, dscore, dx, dw, db, B, T):
         drow = (dscore.reshape(1, B) / T).expand(T, B).reshape(-1)

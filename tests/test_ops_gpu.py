@@ -288,8 +288,28 @@ def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
         dw2, db2 = ops.zeros(3, 3, cin, 4 * F_), ops.zeros(4 * F_)
         ops.convlstm1_bwd(xv, ww, bb, dd, None, None, cin, F_, dw=dw2, dbias=db2)
         res[name] = dict(h=h, dg=dg, dx=dx, dx2=dx2, dx3=dx3, dw=dw, db=db, dw2=dw2, db2=db2)
+        if cin == 5:
+            # the last two input channels from a SECOND tensor (the high-res part of concat(low, high) read in place,
+            # wdg_convlstm1_fwd_x2 / _bwd_x2): x carries garbage there
+            n2 = 2
+            x2 = ops.zeros(n, H, W, 4)
+            x2[..., :n2] = xv[..., cin - n2:cin]
+            xg = xv.clone()
+            xg[..., cin - n2:cin] = 77.0
+            assert ops.convlstm1_x2_supported(cin, F_, n2)
+            h2 = ops.zeros(n, H, W, Fp)
+            ops.convlstm1_fwd(xg, ww, bb, h2, cin, F_, x2=(x2, n2))
+            dx4, dw4, db4 = ops.zeros(n, H, W, cp), ops.zeros(3, 3, cin, 4 * F_), ops.zeros(4 * F_)
+            ops.convlstm1_bwd(xg, ww, bb, dd, None, dx4, cin, F_, dw=dw4, dbias=db4, x2=(x2, n2))
+            dx5 = ops.zeros(n, H, W, cp)
+            ops.convlstm1_bwd(xg, ww, bb, dd, None, dx5, cin, F_, x2=(x2, n2))
+            dw6, db6 = ops.zeros(3, 3, cin, 4 * F_), ops.zeros(4 * F_)
+            ops.convlstm1_bwd(xg, ww, bb, dd, None, None, cin, F_, dw=dw6, dbias=db6, x2=(x2, n2))
+            res[name].update(h_x2=h2, dx_x2=dx4, dw_x2=dw4, db_x2=db4, dx5_x2=dx5, dw6_x2=dw6, db6_x2=db6)
     for k in res["ref"]:
         assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
+    if cin == 5:
+        assert rel_err(res["hip"]["h_x2"], res["hip"]["h"]) < 1e-6 and rel_err(res["hip"]["dx5_x2"], res["hip"]["dx2"]) < 1e-6
     if Fp > F_:
         assert float(res["hip"]["h"][..., F_:].abs().max()) == 0.0
 
@@ -525,6 +545,96 @@ def test_conv_layernorm_fused(case, hip_ops, ref_ops):
     assert rel_err(h["mr"][:, 0], r["mr"][:, 0]) < TOL and rel_err(h["mr"][:, 1], r["mr"][:, 1]) < TOL
     zz = torch.nn.functional.layer_norm(r["y"], (cout,), gamma, beta, 1e-3)
     assert rel_err(r["z"], zz) < 1e-12
+
+
+LNB_CASES = [
+    # name, n, H, W, cin (= channels of dx), cout, k, s, p, c0, C   (the LayerNorm group is channels [c0, c0 + C) of dx)
+    ("d_block0_group16_of_32", 3, 96, 96, 32, 64, 7, 3, 1, 16, 16),     # 256x32 tile, 9 phases: the norm of the low + high branch (models.py:105)
+    ("d_block1_64ch", 3, 31, 31, 64, 128, 7, 3, 1, 0, 64),               # 128x64 tile on 4 x 1 waves
+    ("d_block1_64ch_big", 4, 84, 84, 64, 128, 7, 3, 1, 0, 64),
+    ("d_block2_128ch_tile64x128", 8, 27, 27, 128, 256, 7, 3, 1, 0, 128),  # 64x64 tiling -> the 64x128 tile of the fused route
+    ("d_block3_splitk_256ch", 8, 8, 8, 256, 512, 7, 3, 1, 0, 256),        # split-K: the norm's backward in the second stage
+    ("tail_3x3s2_splitk", 4, 5, 5, 256, 512, 3, 2, 0, 0, 256),
+    ("group8_of_16_thin", 3, 40, 40, 16, 32, 7, 3, 1, 8, 8),             # test-width discriminator (feature_channels = 8)
+    ("halo_route_fallback", 2, 128, 128, 16, 16, 3, 1, 1, 0, 16),         # halo-tile data gradient: the two-launch route
+]
+
+
+@pytest.mark.parametrize("par", [True, False], ids=["param_grads", "input_grad_only"])
+@pytest.mark.parametrize("case", LNB_CASES, ids=[c[0] for c in LNB_CASES])
+def test_conv_dgrad_layernorm_backward_fused(case, par, hip_ops, ref_ops):
+    """wdg_conv_dgrad_lnbwd: the data gradient of a convolution chained with the LayerNorm + LeakyReLU backward of the layer that
+    produced (a channel group of) its input — dx, dgamma, dbeta, dbias (accumulated onto non-zero starting values) against
+    conv_dgrad followed by ln_bwd of the oracle; the scratch is left zeroed; the untouched channels are the plain data gradient."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    name, n, H, W, cin, cout, k, s_, p_, c0, C = case
+    gen = torch.Generator().manual_seed(41)
+    dev = hip_ops.device
+    Ho, Wo = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+    dy = torch.randn(n, Ho, Wo, cout, generator=gen, dtype=torch.float64)
+    w = torch.randn(k, k, cin, cout, generator=gen, dtype=torch.float64) / np.sqrt(k * k * cout)
+    y = torch.randn(n, H, W, C, generator=gen, dtype=torch.float64)          # the norm's input (post-LeakyReLU activation)
+    gamma = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    mean = y.mean(-1).reshape(-1)
+    rstd = 1.0 / torch.sqrt(y.var(-1, unbiased=False).reshape(-1) + 1e-3)
+    mr = torch.stack([mean, rstd], 1).contiguous()
+    start = torch.randn(3, C, generator=gen, dtype=torch.float64)
+    res = {}
+    for tag, ops, cv, G in (("ref", ref_ops, lambda t: t.clone(), RG), ("hip", hip_ops, lambda t: t.float().to(dev).contiguous(), ConvGeom)):
+        pk, g = ops.pack_weights(cv(w)), G(k, k, s_, p_)
+        dx = ops.zeros(n, H, W, cin)
+        dg, db, dbias = (cv(start[0]), cv(start[1]), cv(start[2])) if par else (None, None, None)
+        ws = ops.lnbwd_scratch(C) if par else None
+        ops.conv_dgrad_lnbwd(cv(dy), pk, dx, g, cv(y), cv(mr), cv(gamma), c0, C, 0.2, dg, db, dbias, ws)
+        plain = ops.zeros(n, H, W, cin)
+        ops.conv_dgrad(cv(dy), pk, plain, g)
+        res[tag] = dict(dx=dx, dg=dg, db=db, dbias=dbias, plain=plain, ws=ws)
+    r, h = res["ref"], res["hip"]
+    assert rel_err(h["dx"], r["dx"]) < TOL
+    if c0 > 0:
+        assert rel_err(h["dx"][..., :c0], h["plain"][..., :c0]) < 1e-6
+    assert rel_err(h["dx"][..., c0:c0 + C], h["plain"][..., c0:c0 + C]) > 1e-2     # (the group did go through the norm's backward)
+    if par:
+        for key in ("dg", "db", "dbias"):
+            assert rel_err(h[key], r[key]) < 5 * TOL, key                           # (sums over up to 10^5 pixels in fp32 atomics)
+        assert float(h["ws"].abs().max()) == 0.0
+        # a second call accumulates again from the zeroed scratch
+        ops, cv = hip_ops, (lambda t: t.float().to(dev).contiguous())
+        dx2 = ops.zeros(n, H, W, cin)
+        ops.conv_dgrad_lnbwd(cv(dy), ops.pack_weights(cv(w)), dx2, ConvGeom(k, k, s_, p_), cv(y), cv(mr), cv(gamma), c0, C, 0.2,
+                             h["dg"], h["db"], h["dbias"], h["ws"])
+        assert rel_err(h["dg"], 2 * r["dg"] - start[0]) < 5 * TOL and rel_err(dx2, r["dx"]) < TOL
+
+
+@pytest.mark.parametrize("B,T,npix,C,par", [(4, 1, 4, 512, True), (3, 2, 9, 64, True), (2, 3, 1, 256, False), (32, 1, 4, 512, True)])
+def test_dense_head_backward_through_layernorm(B, T, npix, C, par, hip_ops, ref_ops):
+    """wdg_dense_gap_bwd_ln: Dense(1) + GlobalAveragePooling backward (models.py:137-140) chained with the backward of the
+    LayerNormalization that produced the head's input, against dense_gap_bwd + ln_bwd of the oracle."""
+    gen = torch.Generator().manual_seed(43)
+    dev = hip_ops.device
+    rows, K = B * T, npix * C
+    y = torch.randn(rows * npix, C, generator=gen, dtype=torch.float64)
+    gamma = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    beta = torch.randn(C, generator=gen, dtype=torch.float64)
+    mean, var = y.mean(1), y.var(1, unbiased=False)
+    mr = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-3)], 1).contiguous()
+    x = (((y - mean[:, None]) * mr[:, 1:2]) * gamma + beta).reshape(rows, K).contiguous()      # the norm's output = the head's input
+    w = torch.randn(K, generator=gen, dtype=torch.float64) / np.sqrt(K)
+    dscore = torch.randn(B, generator=gen, dtype=torch.float64)
+    start = torch.randn(3, C, generator=gen, dtype=torch.float64)
+    res = {}
+    for tag, ops, cv in (("ref", ref_ops, lambda t: t.clone()), ("hip", hip_ops, lambda t: t.float().to(dev).contiguous())):
+        dx, dw, dbd = ops.zeros(rows, K), ops.zeros(K), ops.zeros(1)
+        dg, db, dbias = (cv(start[0]), cv(start[1]), cv(start[2])) if par else (None, None, None)
+        ops.dense_gap_bwd_ln(cv(x), cv(w), cv(dscore), dx, dw if par else None, dbd if par else None, B, T, cv(y), cv(mr), cv(gamma), C,
+                             0.2, dg, db, dbias, ops.lnbwd_scratch(C) if par else None)
+        res[tag] = dict(dx=dx, dw=dw, dbd=dbd, dg=dg, db=db, dbias=dbias)
+    r, h = res["ref"], res["hip"]
+    assert rel_err(h["dx"], r["dx"]) < TOL
+    if par:
+        for key in ("dw", "dbd", "dg", "db", "dbias"):
+            assert rel_err(h[key], r[key]) < 5 * TOL, key
 
 
 def test_upconv_batchnorm_hooks(hip_ops, ref_ops):

@@ -115,3 +115,12 @@ __device__ __forceinline__ f32x4 wdg_buffer_load_f32x4(wdg_srd srd, unsigned byt
     return __builtin_bit_cast(f32x4, v);
 }
 #endif
+
+// ---- LayerNorm-backward parameter gradients of the fused launches (conv_igemm.hip EPI 5, the split-K second stage, the dense head):
+// blocks add their partial sums into one of WDG_LNB_REP replica slabs [3][C] (dgamma, dbeta, dbias); wdg_lnb_finish (norms.hip) sums
+// the replicas into the gradient vectors and clears them
+#define WDG_LNB_REP 64
+#if defined(__HIPCC__)
+int wdg_lnb_finish(float* par, int rep, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t stream);
+#endif
+

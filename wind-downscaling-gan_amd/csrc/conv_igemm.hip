@@ -775,26 +775,26 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
         }
         return;
     }
-    if constexpr (EPI == 5) {
+    if constexpr (EPI == 5 || EPI == 6) {
+        // (EPI 6: the same without parameter gradients — the input-gradient-only passes — and without their 12 * NT accumulators)
+        constexpr bool PAR = EPI == 5;
         // One wave owns complete rows (WGN == 1: checked at instantiation), a pixel's channels sit in the four lane >> 4 groups
         // of that wave: both reductions of the LayerNorm backward are in-lane sums + two xor-shuffles.  No bias / activation /
         // accumulate / split-K on this route (the host falls back to the two-launch form otherwise).
-        static_assert(WGN == 1, "EPI 5: a row's channels in one wave");
+        static_assert(WGN == 1, "EPI 5 / 6: a row's channels in one wave");
         const int c0 = p.lnb_c0, C = p.lnb_C;
         const float invC = 1.f / (float)C;
         const int HoWo = p.Ho * p.Wo;
         // this lane's share of the parameter gradients, per column tile of the group (summed over its MT pixels)
-        f32x4 pg[NT], pb[NT], pd[NT];
-#pragma unroll
-        for (int b = 0; b < NT; ++b) pg[b] = pb[b] = pd[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 gm[NT];
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
+        float* const red5 = reinterpret_cast<float*>(lds_all);            // [WGM][3][BN] (the K loop has ended behind a barrier: its stage is free)
+        // (gamma and y are read once per reduction pass instead of being held across both: 32 registers less on the 64-column
+        // tile, whose plain variant runs four waves per SIMD; the second read hits L1)
+        auto gamma4 = [&](int b) -> f32x4 {
             const int n = n0 + b * 16 + q4;
-            const bool in = n >= c0 && n < c0 + C;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gm[b][r] = in ? p.lnb_gamma[n - c0 + r] : 0.f;
-        }
+            f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (n >= c0 && n < c0 + C) g = *reinterpret_cast<const f32x4*>(p.lnb_gamma + (n - c0));
+            return g;
+        };
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
             const int m = m0 + wm * (BM / WGM) + a * 16 + (lane & 15);
@@ -807,29 +807,29 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
             const long long off = (long long)img * p.imgStrideO + pix * p.ldO;
             const float* yrow = p.lnb_y + (long long)img * p.lnb_imgStride + pix * p.lnb_ldy;
             const float* st = p.lnb_stats + 2 * ((long long)img * HoWo + pix);
-            // every load of the pixel first (one memory round trip), then the arithmetic
             float mean = 0.f, rstd = 0.f;
-            f32x4 yv[NT];
             if (rv) {
                 mean = st[0];
                 rstd = st[1];
             }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
+            auto y4 = [&](int b) -> f32x4 {
                 const int n = n0 + b * 16 + q4;
-                yv[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (rv && n >= c0 && n < c0 + C) yv[b] = *reinterpret_cast<const f32x4*>(yrow + (n - c0));
-            }
+                f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rv && n >= c0 && n < c0 + C) y = *reinterpret_cast<const f32x4*>(yrow + (n - c0));
+                return y;
+            };
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
+            for (int b = 0; b < NT; ++b) {
+                const f32x4 yv = y4(b), gm = gamma4(b);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float xh = (yv[b][r] - mean) * rstd;
-                    const float gg = acc[a][b][r] * gm[b][r];       // (gm = 0 outside the group)
+                    const float xh = (yv[r] - mean) * rstd;
+                    const float gg = acc[a][b][r] * gm[r];       // (gamma = 0 outside the group)
                     s1 += gg;
                     s2 += gg * xh;
                 }
+            }
             s1 += __shfl_xor(s1, 16, 64);
             s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64);
@@ -842,15 +842,24 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
                 if (n >= NcP) continue;
                 f32x4 v = acc[a][b];
                 if (n >= c0 && n < c0 + C) {
+                    const f32x4 yv = y4(b), gm = gamma4(b);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float xh = (yv[b][r] - mean) * rstd;
-                        float d = rstd * (v[r] * gm[b][r] - s1 - xh * s2);
-                        if (p.lnb_slope >= 0.f) d *= (yv[b][r] > 0.f ? 1.f : p.lnb_slope);
-                        if (rv) {
-                            pg[b][r] = fmaf(v[r], xh, pg[b][r]);
-                            pb[b][r] += v[r];
-                            pd[b][r] += d;
+                        const float xh = (yv[r] - mean) * rstd;
+                        float d = rstd * (v[r] * gm[r] - s1 - xh * s2);
+                        if (p.lnb_slope >= 0.f) d *= (yv[r] > 0.f ? 1.f : p.lnb_slope);
+                        if constexpr (PAR) {
+                            // this pixel's share of the parameter gradients: summed over the 16 pixels of the lane group at
+                            // once (DPP row sums) and kept in LDS — 12 * NT live accumulators would cost the 64-column tile a wave
+                            const float t0 = wdg_row16_sum(rv ? v[r] * xh : 0.f), t1 = wdg_row16_sum(rv ? v[r] : 0.f),
+                                        t2 = wdg_row16_sum(rv ? d : 0.f);
+                            if ((lane & 15) == 0) {
+                                const int col = b * 16 + q4 + r;
+                                float* rr = red5 + wm * 3 * BN + col;
+                                rr[0] = (a ? rr[0] : 0.f) + t0;
+                                rr[BN] = (a ? rr[BN] : 0.f) + t1;
+                                rr[2 * BN] = (a ? rr[2 * BN] : 0.f) + t2;
+                            }
                         }
                         v[r] = d;
                     }
@@ -858,24 +867,9 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
                 if (rv) *reinterpret_cast<f32x4*>(p.Out + off + n) = v;
             }
         }
+        if constexpr (!PAR) return;
         if (!p.lnb_par) return;
-        // parameter gradients: the 16 pixels of a lane group by DPP row sums, the WGM row-waves through LDS (the K loop's stage is
-        // free behind its last barrier), one atomic per (block, channel, quantity) into a replica slab
-        float* red = reinterpret_cast<float*>(lds_all);                    // [WGM][3][BN]
-        __syncthreads();
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v0 = wdg_row16_sum(pg[b][r]), v1 = wdg_row16_sum(pb[b][r]), v2 = wdg_row16_sum(pd[b][r]);
-                if ((lane & 15) == 0) {
-                    const int col = b * 16 + q4 + r;
-                    red[(wm * 3 + 0) * BN + col] = v0;
-                    red[(wm * 3 + 1) * BN + col] = v1;
-                    red[(wm * 3 + 2) * BN + col] = v2;
-                }
-            }
-        }
+        // the WGM row-waves' sums meet here: one atomic per (block, channel, quantity) into a replica slab
         __syncthreads();
         float* slab = p.lnb_par + (size_t)(blockIdx.x % (unsigned)p.lnb_rep) * 3 * C;
         for (int idx = t; idx < 3 * BN; idx += 256) {
@@ -884,7 +878,7 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
             if (n < c0 || n >= c0 + C) continue;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < WGM; ++w) v += red[(w * 3 + which) * BN + col];
+            for (int w = 0; w < WGM; ++w) v += red5[(w * 3 + which) * BN + col];
             atomicAdd(slab + which * C + (n - c0), v);
         }
         return;
@@ -997,21 +991,6 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
     }
 }
 
-// Replica slabs [rep][3][C] of the LayerNorm-backward epilogue (EPI 5) -> dgamma / dbeta / dbias (accumulated; any may be NULL),
-// and the slabs cleared for the next launch.  One thread per (quantity, channel), replicas summed in order.
-__global__ void __launch_bounds__(256) wdg_ln_param_finish_kernel(float* par, int rep, int C, float* dgamma, float* dbeta, float* dbias) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 3 * C) return;
-    const int which = idx / C, c = idx - which * C;
-    float v = 0.f;
-    for (int r = 0; r < rep; ++r) {
-        v += par[(size_t)r * 3 * C + idx];
-        par[(size_t)r * 3 * C + idx] = 0.f;
-    }
-    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dbias;
-    if (dst) dst[c] += v;
-}
-
 // split-K second stage: sum the slabs, apply the epilogue, scatter to the output view.
 __global__ void __launch_bounds__(256) wdg_igemm_reduce_kernel(const WdgIgemm p) {
     const WdgPhase ph = p.ph[blockIdx.z];
@@ -1098,6 +1077,105 @@ __global__ void __launch_bounds__(256) wdg_igemm_reduce_ln_kernel(const WdgIgemm
             p.mean_rstd[2 * (long long)m] = mean;
             p.mean_rstd[2 * (long long)m + 1] = rstd;
         }
+    }
+}
+
+// split-K second stage of a data gradient whose output is the dz of a LayerNormalization (wdg_conv_dgrad_lnbwd on a split-K
+// launch: the discriminator's small maps): one wave per output pixel sums the slabs of its row — so it holds dz for all channels
+// of the pixel —, runs the LayerNorm + LeakyReLU backward on channels [lnb_c0, lnb_c0 + lnb_C) and writes the row; parameter
+// gradients as in the EPI 5 epilogue (wave partials -> LDS -> one atomic per block, channel and quantity into a replica slab).
+// Ncols % 4 == 0, Ncols <= 1024, every phase of the launch (blockIdx.z).
+__global__ void __launch_bounds__(256) wdg_igemm_reduce_lnbwd_kernel(const WdgIgemm p) {
+    __shared__ float red[4 * 3 * 1024];
+    const WdgPhase ph = p.ph[blockIdx.z];
+    const int PaPb = ph.Pa * ph.Pb;
+    const int Mph = p.n_img * PaPb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4n = p.Ncols >> 2;
+    const int c0 = p.lnb_c0, C = p.lnb_C;
+    const float invC = 1.f / (float)C;
+    const int HoWo = p.Ho * p.Wo;
+    const bool par = p.lnb_par != nullptr;
+    f32x4 pg[4], pb[4], pd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pg[j] = pb[j] = pd[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = blockIdx.x * 4 + wave; m < Mph; m += gridDim.x * 4) {
+        const int img = m / PaPb;
+        const int rem = m - img * PaPb;
+        const int pa = rem / ph.Pb;
+        const int pb_ = rem - pa * ph.Pb;
+        const long long pix = (long long)(pa * p.o_mul + ph.o_off_h) * p.Wo + pb_ * p.o_mul + ph.o_off_w;
+        const long long off = (long long)img * p.imgStrideO + pix * p.ldO;
+        const float* yrow = p.lnb_y + (long long)img * p.lnb_imgStride + pix * p.lnb_ldy;
+        const float mean = p.lnb_stats[2 * ((long long)img * HoWo + pix)], rstd = p.lnb_stats[2 * ((long long)img * HoWo + pix) + 1];
+        f32x4 v[4], y[4], g[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = lane + 64 * j;
+            v[j] = y[j] = g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < c4n) {
+                const float* src = p.partial + (((long long)blockIdx.z * p.splitk) * p.Mmax + m) * p.Ncols + 4 * c4;
+                for (int sp = 0; sp < p.splitk; ++sp) v[j] += *reinterpret_cast<const f32x4*>(src + (long long)sp * p.Mmax * p.Ncols);
+                const int n = 4 * c4;
+                if (n >= c0 && n < c0 + C) {
+                    y[j] = *reinterpret_cast<const f32x4*>(yrow + (n - c0));
+                    g[j] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + (n - c0));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (y[j][r] - mean) * rstd, gg = v[j][r] * g[j][r];
+                        s1 += gg;
+                        s2 += gg * xh;
+                    }
+                }
+            }
+        }
+        s1 = wdg_wave_sum(s1) * invC;
+        s2 = wdg_wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 >= c4n) continue;
+            const int n = 4 * c4;
+            f32x4 o = v[j];
+            if (n >= c0 && n < c0 + C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (y[j][r] - mean) * rstd;
+                    float d = rstd * (v[j][r] * g[j][r] - s1 - xh * s2);
+                    if (p.lnb_slope >= 0.f) d *= (y[j][r] > 0.f ? 1.f : p.lnb_slope);
+                    pg[j][r] = fmaf(v[j][r], xh, pg[j][r]);
+                    pb[j][r] += v[j][r];
+                    pd[j][r] += d;
+                    o[r] = d;
+                }
+            }
+            *reinterpret_cast<f32x4*>(p.Out + off + n) = o;
+        }
+    }
+    if (!par) return;
+    // per-wave partials (a lane owns its channels: no cross-lane sum needed) -> LDS -> the block's four waves summed -> atomics
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < c4n) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(wave * 3 + 0) * 1024 + 4 * c4 + r] = pg[j][r];
+                red[(wave * 3 + 1) * 1024 + 4 * c4 + r] = pb[j][r];
+                red[(wave * 3 + 2) * 1024 + 4 * c4 + r] = pd[j][r];
+            }
+        }
+    }
+    __syncthreads();
+    float* slab = p.lnb_par + (size_t)((blockIdx.x + blockIdx.z) % (unsigned)p.lnb_rep) * 3 * C;
+    for (int idx = threadIdx.x; idx < 3 * p.Ncols; idx += 256) {
+        const int which = idx / p.Ncols, n = idx - which * p.Ncols;
+        if (n < c0 || n >= c0 + C) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += red[(w * 3 + which) * 1024 + n];
+        atomicAdd(slab + which * C + (n - c0), t);
     }
 }
 
@@ -1352,6 +1430,53 @@ __global__ void __launch_bounds__(256) wdg_wgrad_reduce_kernel(const WdgWgrad p)
     }
 }
 
+// The same for Cout % 4 == 0 (every layer of the two networks but the 2-channel ends): 16-byte accesses.  block = 64 groups of four
+// consecutive outputs x 4 split lanes; a lane walks its splits four at a time with the four loads in flight together (the scalar
+// form above moved 64 contiguous bytes per split and wave: 31 MB of slabs of the 7x7 stride-3 32 -> 64 layer in 33 us, 1 TB/s).
+// Fixed summation order (lane l: splits l, l + 4, ...; then lanes 0..3) -> reproducible.
+__global__ void __launch_bounds__(256) wdg_wgrad_reduce4_kernel(const WdgWgrad p) {
+    __shared__ f32x4 red[256];
+    const long long total4 = (long long)p.K4 * p.Cout;              // groups of four consecutive columns of one row
+    const long long stride4 = total4;                                 // one split's slab, in groups
+    const int g = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const f32x4* part = reinterpret_cast<const f32x4*>(p.partial);
+    for (long long base = (long long)blockIdx.x * 64; base < total4; base += (long long)gridDim.x * 64) {
+        const long long idx = base + g;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (idx < total4) {
+            int s = sl;
+            for (; s + 12 < p.splitk; s += 16) {
+                const f32x4 a0 = part[(long long)s * stride4 + idx], a1 = part[(long long)(s + 4) * stride4 + idx],
+                            a2 = part[(long long)(s + 8) * stride4 + idx], a3 = part[(long long)(s + 12) * stride4 + idx];
+                v += a0;
+                v += a1;
+                v += a2;
+                v += a3;
+            }
+            for (; s < p.splitk; s += 4) v += part[(long long)s * stride4 + idx];
+        }
+        red[threadIdx.x] = v;
+        __syncthreads();
+        if (sl == 0 && idx < total4) {
+            f32x4 t = red[g];
+            t += red[64 + g];
+            t += red[128 + g];
+            t += red[192 + g];
+            const long long e = idx * 4;
+            const int R = (int)(e / p.Cout);
+            const int n = (int)(e - (long long)R * p.Cout);
+            const int2 wr = p.wrow[R >> 2];
+            const int r = R & 3;
+            if (r < wr.y) {
+                f32x4* dst = reinterpret_cast<f32x4*>(p.dW + wr.x + (long long)r * p.Cout + n);
+                if (p.accumulate) t += *dst;
+                *dst = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // repack master HWIO -> wF [Cout][taps][Cin_p] and wD [taps][Cin][Cout_p]
 __global__ void __launch_bounds__(256) wdg_weight_pack_kernel(const float* __restrict__ w, float* wF,
                                                               float* wD, int taps, int Cin, int Cout,
@@ -1426,6 +1551,7 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
 // the 7x7 stride-3 32 -> 64 weight gradient 1,726 -> 438 MB per launch, L2 hit 0.16 -> 0.78 (profiles/r05b_*: time in isolation
 // unchanged, 464 vs 467 us — the kernel is not bound by its fetch —, but 1.3 GB less fabric traffic per launch for whatever runs beside it)
 static int g_wgrad_xcd = 32;
+static int g_wgrad_reduce4 = 1;     // wdg_set_tuning("wgrad_reduce4", 0/1): 16-byte second stage of the split weight gradients
 static int g_tap_class_order = 1;   // wdg_set_tuning("tap_class_order", 0/1): forward tables of strided layers in residue-class order (plans created afterwards)
 static int g_wgrad_bn160 = 32;   // wdg_set_tuning("wgrad_bn160", 32 | 64 | 128): column tile of 160-column weight gradients
 static int pick_wgrad_bn(int ncols) {
@@ -1649,7 +1775,7 @@ static int g_phase_major = 1;   // strided data gradients: the s*s phases of an 
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
 static int g_igemm_dma = 4;        // wdg_set_tuning("igemm_dma", mask): tiles that run the LDS-DMA K loop (launch_igemm)
-static int g_dgrad_lnbwd = 1;      // wdg_set_tuning("dgrad_lnbwd", 0/1): LayerNorm backward in the data gradient's epilogue (wdg_conv_dgrad_lnbwd)
+static int g_dgrad_lnbwd = 3;      // wdg_set_tuning("dgrad_lnbwd", 0/1): LayerNorm backward in the data gradient's epilogue (wdg_conv_dgrad_lnbwd)
 static int g_ln_wave = 1;     // wdg_set_tuning("ln_wave", 0/1): the 128 x 64 tile's LayerNorm epilogue on 4 x 1 waves (in-wave reductions)
 static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
 static int g_tuning_epoch = 0;
@@ -1735,7 +1861,11 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         return WDG_OK;
     }
     if (key && !strcmp(key, "dgrad_lnbwd")) {
-        g_dgrad_lnbwd = value != 0;
+        g_dgrad_lnbwd = value;          // bit 0: on; bit 1: a 64 x 128 tile for 128-channel rows on small maps
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "wgrad_reduce4")) {
+        g_wgrad_reduce4 = value != 0;
         return WDG_OK;
     }
     if (key && !strcmp(key, "tap_class_order")) {
@@ -1847,6 +1977,7 @@ static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm&
     static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
     static_assert(EPI != 3 || lds >= (size_t)BM * 4 * WGN * sizeof(float), "LayerNorm scratch fits the K-loop stage");
     static_assert(EPI != 5 || lds >= (size_t)WGM * 3 * BN * sizeof(float), "LayerNorm-backward scratch fits the K-loop stage");
+    static_assert(PIPE != 5 || EPI == 0 || EPI == 3, "LDS-DMA loop: instantiated for the plain and LayerNorm-forward epilogues");
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 48 * 1024)
@@ -1872,11 +2003,11 @@ static void set_b3(WdgIgemm& p, int k_per_tap) {
 }
 
 // tiles whose EPI 5 instantiation exists (4 x 1 waves: a row's channels in one wave)
-static bool lnb_tile_ok(const TileCfg& tc) { return (tc.BM == 256 && tc.BN <= 32) || (tc.BM == 128 && tc.BN == 64); }
+static bool lnb_tile_ok(const TileCfg& tc) { return (tc.BM == 256 && tc.BN <= 32) || (tc.BM == 128 && tc.BN == 64) || (tc.BM == 64 && tc.BN == 128); }
 
 static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws, size_t ws_bytes,
-                        hipStream_t st, bool* bn_fused = nullptr) {
-    TileCfg tc = pick_tile(p.Ncols, true, p.Mmax);
+                        hipStream_t st, bool* bn_fused = nullptr, const TileCfg* force_tile = nullptr) {
+    TileCfg tc = force_tile ? *force_tile : pick_tile(p.Ncols, true, p.Mmax);
     // ConvLSTM step epilogue (complete sums needed, no split-K across workgroups): with fewer tiles than CUs the reduction is
     // split inside the workgroup instead — the widest tile that still gives every other CU a workgroup
     int kg = 1;
@@ -1947,8 +2078,9 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     // fused BatchNorm hooks: only without split-K (the reduce kernel owns the epilogue then; callers fall back to the
     // standalone passes — see conv_fused_bn) and only on the default pipeline
     const bool ln_ok = p.ln_gamma && split == 1 && tiles_n == 1 && nphase == 1 && (p.Ncols & 3) == 0;
-    const int epi = p.lnb_y ? 5 : p.lstm_F ? 4 : (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
-    if (epi == 5 && !(split == 1 && tiles_n == 1 && pipe == 3 && !p.accumulate && !p.bias && !p.act && lnb_tile_ok(tc))) {
+    const bool lnb_reduce = p.lnb_y && split > 1;          // split-K: the norm's backward runs in the second stage
+    const int epi = lnb_reduce ? 0 : p.lnb_y ? (p.lnb_par ? 5 : 6) : p.lstm_F ? 4 : (p.stats && split == 1) ? 1 : (p.affine && split == 1) ? 2 : ln_ok ? 3 : 0;
+    if (epi >= 5 && !(split == 1 && tiles_n == 1 && pipe == 3 && !p.accumulate && !p.bias && !p.act && lnb_tile_ok(tc))) {
         wdg_set_error("igemm: the LayerNorm-backward epilogue needs one column tile of a 4 x 1 wave layout, no split-K, the fp32 pipeline");
         return WDG_ERR_ARG;
     }
@@ -1971,10 +2103,10 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
                 } else rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4>(grid, block, st, p);               \
             } else rc = WDG_ERR_ARG;                                                                    \
         }                                                                                               \
-        else if (epi == 5) {                                                                            \
-            if constexpr ((BM_ == 256 && BN_ <= 32) || (BM_ == 128 && BN_ == 64)) {                     \
-                if (pipe5) rc = launch_variant<BM_, BN_, 4, 1, 5, 5>(grid, block, st, p);               \
-                else rc = launch_variant<BM_, BN_, 4, 1, 3, 5>(grid, block, st, p);                     \
+        else if (epi >= 5) {                                                                            \
+            if constexpr ((BM_ == 256 && BN_ <= 32) || (BM_ == 128 && BN_ == 64) || (BM_ == 64 && BN_ == 128)) { \
+                if (epi == 5) rc = launch_variant<BM_, BN_, 4, 1, 3, 5>(grid, block, st, p);            \
+                else rc = launch_variant<BM_, BN_, 4, 1, 3, 6>(grid, block, st, p);                     \
             } else rc = WDG_ERR_ARG;                                                                    \
         }                                                                                               \
         else if (epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 1>(grid, block, st, p);           \
@@ -1992,6 +2124,11 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         else if (pipe == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 3>(grid, block, st, p);             \
         else rc = launch_variant<BM_, BN_, WM_, WN_, 2>(grid, block, st, p);                            \
     }
+    if (tc.BM == 64 && tc.BN == 128) {       // (the LayerNorm-backward epilogue of a 128-channel row on a small map: instantiated for it alone)
+        if (epi == 5) rc = launch_variant<64, 128, 4, 1, 3, 5>(grid, block, st, p);
+        else if (epi == 6) rc = launch_variant<64, 128, 4, 1, 3, 6>(grid, block, st, p);
+        else rc = WDG_ERR_ARG;
+    }
     WDG_IGEMM_CASE(128, 160, 2, 2)
     WDG_IGEMM_CASE(256, 80, 4, 1)
     WDG_IGEMM_CASE(128, 80, 4, 1)
@@ -2003,6 +2140,12 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
 #undef WDG_IGEMM_CASE
     if (rc != WDG_OK) return rc;
     WDG_LAUNCH_CHECK();
+    if (split > 1 && lnb_reduce) {
+        const int blocks = (int)std::min<long long>(((long long)p.Mmax + 3) / 4, 2048);
+        hipLaunchKernelGGL(wdg_igemm_reduce_lnbwd_kernel, dim3(blocks, 1, nphase), block, 0, st, p);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
     if (split > 1) {
         if (p.ln_gamma && nphase == 1 && (p.Ncols & 3) == 0 && p.Ncols <= 1024 && !p.accumulate) {
             // (the slabs of a 4-aligned column count are dense: NcP == Ncols)
@@ -2223,7 +2366,6 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
     return conv_dgrad_impl(pl, dy, wD, bias, dx, act, slope, accumulate, nullptr, ws, ws_bytes, stream);
 }
 
-#define WDG_LNB_REP 64
 
 // Data gradient of a convolution whose INPUT tensor (channels [c0, c0 + C) of it) was produced by conv -> bias -> LeakyReLU -> LayerNormalization:
 // dx = dgrad(dy), then the LayerNorm + LeakyReLU backward applied to those channels of dx IN PLACE (dx[..., c0:c0+C] becomes the gradient
@@ -2237,11 +2379,15 @@ extern "C" int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* pl, const float* dy, co
     WDG_CHECK_ARG(c0 >= 0 && C > 0 && c0 % 4 == 0 && C % 4 == 0 && c0 + C <= g.Cin, "bad channel group");
     WDG_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ldy_act % 4 == 0 && ldy_act >= C, "y / gamma alignment");
     const bool want_par = dgamma || dbeta || dbias;
-    bool fuse = g_dgrad_lnbwd && !(pl->halo_auto_dgrad && pl->halo_dgrad_nt) && g_igemm_pipe == 3 && pl->dgrad_split == 1 && (!want_par || par_ws);
-    if (fuse) {
+    bool fuse = g_dgrad_lnbwd && !(pl->halo_auto_dgrad && pl->halo_dgrad_nt) && g_igemm_pipe == 3 && (!want_par || par_ws);
+    TileCfg tc_force = {0, 0};
+    if (fuse && pl->dgrad_split > 1) {
+        fuse = g.Cin % 4 == 0 && g.Cin <= 1024;                        // second stage: wdg_igemm_reduce_lnbwd_kernel
+    } else if (fuse) {
         long long Mmax = 0;
         for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g.n_img * ph.Pa * ph.Pb);
-        const TileCfg tc = pick_tile(g.Cin, true, Mmax);
+        TileCfg tc = pick_tile(g.Cin, true, Mmax);
+        if (tc.BM == 64 && tc.BN == 64 && g.Cin == 128 && (g_dgrad_lnbwd & 2)) tc = tc_force = TileCfg{64, 128};   // a 128-channel row in one wave
         fuse = lnb_tile_ok(tc) && g.Cin <= tc.BN;
     }
     if (!fuse) {
@@ -2272,12 +2418,9 @@ extern "C" int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* pl, const float* dy, co
         Mmax = std::max(Mmax, g.n_img * p.ph[i].Pa * p.ph[i].Pb);
     }
     p.Mmax = Mmax;
-    const int rc = launch_igemm(p, np, pl->K4_dgrad_max, 1, ws, ws_bytes, (hipStream_t)stream);
+    const int rc = launch_igemm(p, np, pl->K4_dgrad_max, pl->dgrad_split, ws, ws_bytes, (hipStream_t)stream, nullptr, tc_force.BM ? &tc_force : nullptr);
     if (rc != WDG_OK || !want_par) return rc;
-    hipLaunchKernelGGL(wdg_ln_param_finish_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, par_ws, WDG_LNB_REP, C,
-                       dgamma, dbeta, dbias);
-    WDG_LAUNCH_CHECK();
-    return WDG_OK;
+    return wdg_lnb_finish(par_ws, WDG_LNB_REP, C, dgamma, dbeta, dbias, (hipStream_t)stream);
 }
 
 // floats of the zero-initialised scratch `par_ws` of wdg_conv_dgrad_lnbwd for a group of C channels (the call leaves it zeroed)
@@ -2393,8 +2536,13 @@ extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const flo
     WDG_LAUNCH_CHECK();
     if (split > 1) {
         long long total = (long long)p.K4 * 4 * p.Cout;
-        int blocks = (int)std::min<long long>((total + 15) / 16, 8192);
-        hipLaunchKernelGGL(wdg_wgrad_reduce_kernel, dim3(blocks), block, 0, st, p);
+        if (g_wgrad_reduce4 && (p.Cout & 3) == 0 && ((uintptr_t)p.partial & 15) == 0 && ((uintptr_t)dw & 15) == 0) {
+            int blocks = (int)std::min<long long>((total / 4 + 63) / 64, 8192);
+            hipLaunchKernelGGL(wdg_wgrad_reduce4_kernel, dim3(blocks), block, 0, st, p);
+        } else {
+            int blocks = (int)std::min<long long>((total + 15) / 16, 8192);
+            hipLaunchKernelGGL(wdg_wgrad_reduce_kernel, dim3(blocks), block, 0, st, p);
+        }
         WDG_LAUNCH_CHECK();
     }
     return WDG_OK;

@@ -54,6 +54,13 @@ struct WdgCl1 {
     int n_img, H, W, ldx, ldh, lddh, lddx;
     int accumulate_dx;
     int tiles_h, tiles_w;
+    // second source of the LAST x2_n input channels (5-channel layer only): logical channel c >= CIN - x2_n is read from
+    // X2[img][pixel][c - (CIN - x2_n)] instead of X.  The discriminator's low + high ConvLSTM (models.py:100-101) reads the
+    // concatenation [low | high]: low is constant over a train step and lives in X, high changes with every pass and is read
+    // in place from the tensor the caller holds (12 two-channel copies into the concatenation per step otherwise).
+    const float* X2;
+    long long imgStrideX2;
+    int ldx2, x2_n;
 };
 
 // gate pre-activations (i, c~, o) of FH features starting at f0 for one pixel, x read through `load`
@@ -233,6 +240,8 @@ __global__ void __launch_bounds__(256, PRE ? 1 : 4) wdg_convlstm1_fwd_mfma_kerne
         b_ /= p.tiles_w;
         const int ty_ = b_ % p.tiles_h, img_ = b_ / p.tiles_h;
         const wdg_srd srdX = wdg_make_srd(p.X + (long long)img_ * p.imgStrideX);
+        const wdg_srd srdX2 = wdg_make_srd(p.X2 ? p.X2 + (long long)img_ * p.imgStrideX2 : p.X);
+        (void)srdX2;
 #pragma unroll
         for (int s_ = 0; s_ < NXS; ++s_) {
             const int pix = t + 256 * s_;
@@ -249,6 +258,17 @@ __global__ void __launch_bounds__(256, PRE ? 1 : 4) wdg_convlstm1_fwd_mfma_kerne
 #pragma unroll
             for (int c = CIN / 4 * 4; c < CIN; ++c)
                 xr[s_][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdX, (int)(off + 4 * c), 0, 0));
+            if constexpr (CIN == 5) {
+                // (branch-free: without a second source the two requests are out of range and their results unused)
+                const unsigned off2 = p.X2 ? (((unsigned)((gy * p.W + gx) * p.ldx2 * 4) & ~neg) | (neg & 0x80000000u)) : 0x80000000u;
+#pragma unroll
+                for (int c = CIN - 2; c < CIN; ++c) {
+                    const int rel = c - (CIN - p.x2_n);
+                    const bool in2 = p.X2 != nullptr && rel >= 0;
+                    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdX2, in2 ? (int)(off2 + 4 * rel) : (int)0x80000000u, 0, 0));
+                    xr[s_][c] = in2 ? v2 : xr[s_][c];
+                }
+            }
         }
     };
     if ((int)blockIdx.x < ntiles) x_request(blockIdx.x);
@@ -403,6 +423,8 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
         b_ /= p.tiles_w;
         const int ty_ = b_ % p.tiles_h, img_ = b_ / p.tiles_h;
         const wdg_srd srdX = wdg_make_srd(p.X + (long long)img_ * p.imgStrideX);
+        const wdg_srd srdX2 = wdg_make_srd(p.X2 ? p.X2 + (long long)img_ * p.imgStrideX2 : p.X);
+        (void)srdX2;
         if constexpr (DHPRE) {
             const wdg_srd srdDH = wdg_make_srd(p.dH + (long long)img_ * p.imgStrideDH);
             const int n_items_ = p.dX ? GH * GW : CL_TH * CL_TW;
@@ -426,6 +448,17 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
             const int gy = ty_ * CL_TH - 2 + hy, gx = tx_ * CL_TW - 2 + hx;
             const unsigned neg = (unsigned)((gy | (p.H - 1 - gy) | gx | (p.W - 1 - gx) | (XH * XW * C4 - 1 - idx)) >> 31);
             xr[s_] = wdg_buffer_load_f32x4(srdX, ((unsigned)(((gy * p.W + gx) * p.ldx + 4 * c4) * 4) & ~neg) | (neg & 0x80000000u));
+            if constexpr (CIN == 5) {
+                // second source (WdgCl1::X2): of this slot's four channels only channel 3 (group 0) / channel 4 (group 1) can come
+                // from it — one more 4-byte request per slot, out of range (unused) without a second source
+                const int csel = c4 == 0 ? 3 : 4;
+                const int rel = csel - (CIN - p.x2_n);
+                const bool in2 = p.X2 != nullptr && rel >= 0;
+                const unsigned o2 = (((unsigned)(((gy * p.W + gx) * p.ldx2 + rel) * 4) & ~neg) | (neg & 0x80000000u));
+                const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdX2, in2 ? (int)o2 : (int)0x80000000u, 0, 0));
+                xr[s_][3] = (in2 && c4 == 0) ? v2 : xr[s_][3];
+                xr[s_][0] = (in2 && c4 == 1) ? v2 : xr[s_][0];
+            }
         }
     };
     if ((int)blockIdx.x < ntiles) x_request(blockIdx.x);
@@ -693,14 +726,26 @@ static int cl1_cus() {
 }
 extern "C" int wdg_convlstm1_supported(int cin, int F) { return (cin == 2 && F == 2) || (cin == 5 && F == 16); }
 
+// second source of the last x2_n input channels (WdgCl1::X2): the 5-channel layer on its matrix-pipe forward / its fused backward
+extern "C" int wdg_convlstm1_x2_supported(int cin, int F, int x2_n) { return cin == 5 && F == 16 && x2_n >= 1 && x2_n <= 2 && g_cl1_fwd_mfma; }
+
 extern "C" int wdg_convlstm1_fwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
                                  float* h, int ldh, int64_t img_stride_h, int n_img, int H, int W, int cin, int F,
                                  wdg_stream stream) {
+    return wdg_convlstm1_fwd_x2(x, ldx, img_stride_x, nullptr, 0, 0, 0, wx, bias, h, ldh, img_stride_h, n_img, H, W, cin, F, stream);
+}
+
+extern "C" int wdg_convlstm1_fwd_x2(const float* x, int ldx, int64_t img_stride_x, const float* x2, int ldx2, int64_t img_stride_x2,
+                                    int x2_n, const float* wx, const float* bias, float* h, int ldh, int64_t img_stride_h, int n_img,
+                                    int H, int W, int cin, int F, wdg_stream stream) {
     WDG_CHECK_ARG(x && wx && bias && h, "null argument");
     WDG_CHECK_ARG(wdg_convlstm1_supported(cin, F), "unsupported (cin, F)");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x alignment / ld");
+    WDG_CHECK_ARG(!x2 || (wdg_convlstm1_x2_supported(cin, F, x2_n) && ldx2 >= x2_n && ldh % 4 == 0 && ((uintptr_t)h & 15) == 0 && img_stride_h % 4 == 0),
+                  "second input source: 5 -> 16 layer on the matrix-pipe forward only");
     WdgCl1 p;
     memset(&p, 0, sizeof(p));
+    p.X2 = x2; p.ldx2 = ldx2; p.imgStrideX2 = img_stride_x2; p.x2_n = x2 ? x2_n : 0;
     p.X = x; p.Wx = wx; p.bias = bias; p.Hout = h;
     p.imgStrideX = img_stride_x; p.imgStrideH = img_stride_h;
     p.n_img = n_img; p.H = H; p.W = W; p.ldx = ldx; p.ldh = ldh;
@@ -741,15 +786,24 @@ extern "C" int wdg_convlstm_gates_x(const float* x, int ldx, int64_t img_stride_
     return WDG_OK;
 }
 
+struct Cl1X2 {
+    const float* x2;
+    int ldx2;
+    int64_t img_stride_x2;
+    int x2_n;
+};
+
 static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
                    const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
                    int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
-                   float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream) {
+                   float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream, const Cl1X2* x2 = nullptr) {
     WDG_CHECK_ARG(x && wx && bias && dh, "null argument");
     WDG_CHECK_ARG(wdg_convlstm1_supported(cin, F), "unsupported (cin, F)");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x alignment / ld");
+    WDG_CHECK_ARG(!(x2 && x2->x2) || (wdg_convlstm1_x2_supported(cin, F, x2->x2_n) && x2->ldx2 >= x2->x2_n), "second input source: 5 -> 16 layer only");
     WdgCl1 p;
     memset(&p, 0, sizeof(p));
+    if (x2 && x2->x2) { p.X2 = x2->x2; p.ldx2 = x2->ldx2; p.imgStrideX2 = x2->img_stride_x2; p.x2_n = x2->x2_n; }
     p.X = x; p.Wx = wx; p.bias = bias; p.dH = dh; p.dG = dgates; p.dX = dx;
     p.imgStrideX = img_stride_x; p.imgStrideDH = img_stride_dh; p.imgStrideDX = img_stride_dx;
     p.n_img = n_img; p.H = H; p.W = W; p.ldx = ldx; p.lddh = lddh; p.lddx = lddx;
@@ -825,3 +879,16 @@ extern "C" int wdg_convlstm1_bwd_wgrad(const float* x, int ldx, int64_t img_stri
     return cl1_bwd(x, ldx, img_stride_x, wx, bias, dh, lddh, img_stride_dh, nullptr, dx, lddx, img_stride_dx, accumulate_dx,
                    n_img, H, W, cin, F, dw, dbias, ws, ws_bytes, stream);
 }
+
+// wdg_convlstm1_bwd / wdg_convlstm1_bwd_wgrad with the last x2_n input channels read from a second tensor (WdgCl1::X2);
+// dw == NULL: no weight gradient (dbias, ws unused).
+extern "C" int wdg_convlstm1_bwd_x2(const float* x, int ldx, int64_t img_stride_x, const float* x2, int ldx2, int64_t img_stride_x2, int x2_n,
+                                    const float* wx, const float* bias, const float* dh, int lddh, int64_t img_stride_dh, float* dx,
+                                    int lddx, int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                                    float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream) {
+    const Cl1X2 s2 = {x2, ldx2, img_stride_x2, x2_n};
+    WDG_CHECK_ARG(!dw || dbias, "null gradient buffers");
+    return cl1_bwd(x, ldx, img_stride_x, wx, bias, dh, lddh, img_stride_dh, nullptr, dx, lddx, img_stride_dx, accumulate_dx,
+                   n_img, H, W, cin, F, dw, dw ? dbias : nullptr, ws, ws_bytes, stream, &s2);
+}
+

@@ -579,3 +579,142 @@ extern "C" int wdg_ln_bwd(const float* dz, int lddz, const float* y, int ldy, co
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+
+// Replica slabs [rep][3][C] of the LayerNorm-backward epilogue (EPI 5) -> dgamma / dbeta / dbias (accumulated; any may be NULL),
+// and the slabs cleared for the next launch.  One thread per (quantity, channel), replicas summed in order.
+__global__ void __launch_bounds__(256) wdg_ln_param_finish_kernel(float* par, int rep, int C, float* dgamma, float* dbeta, float* dbias) {
+    // one wave per (quantity, channel): the lanes take the replicas (fixed assignment, then a wave sum) — a thread per value
+    // walking the 64 replicas serially took 17 us for 48 values
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= 3 * C) return;
+    const int which = idx / C, c = idx - which * C;
+    float v = 0.f;
+    for (int r = lane; r < rep; r += 64) {
+        v += par[(size_t)r * 3 * C + idx];
+        par[(size_t)r * 3 * C + idx] = 0.f;
+    }
+    v = wdg_wave_sum_fast(v);
+    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dbias;
+    if (dst && lane == 0) dst[c] += v;
+}
+
+int wdg_lnb_finish(float* par, int rep, int C, float* dgamma, float* dbeta, float* dbias, hipStream_t stream) {
+    hipLaunchKernelGGL(wdg_ln_param_finish_kernel, dim3((3 * C + 3) / 4), dim3(256), 0, stream, par, rep, C, dgamma, dbeta, dbias);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ---- Dense(1) + GlobalAveragePooling head backward (models.py:137-140) chained with the backward of the LayerNormalization
+// (+ LeakyReLU) that produced the head's input (models.py:125,136): dz[row][k] = dscore[b] / T * w[k] never leaves the registers —
+// one wave per pixel of the final map forms its C values of dz, runs the norm's backward on them and writes dpre; the dense
+// layer's own dw / db as in wdg_dense_gap_bwd.  x [rows][K] is the norm's OUTPUT (the head's input), y [rows * npix][C] its input.
+__global__ void __launch_bounds__(256) wdg_dense_gap_bwd_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ dscore, float* dx, float* dw, float* db,
+                                                                   int B, int T, int K, const float* __restrict__ y,
+                                                                   const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                                   int C, float act_slope, float* par, int rep) {
+    __shared__ float red[4 * 3 * 1024];
+    const float invT = 1.f / (float)T;
+    const int npix = K / C, rows = B * T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4n = C >> 2;
+    const float invC = 1.f / (float)C;
+    f32x4 pg[4], pb[4], pd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pg[j] = pb[j] = pd[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = blockIdx.x * 4 + wave; m < rows * npix; m += gridDim.x * 4) {
+        const int r = m / npix, q = m - r * npix;
+        const float ds = dscore[r % B] * invT;           // row = t * B + b
+        const float mean = mean_rstd[2 * (long long)m], rstd = mean_rstd[2 * (long long)m + 1];
+        f32x4 v[4], yy[4], g[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = lane + 64 * j;
+            v[j] = yy[j] = g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < c4n) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + (long long)q * C + 4 * c4);
+                yy[j] = *reinterpret_cast<const f32x4*>(y + (long long)m * C + 4 * c4);
+                g[j] = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[j][k] = ds * w4[k];
+                    const float xh = (yy[j][k] - mean) * rstd, gg = v[j][k] * g[j][k];
+                    s1 += gg;
+                    s2 += gg * xh;
+                }
+            }
+        }
+        s1 = wdg_wave_sum(s1) * invC;
+        s2 = wdg_wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = lane + 64 * j;
+            if (c4 >= c4n) continue;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (yy[j][k] - mean) * rstd;
+                float d = rstd * (v[j][k] * g[j][k] - s1 - xh * s2);
+                if (act_slope >= 0.f) d *= (yy[j][k] > 0.f ? 1.f : act_slope);
+                pg[j][k] = fmaf(v[j][k], xh, pg[j][k]);
+                pb[j][k] += v[j][k];
+                pd[j][k] += d;
+                o[k] = d;
+            }
+            *reinterpret_cast<f32x4*>(dx + (long long)m * C + 4 * c4) = o;
+        }
+    }
+    // the dense layer's own gradients (as wdg_dense_gap_bwd_kernel)
+    if (dw) {
+        for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+            float s = 0.f;
+            for (int r = 0; r < rows; ++r) s += x[(int64_t)r * K + k] * dscore[r % B];
+            dw[k] += s * invT;
+        }
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dscore[b];
+        db[0] += s;
+    }
+    if (!par) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < c4n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                red[(wave * 3 + 0) * 1024 + 4 * c4 + k] = pg[j][k];
+                red[(wave * 3 + 1) * 1024 + 4 * c4 + k] = pb[j][k];
+                red[(wave * 3 + 2) * 1024 + 4 * c4 + k] = pd[j][k];
+            }
+        }
+    }
+    __syncthreads();
+    float* slab = par + (size_t)(blockIdx.x % (unsigned)rep) * 3 * C;
+    for (int idx = threadIdx.x; idx < 3 * C; idx += 256) {
+        const int which = idx / C, n = idx - which * C;
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) t += red[(wv * 3 + which) * 1024 + n];
+        atomicAdd(slab + idx, t);
+    }
+}
+
+extern "C" int wdg_dense_gap_bwd_ln(const float* x, const float* w, const float* dscore, float* dx, float* dw, float* db, int B, int T,
+                                    int K, const float* y, const float* mean_rstd, const float* gamma, int C, float act_slope,
+                                    float* dgamma, float* dbeta, float* dbias, float* par_ws, wdg_stream stream) {
+    WDG_CHECK_ARG(x && w && dscore && dx && y && mean_rstd && gamma, "null argument");
+    WDG_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 1024 && K % C == 0, "the head's input must be whole pixels of C <= 1024 channels, C % 4 == 0");
+    WDG_CHECK_ARG(((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)gamma & 15) == 0, "16-byte alignment");
+    const bool want_par = dgamma || dbeta || dbias;
+    WDG_CHECK_ARG(!want_par || par_ws, "parameter gradients need the scratch");
+    const int64_t rows_px = (int64_t)B * T * (K / C);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((rows_px + 3) / 4, 1024));
+    hipLaunchKernelGGL(wdg_dense_gap_bwd_ln_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, dscore, dx, dw, db, B, T, K, y,
+                       mean_rstd, gamma, C, act_slope, want_par ? par_ws : nullptr, WDG_LNB_REP);
+    WDG_LAUNCH_CHECK();
+    if (!want_par) return WDG_OK;
+    return wdg_lnb_finish(par_ws, WDG_LNB_REP, C, dgamma, dbeta, dbias, (hipStream_t)stream);
+}

@@ -986,11 +986,21 @@ class HipOps:
     def convlstm1_supported(self, cin, F):
         return bool(self.lib.wdg_convlstm1_supported(cin, F))
 
-    def convlstm1_fwd(self, x, wx, bias, h, cin, F):
-        """Fused single-timestep ConvLSTM: x [N,H,W,>=cin] -> h[..., :F] (gates are not stored)."""
+    def convlstm1_x2_supported(self, cin, F, n2):
+        return bool(self.lib.wdg_convlstm1_x2_supported(cin, F, n2))
+
+    def convlstm1_fwd(self, x, wx, bias, h, cin, F, x2=None):
+        """Fused single-timestep ConvLSTM: x [N,H,W,>=cin] -> h[..., :F] (gates are not stored).
+        x2 = (tensor [N,H,W,>=n2], n2): the layer's LAST n2 input channels are read from that tensor instead of x (the
+        high-res part of the [low | high] concatenation read in place — wdg_convlstm1_fwd_x2)."""
         px, ldx, isx = _v4(x)
         ph, ldh, ish = _v4(h)
         n, H, W, _ = x.shape
+        if x2 is not None:
+            p2, ld2, is2 = _v4(x2[0])
+            native.check(self.lib.wdg_convlstm1_fwd_x2(px, ldx, isx, p2, ld2, is2, int(x2[1]), wx.data_ptr(), bias.data_ptr(), ph, ldh, ish,
+                                                       n, H, W, cin, F, self.stream), "convlstm1_fwd_x2")
+            return
         native.check(self.lib.wdg_convlstm1_fwd(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), ph, ldh, ish, n, H, W,
                                                 cin, F, self.stream), "convlstm1_fwd")
 
@@ -1005,13 +1015,22 @@ class HipOps:
         native.check(self.lib.wdg_convlstm_gates_x(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), gates.data_ptr(), n, H, W, cin, F,
                                                    self.stream), "convlstm_gates_x")
 
-    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False, dw=None, dbias=None):
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False, dw=None, dbias=None, x2=None):
         """dgates [N,H,W,4F] (dense, optional) and dx[..., :cin] (optional) from x and dh, recomputing the gates.
         dw / dbias given: the kernel and bias gradient are accumulated in the same pass (no dgates tensor)."""
         px, ldx, isx = _v4(x)
         pdh, lddh, isdh = _v4(dh)
         n, H, W, _ = x.shape
         pdx, lddx, isdx = _v4(dx) if dx is not None else (0, 0, 0)
+        if x2 is not None:
+            # (x2 as in convlstm1_fwd: the last channels of the input from a second tensor — wdg_convlstm1_bwd_x2)
+            assert dgates is None and (dw is None or (dbias is not None and dw.is_contiguous()))
+            p2, ld2, is2 = _v4(x2[0])
+            ws = self._workspace(int(self.lib.wdg_convlstm1_wgrad_ws_bytes(n, H, W, cin, F))) if dw is not None else None
+            native.check(self.lib.wdg_convlstm1_bwd_x2(px, ldx, isx, p2, ld2, is2, int(x2[1]), wx.data_ptr(), bias.data_ptr(), pdh, lddh, isdh,
+                                                       pdx, lddx, isdx, int(accumulate_dx), n, H, W, cin, F, _ptr(dw), _ptr(dbias),
+                                                       _ptr(ws), ws.numel() if ws is not None else 0, self.stream), "convlstm1_bwd_x2")
+            return
         if dw is not None:
             assert dgates is None and dbias is not None and dw.is_contiguous()
             ws = self._workspace(int(self.lib.wdg_convlstm1_wgrad_ws_bytes(n, H, W, cin, F)))
@@ -1099,6 +1118,14 @@ class HipOps:
     def dense_gap_bwd(self, x, w, dscore, dx, dw, db, B, T):
         native.check(self.lib.wdg_dense_gap_bwd(x.data_ptr(), w.data_ptr(), dscore.data_ptr(), _ptr(dx), _ptr(dw),
                                                 _ptr(db), B, T, x.shape[1], self.stream), "dense_gap_bwd")
+
+    def dense_gap_bwd_ln(self, x, w, dscore, dx, dw, db, B, T, y, mean_rstd, gamma, C, act_slope, dgamma, dbeta, dbias, par_ws=None):
+        """dense_gap_bwd chained with the backward of the LayerNormalization (+ LeakyReLU) that produced x from y [rows * K / C, C]:
+        dx receives the gradient w.r.t. that norm's producer's pre-activation (wdg_dense_gap_bwd_ln: dense_gap_bwd + ln_bwd in
+        one launch, dz stays in registers)."""
+        native.check(self.lib.wdg_dense_gap_bwd_ln(x.data_ptr(), w.data_ptr(), dscore.data_ptr(), dx.data_ptr(), _ptr(dw), _ptr(db), B, T,
+                                                   x.shape[1], y.data_ptr(), mean_rstd.data_ptr(), gamma.data_ptr(), int(C), float(act_slope),
+                                                   _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(par_ws), self.stream), "dense_gap_bwd_ln")
 
     # ---- elementwise / reductions -----------------------------------------------------------
     def copy_channels(self, src, dst, accumulate=False):

@@ -292,14 +292,23 @@ class ConvLSTM:
         """Single timestep + few channels: the fused, gate-recomputing kernels (convlstm1.hip)."""
         return T == 1 and self.ops.convlstm1_supported(self.cin, self.F)
 
-    def forward(self, x, h, B, T, bf16=False, fmt="bf16"):
+    def x2_ok(self, T, n2):
+        """Can this layer read its last n2 input channels from a second tensor (forward(..., x2=) / backward(..., x2=))?"""
+        return self._fused1(T) and hasattr(self.ops, "convlstm1_x2_supported") and self.ops.convlstm1_x2_supported(self.cin, self.F, n2)
+
+    def forward(self, x, h, B, T, bf16=False, fmt="bf16", x2=None):
         """x: [T*B,H,W,>=cin] view; h: [T*B,H,W,round4(F)] output buffer (pad channels stay zero).
-        bf16=True: the two convolutions run at inference precision (the cell math stays fp32)."""
+        bf16=True: the two convolutions run at inference precision (the cell math stays fp32).
+        x2 = (tensor, n2) (x2_ok layers only): the last n2 input channels are read from that tensor instead of x."""
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
         if self._fused1(T):
-            o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
+            if x2 is not None:
+                o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F, x2=x2)
+            else:
+                o.convlstm1_fwd(x, self.wx.value, self.b.value, h, self.cin, F)
             return
+        assert x2 is None
         self._buffers(N, H, W)
         if bf16 and T > 1 and hasattr(o, "convlstm16_supported") and \
                 o.convlstm16_supported(x[:B], self.gates[:B], self.pkh, self.g, F) and \
@@ -355,17 +364,19 @@ class ConvLSTM:
         else:
             time_loop()
 
-    def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False):
+    def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False, x2=None):
         """dh: total gradient w.r.t. every h_t (modified in place by the BPTT recursion);
-        dx: view receiving the input gradient (None to skip)."""
+        dx: view receiving the input gradient (None to skip).  x2: as in forward."""
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
         if self._fused1(T):
             # input gradient and (need_wgrad) kernel + bias gradient in ONE kernel: the gates are recomputed from x and
             # the dense dgates tensor is never materialised
+            kw = {} if x2 is None else {"x2": x2}
             o.convlstm1_bwd(x, self.wx.value, self.b.value, dh, None, dx, self.cin, F, accumulate_dx=accumulate_dx,
-                            dw=self.wx.grad if need_wgrad else None, dbias=self.b.grad if need_wgrad else None)
+                            dw=self.wx.grad if need_wgrad else None, dbias=self.b.grad if need_wgrad else None, **kw)
             return
+        assert x2 is None
         if self.dgates is None:
             self.dgates = o.empty(N, H, W, 4 * F)
             self.dc = [o.empty(B, H, W, F), o.empty(B, H, W, F)]

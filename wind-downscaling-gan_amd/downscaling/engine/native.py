@@ -110,6 +110,10 @@ SIGNATURES = {
     "wdg_convlstm1_fwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_bwd": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp, i32, i64, i32,
                                  i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convlstm1_x2_supported": (i32, [i32, i32, i32]),
+    "wdg_convlstm1_fwd_x2": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convlstm1_bwd_x2": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i64, i32,
+                                    i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, szt, c_fp]),
     "wdg_convlstm1_wgrad_ws_bytes": (szt, [i32, i32, i32, i32, i32]),
     "wdg_convlstm1_bwd_wgrad": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i64, i32,
                                       i32, i32, i32, i32, i32, c_fp, c_fp, c_fp, szt, c_fp]),
@@ -139,6 +143,7 @@ SIGNATURES = {
     "wdg_patch_scatter": (i32, [c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_dense_gap_fwd": (i32, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
     "wdg_dense_gap_bwd": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "wdg_dense_gap_bwd_ln": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp, c_fp, c_fp, i32, f32, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "wdg_copy_channels": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, i64, i32, i32, c_fp]),
     "wdg_copy_channels_2level": (i32, [c_fp, i32, i64, i64, c_fp, i32, i64, i64, i32, i32, i64, i32, i32, c_fp]),
     "wdg_colsum": (i32, [c_fp, i32, i64, i32, c_fp, i32, c_fp]),

@@ -455,6 +455,7 @@ class DiscriminatorNet(_Net):
         # writes back / invalidates the per-XCD L2s under the other's running kernel); 91.6 -> 88.4 ms per T = 24 step without it
         # Round 4: OFF by default at every T — beside the generator / twin streams the branch overlap loses (68.9 vs 67.2 ms at eight
         # hardware queues, neutral at four: profiles/r04f_sched.txt)
+        self.mix_in_place = os.environ.get("WDG_MIX_IN_PLACE", "1") != "0"         # (A/B switch: high-res channels of concat(low, high) read in place)
         self.chain_ln_bwd = os.environ.get("WDG_CHAIN_LN_BWD", "1") != "0"       # (A/B switch: LayerNorm backward in the upstream data gradient's epilogue)
         mode = os.environ.get("WDG_OVERLAP_BRANCHES", "0")
         self.overlap_branches = mode != "0"
@@ -549,7 +550,14 @@ class DiscriminatorNet(_Net):
         else:
             self.ops.copy_channels(high_tm[..., :self.ch], b["hi"][..., :self.ch])
             b["hi_view"] = b["hi"]
-        self.ops.copy_channels(high_tm[..., :self.ch], b["mix"][..., self.cl:self.cl + self.ch])
+        # models.py:100: concat(low, high).  Where the low + high ConvLSTM can read its last `ch` channels from a second tensor
+        # (single timestep, fused kernels: ConvLSTM.x2_ok) the high-res part is read in place from hi_view and the concatenation is
+        # never completed — its low-res part was written once per step by set_low; otherwise the two channels are copied in
+        if self.mix_in_place and self.lstm_b.x2_ok(self.T, self.ch):
+            b["mix_x2"] = (b["hi_view"], self.ch)
+        else:
+            b["mix_x2"] = None
+            self.ops.copy_channels(high_tm[..., :self.ch], b["mix"][..., self.cl:self.cl + self.ch])
 
     def forward(self, B, training, prepared=False):
         """Scores [B] for the resident (low, high) buffers.  prepared=True: the caller has run _prepare(training) for this
@@ -566,13 +574,13 @@ class DiscriminatorNet(_Net):
             with o.fork() as side:
                 self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
                 self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
-            self.lstm_b.forward(b["mix"], b["hb"], B, T)
+            self.lstm_b.forward(b["mix"], b["hb"], B, T, x2=b.get("mix_x2"))
             self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
             side.join()
         else:
             self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
             self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
-            self.lstm_b.forward(b["mix"], b["hb"], B, T)
+            self.lstm_b.forward(b["mix"], b["hb"], B, T, x2=b.get("mix_x2"))
             self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
         x = b["cat"]
         for i, (conv, ln, osz, co) in enumerate(self.blocks):
@@ -655,16 +663,27 @@ class DiscriminatorNet(_Net):
             dx = b["dzs"][-1]
         else:
             dx = b["dcat"]
-        o.dense_gap_bwd(x.view(N, self.K), self.dense_w.value.view(-1), dscore, dx.view(N, self.K),
-                        self.dense_w.grad.view(-1) if need_wgrad else None,
-                        self.dense_b.grad if need_wgrad else None, B, T)
+        chain = self.chain_ln_bwd and hasattr(o, "conv_dgrad_lnbwd")
+        top_split = self.shortcut is not None and self.shortcut["block"] == len(self.blocks) - 1
+        ln_done = False
+        if chain and self.blocks and not top_split and self.final_ch % 4 == 0 and self.final_ch <= 1024:
+            # the head's backward and the top block's LayerNorm backward in one launch (dz = dscore / T * w stays in registers)
+            tconv, tln = self.blocks[-1][0], self.blocks[-1][1]
+            o.dense_gap_bwd_ln(x.view(N, self.K), self.dense_w.value.view(-1), dscore, dx.view(N, self.K),
+                               self.dense_w.grad.view(-1) if need_wgrad else None, self.dense_b.grad if need_wgrad else None, B, T,
+                               b["ys"][-1], tln.mean_rstd, tln.gamma.value, self.final_ch, LRELU,
+                               tln.gamma.grad if need_wgrad else None, tln.beta.grad if need_wgrad else None,
+                               tconv.b.grad if need_wgrad else None, tln.lnbwd_scratch() if need_wgrad else None)
+            ln_done = True
+        else:
+            o.dense_gap_bwd(x.view(N, self.K), self.dense_w.value.view(-1), dscore, dx.view(N, self.K),
+                            self.dense_w.grad.view(-1) if need_wgrad else None,
+                            self.dense_b.grad if need_wgrad else None, B, T)
         # The LayerNormalization backward of a block runs in the epilogue of the data gradient that PRODUCES its dz — the
         # data gradient of the block above it (Conv.backward_input_through_ln: the epilogue holds dz for all channels of a
         # pixel, so the norm's two reductions run on the accumulators and the standalone pass over dz disappears) — wherever
         # nothing else adds to that dz afterwards (the shortcut's share arrives by a later accumulate).  ln_done: the dz this
         # iteration starts from has been through its norm's backward already.
-        chain = self.chain_ln_bwd and hasattr(o, "conv_dgrad_lnbwd")
-        ln_done = False
         b_chained = False
         for i in range(len(self.blocks) - 1, -1, -1):
             conv, ln, osz, co = self.blocks[i]
@@ -699,7 +718,8 @@ class DiscriminatorNet(_Net):
 
         def branch_b():   # low + high
             self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad, ln_done=b_chained)
-            self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
+            self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad,
+                                 x2=b.get("mix_x2"))
 
         if getattr(self, "_overlap_now", False):
             with o.fork() as side:

@@ -145,6 +145,7 @@ class GanEngine:
         self.overlap_discriminator = os.environ.get("WDG_OVERLAP_DISC", "1") != "0"
         self.hoist_first_real_pass = os.environ.get("WDG_HOIST_REAL", "0") != "0"      # measured: 66.45 vs 66.25 ms with it (profiles/r04s_hoist.txt) - big kernels of two networks side by side gain nothing
         self._disc_stream = None
+        self.assemble_input = os.environ.get("WDG_ASSEMBLE_INPUT", "0") != "0"     # (A/B switch of _gen_noise_at: measured neutral in the train step - 64.6 vs 64.4 ms, the draw runs on the generator stream under the discriminator passes - and left off)
 
     def _buf(self, key, *shape):
         t = self._tmp.get(key)
@@ -162,6 +163,23 @@ class GanEngine:
             t.fill_(value)
             ent = self._tmp[("const", key)] = (t, value)
         return ent[0]
+
+    def _gen_noise_at(self, low, B, offset):
+        """The generator's noise channels (ganbase.py:28,51,65) drawn at Philox offset `offset`.  Where the backend has the
+        one-pass input assembly (wdg_input_assemble: [image | noise | 0] per pixel with 16-byte stores, the same counters
+        and arithmetic as philox_normal) the whole input row is rewritten — 104 -> ~60 us per draw at the headline shape:
+        the strided 4-byte stores of the noise-only kernel are what it is bound by; otherwise the noise slice alone."""
+        gen, noise = self.gen, self.noise
+        ok = getattr(self.ops, "input_assemble_ok", None)
+        rows = gen.input_rows(B)
+        if self.assemble_input and ok is not None and low.shape[-1] == gen.in_channels and ok(gen.in_channels, gen.noise_channels, rows.shape[1]):
+            noise.assemble_at(low, rows, B, gen.S * gen.S, gen.noise_channels, self.noise_std, offset)
+        else:
+            noise.normal_at(gen.noise_view(B), self.noise_std, offset)
+
+    def _gen_noise(self, low, B):
+        nv = self.gen.noise_view(B)
+        self._gen_noise_at(low, B, self.noise.reserve(nv.shape[0] * nv.shape[1]))
 
     def _reduce_and_step(self, net, opt):
         """Gradient all-reduce + optimizer step.  With several ranks the all-reduce is started asynchronously and the
@@ -245,7 +263,7 @@ class GanEngine:
         disc.params.grads.add_(twin.params.grads)
         return loss.detach(), real_scores.mean(), fake_scores.mean()
 
-    def _critic_pipelined(self, B, T, real, comb, noisy, eps, gsq, ones, sw_mean, d_opt):
+    def _critic_pipelined(self, low, B, T, real, comb, noisy, eps, gsq, ones, sw_mean, d_opt):
         """The critic iterations (ganbase.py:26-47) with the generator forward of iteration i + 1 on a second HIP stream under
         the three discriminator passes of iteration i.  Within a train step the generator's weights do not depend on the
         discriminator's, so the only ordering the reference imposes between them is the data: fake_i feeds the interpolate and
@@ -301,7 +319,7 @@ class GanEngine:
         hoisted = None
         if twin is not None and self.hoist_first_real_pass:
             hoisted = start_real_pass(offs[0][2])
-        noise.normal_at(nview, self.noise_std, offs[0][0])                        # :28
+        self._gen_noise_at(low, B, offs[0][0])                                    # :28
         fake = gen.forward(B, training=True, need_backward=False)                 # :29
         for i in range(self.n_critic):
             o_g, o_e, o_r, o_f = offs[i]
@@ -311,13 +329,13 @@ class GanEngine:
             gs.wait_stream(main)                                                  # fake_i has been consumed
             with torch.cuda.stream(gs):
                 if i + 1 < self.n_critic:
-                    noise.normal_at(nview, self.noise_std, offs[i + 1][0])
+                    self._gen_noise_at(low, B, offs[i + 1][0])
                     fake = gen.forward(B, training=True, need_backward=False)
                 else:
                     # the forward of the GENERATOR step (:50-52) does not read the discriminator either: under the last
                     # iteration's passes
                     gen.params.zero_grad()
-                    noise.normal_at(nview, self.noise_std, o_gstep)
+                    self._gen_noise_at(low, B, o_gstep)
                     fake = gen.forward(B, training=True, need_backward=True)
             if twin is not None:
                 if i == 0 and hoisted is not None:
@@ -385,9 +403,9 @@ class GanEngine:
         ones = self._const("ones", B, 1.0)
 
         if pipelined:
-            disc_loss, gnorm, dscale, fake = self._critic_pipelined(B, T, real, comb, noisy, eps, gsq, ones, sw_mean, d_opt)
+            disc_loss, gnorm, dscale, fake = self._critic_pipelined(low, B, T, real, comb, noisy, eps, gsq, ones, sw_mean, d_opt)
         for _ in range(0 if pipelined else self.n_critic):                        # ganbase.py:26
-            noise.normal_into(gen.noise_view(B), self.noise_std)                   # :28
+            self._gen_noise(low, B)                                               # :28
             fake = gen.forward(B, training=True, need_backward=False)             # :29 (outside any tape)
             noise.uniform_into(eps)                                               # :30
             ops.lerp_batch(v2(real), v2(fake), eps, v2(comb), ppi, B)             # :31
@@ -416,7 +434,7 @@ class GanEngine:
             dscale = self._reduce_and_step(disc, d_opt)                           # :46-47
         if not pipelined:
             gen.params.zero_grad()                                                # generator step, :50-61
-            noise.normal_into(gen.noise_view(B), self.noise_std)
+            self._gen_noise(low, B)
             fake = gen.forward(B, training=True, need_backward=True)              # overlaps the last D exchange
         self._flush(disc)
         d_gradient_param = self._grad_param_metric(disc, dscale)
@@ -456,7 +474,7 @@ class GanEngine:
             real_mean = real_scores.mean()
         self._flush(gen)
         g_gradient_param = self._grad_param_metric(gen, gscale)
-        noise.normal_into(gen.noise_view(B), self.noise_std)
+        self._gen_noise(low, B)
         fake = gen.forward(B, training=False)
         disc.set_high_tm(fake, B)
         fake_scores = disc.forward(B, training=False)
@@ -503,7 +521,7 @@ class GanEngine:
         disc.set_low(low)
         real = self._buf("real", T * B, S, S, chp)
         gen.to_time_major(high, real)
-        self.noise.normal_into(gen.noise_view(B), self.noise_std)                 # :99
+        self._gen_noise(low, B)                                                   # :99
         disc.set_high_tm(real, B)
         real_scores = disc.forward(B, training=False).clone()                     # :100
         fake = gen.forward(B, training=False)                                     # :101
