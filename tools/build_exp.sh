@@ -9,6 +9,7 @@ OBJS=$(ls *.o | grep -v '^conv_igemm.o$')
 for BITS in "$@"; do
   case "$BITS" in
     early) FLAGS="-DWDG_EARLY_LOADS=1";;     # operand requests pinned in front of the MFMAs on the narrow tiles
+    prio) FLAGS="-DWDG_MFMA_PRIO=1";;        # s_setprio(1)/(0) around the MFMA clusters
     *) FLAGS="-DWDG_KLOOP_EXP=$BITS";;
   esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $FLAGS -c conv_igemm.hip -o /tmp/igemm_exp$BITS.o

@@ -137,6 +137,11 @@ __device__ __forceinline__ bool wdg_row_valid(const WdgPhase& ph, int Mph, int m
 #ifndef WDG_EARLY_LOADS
 #define WDG_EARLY_LOADS 0
 #endif
+// -DWDG_MFMA_PRIO=1: s_setprio(1) / (0) around every cluster of MFMAs of the K loops (cdna_hip_programming.md T5: a compiler effect —
+// the cluster stays between the barriers it was written between)
+#ifndef WDG_MFMA_PRIO
+#define WDG_MFMA_PRIO 0
+#endif
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
 __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 && KG == 1 && !WDG_EARLY_LOADS) ? 4 : 1) wdg_igemm_kernel(const WdgIgemm p) {
     static_assert(KG == 1 || (KG == 2 && PIPE == 3 && (EPI == 0 || EPI == 4)), "in-workgroup split: rotated loop, barrier-free epilogues");
@@ -286,6 +291,7 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
         for (int b = 0; b < NT; ++b) bf[b] = ldsB[kgr * BN + ((wn * (BN / WGN) + b * 16 + (lane & 15)) ^ kgr)];
     };
     auto mfma_block = [&](const f32x4 (&af)[MT], const f32x4 (&bf)[NT]) {
+        if constexpr (WDG_MFMA_PRIO != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -295,6 +301,7 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
                     // A = weights, B = pixels: the accumulator holds the TRANSPOSED tile — reg r of lane (i = lane & 15,
                     // q = lane >> 4) is output channel 4q + r of pixel i — so the epilogue writes 16 bytes per lane
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[b][j], af[a][j], acc[a][b], 0, 0, 0);
+        if constexpr (WDG_MFMA_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     };
 
     if constexpr (PIPE == 4) {
@@ -1775,7 +1782,11 @@ static int g_phase_major = 1;   // strided data gradients: the s*s phases of an 
 static int g_igemm_pipe = 3;   // measured (profiles/r01ad_perf_conv_pipe3.log): the rotated single-block loop is 2-12 % faster than 0, 1, 2
 
 static int g_igemm_dma = 4;        // wdg_set_tuning("igemm_dma", mask): tiles that run the LDS-DMA K loop (launch_igemm)
-static int g_dgrad_lnbwd = 3;      // wdg_set_tuning("dgrad_lnbwd", 0/1): LayerNorm backward in the data gradient's epilogue (wdg_conv_dgrad_lnbwd)
+// wdg_set_tuning("dgrad_lnbwd", bits): bit 0: LayerNorm backward in the data gradient's epilogue / split-K second stage (wdg_conv_dgrad_lnbwd);
+// bit 1: a 64 x 128 tile (a 128-channel row in one wave) where the plain launch would take 64 x 64 tiles — measured SLOWER on the 27 x 27 map
+// of the discriminator's third block (137 us against 101 + 15 us for the 64 x 64 launch + the standalone pass: matrix pipe busy 0.38 at
+// 1.4 workgroups per CU, profiles/r05k_pmc_summary.csv) and off
+static int g_dgrad_lnbwd = 1;
 static int g_ln_wave = 1;     // wdg_set_tuning("ln_wave", 0/1): the 128 x 64 tile's LayerNorm epilogue on 4 x 1 waves (in-wave reductions)
 static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
 static int g_tuning_epoch = 0;

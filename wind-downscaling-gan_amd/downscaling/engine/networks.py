@@ -455,7 +455,11 @@ class DiscriminatorNet(_Net):
         # writes back / invalidates the per-XCD L2s under the other's running kernel); 91.6 -> 88.4 ms per T = 24 step without it
         # Round 4: OFF by default at every T — beside the generator / twin streams the branch overlap loses (68.9 vs 67.2 ms at eight
         # hardware queues, neutral at four: profiles/r04f_sched.txt)
-        self.mix_in_place = os.environ.get("WDG_MIX_IN_PLACE", "1") != "0"         # (A/B switch: high-res channels of concat(low, high) read in place)
+        # WDG_MIX_IN_PLACE=1: the high-res channels of concat(low, high) read in place by the fused ConvLSTM kernels (ConvLSTM.x2_ok).
+        # Measured neutral and OFF by default: the 16 two-channel copies per step it removes (0.31 ms on one stream) come back as
+        # pixel-per-lane 4-byte requests in the kernels' halo staging (fused backward 371 -> 406 us, forward 95 -> 105 us: those
+        # stagings are bound by the texture path's line count), 64.26 vs 64.27 ms per step (profiles/r05hij_ab_step_*.txt)
+        self.mix_in_place = os.environ.get("WDG_MIX_IN_PLACE", "0") != "0"
         self.chain_ln_bwd = os.environ.get("WDG_CHAIN_LN_BWD", "1") != "0"       # (A/B switch: LayerNorm backward in the upstream data gradient's epilogue)
         mode = os.environ.get("WDG_OVERLAP_BRANCHES", "0")
         self.overlap_branches = mode != "0"
