@@ -268,10 +268,6 @@ class HipOps:
         self._sn_scratch = None
         # fp32 implicit-GEMM products from three bf16 slices per operand (conv_igemm.hip PIPE 4; measurement mode, off by default):
         # WDG_SPLIT=1 or set_split_mode(True) at any time: the mode is read per launch, plans do not depend on it
-        # WDG_TUNING="key=val,key=val": library tuning knobs (wdg_set_tuning) for A/B runs of whole steps / test suites
-        for item in filter(None, os.environ.get("WDG_TUNING", "").split(",")):
-            k, _, v = item.partition("=")
-            native.check(self.lib.wdg_set_tuning(k.strip().encode(), int(v)), f"WDG_TUNING {item}")
         self.split_mode = False
         if os.environ.get("WDG_SPLIT", "0") == "1":
             self.set_split_mode(True)

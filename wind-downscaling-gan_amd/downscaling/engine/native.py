@@ -189,7 +189,7 @@ def load():
         fn.argtypes = args
     _lib = lib
     # measurement runs: WDG_TUNE="key=int,key=int" -> wdg_set_tuning before anything is planned (unknown keys raise)
-    for kv in filter(None, os.environ.get("WDG_TUNE", "").split(",")):
+    for kv in filter(None, (os.environ.get("WDG_TUNE", "") + "," + os.environ.get("WDG_TUNING", "")).split(",")):      # (WDG_TUNING: alias)
         key, _, val = kv.partition("=")
         if lib.wdg_set_tuning(key.strip().encode(), int(val)) != 0:
             raise NativeError(f"WDG_TUNE: {kv!r} rejected by wdg_set_tuning")
