@@ -26,6 +26,21 @@ export WDG_OVERLAP_GEN=0 WDG_WGRAD_STREAM=0 WDG_OVERLAP_BRANCHES=0
 STATS=$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/${TAG}_kernel_stats_serial.csv
 rm -rf $OUT/${TAG}_trace
+# the dominant kernel's average launch duration under the tracer (one-stream schedule) -> rocprof_dominant.json (bench.py quotes it
+# beside its HIP-event figure when the kernel sources and the launch mix match)
+python3 - "$OUT/${TAG}_kernel_stats_serial.csv" "$OUT/rocprof_dominant.json" <<'PY'
+import csv, hashlib, json, sys
+from pathlib import Path
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Name"].startswith("void wdg_igemm_kernel<128, 128")]
+calls, ns = sum(int(r["Calls"]) for r in rows), sum(float(r["TotalDurationNs"]) for r in rows)
+h = hashlib.sha256()
+for f in sorted((Path("wind-downscaling-gan_amd") / "csrc").glob("*.h*")):
+    h.update(f.name.encode()); h.update(f.read_bytes())
+steps = 2      # bench.py --steps 1 --warmup 1: two train steps in the trace
+json.dump({"kernel": "wdg_igemm_kernel<128,128>", "csrc_sha256": h.hexdigest(), "launches_per_step": calls / steps,
+           "avg_launch_us": ns / calls * 1e-3, "source": sys.argv[1] + " (rocprofv3 --kernel-trace --stats, one-stream schedule)"},
+          open(sys.argv[2], "w"), indent=1)
+PY
 if [ -z "$QUICK" ]; then
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc1.log 2>&1 )
   ( cd /tmp && rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $ROOT/$OUT/pmc_write -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc2.log 2>&1 )

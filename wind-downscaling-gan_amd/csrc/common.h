@@ -116,6 +116,17 @@ __device__ __forceinline__ f32x4 wdg_buffer_load_f32x4(wdg_srd srd, unsigned byt
 }
 #endif
 
+#if defined(__HIPCC__)
+// Bijective XCD-aware remap (cdna_hip_programming.md T1): hardware deals consecutive workgroups round-robin
+// over the 8 XCDs; give XCD x the contiguous tile range [x*q + min(x,r), ...) so that neighbouring output
+// tiles, which share input rows (kh > stride) and the same filter panel, hit the same 4 MiB L2.
+__device__ __forceinline__ int wdg_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+#endif
+
 // ---- LayerNorm-backward parameter gradients of the fused launches (conv_igemm.hip EPI 5, the split-K second stage, the dense head):
 // blocks add their partial sums into one of WDG_LNB_REP replica slabs [3][C] (dgamma, dbeta, dbias); wdg_lnb_finish (norms.hip) sums
 // the replicas into the gradient vectors and clears them

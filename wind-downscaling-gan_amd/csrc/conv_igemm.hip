@@ -90,14 +90,6 @@ struct WdgIgemm {
     WdgPhase ph[9];
 };
 
-// Bijective XCD-aware remap (cdna_hip_programming.md T1): hardware deals consecutive workgroups round-robin
-// over the 8 XCDs; give XCD x the contiguous tile range [x*q + min(x,r), ...) so that neighbouring output
-// tiles, which share input rows (kh > stride) and the same filter panel, hit the same 4 MiB L2.
-__device__ __forceinline__ int wdg_xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
 // row index of a phase -> (image, pa, pb): linear order, or 2-D row tiles (WdgPhase::t2_w: rows are "virtual", tile * BM + row
 // in tile; rows >= t2_rows of a tile are idle — wdg_row_valid)
 template <int BM>
@@ -1557,8 +1549,9 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
 // row / column tiles of one pixel split then run back to back on ONE XCD and share its L2 copy of the x / dy window: fabric fetch of
 // the 7x7 stride-3 32 -> 64 weight gradient 1,726 -> 438 MB per launch, L2 hit 0.16 -> 0.78 (profiles/r05b_*: time in isolation
 // unchanged, 464 vs 467 us — the kernel is not bound by its fetch —, but 1.3 GB less fabric traffic per launch for whatever runs beside it)
-static int g_wgrad_xcd = 32;
+static int g_wgrad_xcd = 64;
 static int g_wgrad_reduce4 = 1;     // wdg_set_tuning("wgrad_reduce4", 0/1): 16-byte second stage of the split weight gradients
+static int g_tap_chunk_order = 1;   // wdg_set_tuning("tap_chunk_order", 0/1): stride-1 layers with > 32 input channels in chunk-major tap order (plans created afterwards)
 static int g_tap_class_order = 1;   // wdg_set_tuning("tap_class_order", 0/1): forward tables of strided layers in residue-class order (plans created afterwards)
 static int g_wgrad_bn160 = 32;   // wdg_set_tuning("wgrad_bn160", 32 | 64 | 128): column tile of 160-column weight gradients
 static int pick_wgrad_bn(int ncols) {
@@ -1635,10 +1628,18 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
         for (int b = 0; b < cls; ++b)
             for (int th = a; th < g->kh; th += cls)
                 for (int tw = b; tw < g->kw; tw += cls) tap_order.push_back(std::make_pair(th, tw));
+    // Channel chunks.  A K-step is 8 table entries = 32 channels of one tap.  With more than 32 input channels and stride 1 (one
+    // residue class: consecutive taps read the same lines shifted by a pixel) tap-major order walks ALL channel chunks of a tap
+    // before the next tap returns to the first chunk's lines — Cin / 32 K-steps later, by which time the other resident workgroups
+    // have evicted them (3x3 128 -> 64 forward: 541 MB fetched for a 67 MB input).  Chunk-major order (all taps of one 32-channel
+    // chunk, then the next chunk) makes the re-reads consecutive K-steps.  wdg_set_tuning("tap_chunk_order", 0/1).
+    const int nchunk = (g_tap_chunk_order && g->stride == 1 && pl->Cin_p > 32 && pl->Cin_p % 32 == 0) ? pl->Cin_p / 32 : 1;
+    const int c4_per_chunk = pl->Cin_p / 4 / nchunk;
+    for (int chunk = 0; chunk < nchunk; ++chunk)
     for (auto& tt : tap_order) {
         const int th = tt.first, tw = tt.second;
         {
-            for (int c4 = 0; c4 < pl->Cin_p / 4; ++c4) {
+            for (int c4 = chunk * c4_per_chunk; c4 < (chunk + 1) * c4_per_chunk; ++c4) {
                 const int tap = th * g->kw + tw;
                 int4 e;
                 e.x = (th * g->W + tw) * g->ldx + 4 * c4;
@@ -1672,12 +1673,17 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
             ph.o_off_w = rw;
             ph.tab_off = (int)td.size();
             int cnt = 0;
+            // (the taps of a phase form one residue class; with more than 32 output channels the reduction walks them chunk-major,
+            // as the forward table: a 3x3 128 -> 512 data gradient otherwise returns to a dy line 16 K-steps later)
+            const int dchunks = (g_tap_chunk_order && pl->Cout_p > 32 && pl->Cout_p % 32 == 0) ? pl->Cout_p / 32 : 1;
+            const int dc4 = pl->Cout_p / 4 / dchunks;
+            for (int chunk = 0; chunk < dchunks; ++chunk)
             for (int th = (rh + g->pad_h) % s; th < g->kh; th += s)
                 for (int tw = (rw + g->pad_w) % s; tw < g->kw; tw += s) {
                     const int dh = (rh + g->pad_h - th) / s;  // exact: numerator divisible by s
                     const int dw = (rw + g->pad_w - tw) / s;
                     const int tap = th * g->kw + tw;
-                    for (int c4 = 0; c4 < pl->Cout_p / 4; ++c4) {
+                    for (int c4 = chunk * dc4; c4 < (chunk + 1) * dc4; ++c4) {
                         int4 e;
                         e.x = (dh * g->Wo + dw) * g->ldy + 4 * c4;
                         e.y = dh;
@@ -1867,6 +1873,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_wgrad_xcd = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "gather_xcd")) {
+        wdg_upconv_set_gather_xcd(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "igemm_dma")) {
         g_igemm_dma = value;
         return WDG_OK;
@@ -1877,6 +1887,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "wgrad_reduce4")) {
         g_wgrad_reduce4 = value != 0;
+        return WDG_OK;
+    }
+    if (key && !strcmp(key, "tap_chunk_order")) {
+        g_tap_chunk_order = value != 0;
         return WDG_OK;
     }
     if (key && !strcmp(key, "tap_class_order")) {

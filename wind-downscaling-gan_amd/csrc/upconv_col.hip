@@ -115,6 +115,8 @@ extern "C" int wdg_upconv_col(const float* dy, int ldy, int64_t img_stride_dy, f
 // pixel) is staged in LDS, reduced horizontally into H[12][16][C], and each thread adds its two vertical terms.
 // ZF: element format of z — 0 fp32, 1 bf16, 2 fp16 (16-bit: wdg_upconv_colgemm_h16 wrote it; a thread's slot is then 8 values =
 // 16 bytes, widened to fp32 on the way into LDS; everything behind the load is the fp32 kernel)
+static int g_gather_xcd = 1;      // wdg_upconv_set_gather_xcd (wdg_set_tuning("gather_xcd", 0/1))
+void wdg_upconv_set_gather_xcd(int v) { g_gather_xcd = v != 0; }
 template <int ZF> struct WdgZT { typedef float T; };
 template <> struct WdgZT<1> { typedef __bf16 T; };
 template <> struct WdgZT<2> { typedef _Float16 T; };
@@ -122,7 +124,7 @@ template <int CQ, int ZF = 0>
 __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename WdgZT<ZF>::T* __restrict__ z, const float* __restrict__ bias,
                                                                 const float* __restrict__ affine, float* __restrict__ y,
                                                                 int ldy, long long isy, int Hl, int Wl, int act, float slope,
-                                                                double* stats, int stats_rep) {
+                                                                double* stats, int stats_rep, int xcd) {
     constexpr int ZW = TS + 4;                       // low-res window edge (12)
     constexpr int PX = 5 * CQ;                       // float4 per window pixel and tap row
     __shared__ f32x4 Z[ZW * ZW * PX];
@@ -132,8 +134,17 @@ __global__ void __launch_bounds__(256) wdg_upconv_gather_kernel(const typename W
     constexpr int HP = CQ + (CQ % 2 == 0 ? 1 : 0);
     __shared__ f32x4 Hs[ZW * 2 * TS * HP];
     const int tiles_x = (Wl + TS - 1) / TS;
-    const int i0 = (blockIdx.x / tiles_x) * TS, j0 = (blockIdx.x % tiles_x) * TS;
-    const long long n = blockIdx.y;
+    // XCD-contiguous order (xcd != 0): hardware deals consecutive workgroups round-robin over the 8 XCDs, so the horizontally
+    // adjacent tiles of an image — which share a 2-pixel ring of z, 2.25 x the tile in window reads — landed on eight different L2s;
+    // each XCD now walks a contiguous range of (image, tile) pairs
+    int tile_id = blockIdx.x;
+    long long n = blockIdx.y;
+    if (xcd) {
+        const int w = wdg_xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+        tile_id = w % (int)gridDim.x;
+        n = w / (int)gridDim.x;
+    }
+    const int i0 = (tile_id / tiles_x) * TS, j0 = (tile_id % tiles_x) * TS;
     const int t = threadIdx.x;
     const int qyl = t >> 4, qxl = t & 15;            // this thread's output pixel within the 16x16 tile
     const int qy = 2 * i0 + qyl, qx = 2 * j0 + qxl;
@@ -294,10 +305,10 @@ extern "C" int wdg_upconv_gather_h16(const void* z16, int fmt, const float* bias
 #define WDG_GATHER16(CQ_)                                                                                                          \
     if (fmt == 0)                                                                                                                  \
         hipLaunchKernelGGL((wdg_upconv_gather_kernel<CQ_, 1>), grid, block, 0, st, (const __bf16*)z16, bias, affine, y, ldy,      \
-                           (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0);                                     \
+                           (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0, g_gather_xcd);                                     \
     else                                                                                                                           \
         hipLaunchKernelGGL((wdg_upconv_gather_kernel<CQ_, 2>), grid, block, 0, st, (const _Float16*)z16, bias, affine, y, ldy,    \
-                           (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0);
+                           (long long)img_stride_y, Hl, Wl, act, slope, (double*)nullptr, 0, g_gather_xcd);
     if (C == 16) { WDG_GATHER16(4) }
     else if (C == 8) { WDG_GATHER16(2) }
     else {
@@ -320,11 +331,11 @@ extern "C" int wdg_upconv_gather(const float* z, const float* bias, const float*
     dim3 grid(tiles, n_img), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (C == 16)
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<4>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep, g_gather_xcd);
     else if (C == 8)
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<2>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep, g_gather_xcd);
     else
-        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep);
+        hipLaunchKernelGGL(wdg_upconv_gather_kernel<1>, grid, block, 0, st, z, bias, affine, y, ldy, (long long)img_stride_y, Hl, Wl, act, slope, stats, stats_rep, g_gather_xcd);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
