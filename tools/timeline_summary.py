@@ -44,6 +44,28 @@ def main():
     for s, e, _, q in evs:
         queues[q] = queues.get(q, 0) + (e - s)
     print("per queue busy ms:", {q: round(v / 1e6, 2) for q, v in sorted(queues.items())})
+    # which kernels run ALONE (no other kernel resident), and for how long: the serial sections of the schedule — a small kernel in
+    # this list is on the critical path (removing it shortens the step), one that never runs alone is hidden
+    bounds = sorted({t for s, e, _, _ in evs for t in (s, e)})
+    import bisect
+    alone = {}
+    active = []
+    evs_by_start = sorted(evs)
+    idx = 0
+    import heapq
+    heap = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        while idx < len(evs_by_start) and evs_by_start[idx][0] <= a:
+            heapq.heappush(heap, (evs_by_start[idx][1], evs_by_start[idx][2]))
+            idx += 1
+        while heap and heap[0][0] <= a:
+            heapq.heappop(heap)
+        if len(heap) == 1:
+            alone[heap[0][1]] = alone.get(heap[0][1], 0) + (b - a)
+    tot_alone = sum(alone.values()) / 1e6
+    print(f"time with exactly one kernel resident, by kernel (total {tot_alone:.2f} ms):")
+    for name, v in sorted(alone.items(), key=lambda kv: -kv[1])[:40]:
+        print(f"  {v / 1e6:7.3f} ms  {name}")
     gaps.sort(reverse=True)
     for g, at in gaps[:8]:
         before = [n for s, e, n, _ in evs if e <= at + 1 and e >= at - 1]

@@ -1022,60 +1022,91 @@ __global__ void __launch_bounds__(256) wdg_igemm_reduce_kernel(const WdgIgemm p)
 // its row (16-byte loads, lanes along the channels), applies bias + LeakyReLU, normalises the row with two wave
 // reductions and writes y, z and (mean, rstd) — the separate wdg_ln_fwd launch and its re-read of y disappear.
 // Ncols % 4 == 0, Ncols <= 1024, one phase.
+template <int WPR>
 __global__ void __launch_bounds__(256) wdg_igemm_reduce_ln_kernel(const WdgIgemm p) {
+    // WPR = 4 (few rows: the 2 x 2 and 8 x 8 maps, 128 .. 2048 rows of up to 32 slabs each): the four waves of a block share ONE
+    // row — wave w sums slabs w, w + 4, ... and the partial rows meet in LDS (fixed order) — so the chain of dependent slab reads is
+    // a quarter as long (one wave per row: 17 us for 128 rows x 32 slabs, twice per discriminator forward)
+    __shared__ f32x4 part[WPR > 1 ? 3 * 256 : 1];
     const WdgPhase ph = p.ph[0];
     const int PaPb = ph.Pa * ph.Pb;
     const int Mph = p.n_img * PaPb;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4n = p.Ncols >> 2;
     const float invC = 1.f / (float)p.Ncols;
-    for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < Mph; m += gridDim.x * 4) {
+    const int rows_per_block = WPR > 1 ? 1 : 4;
+    for (int m0 = blockIdx.x * rows_per_block; m0 < Mph; m0 += gridDim.x * rows_per_block) {
+        const int m = WPR > 1 ? m0 : m0 + wave;
         f32x4 v[4];
         float s_ = 0.f;
+        if (WPR > 1 || m < Mph) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c4 = lane + 64 * j;
-            v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c4 < c4n) {
-                const float* src = p.partial + (long long)m * p.Ncols + 4 * c4;
-                for (int sp = 0; sp < p.splitk; ++sp) v[j] += *reinterpret_cast<const f32x4*>(src + (long long)sp * p.Mmax * p.Ncols);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (p.bias) v[j][r] += p.bias[4 * c4 + r];
-                    if (p.act) v[j][r] = wdg_lrelu(v[j][r], p.slope);
-                    s_ += v[j][r];
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = lane + 64 * j;
+                v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (c4 < c4n) {
+                    const float* src = p.partial + (long long)m * p.Ncols + 4 * c4;
+                    for (int sp = (WPR > 1 ? wave : 0); sp < p.splitk; sp += WPR) v[j] += *reinterpret_cast<const f32x4*>(src + (long long)sp * p.Mmax * p.Ncols);
                 }
             }
         }
-        const float mean = wdg_wave_sum(s_) * invC;
-        float q_ = 0.f;
+        if constexpr (WPR > 1) {
+            if (wave > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (lane + 64 * j < c4n)
+                for (int j = 0; j < 4; ++j) part[((wave - 1) * 4 + j) * 64 + lane] = v[j];
+            }
+            __syncthreads();
+            if (wave == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q_ += (v[j][r] - mean) * (v[j][r] - mean);
-        const float rstd = 1.f / sqrtf(wdg_wave_sum(q_) * invC + p.ln_eps);
-        const int img = m / PaPb;
-        const int rem = m - img * PaPb;
-        const int pa = rem / ph.Pb;
-        const int pb = rem - pa * ph.Pb;
-        const long long off = (long long)img * p.imgStrideO + ((long long)(pa * p.o_mul + ph.o_off_h) * p.Wo + pb * p.o_mul + ph.o_off_w) * p.ldO;
+                for (int w = 0; w < 3; ++w)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c4 = lane + 64 * j;
-            if (c4 < c4n) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * c4), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * c4);
-                f32x4 z;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) z[r] = (v[j][r] - mean) * rstd * g[r] + bt[r];
-                *reinterpret_cast<f32x4*>(p.Out + off + 4 * c4) = v[j];
-                *reinterpret_cast<f32x4*>(p.Out2 + off + 4 * c4) = z;
+                    for (int j = 0; j < 4; ++j) v[j] += part[(w * 4 + j) * 64 + lane];
             }
         }
-        if (p.mean_rstd && lane == 0) {
-            p.mean_rstd[2 * (long long)m] = mean;
-            p.mean_rstd[2 * (long long)m + 1] = rstd;
+        if ((WPR > 1 && wave == 0) || (WPR == 1 && m < Mph)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = lane + 64 * j;
+                if (c4 < c4n) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (p.bias) v[j][r] += p.bias[4 * c4 + r];
+                        if (p.act) v[j][r] = wdg_lrelu(v[j][r], p.slope);
+                        s_ += v[j][r];
+                    }
+                }
+            }
+            const float mean = wdg_wave_sum(s_) * invC;
+            float q_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane + 64 * j < c4n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q_ += (v[j][r] - mean) * (v[j][r] - mean);
+            const float rstd = 1.f / sqrtf(wdg_wave_sum(q_) * invC + p.ln_eps);
+            const int img = m / PaPb;
+            const int rem = m - img * PaPb;
+            const int pa = rem / ph.Pb;
+            const int pb = rem - pa * ph.Pb;
+            const long long off = (long long)img * p.imgStrideO + ((long long)(pa * p.o_mul + ph.o_off_h) * p.Wo + pb * p.o_mul + ph.o_off_w) * p.ldO;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = lane + 64 * j;
+                if (c4 < c4n) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * c4), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * c4);
+                    f32x4 z;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = (v[j][r] - mean) * rstd * g[r] + bt[r];
+                    *reinterpret_cast<f32x4*>(p.Out + off + 4 * c4) = v[j];
+                    *reinterpret_cast<f32x4*>(p.Out2 + off + 4 * c4) = z;
+                }
+            }
+            if (p.mean_rstd && lane == 0) {
+                p.mean_rstd[2 * (long long)m] = mean;
+                p.mean_rstd[2 * (long long)m + 1] = rstd;
+            }
         }
+        if constexpr (WPR > 1) __syncthreads();     // (the next row reuses `part`)
     }
 }
 
@@ -1550,6 +1581,7 @@ static TileCfg pick_tile(int ncols, bool igemm = true, long long M = -1) {
 // the 7x7 stride-3 32 -> 64 weight gradient 1,726 -> 438 MB per launch, L2 hit 0.16 -> 0.78 (profiles/r05b_*: time in isolation
 // unchanged, 464 vs 467 us — the kernel is not bound by its fetch —, but 1.3 GB less fabric traffic per launch for whatever runs beside it)
 static int g_wgrad_xcd = 64;
+static int g_reduce_wpr = 1;        // wdg_set_tuning("reduce_wpr", 0/1): four waves per row in the split-K + LayerNorm second stage of the small maps
 static int g_wgrad_reduce4 = 1;     // wdg_set_tuning("wgrad_reduce4", 0/1): 16-byte second stage of the split weight gradients
 static int g_tap_chunk_order = 1;   // wdg_set_tuning("tap_chunk_order", 0/1): stride-1 layers with > 32 input channels in chunk-major tap order (plans created afterwards)
 static int g_tap_class_order = 1;   // wdg_set_tuning("tap_class_order", 0/1): forward tables of strided layers in residue-class order (plans created afterwards)
@@ -1885,6 +1917,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_dgrad_lnbwd = value;          // bit 0: on; bit 1: a 64 x 128 tile for 128-channel rows on small maps
         return WDG_OK;
     }
+    if (key && !strcmp(key, "reduce_wpr")) {
+        g_reduce_wpr = value != 0;
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "wgrad_reduce4")) {
         g_wgrad_reduce4 = value != 0;
         return WDG_OK;
@@ -2174,8 +2210,12 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     if (split > 1) {
         if (p.ln_gamma && nphase == 1 && (p.Ncols & 3) == 0 && p.Ncols <= 1024 && !p.accumulate) {
             // (the slabs of a 4-aligned column count are dense: NcP == Ncols)
-            const int blocks = (int)std::min<long long>(((long long)p.Mmax + 3) / 4, 8192);
-            hipLaunchKernelGGL(wdg_igemm_reduce_ln_kernel, dim3(blocks), block, 0, st, p);
+            if (g_reduce_wpr && p.Mmax <= 2048 && split >= 8) {
+                hipLaunchKernelGGL(wdg_igemm_reduce_ln_kernel<4>, dim3((unsigned)p.Mmax), block, 0, st, p);
+            } else {
+                const int blocks = (int)std::min<long long>(((long long)p.Mmax + 3) / 4, 8192);
+                hipLaunchKernelGGL(wdg_igemm_reduce_ln_kernel<1>, dim3(blocks), block, 0, st, p);
+            }
             WDG_LAUNCH_CHECK();
             if (bn_fused) *bn_fused = true;
             return WDG_OK;

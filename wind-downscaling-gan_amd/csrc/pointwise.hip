@@ -471,11 +471,41 @@ __global__ void __launch_bounds__(256) wdg_colsum_kernel(const float* __restrict
     const int cx = threadIdx.x & 63, pr = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cx;
     float s = 0.f;
-    if (c < C)
-        for (int64_t p = (int64_t)blockIdx.x * 4 + pr; p < P; p += (int64_t)gridDim.x * 4) s += x[p * ldx + c];
+    if (c < C) {
+        // four pixel rows in flight per thread (one dependent load per trip left the pass latency-bound: 268 MB of the generator's
+        // ConvLSTM gate gradients in 204 us)
+        const int64_t step = (int64_t)gridDim.x * 4;
+        int64_t p = (int64_t)blockIdx.x * 4 + pr;
+        for (; p + 3 * step < P; p += 4 * step) {
+            const float a0 = x[p * ldx + c], a1 = x[(p + step) * ldx + c], a2 = x[(p + 2 * step) * ldx + c], a3 = x[(p + 3 * step) * ldx + c];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; p < P; p += step) s += x[p * ldx + c];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (pr == 0 && c < C) atomicAdd(&out[c], red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx]);
+}
+
+// few channels (the 2-channel output layer's bias gradient: 2 of the 64 channel lanes of the kernel above had work): a thread
+// owns pixels and keeps C <= 8 sums in registers
+template <int C>
+__global__ void __launch_bounds__(256) wdg_colsum_small_kernel(const float* __restrict__ x, int ldx, int64_t P, float* out) {
+    __shared__ float red[4][C];
+    float s[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[c] = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] += x[p * ldx + c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float v = wdg_wave_sum_fast(s[c]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) atomicAdd(&out[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 extern "C" int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out, int accumulate,
@@ -483,6 +513,15 @@ extern "C" int wdg_colsum(const float* x, int ldx, int64_t P, int C, float* out,
     WDG_CHECK_ARG(x && out && C > 0, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate) WDG_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+    if (C <= 4) {
+        const int bs = (int)std::max<int64_t>(1, std::min<int64_t>((P + 255) / 256, 2048));
+        if (C == 1) hipLaunchKernelGGL(wdg_colsum_small_kernel<1>, dim3(bs), dim3(256), 0, st, x, ldx, P, out);
+        else if (C == 2) hipLaunchKernelGGL(wdg_colsum_small_kernel<2>, dim3(bs), dim3(256), 0, st, x, ldx, P, out);
+        else if (C == 3) hipLaunchKernelGGL(wdg_colsum_small_kernel<3>, dim3(bs), dim3(256), 0, st, x, ldx, P, out);
+        else hipLaunchKernelGGL(wdg_colsum_small_kernel<4>, dim3(bs), dim3(256), 0, st, x, ldx, P, out);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
     int bx = (int)std::max<int64_t>(1, std::min<int64_t>((P + 255) / 256, 1024));
     hipLaunchKernelGGL(wdg_colsum_kernel, dim3(bx, (C + 63) / 64), dim3(256), 0, st, x, ldx, P, C, out);
     WDG_LAUNCH_CHECK();
@@ -552,9 +591,25 @@ __global__ void __launch_bounds__(256) wdg_segment_meansq_kernel(const float* __
     __shared__ double red[4];
     const int s = blockIdx.y;
     const int64_t b = off[2 * s], e = off[2 * s + 1];  // {begin, end} pairs
+    // 16-byte loads on the aligned body (every variable starts at a multiple of 4 elements in the flat buffers; the check keeps
+    // any other table correct), two groups in flight per thread; blocks beyond a short segment's end leave at once.  (The scalar
+    // form with 64 blocks per segment read the discriminator's 25.7 MB kernel at 0.3 TB/s: 160 us per call.)
+    const int64_t n4 = ((b & 3) == 0) ? (e - b) >> 2 : 0;
+    if ((int64_t)blockIdx.x * 256 >= (n4 > 0 ? n4 : e - b)) return;
     double acc = 0.0;
-    for (int64_t i = b + (int64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += (int64_t)gridDim.x * 256)
-        acc += (double)x[i] * (double)x[i];
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + b);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4 u = x4[i], v = x4[i + stride];
+        acc += (double)(u[0] * u[0] + u[1] * u[1]) + (double)(u[2] * u[2] + u[3] * u[3]);
+        acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 u = x4[i];
+        acc += (double)(u[0] * u[0] + u[1] * u[1]) + (double)(u[2] * u[2] + u[3] * u[3]);
+    }
+    for (int64_t j = b + 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < e; j += stride) acc += (double)x[j] * (double)x[j];
     acc = wdg_wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -565,10 +620,10 @@ __global__ void __launch_bounds__(256) wdg_segment_meansq_kernel(const float* __
 }
 
 extern "C" int wdg_segment_meansq(const float* x, const int64_t* off, int nseg, float* out, wdg_stream stream) {
-    WDG_CHECK_ARG(x && off && out && nseg > 0, "bad argument");
+    WDG_CHECK_ARG(x && off && out && nseg > 0 && ((uintptr_t)x & 15) == 0, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     WDG_HIP(hipMemsetAsync(out, 0, (size_t)nseg * sizeof(float), st));
-    hipLaunchKernelGGL(wdg_segment_meansq_kernel, dim3(64, nseg), dim3(256), 0, st, x, off, out);
+    hipLaunchKernelGGL(wdg_segment_meansq_kernel, dim3(512, nseg), dim3(256), 0, st, x, off, out);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
