@@ -639,6 +639,10 @@ int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, wd
  * ------------------------------------------------------------------------------------------ */
 int wdg_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                 float beta2, float eps, float grad_scale, wdg_stream stream);
+/* Zero 1..16 element ranges [begin, end) of a flat fp32 buffer in one launch (begin_end: host array of n pairs, every value a
+ * multiple of 4): what `optimizer.zero_grad` leaves of the gradient buffer when the big kernel gradients are stored by their first
+ * weight-gradient launch instead of being zero-filled (ganbase.py:39,50: a fresh tape per update). */
+int wdg_zero_ranges(float* base, const int64_t* begin_end, int n, wdg_stream stream);
 
 #ifdef __cplusplus
 }

@@ -640,6 +640,10 @@ class TorchOps:
     def philox_uniform(self, out, seed, offset):
         out.copy_(torch.from_numpy(philox_uniform_np(out.numel(), seed, offset)).to(self.dtype).reshape(out.shape))
 
+    def zero_ranges(self, flat, ranges):
+        for a, b in ranges:
+            flat[a:b].zero_()
+
     def adam_tf(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
         gg = g * grad_scale
         m += (1 - beta1) * (gg - m)

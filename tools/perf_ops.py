@@ -132,6 +132,25 @@ def build_cases(ops, want):
             dz, y, mr, gm = rnd(P, C), rnd(P, C), torch.rand(P, 2, device=dev) + 0.5, rnd(C)
             dg, db_, dbi = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
             cases[tag] = (lambda dz=dz, y=y, mr=mr, gm=gm, dg=dg, db_=db_, dbi=dbi: ops.ln_bwd(dz, y, mr, gm, 0.2, dz, dg, db_, dbi), 0.0)
+    if need("bn_bwd"):
+        # the generator's BatchNorm backward passes (models.py:34,69): reduce (sum dz, sum dz xh) + apply, on the 16 @ 256^2 and 128 @ 128^2 tensors
+        for tag, P, C in (("bn_bwd_c16", B * 65536, 16), ("bn_bwd_c128", B * 16384, 128)):
+            dz, y = rnd(P, C), rnd(P, C)
+            saved, gm = torch.cat([rnd(C) * 0.1, torch.rand(C, device=dev) + 0.5]), rnd(C)
+            red = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            dg, db_, dbi = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            cases[tag + "_reduce"] = (lambda dz=dz, y=y, saved=saved, red=red: ops.bn_bwd_reduce(dz, y, saved, red), 0.0)
+            cases[tag + "_apply"] = (lambda dz=dz, y=y, saved=saved, gm=gm, red=red, P=P, dg=dg, db_=db_, dbi=dbi:
+                                     ops.bn_bwd_apply(dz, y, saved, gm, red, red, float(P), 0.2, dz, dg, db_, dbi), 0.0)
+    if need("misc"):
+        flat = rnd(8_600_000)
+        offs = torch.tensor([0, 6_422_528, 6_422_528, 8_000_000, 8_000_000, 8_600_000], dtype=torch.int64, device=dev)
+        out3 = torch.zeros(3, device=dev)
+        cases["misc_meansq"] = (lambda: ops.segment_meansq(flat, offs, out3), 0.0)
+        xg, og = rnd(B * 4096, 512), torch.zeros(512, device=dev)
+        cases["misc_colsum512"] = (lambda: ops.colsum(xg, og, accumulate=True), 0.0)
+        x2c, o2 = rnd(B * 65536, 4), torch.zeros(2, device=dev)
+        cases["misc_colsum2"] = (lambda: ops.colsum(x2c[:, :2], o2, accumulate=True), 0.0)
     if want is not None:
         missing = [w for w in want if w not in cases]
         if missing:
@@ -178,7 +197,7 @@ def main():
         row = f"{cname:20s} "
         for vname, _ in variants:
             t = med(times[(cname, vname)])
-            row += f" {1e3 * t:8.1f}us {fl / t * 1e-9:6.1f}TF {t / base:5.3f}"
+            row += f" {1e3 * t:8.1f}us {fl / max(t, 1e-9) * 1e-9:6.1f}TF {t / base:5.3f}"
         print(row)
 
 

@@ -1905,6 +1905,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_wgrad_xcd = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "bn_bwd_blocks")) {
+        wdg_bn_set_bwd_blocks(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "gather_xcd")) {
         wdg_upconv_set_gather_xcd(value);
         return WDG_OK;

@@ -75,6 +75,7 @@ int wdg_halo_plan_init(wdg_conv_plan* pl);
 void wdg_halo_plan_free(wdg_conv_plan* pl);
 void wdg_halo_set_wg(int v);
 void wdg_upconv_set_gather_xcd(int v);
+void wdg_bn_set_bwd_blocks(int v);
 void wdg_halo_set_persistent(int v);
 void wdg_halo_set_stage(int v);
 void wdg_halo_bf16_set_thin(int v);   // conv_halo_bf16.hip: the specialised 16 -> (<= 4) output-conv kernel on / off

@@ -214,6 +214,9 @@ extern "C" int wdg_bn_apply(const float* x, int ldx, const float* scale_shift, f
     return WDG_OK;
 }
 
+static int g_bn_bwd_blocks = 256;         // wdg_set_tuning("bn_bwd_blocks", n): grid cap of the BatchNorm backward passes (reduce: n, apply: 2 n).  Swept in round 5 (profiles/r05u_perf_bn_bwd_blocks.txt): 64 -> 182 us, 128 -> 103, 256 -> 86, 512 -> 102, 1024 -> 140 on the 16 @ 256^2 tensor - beyond one block per CU the per-block tail (column reduce + atomics on 2 C addresses) outweighs the extra waves
+void wdg_bn_set_bwd_blocks(int v) { g_bn_bwd_blocks = v > 0 ? v : 256; }
+constexpr int BNB_U = 4;      // pixels per trip and thread of the BatchNorm backward passes (2 x BNB_U 16-byte loads in flight)
 __global__ void __launch_bounds__(256) wdg_bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
                                                                 const float* __restrict__ y, int ldy,
                                                                 const float* __restrict__ saved, int64_t P,
@@ -227,24 +230,28 @@ __global__ void __launch_bounds__(256) wdg_bn_bwd_reduce_kernel(const float* __r
         const f32x4 mean = *reinterpret_cast<const f32x4*>(saved + 4 * c4);
         const f32x4 inv = *reinterpret_cast<const f32x4*>(saved + C + 4 * c4);
         const int64_t stride = (int64_t)gridDim.x * rows;
-        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += 4 * stride) {
-            f32x4 g[4], a[4];   // four pixels per trip, loads first
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += BNB_U * stride) {
+            // four pixels per trip, the eight loads first and UNCONDITIONAL (tail pixels re-read the last one and are masked out of
+            // the sums): `if (q < P) load` compiles to an exec-masked block per load with a full wait at its join — one round trip
+            // after the other, and with two waves per SIMD (the fp64 atomics keep the grid small) nothing hides them: 2.1 TB/s
+            f32x4 g[BNB_U], a[BNB_U];
+            float m[BNB_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BNB_U; ++u) {
                 const int64_t q = p + u * stride;
-                g[u] = a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (q < P) {
-                    g[u] = *reinterpret_cast<const f32x4*>(dz + q * lddz + 4 * c4);
-                    a[u] = *reinterpret_cast<const f32x4*>(y + q * ldy + 4 * c4);
-                }
+                const int64_t qq = q < P ? q : P - 1;
+                m[u] = q < P ? 1.f : 0.f;
+                g[u] = *reinterpret_cast<const f32x4*>(dz + qq * lddz + 4 * c4);
+                a[u] = *reinterpret_cast<const f32x4*>(y + qq * ldy + 4 * c4);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < BNB_U; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xh = (a[u][j] - mean[j]) * inv[j];
-                    v[0][j] += g[u][j];
-                    v[1][j] += g[u][j] * xh;
+                    const float gm = g[u][j] * m[u];
+                    v[0][j] += gm;
+                    v[1][j] += gm * xh;
                 }
         }
     }
@@ -257,7 +264,7 @@ extern "C" int wdg_bn_bwd_reduce(const float* dz, int lddz, const float* y, int 
     WDG_CHECK_ARG(dz && y && saved_mean_invstd && red && C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0,
                   "bad argument");
     ColGeom g = col_geom(C);
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), 512));   // see wdg_bn_stats
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 32 - 1) / (g.rows * 32), g_bn_bwd_blocks));   // see wdg_bn_stats
     hipLaunchKernelGGL(wdg_bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
                        ldy, saved_mean_invstd, P, C, red, g.c4n, g.rows);
     WDG_LAUNCH_CHECK();
@@ -286,19 +293,17 @@ __global__ void __launch_bounds__(256) wdg_bn_bwd_apply_kernel(
         }
         // four pixels per trip with the loads first (dpre may alias dz: each thread only touches its own slots)
         const int64_t stride = (int64_t)gridDim.x * rows;
-        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += 4 * stride) {
-            f32x4 g[4], a[4];
+        for (int64_t p = (int64_t)blockIdx.x * rows + prow; p < P; p += BNB_U * stride) {
+            f32x4 g[BNB_U], a[BNB_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BNB_U; ++u) {
                 const int64_t q = p + u * stride;
-                g[u] = a[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (q < P) {
-                    g[u] = *reinterpret_cast<const f32x4*>(dz + q * lddz + 4 * c4);
-                    a[u] = *reinterpret_cast<const f32x4*>(y + q * ldy + 4 * c4);
-                }
+                const int64_t qq = q < P ? q : P - 1;                  // (unconditional loads: see wdg_bn_bwd_reduce_kernel)
+                g[u] = *reinterpret_cast<const f32x4*>(dz + qq * lddz + 4 * c4);
+                a[u] = *reinterpret_cast<const f32x4*>(y + qq * ldy + 4 * c4);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BNB_U; ++u) {
                 const int64_t q = p + u * stride;
                 if (q >= P) continue;
                 f32x4 r;
@@ -335,7 +340,7 @@ extern "C" int wdg_bn_bwd_apply(const float* dz, int lddz, const float* y, int l
     WDG_CHECK_ARG(dz && y && saved_mean_invstd && gamma && red_mean && dpre, "null argument");
     WDG_CHECK_ARG(C % 4 == 0 && C <= 1024 && lddz % 4 == 0 && ldy % 4 == 0 && lddpre % 4 == 0, "bad sizes");
     ColGeom g = col_geom(C);
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 16 - 1) / (g.rows * 16), 1024));
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((P + g.rows * 16 - 1) / (g.rows * 16), 2 * g_bn_bwd_blocks));
     hipLaunchKernelGGL(wdg_bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dz, lddz, y,
                        ldy, saved_mean_invstd, gamma, red_mean, red_param, count, act_slope, dpre, lddpre,
                        dgamma, dbeta, dbias, P, C, g.c4n, g.rows);

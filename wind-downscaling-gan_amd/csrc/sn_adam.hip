@@ -408,3 +408,35 @@ extern "C" int wdg_adam_tf(float* p, const float* g, float* m, float* v, int64_t
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+
+// ---- several ranges of a flat buffer zeroed in ONE launch (ParamStore.zero_grad(lazy=True): the alignment ranges between the lazily
+// zeroed kernel gradients were one torch fill launch each, ~25 per step on the streams' serial sections) ------------------------
+struct WdgZeroRanges {
+    long long begin[16], end[16];     // element ranges, every begin / end a multiple of 4
+    int n;
+};
+__global__ void __launch_bounds__(256) wdg_zero_ranges_kernel(float* base, const WdgZeroRanges r) {
+    const int which = blockIdx.y;
+    if (which >= r.n) return;
+    f32x4* p = reinterpret_cast<f32x4*>(base + r.begin[which]);
+    const long long n4 = (r.end[which] - r.begin[which]) >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+extern "C" int wdg_zero_ranges(float* base, const int64_t* begin_end, int n, wdg_stream stream) {
+    WDG_CHECK_ARG(base && begin_end && n >= 1 && n <= 16 && ((uintptr_t)base & 15) == 0, "1..16 ranges of a 16-byte aligned buffer");
+    WdgZeroRanges r;
+    long long longest = 0;
+    for (int i = 0; i < n; ++i) {
+        r.begin[i] = begin_end[2 * i];
+        r.end[i] = begin_end[2 * i + 1];
+        WDG_CHECK_ARG(r.begin[i] >= 0 && r.end[i] >= r.begin[i] && (r.begin[i] & 3) == 0 && (r.end[i] & 3) == 0, "ranges must be multiples of 4 elements");
+        longest = std::max(longest, r.end[i] - r.begin[i]);
+    }
+    r.n = n;
+    const int bx = (int)std::max<long long>(1, std::min<long long>((longest / 4 + 255) / 256, 512));
+    hipLaunchKernelGGL(wdg_zero_ranges_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, base, r);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+

@@ -1224,6 +1224,13 @@ class HipOps:
     def philox_uniform(self, out, seed, offset):
         native.check(self.lib.wdg_philox_uniform(out.data_ptr(), out.numel(), seed & (2**64 - 1), offset, self.stream), "philox_uniform")
 
+    def zero_ranges(self, flat, ranges):
+        """flat[a:b] = 0 for every (a, b) of `ranges` (multiples of 4 elements) in one launch per 16 ranges (wdg_zero_ranges)."""
+        for k in range(0, len(ranges), 16):
+            part = ranges[k:k + 16]
+            arr = (C.c_int64 * (2 * len(part)))(*[int(x) for ab in part for x in ab])
+            native.check(self.lib.wdg_zero_ranges(flat.data_ptr(), arr, len(part), self.stream), "zero_ranges")
+
     def adam_tf(self, p, g, m, v, lr_t, beta1, beta2, eps, grad_scale=1.0):
         native.check(self.lib.wdg_adam_tf(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_t,
                                           beta1, beta2, eps, grad_scale, self.stream), "adam_tf")

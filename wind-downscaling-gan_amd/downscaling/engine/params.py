@@ -145,8 +145,11 @@ class ParamStore:
             if pos < self.n_train:
                 ranges.append((pos, self.n_train))
             self._lazy_big, self._lazy_ranges = big, ranges
-        for a, b in self._lazy_ranges:
-            self.grads[a:b].zero_()
+        if hasattr(self.ops, "zero_ranges") and self._lazy_ranges:
+            self.ops.zero_ranges(self.grads, self._lazy_ranges)          # (one launch instead of one fill per range)
+        else:
+            for a, b in self._lazy_ranges:
+                self.grads[a:b].zero_()
         for v in self._lazy_big:
             v.fresh = True
 
