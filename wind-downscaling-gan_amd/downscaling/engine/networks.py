@@ -49,20 +49,24 @@ class _Net:
         self._packed_version = self.params.version
 
     # ---- weight gradients off the critical path ---------------------------------------------------
-    # OFF by default since round 4 (WDG_WGRAD_STREAM=1 enables): with the generator and the twin discriminator on streams of
-    # their own the chip is already shared three ways, and a fourth stream of big weight-gradient kernels beside the data
-    # gradients costs more than its tails save — 66.1-66.7 ms per headline step without it against 66.9 with it at four
-    # hardware queues and 73-81 ms at eight (profiles/r04e_queues.txt, r04f_sched.txt)
-    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "0") != "0"
+    # History: round 3 on (70.9 -> 69.75 ms), round 4 off (with the generator and the twin discriminator on streams of their own a
+    # fourth stream cost more than its tails saved: 66.1-66.7 ms without against 66.9 with, profiles/r04e_queues.txt), round 5 ON
+    # again: once the LayerNorm backward moved into the data gradients and the second stages got short, the weight gradients are
+    # what is left to run beside the data-gradient chain — 64.2 / 64.0 -> 63.6 / 63.3 ms, same box, alternating
+    # (profiles/r05x_ab_step_wgrad_stream.txt).  WDG_WGRAD_STREAM=0 disables.
+    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "1") == "1"
+    # WDG_WGRAD_STREAM=2: only the weight gradients flagged `small` (the discriminator's 27 x 27 / 8 x 8 / 2 x 2 blocks: launches of
+    # 25-45 TFLOP/s that leave most of the chip idle beside an equally small data-gradient chain)
+    wgrad_stream_small = os.environ.get("WDG_WGRAD_STREAM", "0") == "2"
 
-    def _wgrad(self, fn, joins):
+    def _wgrad(self, fn, joins, small=False):
         """Runs `fn` (the weight-gradient launches of one layer) on the "wgrad" side stream, after everything enqueued so far
         (its operands are ready), while the caller goes on with the data gradient on the current stream: the two read the
         same dz and write different buffers, and nothing needs dW before the optimizer step.  On the small maps of the
         discriminator's stack and at T > 1 neither kernel fills the chip, and everywhere the one's tail runs under the
         other.  `joins` collects the forks; the pass joins them before it returns (the next pass overwrites the
         activations and gradient buffers the weight gradients read)."""
-        if not self.wgrad_stream:
+        if not (self.wgrad_stream or (small and self.wgrad_stream_small)):
             fn()
             return
         with self.ops.fork("wgrad", stream=getattr(self, "wgrad_side", None)) as side:
@@ -536,6 +540,7 @@ class DiscriminatorNet(_Net):
         — the variable values that pass read and its activations — while this network runs the generated pass."""
         if self._twin is None:
             self._twin = DiscriminatorNet(self.ops, **self._ctor)
+            self._twin.wgrad_stream = self.wgrad_stream
         return self._twin
 
     def set_low(self, low):
@@ -701,7 +706,7 @@ class DiscriminatorNet(_Net):
             xin = b["zs"][i - 1] if i > 0 else b["cat"]
             dxin = b["dzs"][i - 1] if i > 0 else b["dcat"]
             if need_wgrad:
-                self._wgrad(lambda conv=conv, xin=xin, dz=dz: conv.backward_weights(xin, dz), joins)
+                self._wgrad(lambda conv=conv, xin=xin, dz=dz: conv.backward_weights(xin, dz), joins, small=osz <= 32)
             below_split = self.shortcut is not None and i - 1 == self.shortcut["block"]    # (its dz is copied for the shortcut first)
             ln_done = False
             if chain and not split and not below_split and i > 0:

@@ -143,6 +143,11 @@ class GanEngine:
         # the discriminator's gradient-penalty pass beside its real pass on a twin network (WDG_OVERLAP_DISC=0 disables):
         # 69.0 -> 68.6 ms at the headline shape, +0.8 % at T = 24 (same-box A/B) — see _critic_pipelined
         self.overlap_discriminator = os.environ.get("WDG_OVERLAP_DISC", "1") != "0"
+        only = os.environ.get("WDG_WGRAD_STREAM_ONLY")           # A/B switch: "g" / "d" keep the weight-gradient stream on one network
+        if only == "g":
+            disc.wgrad_stream = False
+        elif only == "d":
+            gen.wgrad_stream = False
         self.hoist_first_real_pass = os.environ.get("WDG_HOIST_REAL", "0") != "0"      # measured: 66.45 vs 66.25 ms with it (profiles/r04s_hoist.txt) - big kernels of two networks side by side gain nothing
         self._disc_stream = None
         self.assemble_input = os.environ.get("WDG_ASSEMBLE_INPUT", "0") != "0"     # (A/B switch of _gen_noise_at: measured neutral in the train step - 64.6 vs 64.4 ms, the draw runs on the generator stream under the discriminator passes - and left off)
@@ -284,6 +289,8 @@ class GanEngine:
         nf = self._buf("noisy_fake", *noisy.shape)
         if self._gen_stream is None or self._disc_stream is None:
             # (streams chosen by a measured concurrency probe: on distinct hardware queues whatever else holds pool streams)
+            # (the weight-gradient side stream of the networks stays the pool's "wgrad" stream: a third probe-chosen stream measured
+            # 0.15 ms worse, 63.44 against 63.28 ms, profiles/r05y_ab_step.txt)
             self._gen_stream, self._disc_stream = ops.concurrent_streams(2)
         gs, main = self._gen_stream, torch.cuda.current_stream(ops.device)
         twin = disc.twin() if self.overlap_discriminator else None
