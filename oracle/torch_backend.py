@@ -281,7 +281,7 @@ class TorchOps:
         C = min(src.shape[4], dst.shape[4])
         dst[..., :C] = src.permute(1, 0, 2, 3, 4)[..., :C]
 
-    def fork(self, name="side"):
+    def fork(self, name="side", stream=None):
         """HipOps.fork restated for a backend without streams: run in place."""
         class _Inline:
             def __enter__(self):
