@@ -123,7 +123,7 @@ def test_config2_rccl_collectives_single_rank():
     assert a["rccl"]["backend"].startswith("nccl") and a["rccl"]["world_size"] == 1 and a["rccl"]["distinct_devices"] == 1
     assert a["rccl"]["devices"][0]["name"] and a["rccl"]["grad_allreduce_bytes_per_step"] > a["rccl"]["d_grad_allreduce_bytes"]
     # the data-parallel step runs the headline's multi-stream schedule on streams placed by the probe (trainer.py, hipops.py)
-    assert a["stream_placement"]["concurrent_found"] == 2
+    assert a["stream_placement"]["concurrent_found"] == 3          # generator, real pass, generated pass (+ the main stream)
     b = _torchrun_bench({}, 1, common)
     assert b["config"]["parallelism"] == "dp1"
     for k, v in b["losses"].items():

@@ -1,3 +1,4 @@
 set -u
-AB_STEPS=12 bash tools/ab_step.sh "both:" "g:WDG_WGRAD_STREAM_ONLY=g" "d:WDG_WGRAD_STREAM_ONLY=d" "both:" "g:WDG_WGRAD_STREAM_ONLY=g" "d:WDG_WGRAD_STREAM_ONLY=d" > gpurun_out/r05y2_ab.txt 2>&1; cut -c1-20 gpurun_out/r05y2_ab.txt
-python bench.py > gpurun_out/r05y_bench.txt 2>&1; tail -1 gpurun_out/r05y_bench.txt | cut -c1-1500
+python -m pytest tests -x -q -m gpu > gpurun_out/r05ad_tests.txt 2>&1; tail -3 gpurun_out/r05ad_tests.txt
+T="-- --size 96 --timesteps 24 --batch 8"
+AB_STEPS=10 bash tools/ab_step.sh "new:" "gs:WDG_TRIPLE_WGRAD=gs" "gs_real:WDG_TRIPLE_WGRAD=gs_real" "new:" "gs:WDG_TRIPLE_WGRAD=gs" "gs_real:WDG_TRIPLE_WGRAD=gs_real" "t24new:$T" "t24gs:WDG_TRIPLE_WGRAD=gs $T" "t24gs_real:WDG_TRIPLE_WGRAD=gs_real $T" > gpurun_out/r05ae_ab.txt 2>&1; cut -c1-60 gpurun_out/r05ae_ab.txt

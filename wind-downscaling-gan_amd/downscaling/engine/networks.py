@@ -534,14 +534,17 @@ class DiscriminatorNet(_Net):
         self._bufs = {B: b}
         return b
 
-    def twin(self):
-        """A second network of the same graph with its OWN variables and activations, for train steps whose
-        discriminator loss couples the real and the generated scores (GanEngine._critic_coupled): it holds the real pass
-        — the variable values that pass read and its activations — while this network runs the generated pass."""
+    def twin(self, k=0):
+        """A second (k = 0) / third (k = 1) network of the same graph with its OWN variables and activations, for train steps
+        whose discriminator loss couples the real and the generated scores (GanEngine._critic_coupled) and for the critic
+        schedules that run the real / generated passes beside the gradient-penalty pass (GanEngine._critic_pipelined): it holds
+        a pass — the variable values that pass read and its activations — while this network runs another one."""
         if self._twin is None:
-            self._twin = DiscriminatorNet(self.ops, **self._ctor)
-            self._twin.wgrad_stream = self.wgrad_stream
-        return self._twin
+            self._twin = {}
+        if k not in self._twin:
+            self._twin[k] = DiscriminatorNet(self.ops, **self._ctor)
+            self._twin[k].wgrad_stream = self.wgrad_stream
+        return self._twin[k]
 
     def set_low(self, low):
         """low [B,T,S,S,cl] -> channels [0:cl] of the mix buffer (constant over a train step)."""

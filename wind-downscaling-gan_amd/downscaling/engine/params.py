@@ -161,6 +161,12 @@ class ParamStore:
                 v.grad.zero_()
                 v.fresh = False
 
+    def set_grads_sum(self, a, b):
+        """grads <- a.grads + b.grads (both settled): the weight gradients of two passes that ran on copies of this network."""
+        torch.add(a.grads, b.grads, out=self.grads)
+        for v in self.trainable:
+            v.fresh = False
+
     def num_trainable(self):
         return sum(v.tf_size for v in self.trainable)
 

@@ -143,6 +143,13 @@ class GanEngine:
         # the discriminator's gradient-penalty pass beside its real pass on a twin network (WDG_OVERLAP_DISC=0 disables):
         # 69.0 -> 68.6 ms at the headline shape, +0.8 % at T = 24 (same-box A/B) — see _critic_pipelined
         self.overlap_discriminator = os.environ.get("WDG_OVERLAP_DISC", "1") != "0"
+        # WDG_OVERLAP_DISC=2 (default): the generated pass on a THIRD network and stream as well — all three passes of an
+        # iteration side by side, main / generator / real / generated = the four hardware queues; the weight gradients of the two
+        # copies then stay on their pass' stream and the generator's go to the (then idle) real-pass stream: a fifth stream costs
+        # more than it hides.  Same box, alternating: 62.9 -> 60.8 ms at the headline shape, 80.4 -> 76.7 ms at T = 24
+        # (profiles/r05aa_ab_step_triple.txt ... r05ac); =1: two networks (rounds 4-5)
+        self.triple_discriminator = os.environ.get("WDG_OVERLAP_DISC", "2")
+        self._fake_stream = None
         only = os.environ.get("WDG_WGRAD_STREAM_ONLY")           # A/B switch: "g" / "d" keep the weight-gradient stream on one network
         if only == "g":
             disc.wgrad_stream = False
@@ -295,6 +302,17 @@ class GanEngine:
         gs, main = self._gen_stream, torch.cuda.current_stream(ops.device)
         twin = disc.twin() if self.overlap_discriminator else None
         ds = self._disc_stream
+        triple = twin is not None and self.triple_discriminator == "2"
+        if triple and self._fake_stream is None:
+            self._fake_stream = ops.concurrent_streams(3)[2]
+        fs, twin2 = self._fake_stream, (disc.twin(1) if triple else None)
+        if triple:
+            tw = os.environ.get("WDG_TRIPLE_WGRAD", "0")       # (A/B switch: 1 = the pool's "wgrad" stream, gs / gs_real = the generator's stream)
+            twin.wgrad_stream = tw in ("1", "gs", "gs_real")
+            twin2.wgrad_stream = tw in ("1", "gs")
+            twin.wgrad_side = twin2.wgrad_side = gs if tw.startswith("gs") else None
+            if os.environ.get("WDG_WGRAD_STREAM_G", "1") == "1":
+                gen.wgrad_side = ds               # the generator's backward runs when the real-pass stream has nothing to do
 
         def start_real_pass(o_r):
             """The three discriminator passes of an iteration on TWO networks (this one and its twin: own variables and
@@ -344,7 +362,36 @@ class GanEngine:
                     gen.params.zero_grad()
                     self._gen_noise_at(low, B, o_gstep)
                     fake = gen.forward(B, training=True, need_backward=True)
-            if twin is not None:
+            if triple:
+                # three networks, three streams: gradient-penalty pass here (W1), real pass on the twin (W2 = SN(W1)), generated
+                # pass on the third network (W3 = SN(W2), prepared from the twin's copy as soon as W2 exists).  This network
+                # takes W3 and the sum of the two weight-gradient buffers before the optimizer step.
+                if i == 0 and hoisted is not None:
+                    w2_ready, real_mean = hoisted
+                else:
+                    w2_ready, real_mean = start_real_pass(o_r)
+                fs.wait_stream(main)                                              # nf drawn, the previous iteration's step done
+                fs.wait_event(w2_ready)
+                with torch.cuda.stream(fs):
+                    twin2.params.copy_from(twin.params)                           # W2 (+ its SN state)
+                    twin2.params.zero_grad(lazy=True)
+                    twin2.set_high_tm(nf, B)
+                    fake_mean = twin2.forward(B, training=True).mean()            # :43 (prepares W3 = SN(W2))
+                    fake_mean.record_stream(main)
+                    twin2.backward(B, self._const("fake", B, sw_mean / B), need_wgrad=True, need_input_grad=False)
+                disc.set_high_tm(comb, B)
+                disc.forward(B, training=True, prepared=True)                     # :32-34 (W1)
+                dcomb = disc.backward(B, ones, need_wgrad=False)                  # :35
+                ops.sumsq_batch_ch(v2(dcomb), ppi, T, B, gsq)                     # :36
+                gnorm = torch.sqrt(gsq[:, :ch])
+                gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()           # :37
+                main.wait_stream(ds)
+                main.wait_stream(fs)
+                twin.params.settle()
+                twin2.params.settle()
+                disc.params.set_grads_sum(twin.params, twin2.params)              # R + F
+                disc.params.copy_from(twin2.params)                               # W3
+            elif twin is not None:
                 if i == 0 and hoisted is not None:
                     w2_ready, real_mean = hoisted
                 else:
@@ -403,6 +450,8 @@ class GanEngine:
         disc.set_low(low)
         if pipelined and self.overlap_discriminator:
             disc.twin().set_low(low)          # (the twin network of the two-stream critic schedule reads the same low-res input)
+            if self.triple_discriminator == "2":
+                disc.twin(1).set_low(low)
         real = self._buf("real", N, S, S, chp)
         gen.to_time_major(high, real)
         comb, noisy = self._buf("comb", N, S, S, chp), self._buf("noisy", N, S, S, chp)
@@ -468,9 +517,6 @@ class GanEngine:
                 disc.set_high_tm(real, B)
                 real_mean = disc.forward(B, training=False).mean()
                 real_mean.record_stream(main)
-        if pipelined and os.environ.get("WDG_WGRAD_STREAM_G", "0") == "1" and self._disc_stream is not None:
-            # A/B switch: the generator backward's weight gradients on the (idle here) twin-discriminator stream
-            gen.wgrad_stream, gen.wgrad_side = True, self._disc_stream
         gen.backward(B, dfake)
         gscale = self._reduce_and_step(gen, g_opt)
         if pipelined:
