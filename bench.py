@@ -626,6 +626,8 @@ def main():
 
     for _ in range(args.warmup):
         gan.train_step((low, high))
+    if os.environ.get("WDG_SYNC_DEBUG") == "1":       # (diagnostic: torch warns at every call that makes the host wait for the device)
+        torch.cuda.set_sync_debug_mode("warn")
     timer = ConvTimer()
     timer.wrap(ops)
     barrier()
