@@ -50,7 +50,8 @@ def generator_flops(net, executed=False):
     conv = lambda c, px: 2.0 * c.g.kh * c.g.kw * c.cin * c.cout * px      # noqa: E731
     lstm = net.lstm
     f = conv(net.c0, (S // 2) ** 2) + conv(net.c2, (S // 4) ** 2) + conv(net.c5, (S // 4) ** 2)
-    f += 2.0 * 9 * lstm.cin * 4 * lstm.F * (S // 4) ** 2                  # input convolution of the gates
+    # input convolution of the gates; executed, T = 1: c_0 = 0, the forget gate is dead in all three directions -> 3 of 4 gates
+    f += 2.0 * 9 * lstm.cin * (3 if executed and T == 1 else 4) * lstm.F * (S // 4) ** 2
     f += 2.0 * 9 * lstm.F * 4 * lstm.F * (S // 4) ** 2 * (T - 1) / T      # recurrent convolution (absent at t = 0)
     f += 2.0 * net.c7.cout * net.c7.cin * (S // 2) ** 2                   # 2x2 stride-2 transposed: one tap per output pixel
     c9 = net.c9
@@ -59,12 +60,13 @@ def generator_flops(net, executed=False):
     return f
 
 
-def discriminator_flops(net):
-    """Forward FLOPs of make_discriminator per tile-timestep (models.py:93-138), from the layer objects."""
+def discriminator_flops(net, executed=False):
+    """Forward FLOPs of make_discriminator per tile-timestep (models.py:93-138), from the layer objects.  executed=True: at
+    T = 1 the fused ConvLSTM kernels (csrc/convlstm1.hip) skip the forget gate (c_0 = 0)."""
     S, T = net.S, net.T
     f = 0.0
     for l in (net.lstm_a, net.lstm_b):
-        f += 2.0 * 9 * l.cin * 4 * l.F * S * S + 2.0 * 9 * l.F * 4 * l.F * S * S * (T - 1) / T
+        f += 2.0 * 9 * l.cin * (3 if executed and T == 1 else 4) * l.F * S * S + 2.0 * 9 * l.F * 4 * l.F * S * S * (T - 1) / T
     for c in (net.conv_a, net.conv_b):
         f += 2.0 * 9 * c.cin * c.cout * S * S
     for conv, _, osz, _ in net.blocks:
@@ -112,6 +114,20 @@ class ConvTimer:
             timed(ops.conv_kernel_label("wgrad", x, dy, pk, g), flops(x, dy, pk, g), orig_wgrad, x, dy, pk, dw, g,
                   layer=geom("wgrad", x, dy, pk, g), **k)
 
+        orig_dslice, orig_wslice = ops.conv_dgrad_slice, ops.conv_wgrad_slice
+
+        def conv_dgrad_slice(dy, pk, n0, n1, dx, g, **k):
+            # (a channel range of the layer: the live gate columns of the generator's ConvLSTM at T = 1 — the FLOPs of the range)
+            fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * (n1 - n0) * g.kh * g.kw * pk.cin
+            timed(ops.conv_kernel_label("dgrad", dx, dy, pk, g, cout=n1 - n0, w_ld=pk.cout), fl, orig_dslice, dy, pk, n0, n1, dx, g,
+                  layer=geom("dgrad", dx, dy, pk, g) + f" cols[{n0}:{n1}]", **k)
+
+        def conv_wgrad_slice(x, dy, pk, n0, n1, dw, g, **k):
+            fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * (n1 - n0) * g.kh * g.kw * pk.cin
+            timed(ops.conv_kernel_label("wgrad", x, dy, pk, g, cout=n1 - n0, w_ld=pk.cout), fl, orig_wslice, x, dy, pk, n0, n1, dw, g,
+                  layer=geom("wgrad", x, dy, pk, g) + f" cols[{n0}:{n1}]", **k)
+
+        ops.conv_dgrad_slice, ops.conv_wgrad_slice = conv_dgrad_slice, conv_wgrad_slice
         orig_fwd_ln = ops.conv_fwd_ln
 
         def conv_fwd_ln(x, pk, bias, y, z, g, *a, **k):
@@ -261,7 +277,7 @@ def generator_leg(generator, gan, dev, batch=64, warm=3, iters=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    gf_alg, gf_exec = generator_flops(net), generator_flops(net, executed=True)   # 22.385 / 16.09 GFLOP at S = 256, T = 1
+    gf_alg, gf_exec = generator_flops(net), generator_flops(net, executed=True)   # 22.385 / 14.88 GFLOP at S = 256, T = 1
     return {"ms": ms, "batch": batch, "samples_per_s": batch / ms * 1e3,
             "tflops_algorithmic": gf_alg * batch / ms * 1e-9,
             "tflops_executed": gf_exec * batch / ms * 1e-9, "frac_executed": gf_exec * batch / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS,
@@ -685,7 +701,7 @@ def main():
         # algorithmic FLOPs of one reference step per tile-timestep: 7*Gf + 28*Df (SURVEY §8 d; 240.5 GFLOP at S = 256, T = 1,
         # 41.7 at S = 96, T = 24), Gf / Df from the layer objects of the networks that ran
         gf, df = generator_flops(generator.net), discriminator_flops(discriminator.net)
-        gf_exec = generator_flops(generator.net, executed=True)
+        gf_exec, df_exec = generator_flops(generator.net, executed=True), discriminator_flops(discriminator.net, executed=True)
         step_flops = (7 * gf + 28 * df) * B * T
         timer.records = serial_records
         agg = timer.summary()
@@ -720,8 +736,9 @@ def main():
             "step_tflops_algorithmic": step_flops * 1e-12,
             "step_frac_of_mfma_f32_peak": step_flops / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
             # the same on the multiply-adds the kernels EXECUTE: the upsample + 5x5 block runs in column form in all seven
-            # generator passes (16.09 instead of 22.385 GFLOP per sample and pass at S = 256)
-            "step_frac_executed": (7 * gf_exec + 28 * df) * B * T / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            # generator passes, and at T = 1 (14.88 instead of 22.385 GFLOP per sample and pass at S = 256) the ConvLSTMs' dead
+            # forget gate (c_0 = 0) is not computed in any direction
+            "step_frac_executed": (7 * gf_exec + 28 * df_exec) * B * T / (dt / args.steps) / (PEAK_F32_MFMA_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": dom[0],
                          "achieved": dom[1][0] / dom[1][1] * 1e-12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom[1][0] / dom[1][1] * 1e-12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,

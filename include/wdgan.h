@@ -79,6 +79,12 @@ typedef struct wdg_conv_plan wdg_conv_plan;
 
 /* Builds the device-side index tables (tap/channel offsets, dgrad phases). Not on the launch path. */
 int wdg_conv_plan_create(wdg_conv_plan** plan, const wdg_conv_geom* geom);
+/* A plan for a RANGE of output channels [n0, n0 + geom->Cout) of a layer whose HWIO weight tensor has w_ld output channels:
+ * wdg_conv_dgrad / wdg_conv_wgrad then take wD + n0 / dW + n0 of the FULL tensors and the y / dy views start at channel n0
+ * (forward needs no special plan: the rows of wF are contiguous per output channel).  Use: keras ConvLSTM2D at
+ * n_timesteps = 1 (gan/models.py:45, 93, 101) — c_0 = 0, the forget gate is never read and its gradient is zero, so its
+ * quarter of the input convolution is dead in all three directions.  Implicit-GEMM layers only. */
+int wdg_conv_plan_create_sliced(wdg_conv_plan** plan, const wdg_conv_geom* geom, int w_ld);
 int wdg_conv_plan_destroy(wdg_conv_plan* plan);
 /* Bytes of split-K scratch the plan may use (max over fwd/dgrad/wgrad). */
 size_t wdg_conv_ws_bytes(const wdg_conv_plan* plan);

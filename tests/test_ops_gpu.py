@@ -131,6 +131,40 @@ def test_conv_fwd_dgrad_wgrad(case, hip_ops, ref_ops):
     assert rel_err(db_g, db_r) < TOL, "wgrad+bias: dbias"
 
 
+@pytest.mark.parametrize("n,H,W,cin,F_,k,s,p", [(3, 20, 24, 128, 128, 3, 1, 1), (2, 17, 19, 32, 16, 3, 1, 1), (2, 30, 28, 64, 32, 4, 2, 1)])
+def test_conv_gradients_over_channel_ranges(n, H, W, cin, F_, k, s, p, hip_ops, ref_ops):
+    """wdg_conv_plan_create_sliced (HipOps.conv_dgrad_slice / conv_wgrad_slice): the data and weight gradient of the LIVE gate
+    columns of a ConvLSTM2D at n_timesteps = 1 (models.py:45 — gates i, c~, o = channel ranges [0, F) and [2F, 4F) of the 4F-channel
+    gate tensor; the forget gate's gradient is exactly zero) against the full-width gradients of the oracle on a dgates tensor
+    whose forget-gate channels are zero.  The forget-gate columns of dW must be left untouched."""
+    from downscaling.engine.hipops import ConvGeom
+    from oracle.torch_backend import ConvGeom as RG
+    d = _mk(("ranges", n, H, W, cin, 4 * F_, k, s, p), seed=3)
+    d["dy"][..., F_:2 * F_] = 0
+    g, rg = ConvGeom(k, k, s, p), RG(k, k, s, p)
+    dev = hip_ops.device
+    w_g = d["w"].float().to(dev).contiguous()
+    pk_g, pk_r = hip_ops.pack_weights(w_g), ref_ops.pack_weights(d["w"])
+    x_g, dy_g = d["x"].float().to(dev), d["dy"].float().to(dev)
+    dx_r = torch.zeros(n, H, W, d["cin_p"], dtype=torch.float64)
+    ref_ops.conv_dgrad(d["dy"], pk_r, dx_r, rg)
+    dx_g = torch.full((n, H, W, d["cin_p"]), 3.0, dtype=torch.float32, device=dev)
+    hip_ops.conv_dgrad_slice(dy_g[..., :F_], pk_g, 0, F_, dx_g, g, accumulate=False)
+    hip_ops.conv_dgrad_slice(dy_g[..., 2 * F_:], pk_g, 2 * F_, 4 * F_, dx_g, g, accumulate=True)
+    assert rel_err(dx_g, dx_r) < TOL, "dgrad over the live ranges"
+    dw_r = torch.zeros_like(d["w"])
+    ref_ops.conv_wgrad(d["x"], d["dy"], pk_r, dw_r, rg, accumulate=False)
+    dw_g = torch.full_like(w_g, 7.0)
+    hip_ops.conv_wgrad_slice(x_g, dy_g[..., :F_], pk_g, 0, F_, dw_g, g, accumulate=False)
+    hip_ops.conv_wgrad_slice(x_g, dy_g[..., 2 * F_:], pk_g, 2 * F_, 4 * F_, dw_g, g, accumulate=False)
+    assert float((dw_g[..., F_:2 * F_] - 7.0).abs().max()) == 0.0, "forget-gate columns of dW untouched"
+    live = torch.cat([dw_g[..., :F_], dw_g[..., 2 * F_:]], -1)
+    live_r = torch.cat([dw_r[..., :F_], dw_r[..., 2 * F_:]], -1)
+    assert rel_err(live, live_r) < TOL, "wgrad over the live ranges"
+    hip_ops.conv_wgrad_slice(x_g, dy_g[..., :F_], pk_g, 0, F_, dw_g, g, accumulate=True)
+    assert rel_err(dw_g[..., :F_], 2 * dw_r[..., :F_]) < TOL, "wgrad accumulate"
+
+
 def test_conv_on_concat_and_time_views(hip_ops, ref_ops):
     """Zero-copy channel concat (ld > C, channel offset) and time-sliced image stride."""
     from downscaling.engine.hipops import ConvGeom

@@ -1228,6 +1228,7 @@ struct WdgWgrad {
     int stride, pad_h, pad_w;
     int K4;             // row groups (padded to a multiple of 8; padding has valid rows = 0)
     int Cout, Cout_p;
+    int w_ld;           // row stride of dW (= Cout unless the plan covers a channel range of a wider layer: wdg_conv_plan_create_sliced)
     int accumulate;
     int splitk;
     long long pix_per_split, Ptot;
@@ -1416,7 +1417,7 @@ __global__ void __launch_bounds__(256, WDG_WGRAD_LB) wdg_wgrad_kernel(const WdgW
             } else {
                 const int2 wr = p.wrow[rg];
                 if (rr >= wr.y) continue;
-                float* dst = p.dW + wr.x + (long long)rr * p.Cout + ncol0;
+                float* dst = p.dW + wr.x + (long long)rr * p.w_ld + ncol0;
 #pragma unroll
                 for (int b = 0; b < NT; ++b) {
                     if (ncol0 + b < p.Cout) {
@@ -1451,7 +1452,7 @@ __global__ void __launch_bounds__(256) wdg_wgrad_reduce_kernel(const WdgWgrad p)
             const int2 wr = p.wrow[R >> 2];
             const int r = R & 3;
             if (r < wr.y) {
-                float* dst = p.dW + wr.x + (long long)r * p.Cout + n;
+                float* dst = p.dW + wr.x + (long long)r * p.w_ld + n;
                 if (p.accumulate) t += *dst;
                 *dst = t;
             }
@@ -1498,7 +1499,7 @@ __global__ void __launch_bounds__(256) wdg_wgrad_reduce4_kernel(const WdgWgrad p
             const int2 wr = p.wrow[R >> 2];
             const int r = R & 3;
             if (r < wr.y) {
-                f32x4* dst = reinterpret_cast<f32x4*>(p.dW + wr.x + (long long)r * p.Cout + n);
+                f32x4* dst = reinterpret_cast<f32x4*>(p.dW + wr.x + (long long)r * p.w_ld + n);
                 if (p.accumulate) t += *dst;
                 *dst = t;
             }
@@ -1625,7 +1626,29 @@ static int pick_split(long long tiles, int K4, int cus, int bn) {
     return pick_split_model(tiles, std::max(1, K4 / 16), cus, igemm_blocks_per_cu(bn));
 }
 
-extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g) {
+static int conv_plan_create_impl(wdg_conv_plan** out, const wdg_conv_geom* g, int w_ld);
+extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g) { return conv_plan_create_impl(out, g, 0); }
+
+// A plan for output channels [n0, n0 + geom->Cout) of a layer with w_ld output channels (the live gate columns of a ConvLSTM2D at
+// n_timesteps = 1: the forget gate multiplies c_0 = 0, its quarter of the input convolution is dead in all three directions).
+// Forward: wF rows are contiguous per output channel, so the range is a row range of the full packed matrix (any plan does).
+// wdg_conv_dgrad / wdg_conv_wgrad: pass wD + n0 / dW + n0 of the FULL HWIO tensors; y / dy views start at channel n0.
+extern "C" int wdg_conv_plan_create_sliced(wdg_conv_plan** out, const wdg_conv_geom* g, int w_ld) {
+    WDG_CHECK_ARG(g && w_ld % 4 == 0 && w_ld >= g->Cout && g->Cout % 4 == 0, "sliced plan: w_ld and Cout multiples of 4, w_ld >= Cout");
+    const int rc = conv_plan_create_impl(out, g, w_ld);
+    if (rc != WDG_OK) return rc;
+    wdg_conv_plan* pl = *out;
+    if ((pl->halo_auto_fwd && pl->halo_fwd_nt) || (pl->halo_auto_dgrad && pl->halo_dgrad_nt) || wdg_wgrad_halo_eligible(pl) ||
+        wdg_wgrad_thin_eligible(pl)) {
+        wdg_conv_plan_destroy(pl);
+        *out = nullptr;
+        wdg_set_error("sliced plan: only layers that run on the implicit-GEMM kernels");
+        return WDG_ERR_ARG;
+    }
+    return WDG_OK;
+}
+
+static int conv_plan_create_impl(wdg_conv_plan** out, const wdg_conv_geom* g, int w_ld) {
     WDG_CHECK_ARG(out && g, "null argument");
     WDG_CHECK_ARG(g->n_img > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "bad sizes");
     WDG_CHECK_ARG(g->kh > 0 && g->kw > 0 && g->stride > 0 && g->stride <= 3, "bad kernel/stride");
@@ -1643,6 +1666,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
     pl->Cout_p = wdg_round_up(g->Cout, 4);
     pl->taps = g->kh * g->kw;
     pl->cus = wdg_device_cus();
+    pl->w_ld = w_ld;
     const int s = g->stride;
 
     // ---- forward table
@@ -1680,7 +1704,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
                 e.w = tap * pl->Cin_p + 4 * c4;
                 tf.push_back(e);
                 int2 r;
-                r.x = (tap * g->Cin + 4 * c4) * g->Cout;
+                r.x = (tap * g->Cin + 4 * c4) * (w_ld ? w_ld : g->Cout);
                 r.y = std::min(4, g->Cin - 4 * c4);
                 wr.push_back(r);
             }
@@ -1720,7 +1744,7 @@ extern "C" int wdg_conv_plan_create(wdg_conv_plan** out, const wdg_conv_geom* g)
                         e.x = (dh * g->Wo + dw) * g->ldy + 4 * c4;
                         e.y = dh;
                         e.z = dw;
-                        e.w = tap * g->Cin * pl->Cout_p + 4 * c4;
+                        e.w = tap * g->Cin * (w_ld ? w_ld : pl->Cout_p) + 4 * c4;
                         td.push_back(e);
                         ++cnt;
                     }
@@ -2307,7 +2331,7 @@ static int conv_dgrad_impl(const wdg_conv_plan* pl, const float* dy, const float
     p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
     p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
     p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
-    p.Ncols = g.Cin; p.ldB = pl->Cout_p;
+    p.Ncols = g.Cin; p.ldB = pl->w_ld ? pl->w_ld : pl->Cout_p;
     p.a_mul = 1; p.o_mul = g.stride;
     p.act = act; p.slope = slope; p.accumulate = accumulate;
     if (hook) { p.stats = hook->stats; p.stats_C = hook->stats_C; p.stats_rep = hook->stats_rep; p.affine = hook->affine; p.affine_ld = hook->affine_ld; }
@@ -2476,7 +2500,7 @@ extern "C" int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* pl, const float* dy, co
     p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
     p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
     p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
-    p.Ncols = g.Cin; p.ldB = pl->Cout_p;
+    p.Ncols = g.Cin; p.ldB = pl->w_ld ? pl->w_ld : pl->Cout_p;
     p.a_mul = 1; p.o_mul = g.stride;
     p.lnb_y = y; p.lnb_ldy = ldy_act; p.lnb_imgStride = img_stride_act; p.lnb_stats = mean_rstd; p.lnb_gamma = gamma;
     p.lnb_c0 = c0; p.lnb_C = C; p.lnb_slope = act_slope; p.lnb_par = want_par ? par_ws : nullptr; p.lnb_rep = WDG_LNB_REP;
@@ -2560,6 +2584,7 @@ extern "C" int wdg_conv_wgrad(const wdg_conv_plan* pl, const float* x, const flo
     p.Ho = g.Ho; p.Wo = g.Wo; p.ldy = g.ldy;
     p.stride = g.stride; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.K4 = pl->K4_fwd; p.Cout = g.Cout; p.Cout_p = pl->Cout_p;
+    p.w_ld = pl->w_ld ? pl->w_ld : g.Cout;
     p.accumulate = accumulate;
     p.Ptot = (long long)g.n_img * g.Ho * g.Wo;
     int split = pl->wgrad_split;

@@ -50,6 +50,10 @@ struct wdg_conv_plan {
     wdg_conv_geom g;
     int Cin_p, Cout_p, taps;
     int cus;
+    // > 0 (wdg_conv_plan_create_sliced): the plan covers a RANGE of output channels of a layer whose HWIO weight tensor has w_ld of
+    // them; the data- and weight-gradient entry points then address that tensor (pointers offset to the range's first channel) with
+    // this channel stride instead of the plan's own channel count
+    int w_ld = 0;
     // forward
     int4* d_tab_fwd = nullptr;
     int2* d_wrow = nullptr;

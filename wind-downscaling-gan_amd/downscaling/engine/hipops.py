@@ -439,20 +439,43 @@ class HipOps:
         self.split_mode = bool(on)
         native.check(self.lib.wdg_set_tuning(b"igemm_pipe", 4 if on else 3), "set_tuning")
 
-    def _plan(self, x, y, cin, cout, g: ConvGeom):
+    def _plan(self, x, y, cin, cout, g: ConvGeom, w_ld=0):
         px, ldx, isx = _v4(x)
         py, ldy, isy = _v4(y)
         n, H, W, _ = x.shape
         _, Ho, Wo, _ = y.shape
-        return self._plan_dims(n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g)
+        return self._plan_dims(n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g, w_ld)
 
-    def _plan_dims(self, n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g):
-        key = (n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad)
+    supports_weight_slices = True
+
+    def conv_dgrad_slice(self, dy, pk, n0, n1, dx, g, accumulate=False):
+        """dx (+)= conv_transpose(dy, W[..., n0:n1]) for a channel RANGE of the layer's output: dy is the [.., n0:n1] view of the
+        output-gradient tensor, pk the pack of the FULL layer (wdg_conv_plan_create_sliced).  A ConvLSTM2D at n_timesteps = 1 has
+        a dead forget gate (c_0 = 0): its quarter of the reduction is skipped this way."""
+        assert pk.cout % 4 == 0 and n0 % 4 == 0 and n1 % 4 == 0 and dy.shape[-1] == n1 - n0 and not self.split_mode
+        plan, wsb, _ = self._plan(dx, dy, pk.cin, n1 - n0, g, w_ld=pk.cout)
+        ws = self._workspace(wsb)
+        native.check(self.lib.wdg_conv_dgrad(plan, dy.data_ptr(), pk.wD.data_ptr() + 4 * n0, None, dx.data_ptr(), 0, 0.2,
+                                             int(accumulate), ws.data_ptr(), ws.numel(), self.stream), "conv_dgrad(slice)")
+
+    def conv_wgrad_slice(self, x, dy, pk, n0, n1, dw, g, accumulate=True):
+        """dw[..., n0:n1] (+)= x (*) dy for a channel range (see conv_dgrad_slice); dw is the FULL [kh,kw,Cin,Cout] gradient."""
+        assert dw.is_contiguous() and dw.shape[-1] == pk.cout and pk.cout % 4 == 0 and n0 % 4 == 0 and dy.shape[-1] == n1 - n0
+        plan, wsb, _ = self._plan(x, dy, pk.cin, n1 - n0, g, w_ld=pk.cout)
+        ws = self._workspace(wsb)
+        native.check(self.lib.wdg_conv_wgrad(plan, x.data_ptr(), dy.data_ptr(), dw.data_ptr() + 4 * n0, int(accumulate),
+                                             ws.data_ptr(), ws.numel(), self.stream), "conv_wgrad(slice)")
+
+    def _plan_dims(self, n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g, w_ld=0):
+        key = (n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad) + ((w_ld,) if w_ld else ())
         plan = self._plans.get(key)
         if plan is None:
             geom = native.ConvGeom(n, H, W, cin, ldx, isx, Ho, Wo, cout, ldy, isy, g.kh, g.kw, g.stride, g.pad, g.pad)
             handle = C.c_void_p()
-            native.check(self.lib.wdg_conv_plan_create(C.byref(handle), C.byref(geom)), f"plan_create{key}")
+            if w_ld:
+                native.check(self.lib.wdg_conv_plan_create_sliced(C.byref(handle), C.byref(geom), int(w_ld)), f"plan_create_sliced{key}")
+            else:
+                native.check(self.lib.wdg_conv_plan_create(C.byref(handle), C.byref(geom)), f"plan_create{key}")
             info = (C.c_int32 * 8)()
             native.check(self.lib.wdg_conv_plan_info(handle, info), "plan_info")
             plan = (handle, int(self.lib.wdg_conv_ws_bytes(handle)), tuple(info))
@@ -463,9 +486,10 @@ class HipOps:
     def _label(bm, bn):
         return "wdg_conv_halo_kernel<%d>" % (bn // 16) if bm == 0 else "wdg_igemm_kernel<%d,%d>" % (bm, bn)
 
-    def conv_kernel_label(self, which, x, y, pk, g):
-        """Name of the kernel template a conv call launches (profiling labels; which: fwd|dgrad|wgrad)."""
-        info = self._plan(x, y, pk.cin, pk.cout, g)[2]
+    def conv_kernel_label(self, which, x, y, pk, g, cout=None, w_ld=0):
+        """Name of the kernel template a conv call launches (profiling labels; which: fwd|dgrad|wgrad).  cout / w_ld: the
+        channel-range calls (conv_dgrad_slice / conv_wgrad_slice)."""
+        info = self._plan(x, y, pk.cin, pk.cout if cout is None else cout, g, w_ld=w_ld)[2]
         if which == "fwd":
             return self._label(info[0], info[1])
         if which == "dgrad":

@@ -7,6 +7,8 @@ backward needs and the networks call the backward passes in reverse order.  Laye
 operations follows the reference: conv -> bias -> LeakyReLU(0.2) -> norm; the LeakyReLU derivative
 is taken from the sign of the stored activation and fused into the norm backward.
 """
+import os
+
 from . import params as P
 from .common import ConvGeom, round4, v2
 
@@ -412,10 +414,19 @@ class ConvLSTM:
                     + tuple(packs), time_loop, graphs=self._chain_graphs)
         else:
             time_loop()
+        # n_timesteps = 1: dgates of the forget gate = dc * c_0 * hs' = 0 -> its quarter of the weight gradient and of the data
+        # gradient's reduction is skipped (channel ranges [0, F) and [2F, 4F) of the gate tensor: HipOps.conv_dgrad_slice)
+        live = T == 1 and F % 4 == 0 and getattr(o, "supports_weight_slices", False) and not getattr(o, "split_mode", False) \
+            and os.environ.get("WDG_LSTM_LIVE_GATES", "1") != "0"
         if need_wgrad:
             def weight_grads():
                 # (the bias gradient — the column sums of dgates, 453 MB at batch 8 x T 24 — rides on the input kernel's weight
                 # gradient where that kernel has a spare constant-1 row: the discriminator's 5- and 2-channel layers)
+                if live:
+                    o.conv_wgrad_slice(x, self.dgates[..., :F], self.pkx, 0, F, self.wx.grad, self.g, accumulate=True)
+                    o.conv_wgrad_slice(x, self.dgates[..., 2 * F:], self.pkx, 2 * F, 4 * F, self.wx.grad, self.g, accumulate=True)
+                    o.colsum(v2(self.dgates), self.b.grad, accumulate=True)
+                    return
                 o.conv_wgrad(x, self.dgates, self.pkx, self.wx.grad, self.g, accumulate=True, dbias=self.b.grad)
                 if T > 1:
                     o.conv_wgrad(h[:(T - 1) * B], self.dgates[B:], self.pkh, self.wh.grad, self.g, accumulate=True)
@@ -424,5 +435,8 @@ class ConvLSTM:
                 self.net._wgrad(weight_grads, joins)      # under the input gradient below (the network's pass joins)
             else:
                 weight_grads()
-        if dx is not None:
+        if dx is not None and live:
+            o.conv_dgrad_slice(self.dgates[..., :F], self.pkx, 0, F, dx, self.g, accumulate=accumulate_dx)
+            o.conv_dgrad_slice(self.dgates[..., 2 * F:], self.pkx, 2 * F, 4 * F, dx, self.g, accumulate=True)
+        elif dx is not None:
             o.conv_dgrad(self.dgates, self.pkx, dx, self.g, accumulate=accumulate_dx)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "wdg_split_bf16x3": (i32, [c_fp, c_fp, i64, c_fp]),
     "wdg_split_register": (i32, [c_fp, c_fp, i64]),
     "wdg_conv_plan_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom)]),
+    "wdg_conv_plan_create_sliced": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom), i32]),
     "wdg_conv_plan_destroy": (i32, [C.c_void_p]),
     "wdg_conv_ws_bytes": (szt, [C.c_void_p]),
     "wdg_conv_plan_info": (i32, [C.c_void_p, C.POINTER(i32)]),
