@@ -428,6 +428,16 @@ int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float
                       int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
                       wdg_stream stream);
 
+/* Input gradient of the LAST cin - dx_c0 input channels only: dx[..., 0 : cin - dx_c0] (+)= d x[..., dx_c0 : cin].  The
+ * discriminator's 5 -> 16 layer reads concat(low, high) (models.py:100-101); only the gradient of the two high-resolution
+ * channels is ever used (gradient penalty ganbase.py:35, generator step :60) — with dx = the buffer that already holds the
+ * 2 -> 2 layer's input gradient (models.py:93) and accumulate_dx = 1, d(high) is complete after this call.  dx_c0: 0, or 3
+ * with cin = 5. */
+int wdg_convlstm1_bwd_dx_from(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                              const float* dh, int lddh, int64_t img_stride_dh, float* dx, int lddx,
+                              int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                              int dx_c0, wdg_stream stream);
+
 /* wdg_convlstm1_bwd plus the layer's weight and bias gradient in the same pass: dw [3][3][cin][4F] += and
  * dbias [4F] += (MFMA over the LDS-resident x / dgates tiles, persistent blocks, block partials summed in block
  * order by a second kernel) — no dense dgates tensor is written.  ws: wdg_convlstm1_wgrad_ws_bytes() of scratch. */

@@ -496,7 +496,20 @@ class TorchOps:
         self.lstm_fwd(gates.view(-1, 4 * F_), None, c.view(-1, F_), hh.view(-1, F_), F_)
         h[..., :F_] = hh
 
-    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False, dw=None, dbias=None, x2=None):
+    def convlstm1_dx_from_supported(self, cin, F_, c0):
+        return cin == 5 and F_ == 16 and c0 == 3
+
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F_, accumulate_dx=False, dw=None, dbias=None, x2=None, dx_c0=0):
+        if dx_c0:
+            # HipOps.convlstm1_bwd(dx_c0=): the gradient of input channels [dx_c0, cin) only, into dx[..., :cin - dx_c0]
+            full = torch.zeros(*x.shape[:3], (cin + 3) // 4 * 4, dtype=x.dtype)
+            self.convlstm1_bwd(x, wx, bias, dh, None, full, cin, F_)
+            part = full[..., dx_c0:cin]
+            if accumulate_dx:
+                dx[..., :cin - dx_c0] += part
+            else:
+                dx[..., :cin - dx_c0] = part
+            return
         x = self._with_x2(x, cin, x2)
         pk = PackedWeights(self, wx)
         gates = torch.zeros(*x.shape[:3], 4 * F_, dtype=x.dtype)

@@ -340,9 +340,19 @@ def test_fused_single_step_convlstm(cin, F_, n, H, W, hip_ops, ref_ops):
             dw6, db6 = ops.zeros(3, 3, cin, 4 * F_), ops.zeros(4 * F_)
             ops.convlstm1_bwd(xg, ww, bb, dd, None, None, cin, F_, dw=dw6, dbias=db6, x2=(x2, n2))
             res[name].update(h_x2=h2, dx_x2=dx4, dw_x2=dw4, db_x2=db4, dx5_x2=dx5, dw6_x2=dw6, db6_x2=db6)
+            # the gradient of the two high-resolution channels ALONE, added onto a 4-channel buffer that already holds the other
+            # branch's gradient (wdg_convlstm1_bwd_dx_from): channels 2, 3 of that buffer stay as they are
+            assert ops.convlstm1_dx_from_supported(cin, F_, 3)
+            dhi = cv(torch.full((n, H, W, 4), 0.75, dtype=torch.float64))
+            ops.convlstm1_bwd(xv, ww, bb, dd, None, dhi, cin, F_, accumulate_dx=True, dx_c0=3)
+            dhi0 = cv(torch.full((n, H, W, 4), 0.75, dtype=torch.float64))
+            ops.convlstm1_bwd(xv, ww, bb, dd, None, dhi0, cin, F_, accumulate_dx=False, dx_c0=3)
+            res[name].update(dhi=dhi, dhi0=dhi0)
     for k in res["ref"]:
         assert rel_err(res["hip"][k], res["ref"][k]) < TOL, k
     if cin == 5:
+        assert float((res["hip"]["dhi"][..., 2:] - 0.75).abs().max()) == 0.0 and float((res["hip"]["dhi0"][..., 2:] - 0.75).abs().max()) == 0.0
+        assert rel_err(res["hip"]["dhi"][..., :2] - 0.75, res["ref"]["dx2"][..., 3:5]) < 10 * TOL
         assert rel_err(res["hip"]["h_x2"], res["hip"]["h"]) < 1e-6 and rel_err(res["hip"]["dx5_x2"], res["hip"]["dx2"]) < 1e-6
     if Fp > F_:
         assert float(res["hip"]["h"][..., F_:].abs().max()) == 0.0

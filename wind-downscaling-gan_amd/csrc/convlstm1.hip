@@ -346,10 +346,13 @@ __global__ void __launch_bounds__(256, PRE ? 1 : 4) wdg_convlstm1_fwd_mfma_kerne
 // for the life of the persistent block (36 per lane: the MFMA's row operand does not depend on the pixel) — and the cell backward runs on the transposed accumulators (a lane holds gates
 // i, c~, o of four features of one pixel).  The vector pipe keeps the cell math and the input-gradient stage; with three
 // workgroups per CU in different stages the two pipes overlap (MI355X_MICROARCH.md: MFMA and VALU issue are separate).
-template <int CIN, int F, bool WG, bool MF = false>
+// DXC0 > 0: the input gradient of channels [DXC0, CIN) only, written to dX[..., 0 : CIN - DXC0] (the discriminator needs the
+// gradient of the two high-resolution channels of concat(low, high), models.py:100: the three low-resolution ones are data)
+template <int CIN, int F, bool WG, bool MF = false, int DXC0 = 0>
 __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, const float* __restrict__ Wx,
                                                                 const float* __restrict__ bias) {
     static_assert(!MF || F == 16, "the MFMA gate stage is written for 16 features");
+    static_assert(DXC0 >= 0 && DXC0 < CIN, "channel range");
     constexpr int FH = F >= 2 ? F / 2 : 1;
     constexpr int C4 = (CIN + 3) / 4;
     constexpr int XH = CL_TH + 4, XW = CL_TW + 4;    // x halo (two 3x3 stages)
@@ -609,11 +612,11 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
     const int py = cp >> 5, px = cp & 31;
     float dx[CIN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) dx[c] = 0.f;
+    for (int c = DXC0; c < CIN; ++c) dx[c] = 0.f;
     if (half_on) {
         f32x2 dx2[CIN];   // packed partial sums over even / odd features
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) dx2[c] = (f32x2){0.f, 0.f};
+        for (int c = DXC0; c < CIN; ++c) dx2[c] = (f32x2){0.f, 0.f};
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int th = tap / 3, tw = tap % 3;
@@ -626,7 +629,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
                 v[2][f] = dgp[2 * F + f];
             }
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
+            for (int c = DXC0; c < CIN; ++c) {
                 const float* w = Wx + (tap * CIN + c) * 4 * F + f0;
                 if constexpr (FH % 2 == 0) {
 #pragma unroll
@@ -646,27 +649,27 @@ __global__ void __launch_bounds__(256) wdg_convlstm1_bwd_kernel(const WdgCl1 p, 
             }
         }
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) dx[c] += dx2[c][0] + dx2[c][1];
+        for (int c = DXC0; c < CIN; ++c) dx[c] += dx2[c][0] + dx2[c][1];
     }
     if (half == 1) {
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) dxp[cp * CIN + c] = dx[c];
+        for (int c = DXC0; c < CIN; ++c) dxp[cp * CIN + c] = dx[c];
     }
     __syncthreads();
     if (half == 0) {
         const int gy = oy0 + py, gx = ox0 + px;
         float prev[CIN];
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) prev[c] = 0.f;
+        for (int c = DXC0; c < CIN; ++c) prev[c] = 0.f;
         if (p.accumulate_dx) {          // (the previous values together, from a clamped = always valid address)
             const float* src = p.dX + (long long)img * p.imgStrideDX + ((long long)min(gy, p.H - 1) * p.W + min(gx, p.W - 1)) * p.lddx;
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) prev[c] = src[c];
+            for (int c = DXC0; c < CIN; ++c) prev[c] = src[c - DXC0];
         }
         if (gy < p.H && gx < p.W) {
             float* dst = p.dX + (long long)img * p.imgStrideDX + ((long long)gy * p.W + gx) * p.lddx;
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) dst[c] = dx[c] + (F >= 2 ? dxp[cp * CIN + c] : 0.f) + prev[c];
+            for (int c = DXC0; c < CIN; ++c) dst[c - DXC0] = dx[c] + (F >= 2 ? dxp[cp * CIN + c] : 0.f) + prev[c];
         }
     }
     }   // if (p.dX)
@@ -796,8 +799,9 @@ struct Cl1X2 {
 static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
                    const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
                    int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
-                   float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream, const Cl1X2* x2 = nullptr) {
+                   float* dw, float* dbias, void* ws, size_t ws_bytes, wdg_stream stream, const Cl1X2* x2 = nullptr, int dx_c0 = 0) {
     WDG_CHECK_ARG(x && wx && bias && dh, "null argument");
+    WDG_CHECK_ARG(dx_c0 == 0 || (dx_c0 == 3 && cin == 5 && dx && !dw && !dgates), "dx_c0: 0, or 3 on the 5 -> 16 layer's input-gradient-only call");
     WDG_CHECK_ARG(wdg_convlstm1_supported(cin, F), "unsupported (cin, F)");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x alignment / ld");
     WDG_CHECK_ARG(!(x2 && x2->x2) || (wdg_convlstm1_x2_supported(cin, F, x2->x2_n) && x2->ldx2 >= x2->x2_n), "second input source: 5 -> 16 layer only");
@@ -817,12 +821,18 @@ static int cl1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* w
         dim3 grid((unsigned)ntiles);
         if (cin == 2)
             hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<2, 2, false>), grid, block, 0, st, p, wx, bias);
-        else if (dgates || !g_cl1_mfma)
-            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false>), grid, block, 0, st, p, wx, bias);
-        else {
+        else if (dgates || !g_cl1_mfma) {
+            if (dx_c0 == 3)
+                hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false, false, 3>), grid, block, 0, st, p, wx, bias);
+            else
+                hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false>), grid, block, 0, st, p, wx, bias);
+        } else {
             // persistent like the weight-gradient form: the LDS-resident weights are loaded once per workgroup
             dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 2));   // (three fit — 52 KB of LDS, <= 168 registers — and measured slower: 594 vs 480 us with the weight gradient)
-            hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false, true>), pgrid, block, 0, st, p, wx, bias);
+            if (dx_c0 == 3)
+                hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false, true, 3>), pgrid, block, 0, st, p, wx, bias);
+            else
+                hipLaunchKernelGGL((wdg_convlstm1_bwd_kernel<5, 16, false, true>), pgrid, block, 0, st, p, wx, bias);
         }
         WDG_LAUNCH_CHECK();
         return WDG_OK;
@@ -861,6 +871,19 @@ extern "C" int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, 
                                  wdg_stream stream) {
     return cl1_bwd(x, ldx, img_stride_x, wx, bias, dh, lddh, img_stride_dh, dgates, dx, lddx, img_stride_dx, accumulate_dx,
                    n_img, H, W, cin, F, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Input gradient of the LAST cin - dx_c0 channels only: dx[..., 0 : cin - dx_c0] (+)= d(x[..., dx_c0 : cin]).  The discriminator's
+// 5 -> 16 layer reads concat(low, high) (models.py:100) and only the two high-resolution channels' gradient is ever used — by the
+// gradient penalty (ganbase.py:35) and by the generator step (:60): with dx = the buffer that holds the 2 -> 2 layer's input
+// gradient and accumulate_dx = 1 the sum d(high) is complete after this call.  dx_c0: 0 or 3 (cin = 5).
+extern "C" int wdg_convlstm1_bwd_dx_from(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
+                                         const float* dh, int lddh, int64_t img_stride_dh, float* dx, int lddx,
+                                         int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,
+                                         int dx_c0, wdg_stream stream) {
+    WDG_CHECK_ARG(dx, "null dx");
+    return cl1_bwd(x, ldx, img_stride_x, wx, bias, dh, lddh, img_stride_dh, nullptr, dx, lddx, img_stride_dx, accumulate_dx,
+                   n_img, H, W, cin, F, nullptr, nullptr, nullptr, 0, stream, nullptr, dx_c0);
 }
 
 // As wdg_convlstm1_bwd, plus dw [3][3][cin][4F] += and dbias [4F] += formed in the same pass (no dgates tensor).

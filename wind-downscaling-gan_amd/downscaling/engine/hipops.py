@@ -1035,13 +1035,22 @@ class HipOps:
         native.check(self.lib.wdg_convlstm_gates_x(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), gates.data_ptr(), n, H, W, cin, F,
                                                    self.stream), "convlstm_gates_x")
 
-    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False, dw=None, dbias=None, x2=None):
+    def convlstm1_dx_from_supported(self, cin, F, c0):
+        return cin == 5 and F == 16 and c0 == 3
+
+    def convlstm1_bwd(self, x, wx, bias, dh, dgates, dx, cin, F, accumulate_dx=False, dw=None, dbias=None, x2=None, dx_c0=0):
         """dgates [N,H,W,4F] (dense, optional) and dx[..., :cin] (optional) from x and dh, recomputing the gates.
-        dw / dbias given: the kernel and bias gradient are accumulated in the same pass (no dgates tensor)."""
+        dw / dbias given: the kernel and bias gradient are accumulated in the same pass (no dgates tensor).
+        dx_c0 > 0 (convlstm1_dx_from_supported): only the gradient of input channels [dx_c0, cin), written to dx[..., :cin - dx_c0]."""
         px, ldx, isx = _v4(x)
         pdh, lddh, isdh = _v4(dh)
         n, H, W, _ = x.shape
         pdx, lddx, isdx = _v4(dx) if dx is not None else (0, 0, 0)
+        if dx_c0:
+            assert dx is not None and dw is None and dgates is None and x2 is None and self.convlstm1_dx_from_supported(cin, F, dx_c0)
+            native.check(self.lib.wdg_convlstm1_bwd_dx_from(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), pdh, lddh, isdh, pdx, lddx, isdx,
+                                                            int(accumulate_dx), n, H, W, cin, F, int(dx_c0), self.stream), "convlstm1_bwd_dx_from")
+            return
         if x2 is not None:
             # (x2 as in convlstm1_fwd: the last channels of the input from a second tensor — wdg_convlstm1_bwd_x2)
             assert dgates is None and (dw is None or (dbias is not None and dw.is_contiguous()))

@@ -366,11 +366,21 @@ class ConvLSTM:
         else:
             time_loop()
 
-    def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False, x2=None):
+    def dx_from_ok(self, T, c0, need_wgrad, x2=None):
+        """Can backward(..., dx_c0=c0) produce the gradient of the input channels [c0, cin) alone?"""
+        return (self._fused1(T) and not need_wgrad and x2 is None and hasattr(self.ops, "convlstm1_dx_from_supported")
+                and self.ops.convlstm1_dx_from_supported(self.cin, self.F, c0))
+
+    def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False, x2=None, dx_c0=0):
         """dh: total gradient w.r.t. every h_t (modified in place by the BPTT recursion);
-        dx: view receiving the input gradient (None to skip).  x2: as in forward."""
+        dx: view receiving the input gradient (None to skip).  x2: as in forward.
+        dx_c0 > 0 (dx_from_ok): dx[..., :cin - dx_c0] receives the gradient of input channels [dx_c0, cin) only."""
         o, F = self.ops, self.F
         N, H, W, _ = h.shape
+        if dx_c0:
+            assert self.dx_from_ok(T, dx_c0, need_wgrad, x2) and dx is not None
+            o.convlstm1_bwd(x, self.wx.value, self.b.value, dh, None, dx, self.cin, F, accumulate_dx=accumulate_dx, dx_c0=dx_c0)
+            return
         if self._fused1(T):
             # input gradient and (need_wgrad) kernel + bias gradient in ONE kernel: the gates are recomputed from x and
             # the dense dgates tensor is never materialised

@@ -728,8 +728,17 @@ class DiscriminatorNet(_Net):
             self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dha"], need_wgrad)
             self.lstm_a.backward(b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None, B, T, need_wgrad)
 
+        # d(high) = d(hi) + d(mix)[cl:cl+ch].  Where the low + high layer can produce the gradient of its high-resolution channels
+        # alone (one timestep, no weight gradient in this pass: the gradient-penalty pass and the generator step), it adds them
+        # onto d(hi) directly — the three low-resolution channels' gradient is never used, and the two channel copies go away
+        direct = (need_input_grad and not getattr(self, "_overlap_now", False) and os.environ.get("WDG_DHIGH_DIRECT", "1") != "0"
+                  and self.lstm_b.dx_from_ok(T, self.cl, need_wgrad, b.get("mix_x2")))
+
         def branch_b():   # low + high
             self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad, ln_done=b_chained)
+            if direct:
+                self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dhi"], B, T, need_wgrad, accumulate_dx=True, dx_c0=self.cl)
+                return
             self.lstm_b.backward(b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad,
                                  x2=b.get("mix_x2"))
 
@@ -744,6 +753,8 @@ class DiscriminatorNet(_Net):
         self._join(joins)
         if not need_input_grad:
             return None
+        if direct:
+            return b["dhi"]
         # d(high) = d(hi) + d(mix)[cl:cl+ch]
         o.copy_channels(b["dhi"][..., :self.ch], b["dhigh"][..., :self.ch])
         o.copy_channels(b["dmix"][..., self.cl:self.cl + self.ch], b["dhigh"][..., :self.ch], accumulate=True)
