@@ -142,8 +142,13 @@ def test_time_loops_replayed_from_hip_graphs(hip_ops):
     assert rel_err(eager[0][0], eager[3][0]) > 1e-3      # (the updates do move the score)
 
 
+@pytest.mark.parametrize("schedule", ["three_networks", "twin", "one_network", "serial"])
 @pytest.mark.parametrize("S,T", [(32, 2), (20, 1), (96, 1)])
-def test_train_step(hip_ops, S, T):
+def test_train_step(hip_ops, S, T, schedule):
+    """GanEngine.train_step on the HIP kernels against the autograd restatement of ganbase.py:21-94, two steps, under every
+    critic schedule of GanEngine._critic_pipelined: the default (gradient-penalty / real / generated pass on three networks and
+    streams), the real pass on a twin only (rounds 4-5), all three on this network beside the generator's stream, and the
+    reference's serial order on one stream."""
     from downscaling.engine.networks import DiscriminatorNet, GeneratorNet
     from downscaling.engine.trainer import AdamTF, GanEngine, PhiloxSource
     B, cin, nz, ch = 2, 3, 4, 2
@@ -152,6 +157,14 @@ def test_train_step(hip_ops, S, T):
     disc = DiscriminatorNet(hip_ops, S, S, cin, ch, T, feature_channels=8, seed=6)
     gw, dw = randomize(gen, 21), randomize(disc, 22)
     eng = GanEngine(gen, disc, PhiloxSource(hip_ops, seed=99), noise_std=0.1, n_critic=3)
+    if schedule == "three_networks":
+        assert eng.overlap_generator and eng.overlap_discriminator and eng.triple_discriminator == "2"      # the default
+    elif schedule == "twin":
+        eng.triple_discriminator = "1"
+    elif schedule == "one_network":
+        eng.overlap_discriminator = False
+    else:
+        eng.overlap_generator = False
     g_opt, d_opt = AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1)
     og, od = TM.AdamTF(1e-4), TM.AdamTF(4e-4)
     draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
