@@ -1,3 +1,5 @@
 set -u
-T="-- --size 96 --timesteps 24 --batch 8"
-AB_STEPS=8 bash tools/ab_step.sh "t24:$T" "t24nograph:WDG_CHAIN_GRAPHS=0 $T" "t24:$T" "t24nograph:WDG_CHAIN_GRAPHS=0 $T" "t24twin_nograph:WDG_CHAIN_GRAPHS=0 WDG_OVERLAP_DISC=1 $T" > gpurun_out/r05ap_ab.txt 2>&1; cut -c1-60 gpurun_out/r05ap_ab.txt
+C=g4_wgrad,g2_wgrad,g0_wgrad,d1_wgrad,d2_wgrad,g5_wgrad
+python tools/perf_ops.py --reps 7 --cases $C 2>&1 | tail -7 > gpurun_out/r05ar_base.txt
+WDG_LIB=gpurun_variants/libwdgan_exp8.so python tools/perf_ops.py --reps 7 --cases $C 2>&1 | tail -7 > gpurun_out/r05ar_nobarrier.txt
+paste gpurun_out/r05ar_base.txt gpurun_out/r05ar_nobarrier.txt | cut -c1-200
