@@ -423,6 +423,12 @@ int wdg_convlstm1_bwd_x2(const float* x, int ldx, int64_t img_stride_x, const fl
 int wdg_convlstm_gates_x_supported(int cin, int F);
 int wdg_convlstm_gates_x(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias, float* gates,
                          int n_img, int H, int W, int cin, int F, wdg_stream stream);
+/* Data gradient of wdg_convlstm_gates_x for the 2 -> 2-feature layer (models.py:93 under ganbase.py:35,60):
+ * dx[..., 0:2] (+)= conv_transpose(dgates, wx); dgates dense [n][H][W][8], wx the kernel [3][3][2][8] (HWIO) as stored.
+ * (wdg_convlstm_gates_x covers this layer too: one pixel per thread on the vector unit, both directions.) */
+int wdg_convlstm_gates_dx_supported(int cin, int F);
+int wdg_convlstm_gates_dx(const float* dgates, const float* wx, float* dx, int lddx, int64_t img_stride_dx, int accumulate,
+                          int n_img, int H, int W, int cin, int F, wdg_stream stream);
 int wdg_convlstm1_bwd(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias,
                       const float* dh, int lddh, int64_t img_stride_dh, float* dgates, float* dx, int lddx,
                       int64_t img_stride_dx, int accumulate_dx, int n_img, int H, int W, int cin, int F,

@@ -972,6 +972,40 @@ def test_convlstm_gates_x(hip_ops, ref_ops, n, H, W):
     assert rel_err(y_g, y_r) < TOL
 
 
+@pytest.mark.parametrize("n,H,W", [(3, 19, 33), (5, 96, 96), (2, 8, 32), (1, 41, 70)])
+def test_convlstm_gates_x_two_features(hip_ops, ref_ops, n, H, W):
+    """The 2 -> 2-feature layer (models.py:93) at n_timesteps > 1: input part of the gates for all timesteps
+    (wdg_convlstm_gates_x, one pixel per thread) and its data gradient (wdg_convlstm_gates_dx: overwrite and accumulate, dx a
+    channel-padded view whose pad channels stay untouched) against the oracle's convolution / transposed convolution."""
+    from oracle.torch_backend import ConvGeom as RG
+    gen = torch.Generator().manual_seed(H * W + 1)
+    dev = hip_ops.device
+    x = torch.zeros(n, H, W, 4, dtype=torch.float64)
+    x[..., :2] = torch.randn(n, H, W, 2, generator=gen, dtype=torch.float64)
+    w = torch.randn(3, 3, 2, 8, generator=gen, dtype=torch.float64) * 0.3
+    b = torch.randn(8, generator=gen, dtype=torch.float64)
+    pk_r = ref_ops.pack_weights(w)
+    y_r = torch.zeros(n, H, W, 8, dtype=torch.float64)
+    ref_ops.conv_fwd(x, pk_r, b, y_r, RG(3, 3, 1, 1), act=False)
+    y_g = torch.full((n, H, W, 8), float("nan"), device=dev)
+    x_g = x.float().to(dev)
+    x_g[..., 2:] = 7.0          # the pad channels of the stored input are not part of the layer
+    w_g = w.float().to(dev).contiguous()
+    assert hip_ops.convlstm_gates_x_supported(x_g, y_g, 2, 2)
+    hip_ops.convlstm_gates_x(x_g, w_g, b.float().to(dev), y_g, 2, 2)
+    assert rel_err(y_g, y_r) < TOL
+    dg = torch.randn(n, H, W, 8, generator=gen, dtype=torch.float64)
+    dx_r = torch.zeros(n, H, W, 4, dtype=torch.float64)
+    ref_ops.conv_dgrad(dg, pk_r, dx_r, RG(3, 3, 1, 1))
+    dg_g = dg.float().to(dev)
+    dx_g = torch.full((n, H, W, 4), 5.0, device=dev)
+    assert hip_ops.convlstm_gates_dx_supported(dg_g, dx_g, 2, 2)
+    hip_ops.convlstm_gates_dx(dg_g, w_g, dx_g, 2, 2, accumulate=False)
+    assert rel_err(dx_g[..., :2], dx_r[..., :2]) < TOL and float((dx_g[..., 2:] - 5.0).abs().max()) == 0.0
+    hip_ops.convlstm_gates_dx(dg_g, w_g, dx_g, 2, 2, accumulate=True)
+    assert rel_err(dx_g[..., :2], 2 * dx_r[..., :2]) < TOL
+
+
 @pytest.mark.parametrize("F,cinp,n,H,W,first", [(16, 16, 3, 24, 40, False), (16, 16, 8, 96, 96, True), (2, 4, 3, 24, 40, False),
                                                 (2, 4, 8, 96, 96, True), (16, 16, 2, 19, 33, False)])
 def test_convlstm_recurrent_bwd_step_fused(hip_ops, ref_ops, F, cinp, n, H, W, first):

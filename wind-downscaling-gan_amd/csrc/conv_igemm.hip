@@ -2007,6 +2007,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_tile2d = value;
         return WDG_OK;
     }
+    if (key && !strcmp(key, "lstm2_thin")) {
+        wdg_cl2_set_thin(value);
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "convlstm1_mfma")) {
         wdg_convlstm1_set_mfma(value);
         return WDG_OK;

@@ -89,6 +89,7 @@ void wdg_h16_set_small_tiles(int v);   // conv_igemm_bf16.hip
 void wdg_h16_set_lstm_fused(int v);
 void wdg_patch_h16_set_lstm_small(int v);
 void wdg_lstm16_set_step(int v);       // convlstm16.hip
+void wdg_cl2_set_thin(int v);          // convlstm1.hip
 struct WdgHaloLstm {   // ConvLSTM cell update / cell backward in the epilogue of the recurrent convolution (conv_halo.hip)
     int F, ldc, ldh;
     const float* c_prev;

@@ -770,11 +770,92 @@ extern "C" int wdg_convlstm1_fwd_x2(const float* x, int ldx, int64_t img_stride_
 
 // Input part of the gate pre-activations of the 5 -> 16-feature ConvLSTM2D for all timesteps (n_timesteps > 1, models.py:101):
 // gates[n, y, x, i | f | c~ | o] = conv(x, kernel)[...] + bias.  wx: the kernel [3][3][5][64] (HWIO) as stored.
-extern "C" int wdg_convlstm_gates_x_supported(int cin, int F) { return g_cl1_fwd_mfma && cin == 5 && F == 16; }
+// ---- the 2 -> 2-feature layer at n_timesteps > 1 (models.py:93): input part of the gates for ALL timesteps and its data gradient on
+// the vector unit, one pixel per thread.  8 output columns from 2 channels x 9 taps (144 FMAs, weights wave-uniform = scalar
+// operands): 48 bytes of HBM traffic per pixel.  The general halo-tile kernel (16-column MFMA tiles, K padded to 36) took 139 us for
+// the 1.77 M pixels of batch 8 x T 24 x 96^2 — ten times the 85 MB it moves.
+__global__ void __launch_bounds__(256) wdg_convlstm2_gates_x_kernel(const float* __restrict__ X, int ldx, long long imgStrideX,
+                                                                    const float* __restrict__ Wx, const float* __restrict__ bias,
+                                                                    float* __restrict__ gates, int n_img, int H, int W) {
+    const long long P = (long long)n_img * H * W;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= P) return;
+    const int img = (int)(pix / ((long long)H * W));
+    const int rem = (int)(pix - (long long)img * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    const float* Ximg = X + (long long)img * imgStrideX;
+    float acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = bias[n];
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int gy = oy + tap / 3 - 1, gx = ox + tap % 3 - 1;
+        float x0 = 0.f, x1 = 0.f;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            const float* q = Ximg + ((long long)gy * W + gx) * ldx;
+            x0 = q[0];
+            x1 = q[1];
+        }
+        const float* w = Wx + tap * 16;                 // [tap][c][8]
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[n] = fmaf(x1, w[8 + n], fmaf(x0, w[n], acc[n]));
+    }
+    f32x4* g = reinterpret_cast<f32x4*>(gates + pix * 8);
+    g[0] = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    g[1] = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+}
+
+// dx[p][c] (+)= sum_tap sum_n dgates[p + (1 - th, 1 - tw)][n] * Wx[tap][c][n]   (the transposed convolution of the above)
+__global__ void __launch_bounds__(256) wdg_convlstm2_dx_kernel(const float* __restrict__ dG, const float* __restrict__ Wx,
+                                                               float* __restrict__ dX, int lddx, long long imgStrideDX, int accumulate,
+                                                               int n_img, int H, int W) {
+    const long long P = (long long)n_img * H * W;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= P) return;
+    const int img = (int)(pix / ((long long)H * W));
+    const int rem = (int)(pix - (long long)img * H * W);
+    const int oy = rem / W, ox = rem - oy * W;
+    const float* Gimg = dG + (long long)img * H * W * 8;
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int gy = oy + 1 - tap / 3, gx = ox + 1 - tap % 3;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(Gimg + ((long long)gy * W + gx) * 8);
+            const f32x4 a = q[0], b = q[1];
+            const float* w = Wx + tap * 16;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                d0 = fmaf(a[n], w[n], d0);
+                d0 = fmaf(b[n], w[4 + n], d0);
+                d1 = fmaf(a[n], w[8 + n], d1);
+                d1 = fmaf(b[n], w[12 + n], d1);
+            }
+        }
+    }
+    float* dst = dX + (long long)img * imgStrideDX + (long long)rem * lddx;
+    if (accumulate) {
+        d0 += dst[0];
+        d1 += dst[1];
+    }
+    dst[0] = d0;
+    dst[1] = d1;
+}
+
+static int g_cl2_thin = 1;      // wdg_set_tuning("lstm2_thin", 0/1): the one-pixel-per-thread kernels of the 2 -> 2-feature layer
+void wdg_cl2_set_thin(int v) { g_cl2_thin = v != 0; }
+extern "C" int wdg_convlstm_gates_x_supported(int cin, int F) { return (g_cl1_fwd_mfma && cin == 5 && F == 16) || (g_cl2_thin && cin == 2 && F == 2); }
 extern "C" int wdg_convlstm_gates_x(const float* x, int ldx, int64_t img_stride_x, const float* wx, const float* bias, float* gates,
                                     int n_img, int H, int W, int cin, int F, wdg_stream stream) {
     WDG_CHECK_ARG(x && wx && bias && gates && wdg_convlstm_gates_x_supported(cin, F), "unsupported");
     WDG_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)gates & 15) == 0 && ldx % 4 == 0 && ldx >= wdg_round_up(cin, 4), "x / gates alignment, ld");
+    if (cin == 2) {
+        const long long P = (long long)n_img * H * W;
+        hipLaunchKernelGGL(wdg_convlstm2_gates_x_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           (long long)img_stride_x, wx, bias, gates, n_img, H, W);
+        WDG_LAUNCH_CHECK();
+        return WDG_OK;
+    }
     WdgCl1 p;
     memset(&p, 0, sizeof(p));
     p.X = x; p.Wx = wx; p.bias = bias; p.Hout = gates;
@@ -785,6 +866,20 @@ extern "C" int wdg_convlstm_gates_x(const float* x, int ldx, int64_t img_stride_
     const long long ntiles = (long long)n_img * p.tiles_h * p.tiles_w;
     dim3 pgrid((unsigned)std::min<long long>(ntiles, (long long)cl1_cus() * 4)), block(256);
     hipLaunchKernelGGL((wdg_convlstm1_fwd_mfma_kernel<5, 16, true>), pgrid, block, 0, (hipStream_t)stream, p, wx, bias);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// Data gradient of wdg_convlstm_gates_x for the 2 -> 2-feature layer: dx[..., 0:2] (+)= conv_transpose(dgates, wx).
+// dgates: dense [n][H][W][8]; wx: the kernel [3][3][2][8] (HWIO) as stored.
+extern "C" int wdg_convlstm_gates_dx_supported(int cin, int F) { return g_cl2_thin && cin == 2 && F == 2; }
+extern "C" int wdg_convlstm_gates_dx(const float* dgates, const float* wx, float* dx, int lddx, int64_t img_stride_dx, int accumulate,
+                                     int n_img, int H, int W, int cin, int F, wdg_stream stream) {
+    WDG_CHECK_ARG(dgates && wx && dx && wdg_convlstm_gates_dx_supported(cin, F), "unsupported");
+    WDG_CHECK_ARG(((uintptr_t)dgates & 15) == 0 && lddx >= 2, "dgates alignment / dx stride");
+    const long long P = (long long)n_img * H * W;
+    hipLaunchKernelGGL(wdg_convlstm2_dx_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dgates, wx, dx, lddx,
+                       (long long)img_stride_dx, accumulate, n_img, H, W);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -1035,6 +1035,17 @@ class HipOps:
         native.check(self.lib.wdg_convlstm_gates_x(px, ldx, isx, wx.data_ptr(), bias.data_ptr(), gates.data_ptr(), n, H, W, cin, F,
                                                    self.stream), "convlstm_gates_x")
 
+    def convlstm_gates_dx_supported(self, dgates, dx, cin, F):
+        return bool(self.gates_x and self.lib.wdg_convlstm_gates_dx_supported(cin, F)) and dgates.is_contiguous() and \
+            dgates.shape[3] == 4 * F and dgates.data_ptr() % 16 == 0
+
+    def convlstm_gates_dx(self, dgates, wx, dx, cin, F, accumulate=False):
+        """dx[..., :cin] (+)= conv_transpose(dgates, wx): the data gradient of convlstm_gates_x (2 -> 2-feature layer)."""
+        pdx, lddx, isdx = _v4(dx)
+        n, H, W, _ = dgates.shape
+        native.check(self.lib.wdg_convlstm_gates_dx(dgates.data_ptr(), wx.data_ptr(), pdx, lddx, isdx, int(accumulate), n, H, W, cin, F,
+                                                    self.stream), "convlstm_gates_dx")
+
     def convlstm1_dx_from_supported(self, cin, F, c0):
         return cin == 5 and F == 16 and c0 == 3
 

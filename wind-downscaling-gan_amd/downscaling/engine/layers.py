@@ -448,5 +448,8 @@ class ConvLSTM:
         if dx is not None and live:
             o.conv_dgrad_slice(self.dgates[..., :F], self.pkx, 0, F, dx, self.g, accumulate=accumulate_dx)
             o.conv_dgrad_slice(self.dgates[..., 2 * F:], self.pkx, 2 * F, 4 * F, dx, self.g, accumulate=True)
+        elif dx is not None and hasattr(o, "convlstm_gates_dx_supported") and o.convlstm_gates_dx_supported(self.dgates, dx, self.cin, F):
+            # (the 2 -> 2-feature layer: one pixel per thread on the vector unit, csrc/convlstm1.hip)
+            o.convlstm_gates_dx(self.dgates, self.wx.value, dx, self.cin, F, accumulate=accumulate_dx)
         elif dx is not None:
             o.conv_dgrad(self.dgates, self.pkx, dx, self.g, accumulate=accumulate_dx)

@@ -113,6 +113,8 @@ SIGNATURES = {
                                  i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_bwd_dx_from": (i32, [c_fp, i32, i64, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i64, i32,
                                          i32, i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convlstm_gates_dx_supported": (i32, [i32, i32]),
+    "wdg_convlstm_gates_dx": (i32, [c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_x2_supported": (i32, [i32, i32, i32]),
     "wdg_convlstm1_fwd_x2": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_bwd_x2": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i64, i32,
