@@ -237,6 +237,20 @@ int wdg_convlstm_bwd_step(const wdg_conv_plan* plan, const float* dgates_next, c
  * wdg_convlstm_step; wdg_convlstm16_supported: 1 when the plan is that layer (else use wdg_convlstm_step / _bwd_step). */
 int wdg_convlstm16_supported(const wdg_conv_plan* plan);
 int wdg_convlstm16_pack(const float* w_hwio, float* wl_fwd, float* wl_bwd, wdg_stream stream);
+/* BOTH recurrent layers of the discriminator (models.py:93 ConvLSTM2D(2) and :101 ConvLSTM2D(16): independent chains of T - 1
+ * dependent steps) in ONE launch per timestep and direction: the workgroups of the two-feature layer's pixel-per-thread step ride
+ * behind those of the 16-feature step.  plan16 / first argument group as wdg_convlstm16_step / _bwd_step; plan2 / second group as
+ * wdg_convlstm_step / wdg_convlstm_bwd_step with F = 2 (wF2 / wD2: that layer's packed forward / data-gradient weights). */
+int wdg_convlstm16_pair_supported(const wdg_conv_plan* plan16, const wdg_conv_plan* plan2);
+int wdg_convlstm16_pair_step(const wdg_conv_plan* plan16, const float* h_prev, const float* wl_fwd, float* gates, const float* c_prev,
+                             float* c_out, int ldc, float* h_out, int ldh, const wdg_conv_plan* plan2, const float* h_prev2,
+                             const float* wF2, float* gates2, const float* c_prev2, float* c_out2, int ldc2, float* h_out2, int ldh2,
+                             wdg_stream stream);
+int wdg_convlstm16_pair_bwd_step(const wdg_conv_plan* plan16, const float* dgates_next, const float* wl_bwd, float* dh_prev,
+                                 const float* gates_t, const float* c_prev, const float* c_cur, const float* dc_in, float* dgates_out,
+                                 float* dc_out, int ldc, const wdg_conv_plan* plan2, const float* dgates_next2, const float* wD2,
+                                 float* dh_prev2, const float* gates_t2, const float* c_prev2, const float* c_cur2, const float* dc_in2,
+                                 float* dgates_out2, float* dc_out2, int ldc2, wdg_stream stream);
 int wdg_convlstm16_step(const wdg_conv_plan* plan, const float* h_prev, const float* wl_fwd, float* gates, const float* c_prev,
                         float* c_out, int ldc, float* h_out, int ldh, wdg_stream stream);
 int wdg_convlstm16_bwd_step(const wdg_conv_plan* plan, const float* dgates_next, const float* wl_bwd, float* dh_prev,

@@ -15,6 +15,7 @@
 // pixel count padded to a multiple of 16, which makes every ds_read_b128 fragment read conflict-free
 // for any tap displacement.
 #include "conv_plan.h"
+#include "convlstm2.h"
 #include <algorithm>
 
 constexpr int HALO_TH = 8, HALO_TW = 32;
@@ -787,7 +788,6 @@ extern "C" int wdg_upconv_fwd(const wdg_conv_plan* pl, const float* x_low, int l
                            (hipStream_t)stream);
 }
 
-typedef float wdg_f32x2 __attribute__((ext_vector_type(2)));
 static int g_lstm_step_fused = 7;       // bit 0: forward step, bit 1: backward step, bit 2: the two-feature layer on its pixel-per-thread kernels
 // ---- two-feature ConvLSTM recurrent steps without the matrix pipe (the discriminator's first ConvLSTM, models.py:93: 2 -> 2
 // features at full resolution).  The work per timestep is tiny (144 multiply-adds per pixel); through the halo-tile MFMA
@@ -797,37 +797,7 @@ __global__ void __launch_bounds__(256) wdg_convlstm2_fwd_kernel(const float* __r
                                                                 const float* __restrict__ wF, float* gates,
                                                                 const float* __restrict__ c_prev, float* c_out, int ldc,
                                                                 float* h_out, int ldh, int n_img, int H, int W) {
-    const long long P = (long long)n_img * H * W;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const int img = (int)(idx / ((long long)H * W));
-    const int rem = (int)(idx - (long long)img * H * W);
-    const int y = rem / W, x = rem - y * W;
-    float* gp = gates + idx * 8;
-    f32x4 z0 = *reinterpret_cast<const f32x4*>(gp), z1 = *reinterpret_cast<const f32x4*>(gp + 4);
-    float z[8] = {z0[0], z0[1], z0[2], z0[3], z1[0], z1[1], z1[2], z1[3]};
-    const float* hb = h_prev + (long long)img * imgStrideX;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int yy = y + dy - 1, xx = x + dx - 1;
-            wdg_f32x2 hv = (wdg_f32x2){0.f, 0.f};
-            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                hv = *reinterpret_cast<const wdg_f32x2*>(hb + ((long long)yy * W + xx) * ldx);
-            const int tap = dy * 3 + dx;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) z[g] = fmaf(hv[1], wF[(g * 9 + tap) * 4 + 1], fmaf(hv[0], wF[(g * 9 + tap) * 4], z[g]));
-        }
-    *reinterpret_cast<f32x4*>(gp) = (f32x4){z[0], z[1], z[2], z[3]};
-    *reinterpret_cast<f32x4*>(gp + 4) = (f32x4){z[4], z[5], z[6], z[7]};
-    auto hs = [](float v) { return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); };
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const float cn = hs(z[2 + f]) * c_prev[idx * ldc + f] + hs(z[f]) * wdg_tanh(z[4 + f]);
-        c_out[idx * ldc + f] = cn;
-        h_out[idx * ldh + f] = hs(z[6 + f]) * wdg_tanh(cn);
-    }
+    wdg_convlstm2_fwd_body((long long)blockIdx.x * 256 + threadIdx.x, h_prev, ldx, imgStrideX, wF, gates, c_prev, c_out, ldc, h_out, ldh, n_img, H, W);
 }
 
 __global__ void __launch_bounds__(256) wdg_convlstm2_bwd_kernel(const float* __restrict__ dg_next, const float* __restrict__ wD,
@@ -835,52 +805,10 @@ __global__ void __launch_bounds__(256) wdg_convlstm2_bwd_kernel(const float* __r
                                                                 const float* __restrict__ gates_t, const float* __restrict__ c_prev,
                                                                 const float* __restrict__ c_cur, const float* __restrict__ dc_in,
                                                                 float* dgates_out, float* dc_out, int ldc, int n_img, int H, int W) {
-    const long long P = (long long)n_img * H * W;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    const int img = (int)(idx / ((long long)H * W));
-    const int rem = (int)(idx - (long long)img * H * W);
-    const int y = rem / W, x = rem - y * W;
-    float* dhp = dh_prev + (long long)img * imgStrideX + ((long long)y * W + x) * ldx;
-    float dh[2] = {dhp[0], dhp[1]};
-    const float* db = dg_next + (long long)img * H * W * 8;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int qy = y - (dy - 1), qx = x - (dx - 1);     // the output pixel whose tap (dy, dx) read this pixel
-            if ((unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W) {
-                const float* q = db + ((long long)qy * W + qx) * 8;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
-                const int tap = dy * 3 + dx;
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci) {
-                    const float* w = wD + (tap * 2 + ci) * 8;
-                    dh[ci] += (a[0] * w[0] + a[1] * w[1]) + (a[2] * w[2] + a[3] * w[3]) + (b[0] * w[4] + b[1] * w[5]) + (b[2] * w[6] + b[3] * w[7]);
-                }
-            }
-        }
-    dhp[0] = dh[0];
-    dhp[1] = dh[1];
-    auto hs = [](float v) { return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); };
-    auto hsg = [](float v) { const float u = 0.2f * v + 0.5f; return (u >= 0.f && u <= 1.f) ? 0.2f : 0.f; };
-    const float* g = gates_t + idx * 8;
-    float* dg = dgates_out + idx * 8;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const float xi = g[f], xf = g[2 + f], xc = g[4 + f], xo = g[6 + f];
-        const float gi = hs(xi), gf = hs(xf), gc = wdg_tanh(xc), go = hs(xo);
-        const float cp = c_prev ? c_prev[idx * ldc + f] : 0.f;
-        const float tc = wdg_tanh(c_cur[idx * ldc + f]);
-        const float dc = dh[f] * go * (1.f - tc * tc) + dc_in[idx * ldc + f];
-        dg[f] = dc * gc * hsg(xi);
-        dg[2 + f] = dc * cp * hsg(xf);
-        dg[4 + f] = dc * gi * (1.f - gc * gc);
-        dg[6 + f] = dh[f] * tc * hsg(xo);
-        if (dc_out) dc_out[idx * ldc + f] = dc * gf;
-    }
+    wdg_convlstm2_bwd_body((long long)blockIdx.x * 256 + threadIdx.x, dg_next, wD, dh_prev, ldx, imgStrideX, gates_t, c_prev, c_cur, dc_in,
+                           dgates_out, dc_out, ldc, n_img, H, W);
 }
-static bool lstm2_geom(const wdg_conv_plan* pl) {
+bool wdg_lstm2_geom(const wdg_conv_plan* pl) {
     const wdg_conv_geom& g = pl->g;
     return (g_lstm_step_fused & 4) && g.Cin == 2 && g.Cout == 8 && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad_h == 1 && g.pad_w == 1 &&
            g.H == g.Ho && g.W == g.Wo && g.ldx >= 2 && g.ldx % 2 == 0 && pl->Cin_p == 4 && pl->Cout_p == 8;
@@ -900,7 +828,7 @@ extern "C" int wdg_convlstm_step(const wdg_conv_plan* pl, const float* h_prev, c
     WDG_CHECK_ARG(pl && h_prev && wF && gates && c_prev && c_out && h_out && wdg_convlstm_step_supported(pl, F), "not supported for this geometry");
     WDG_CHECK_ARG(ldc >= F && ldh >= F && (F != 16 || (ldc % 4 == 0 && ldh % 4 == 0 && (((uintptr_t)c_prev | (uintptr_t)c_out | (uintptr_t)h_out) & 15) == 0)),
                   "bad strides / alignment");
-    if (F == 2 && lstm2_geom(pl) && (((uintptr_t)h_prev | (uintptr_t)gates) & 15) == 0) {
+    if (F == 2 && wdg_lstm2_geom(pl) && (((uintptr_t)h_prev | (uintptr_t)gates) & 15) == 0) {
         const wdg_conv_geom& g = pl->g;
         const long long P = (long long)g.n_img * g.H * g.W;
         hipLaunchKernelGGL(wdg_convlstm2_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h_prev, g.ldx,
@@ -930,7 +858,7 @@ extern "C" int wdg_convlstm_bwd_step(const wdg_conv_plan* pl, const float* dgate
     WDG_CHECK_ARG(pl && dgates_next && wD && dh_prev && gates_t && c_cur && dc_in && dgates_out && wdg_convlstm_bwd_step_supported(pl, F),
                   "not supported for this geometry");
     WDG_CHECK_ARG(ldc >= F, "bad stride");
-    if (F == 2 && lstm2_geom(pl) && (((uintptr_t)dgates_next | (uintptr_t)dgates_out) & 15) == 0) {
+    if (F == 2 && wdg_lstm2_geom(pl) && (((uintptr_t)dgates_next | (uintptr_t)dgates_out) & 15) == 0) {
         const wdg_conv_geom& g = pl->g;
         const long long P = (long long)g.n_img * g.H * g.W;
         hipLaunchKernelGGL(wdg_convlstm2_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dgates_next, wD,

@@ -90,6 +90,7 @@ void wdg_h16_set_lstm_fused(int v);
 void wdg_patch_h16_set_lstm_small(int v);
 void wdg_lstm16_set_step(int v);       // convlstm16.hip
 void wdg_cl2_set_thin(int v);          // convlstm1.hip
+bool wdg_lstm2_geom(const wdg_conv_plan* pl);   // conv_halo.hip: the two-feature layer on its pixel-per-thread step kernels?
 struct WdgHaloLstm {   // ConvLSTM cell update / cell backward in the epilogue of the recurrent convolution (conv_halo.hip)
     int F, ldc, ldh;
     const float* c_prev;

@@ -673,6 +673,41 @@ class HipOps:
                                                     _ptr(c_prev), c_cur.data_ptr(), dc_in.data_ptr(), dgates_out.data_ptr(), _ptr(dc_out),
                                                     ldc, F, self.stream), "convlstm_bwd_step")
 
+    # ---- both recurrent layers of the discriminator in one launch per timestep (csrc/convlstm16.hip: wdg_convlstm16_pair_*) ----
+    def convlstm_pair_supported(self, h16, gates16, pk16, h2, gates2, pk2, g):
+        """h16 / gates16 / pk16: one timestep's views and the recurrent pack of the 16-feature layer; h2 / gates2 / pk2: the
+        two-feature layer's."""
+        if os.environ.get("WDG_LSTM_PAIR", "1") == "0" or self.split_mode:
+            return False
+        p16, _, _ = self._plan(h16, gates16, pk16.cin, pk16.cout, g)
+        p2, _, _ = self._plan(h2, gates2, pk2.cin, pk2.cout, g)
+        return self._lstm16(p16, pk16, 16) and pk2.wD is not None and bool(self.lib.wdg_convlstm16_pair_supported(p16, p2))
+
+    def convlstm_pair_step(self, a, b, g):
+        """a = (h_prev, pk, gates_t, c_prev, c_out, h_out) of the 16-feature layer, b the same of the two-feature layer: convlstm_step
+        of both in one launch."""
+        h1, pk1, g1, cp1, co1, ho1 = a
+        h2, pk2, g2, cp2, co2, ho2 = b
+        p16, _, _ = self._plan(h1, g1, pk1.cin, pk1.cout, g)
+        p2, _, _ = self._plan(h2, g2, pk2.cin, pk2.cout, g)
+        native.check(self.lib.wdg_convlstm16_pair_step(p16, h1.data_ptr(), pk1.lstm16()[0].data_ptr(), g1.data_ptr(), cp1.data_ptr(),
+                                                       co1.data_ptr(), _v4(co1)[1], ho1.data_ptr(), _v4(ho1)[1],
+                                                       p2, h2.data_ptr(), pk2.wF.data_ptr(), g2.data_ptr(), cp2.data_ptr(), co2.data_ptr(),
+                                                       _v4(co2)[1], ho2.data_ptr(), _v4(ho2)[1], self.stream), "convlstm16_pair_step")
+
+    def convlstm_pair_bwd_step(self, a, b, g):
+        """a = (dgates_next, pk, dh_prev, gates_t, c_prev | None, c_cur, dc_in, dgates_out, dc_out | None) of the 16-feature layer, b of
+        the two-feature layer: convlstm_bwd_step of both in one launch."""
+        d1, pk1, dh1, g1, cp1, cc1, dci1, do1, dco1 = a
+        d2, pk2, dh2, g2, cp2, cc2, dci2, do2, dco2 = b
+        p16, _, _ = self._plan(dh1, d1, pk1.cin, pk1.cout, g)
+        p2, _, _ = self._plan(dh2, d2, pk2.cin, pk2.cout, g)
+        native.check(self.lib.wdg_convlstm16_pair_bwd_step(p16, d1.data_ptr(), pk1.lstm16()[1].data_ptr(), dh1.data_ptr(), g1.data_ptr(),
+                                                           _ptr(cp1), cc1.data_ptr(), dci1.data_ptr(), do1.data_ptr(), _ptr(dco1), _v4(cc1)[1],
+                                                           p2, d2.data_ptr(), pk2.wD.data_ptr(), dh2.data_ptr(), g2.data_ptr(), _ptr(cp2),
+                                                           cc2.data_ptr(), dci2.data_ptr(), do2.data_ptr(), _ptr(dco2), _v4(cc2)[1],
+                                                           self.stream), "convlstm16_pair_bwd_step")
+
     def convlstm16_supported(self, x, gates, pk, g, F):
         """16-bit ConvLSTM with the cell update in the recurrent convolution's epilogue (wdg_convlstm_step_h16)?"""
         plan, _, _ = self._plan(x, gates, pk.cin, pk.cout, g)

@@ -312,6 +312,10 @@ class ConvLSTM:
             return
         assert x2 is None
         self._buffers(N, H, W)
+        if not bf16 and T > 1:
+            self._gates_x(x, T)
+            self._time_loop_fwd(h, B, T)
+            return
         if bf16 and T > 1 and hasattr(o, "convlstm16_supported") and \
                 o.convlstm16_supported(x[:B], self.gates[:B], self.pkh, self.g, F) and \
                 o.convlstm16_supported(x, self.gates, self.pkx, self.g, F):
@@ -371,6 +375,43 @@ class ConvLSTM:
         return (self._fused1(T) and not need_wgrad and x2 is None and hasattr(self.ops, "convlstm1_dx_from_supported")
                 and self.ops.convlstm1_dx_from_supported(self.cin, self.F, c0))
 
+    def _gates_x(self, x, T):
+        """fp32, n_timesteps > 1: the input part of the gates for all timesteps in one launch."""
+        o, F = self.ops, self.F
+        if hasattr(o, "convlstm_gates_x_supported") and o.convlstm_gates_x_supported(x, self.gates, self.cin, F):
+            # (the 5 -> 16 layer: 45-row reduction on the matrix pipe with the weights in registers; the 2 -> 2 layer: one pixel per
+            # thread on the vector unit — csrc/convlstm1.hip)
+            o.convlstm_gates_x(x, self.wx.value, self.b.value, self.gates, self.cin, F)
+        else:
+            o.conv_fwd(x, self.pkx, self.b.value, self.gates, self.g, act=False)
+
+    def _time_loop_fwd(self, h, B, T):
+        """fp32 recurrence of this layer alone (forward_pair: both discriminator layers together)."""
+        o, F = self.ops, self.F
+        step1 = hasattr(o, "convlstm_step_supported") and o.convlstm_step_supported(h[:B], self.gates[:B], self.pkh, self.g, F)
+
+        def time_loop():
+            for t in range(T):
+                sl = slice(t * B, (t + 1) * B)
+                if t > 0:
+                    pv = slice((t - 1) * B, t * B)
+                    if step1:
+                        o.convlstm_step(h[pv], self.pkh, self.gates[sl], self.c[pv], self.c[sl], h[sl], self.g, F)
+                        continue
+                    o.conv_fwd(h[pv], self.pkh, None, self.gates[sl], self.g, act=False, accumulate=True)
+                    o.lstm_fwd(v2(self.gates[sl]), v2(self.c[pv]), v2(self.c[sl]), v2(h[sl]), F)
+                else:
+                    o.lstm_fwd(v2(self.gates[sl]), None, v2(self.c[sl]), v2(h[sl]), F)
+
+        packs = ()
+        if step1 and hasattr(o, "convlstm_step_prepare"):
+            packs = o.convlstm_step_prepare(h[:B], self.pkh, self.gates[:B], self.g, F) or ()
+        if T > 2 and hasattr(o, "chain"):
+            o.chain(("lstm_fwd", h.data_ptr(), tuple(h.shape), self.gates.data_ptr(), self.c.data_ptr(), self.pkh.wF.data_ptr(),
+                     B, T, False, "bf16", bool(step1)) + tuple(packs), time_loop, graphs=self._chain_graphs)
+        else:
+            time_loop()
+
     def backward(self, x, h, dh, dx, B, T, need_wgrad, accumulate_dx=False, x2=None, dx_c0=0):
         """dh: total gradient w.r.t. every h_t (modified in place by the BPTT recursion);
         dx: view receiving the input gradient (None to skip).  x2: as in forward.
@@ -389,9 +430,19 @@ class ConvLSTM:
                             dw=self.wx.grad if need_wgrad else None, dbias=self.b.grad if need_wgrad else None, **kw)
             return
         assert x2 is None
+        self._bwd_buffers(h, B)
+        self._time_loop_bwd(h, dh, B, T)
+        self._bwd_tail(x, h, dx, B, T, need_wgrad, accumulate_dx)
+
+    def _bwd_buffers(self, h, B):
+        N, H, W, _ = h.shape
         if self.dgates is None:
-            self.dgates = o.empty(N, H, W, 4 * F)
-            self.dc = [o.empty(B, H, W, F), o.empty(B, H, W, F)]
+            self.dgates = self.ops.empty(N, H, W, 4 * self.F)
+            self.dc = [self.ops.empty(B, H, W, self.F), self.ops.empty(B, H, W, self.F)]
+
+    def _time_loop_bwd(self, h, dh, B, T):
+        """BPTT recursion of this layer alone (convlstm_pair_backward: both discriminator layers together)."""
+        o, F = self.ops, self.F
         # one launch per timestep where the halo-tile kernel runs the recurrent data gradient (the discriminator's ConvLSTMs):
         # dh_{t-1} += conv_transpose(dgates_t) and, in the same epilogue, the cell backward of timestep t-1
         bstep = T > 1 and hasattr(o, "convlstm_bwd_step_supported") and \
@@ -424,6 +475,10 @@ class ConvLSTM:
                     + tuple(packs), time_loop, graphs=self._chain_graphs)
         else:
             time_loop()
+
+    def _bwd_tail(self, x, h, dx, B, T, need_wgrad, accumulate_dx):
+        """Weight gradients and the input gradient from the dense dgates tensor."""
+        o, F = self.ops, self.F
         # n_timesteps = 1: dgates of the forget gate = dc * c_0 * hs' = 0 -> its quarter of the weight gradient and of the data
         # gradient's reduction is skipped (channel ranges [0, F) and [2F, 4F) of the gate tensor: HipOps.conv_dgrad_slice)
         live = T == 1 and F % 4 == 0 and getattr(o, "supports_weight_slices", False) and not getattr(o, "split_mode", False) \
@@ -453,3 +508,80 @@ class ConvLSTM:
             o.convlstm_gates_dx(self.dgates, self.wx.value, dx, self.cin, F, accumulate=accumulate_dx)
         elif dx is not None:
             o.conv_dgrad(self.dgates, self.pkx, dx, self.g, accumulate=accumulate_dx)
+
+
+def convlstm_pair_ok(la, lb, ha, hb, B, T):
+    """Can the recurrences of the two-feature layer `la` and the 16-feature layer `lb` (the discriminator's two ConvLSTM2D,
+    models.py:93,101: independent chains) share their per-timestep launches?  (HipOps.convlstm_pair_step / _bwd_step)"""
+    o = la.ops
+    if T < 2 or la.F != 2 or lb.F != 16 or not hasattr(o, "convlstm_pair_supported") or la._shape is None or lb._shape is None:
+        return False
+    return o.convlstm_pair_supported(hb[:B], lb.gates[:B], lb.pkh, ha[:B], la.gates[:B], la.pkh, lb.g)
+
+
+def convlstm_pair_forward(la, xa, ha, lb, xb, hb, B, T):
+    """ConvLSTM.forward of both layers with ONE launch per timestep for the two recurrences (fp32, n_timesteps > 1).  Falls back to
+    the layers' own loops where the joint step is not available."""
+    o = la.ops
+    for l, x, h in ((la, xa, ha), (lb, xb, hb)):
+        l._buffers(h.shape[0], h.shape[1], h.shape[2])
+        l._gates_x(x, T)
+    if not convlstm_pair_ok(la, lb, ha, hb, B, T):
+        la._time_loop_fwd(ha, B, T)
+        lb._time_loop_fwd(hb, B, T)
+        return
+
+    def time_loop():
+        for t in range(T):
+            sl = slice(t * B, (t + 1) * B)
+            if t == 0:
+                o.lstm_fwd(v2(la.gates[sl]), None, v2(la.c[sl]), v2(ha[sl]), la.F)
+                o.lstm_fwd(v2(lb.gates[sl]), None, v2(lb.c[sl]), v2(hb[sl]), lb.F)
+                continue
+            pv = slice((t - 1) * B, t * B)
+            o.convlstm_pair_step((hb[pv], lb.pkh, lb.gates[sl], lb.c[pv], lb.c[sl], hb[sl]),
+                                 (ha[pv], la.pkh, la.gates[sl], la.c[pv], la.c[sl], ha[sl]), lb.g)
+
+    packs = o.convlstm_step_prepare(hb[:B], lb.pkh, lb.gates[:B], lb.g, lb.F) or ()      # (weight layouts current before a replayed loop)
+    if T > 2 and hasattr(o, "chain"):
+        o.chain(("lstm_pair_fwd", ha.data_ptr(), hb.data_ptr(), tuple(hb.shape), la.gates.data_ptr(), lb.gates.data_ptr(), la.c.data_ptr(),
+                 lb.c.data_ptr(), la.pkh.wF.data_ptr(), B, T) + tuple(packs), time_loop, graphs=lb._chain_graphs)
+    else:
+        time_loop()
+
+
+def convlstm_pair_backward(la, xa, ha, dha, dxa, lb, xb, hb, dhb, dxb, B, T, need_wgrad, accumulate_dxb=False):
+    """ConvLSTM.backward of both layers with one launch per timestep for the two BPTT recursions; dxa / dxb: the views that
+    receive the input gradients (None to skip)."""
+    o = la.ops
+    if not convlstm_pair_ok(la, lb, ha, hb, B, T):
+        la.backward(xa, ha, dha, dxa, B, T, need_wgrad)
+        lb.backward(xb, hb, dhb, dxb, B, T, need_wgrad, accumulate_dx=accumulate_dxb)
+        return
+    la._bwd_buffers(ha, B)
+    lb._bwd_buffers(hb, B)
+
+    def time_loop():
+        for t in range(T - 1, -1, -1):
+            sl, pv, pp = slice(t * B, (t + 1) * B), slice((t - 1) * B, t * B), slice((t - 2) * B, (t - 1) * B)
+            if t == T - 1:          # (every later cell backward is done by the previous iteration's joint launch)
+                for l, dh in ((la, dha), (lb, dhb)):
+                    o.lstm_bwd(v2(l.gates[sl]), v2(l.c[pv]) if t > 0 else None, v2(l.c[sl]), v2(dh[sl]), None, v2(l.dgates[sl]),
+                               v2(l.dc[t & 1]) if t > 0 else None, l.F)
+            if t > 0:
+                args = []
+                for l, dh in ((lb, dhb), (la, dha)):
+                    args.append((l.dgates[sl], l.pkh, dh[pv], l.gates[pv], l.c[pp] if t > 1 else None, l.c[pv], l.dc[t & 1], l.dgates[pv],
+                                 l.dc[(t - 1) & 1] if t > 1 else None))
+                o.convlstm_pair_bwd_step(args[0], args[1], lb.g)
+
+    packs = o.convlstm_step_prepare(hb[:B], lb.pkh, lb.gates[:B], lb.g, lb.F) or ()
+    if T > 2 and hasattr(o, "chain"):
+        o.chain(("lstm_pair_bwd", ha.data_ptr(), hb.data_ptr(), tuple(hb.shape), dha.data_ptr(), dhb.data_ptr(), la.gates.data_ptr(),
+                 lb.gates.data_ptr(), la.c.data_ptr(), lb.c.data_ptr(), la.dgates.data_ptr(), lb.dgates.data_ptr(), la.dc[0].data_ptr(),
+                 la.dc[1].data_ptr(), lb.dc[0].data_ptr(), lb.dc[1].data_ptr(), la.pkh.wD.data_ptr(), B, T) + tuple(packs), time_loop,
+                graphs=lb._chain_graphs)
+    else:
+        time_loop()
+    la._bwd_tail(xa, ha, dxa, B, T, need_wgrad, False)
+    lb._bwd_tail(xb, hb, dxb, B, T, need_wgrad, accumulate_dxb)

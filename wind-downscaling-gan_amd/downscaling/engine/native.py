@@ -115,6 +115,11 @@ SIGNATURES = {
                                          i32, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm_gates_dx_supported": (i32, [i32, i32]),
     "wdg_convlstm_gates_dx": (i32, [c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, i32, c_fp]),
+    "wdg_convlstm16_pair_supported": (i32, [C.c_void_p, C.c_void_p]),
+    "wdg_convlstm16_pair_step": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32,
+                                        C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, c_fp]),
+    "wdg_convlstm16_pair_bwd_step": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32,
+                                            C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp]),
     "wdg_convlstm1_x2_supported": (i32, [i32, i32, i32]),
     "wdg_convlstm1_fwd_x2": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, c_fp, c_fp, c_fp, i32, i64, i32, i32, i32, i32, i32, c_fp]),
     "wdg_convlstm1_bwd_x2": (i32, [c_fp, i32, i64, c_fp, i32, i64, i32, c_fp, c_fp, c_fp, i32, i64, c_fp, i32, i64, i32,

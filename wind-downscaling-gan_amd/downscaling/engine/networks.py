@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 from .common import ConvGeom, round4, v2
-from .layers import LN_EPS, LRELU, BatchNorm, Conv, ConvLSTM, Dense, LayerNorm
+from .layers import (LN_EPS, LRELU, BatchNorm, Conv, ConvLSTM, Dense, LayerNorm, convlstm_pair_backward,
+                     convlstm_pair_forward)
 from .params import ParamStore, glorot_uniform, zeros_init
 
 
@@ -589,6 +590,12 @@ class DiscriminatorNet(_Net):
             self.lstm_b.forward(b["mix"], b["hb"], B, T, x2=b.get("mix_x2"))
             self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
             side.join()
+        elif T > 1 and b.get("mix_x2") is None:
+            # n_timesteps > 1: the two recurrences are independent chains of T - 1 dependent steps — one launch per timestep for both
+            # (layers.convlstm_pair_forward; falls back to the layers' own loops where the joint step is not available)
+            convlstm_pair_forward(self.lstm_a, b["hi_view"], b["ha"], self.lstm_b, b["mix"], b["hb"], B, T)
+            self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
+            self._conv_ln_fwd(self.conv_b, self.ln_b, b["hb"], b["yb"], b["cat"][..., Fd:])
         else:
             self.lstm_a.forward(b["hi_view"], b["ha"], B, T)
             self._conv_ln_fwd(self.conv_a, self.ln_a, b["ha"], b["ya"], b["cat"][..., :Fd])
@@ -747,6 +754,11 @@ class DiscriminatorNet(_Net):
                 branch_a()
             branch_b()
             side.join()
+        elif T > 1 and b.get("mix_x2") is None:
+            self._conv_ln_bwd(self.conv_a, self.ln_a, b["dcat"][..., :Fd], b["ya"], b["ha"], b["dha"], need_wgrad)
+            self._conv_ln_bwd(self.conv_b, self.ln_b, b["dcat"][..., Fd:], b["yb"], b["hb"], b["dhb"], need_wgrad, ln_done=b_chained)
+            convlstm_pair_backward(self.lstm_a, b["hi_view"], b["ha"], b["dha"], b["dhi"] if need_input_grad else None,
+                                   self.lstm_b, b["mix"], b["hb"], b["dhb"], b["dmix"] if need_input_grad else None, B, T, need_wgrad)
         else:
             branch_a()
             branch_b()
