@@ -1,5 +1,2 @@
 set -u
-true
-timeout 1500 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "discriminator or default_widths or graphs or test_train_step" 2>&1 | tail -3
-T="-- --size 96 --timesteps 24 --batch 8"
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+AB_STEPS=10 bash tools/ab_step.sh "q4:" "q5:GPU_MAX_HW_QUEUES=5" "q6:GPU_MAX_HW_QUEUES=6" "q8:GPU_MAX_HW_QUEUES=8" "q5_wg:GPU_MAX_HW_QUEUES=5 WDG_TRIPLE_WGRAD=1" "q6_wg:GPU_MAX_HW_QUEUES=6 WDG_TRIPLE_WGRAD=1" "q4:" > gpurun_out/r05ba_ab.txt 2>&1; cut -c1-140 gpurun_out/r05ba_ab.txt
