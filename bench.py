@@ -128,6 +128,15 @@ class ConvTimer:
                   layer=geom("wgrad", x, dy, pk, g) + f" cols[{n0}:{n1}]", **k)
 
         ops.conv_dgrad_slice, ops.conv_wgrad_slice = conv_dgrad_slice, conv_wgrad_slice
+        orig_dgrad_ln = ops.conv_dgrad_lnbwd
+
+        def conv_dgrad_lnbwd(dy, pk, dx, g, *a, **k):
+            # data gradient -> LayerNorm + LeakyReLU backward of the producer in one call (epilogues 5 / 6 of wdg_igemm_kernel):
+            # the convolution's FLOPs, timed with its fused norm backward
+            timed(ops.conv_kernel_label("dgrad", dx, dy, pk, g) + " +LNbwd", flops(dx, dy, pk, g), orig_dgrad_ln, dy, pk, dx, g, *a,
+                  layer=geom("dgrad+LNbwd", dx, dy, pk, g), **k)
+
+        ops.conv_dgrad_lnbwd = conv_dgrad_lnbwd
         orig_fwd_ln = ops.conv_fwd_ln
 
         def conv_fwd_ln(x, pk, bias, y, z, g, *a, **k):
@@ -402,13 +411,17 @@ def other_config_legs(dev, ops):
     # ---- configs[4]: 64 noise realisations x 8 tiles, fp16 operands (one GPU runs all 64; N ranks take 64 / N each)
     gen.inference_precision = "fp32"
     tiles8 = tiles[:8].contiguous()
-    api.predict_ensemble(tiles8, 4, network=network, precision="fp16")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ens = api.predict_ensemble(tiles8, 64, network=network, precision="fp16")
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out["config4_fp16_64x8"] = {"seconds": dt, "realisations_per_s": 64 * 8 / dt, "tile_timesteps_per_s": 64 * 8 * 24 / dt,
+    api.predict_ensemble(tiles8, 64, network=network, precision="fp16")      # warm-up at the timed draw count (same batch shapes / graphs)
+    runs4 = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ens = api.predict_ensemble(tiles8, 64, network=network, precision="fp16")
+        torch.cuda.synchronize()
+        runs4.append(time.perf_counter() - t0)
+    dt = sorted(runs4)[2]
+    out["config4_fp16_64x8"] = {"seconds": dt, "seconds_all": [round(x, 5) for x in runs4], "timing": "median of 5 calls after one warm-up call at 64 draws",
+                                "realisations_per_s": 64 * 8 / dt, "tile_timesteps_per_s": 64 * 8 * 24 / dt,
                                 "tflops": 64 * 8 * 24 * gf_tt / dt * 1e-12, "frac_of_16bit_mfma_peak": 64 * 8 * 24 * gf_tt / dt * 1e-12 / PEAK_16BIT_MFMA_TFLOPS,
                                 "dtype": "fp16 operands, f32 accumulate", "finite": bool(torch.isfinite(ens).all()),
                                 "note": "api.predict_ensemble(8 tiles, 64 draws), member-keyed Philox streams; parity bound 4e-3 vs the fp64 oracle"}
@@ -590,9 +603,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches its own ranks: torch.distributed.run as a CHILD process (never an exec — nothing in
+        # this process has touched the GPU yet, and it never will), one rank per GPU; rank 0's JSON line is relayed, the
+        # child's return code becomes this process's.
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29541")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", port, str(Path(__file__).resolve())] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, cwd=str(ROOT))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        for ln in r.stdout.splitlines():
+            if not ln.startswith("{"):
+                print(ln, file=sys.stderr)
+        if lines:
+            print(lines[-1], flush=True)
+        raise SystemExit(r.returncode if r.returncode or lines else 1)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     # one process per GPU over RCCL ("nccl").  For a functional check of the multi-rank path on a single-GPU box:
     # WDG_DIST_BACKEND=gloo WDG_DEVICE=0 runs every rank on cuda:0 with host-staged reductions (not a benchmark).
@@ -784,9 +812,18 @@ def main():
             r = json.loads(rj.read_text())
             if r.get("kernel") == dom[0] and r.get("csrc_sha256") == csrc_hash() and r.get("launches_per_step") == dom[1][2] / serial_steps:
                 flops_per_launch = out["roofline"]["achieved"] * 1e12 * out["roofline"]["avg_launch_ms"] * 1e-3
-                tf = flops_per_launch / (r["avg_launch_us"] * 1e-6) * 1e-12
-                out["roofline"]["rocprof"] = {"avg_launch_us": r["avg_launch_us"], "achieved": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS,
-                                              "source": r["source"]}
+                # the tracer's figure for the TIMED step of its run (its --stats mean also covers the warm-up step, whose launches
+                # run at ramping clocks: profiles/rocprof_dominant.json keeps both, and the HIP-event figure of the same process)
+                us = r.get("avg_launch_us_timed_step", r["avg_launch_us"])
+                tf = flops_per_launch / (us * 1e-6) * 1e-12
+                out["roofline"]["rocprof"] = {"avg_launch_us": us, "avg_launch_us_incl_warmup_step": r["avg_launch_us"],
+                                              "hip_events_us_same_traced_process": r.get("hip_events_us"),
+                                              "achieved": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS, "source": r["source"]}
+                if tf < out["roofline"]["achieved"]:
+                    # quote the LOWER of the two clocks as the line's figure; the live HIP-event figure stays beside it
+                    out["roofline"]["hip_events"] = {"achieved": out["roofline"]["achieved"], "frac": out["roofline"]["frac"]}
+                    out["roofline"]["achieved"], out["roofline"]["frac"] = tf, tf / PEAK_F32_MFMA_TFLOPS
+                    out["roofline"]["frac_source"] = "rocprofv3 kernel trace of the same one-stream schedule (lower than the live HIP events)"
         if headline and world == 1 and not args.no_generator_leg:
             out["generator_fwd_b64"] = generator_leg(generator, gan, dev)
         if headline and world == 1 and not args.no_config_legs:

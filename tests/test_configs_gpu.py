@@ -112,6 +112,26 @@ def test_config2_bench_launch_two_ranks():
 
 
 @pytest.mark.timeout(1200)
+def test_config2_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the form the driver uses for N = 1) starts its own ranks: a child
+    `torch.distributed.run`, rank 0's ONE JSON line relayed on stdout, the child's return code propagated."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    env.update({"WDG_DIST_BACKEND": "gloo", "WDG_DEVICE": "0", "MASTER_PORT": str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--batch", "2", "--size", "32", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["rccl"]["world_size"] == 2
+    # a failing child is a failing bench: a rejected tuning key makes every rank exit non-zero
+    r = subprocess.run(cmd + ["--tune", "no_such_key=1"], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(1200)
 def test_config2_rccl_collectives_single_rank():
     """The "nccl" (= RCCL) branch itself: init_process_group("nccl", device_id=...), asynchronous all-reduce of the flat
     gradient buffers on RCCL's stream, deferred Adam, SyncBN statistics (fp64) and the scalar-metric reduce, on a

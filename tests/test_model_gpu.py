@@ -30,8 +30,21 @@ def test_generator(hip_ops, S, T, F, nz, training):
     """F = 16 / 48 / 80: feature_channels % 16 == 0 but not % 32 (feature_channels / 8 = 2 / 6 / 10 channels in the last
     decoder stage, run at the zero-padded width); F = 24 / 40 / 56: 8 mod 16 (zero alignment channels inside the
     [conv-transpose path | res_2] concatenation, params.Var.gap)."""
+    _check_generator(hip_ops, S, T, F, nz, training)
+
+
+@pytest.mark.parametrize("S,B,F", [(128, 64, 16), (128, 64, 32), (128, 64, 64)])
+def test_generator_narrow_features_on_large_maps(hip_ops, S, B, F):
+    """feature_channels in 8..64 at n_timesteps = 1 with >= 65536 pixels on the ConvLSTM's map: its 3x3 stride-1 layer runs on
+    the halo / thin kernels, which cannot take a channel range of the gate tensor (wdg_conv_plan_create_sliced refuses), so
+    ConvLSTM._bwd_tail must keep the full-width gradient calls there (HipOps.weight_slices_ok) instead of raising."""
+    from downscaling.engine.layers import ConvLSTM  # noqa: F401
+    _check_generator(hip_ops, S, 1, F, 4, True, B=B)
+
+
+def _check_generator(hip_ops, S, T, F, nz, training, B=2):
     from downscaling.engine.networks import GeneratorNet
-    B, cin, ch = 2, 3, 2
+    cin, ch = 3, 2
     dev = hip_ops.device
     net = GeneratorNet(hip_ops, S, cin, nz, ch, T, feature_channels=F, seed=3)
     w = randomize(net, 11)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The bench's config3_bf16_group16_T24 leg (one predict() group of 16 tiles x 24 h through the shipped generator at
 inference precision, image + noise assembled on the device) with eager launches, for `rocprofv3 --kernel-trace --stats`:
-    python tools/prof_infer_group.py [bf16|fp16] [reps] [graph]"""
+    python tools/prof_infer_group.py [bf16|fp16] [reps] [graph|eager] [tiles]"""
 import sys
 import time
 from pathlib import Path
@@ -15,14 +15,15 @@ def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 16
     import downscaling.api as api
     network = api.get_network(allow_random_init=True, random_seed=5)
     gen = network.generator
     gen.inference_precision = prec
     gen.graph_inference = graph
     dev = gen.ops.device
-    tiles = torch.randn(16, api.SEQUENCE_LENGTH, api.IMG_SIZE, api.IMG_SIZE, 3, device=dev)
-    fn = lambda: gen([tiles, network.noise_generator.lazy(bs=16, channels=api.NOISE_CHANNELS)])   # noqa: E731
+    tiles = torch.randn(n, api.SEQUENCE_LENGTH, api.IMG_SIZE, api.IMG_SIZE, 3, device=dev)
+    fn = lambda: gen([tiles, network.noise_generator.lazy(bs=n, channels=api.NOISE_CHANNELS)])   # noqa: E731
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -30,7 +31,7 @@ def main():
     for _ in range(reps):
         fn()
     torch.cuda.synchronize()
-    print(f"{prec} graph={graph}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per 16-tile group")
+    print(f"{prec} graph={graph}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per {n}-tile group")
 
 
 if __name__ == "__main__":

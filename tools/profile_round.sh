@@ -25,10 +25,14 @@ export WDG_OVERLAP_GEN=0 WDG_WGRAD_STREAM=0 WDG_OVERLAP_BRANCHES=0
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_trace -o run -- $BENCH --steps 1 --warmup 1 > $ROOT/$OUT/${TAG}_trace_serial.log 2>&1 )
 STATS=$(find $OUT/${TAG}_trace -name '*kernel_stats.csv' | head -1)
 [ -n "$STATS" ] && cp "$STATS" $OUT/${TAG}_kernel_stats_serial.csv
-rm -rf $OUT/${TAG}_trace
+TRACE=$(find $OUT/${TAG}_trace -name '*kernel_trace.csv' | head -1)
 # the dominant kernel's average launch duration under the tracer (one-stream schedule) -> rocprof_dominant.json (bench.py quotes it
-# beside its HIP-event figure when the kernel sources and the launch mix match)
-python3 - "$OUT/${TAG}_kernel_stats_serial.csv" "$OUT/rocprof_dominant.json" <<'PY'
+# beside its HIP-event figure when the kernel sources and the launch mix match).  Three figures of the SAME process, so that a
+# reader can see where a difference between "the tracer" and "the HIP events" comes from:
+#   avg_launch_us            all launches in the trace = warm-up step + timed step (what --stats averages)
+#   avg_launch_us_timed_step the launches of the timed step only (the second half of the dispatches, by start time)
+#   hip_events_us            bench.py's own HIP-event average over the timed step, read from the JSON line of this traced run
+python3 - "$OUT/${TAG}_kernel_stats_serial.csv" "$OUT/rocprof_dominant.json" "$TRACE" "$OUT/${TAG}_trace_serial.log" <<'PY'
 import csv, hashlib, json, sys
 from pathlib import Path
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Name"].startswith("void wdg_igemm_kernel<128, 128")]
@@ -37,10 +41,23 @@ h = hashlib.sha256()
 for f in sorted((Path("wind-downscaling-gan_amd") / "csrc").glob("*.h*")):
     h.update(f.name.encode()); h.update(f.read_bytes())
 steps = 2      # bench.py --steps 1 --warmup 1: two train steps in the trace
-json.dump({"kernel": "wdg_igemm_kernel<128,128>", "csrc_sha256": h.hexdigest(), "launches_per_step": calls / steps,
-           "avg_launch_us": ns / calls * 1e-3, "source": sys.argv[1] + " (rocprofv3 --kernel-trace --stats, one-stream schedule)"},
-          open(sys.argv[2], "w"), indent=1)
+out = {"kernel": "wdg_igemm_kernel<128,128>", "csrc_sha256": h.hexdigest(), "launches_per_step": calls / steps,
+       "avg_launch_us": ns / calls * 1e-3, "source": sys.argv[1] + " (rocprofv3 --kernel-trace --stats, one-stream schedule)"}
+try:
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(sys.argv[3]))
+               if r["Kernel_Name"].startswith("void wdg_igemm_kernel<128, 128"))
+    last = d[len(d) // 2:]
+    out["avg_launch_us_warmup_step"] = sum(e - s for s, e in d[:len(d) // 2]) / (len(d) // 2) * 1e-3
+    out["avg_launch_us_timed_step"] = sum(e - s for s, e in last) / len(last) * 1e-3
+    for ln in open(sys.argv[4]):
+        if ln.startswith("{"):
+            out["hip_events_us"] = json.loads(ln)["roofline"]["avg_launch_ms"] * 1e3
+except Exception as exc:
+    out["per_step_error"] = repr(exc)
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out))
 PY
+rm -rf $OUT/${TAG}_trace
 if [ -z "$QUICK" ]; then
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc1.log 2>&1 )
   ( cd /tmp && rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $ROOT/$OUT/pmc_write -o run -- $BENCH --steps 1 --warmup 0 > $ROOT/$OUT/${TAG}_pmc2.log 2>&1 )

@@ -58,6 +58,7 @@ struct WdgPatchH16 {
     int CK8, nchunk, kcn;      // channel groups per chunk, chunks, K-steps per tap and chunk
     int flat, nent;            // flat: one chunk whose group count is not a multiple of 4 (24 or 40 channels) — the K-steps walk the
                                // flattened (tap, channel group) list, 4 entries each, instead of padding every tap to 4 groups
+    int npad, ntab;            // weight stages per chunk rounded up to the pipeline depth; entries of each K-step table
     wdg_fastdiv div_kw, div_kcn;
     int tiles_x, tiles_y, tiles_n, ntn_blk;   // tiles_n counts workgroups along the channels, each doing ntn_blk channel tiles
     wdg_fastdiv div_tn, div_tx, div_ty, div_ck, div_pw;
@@ -72,7 +73,7 @@ struct WdgPatchH16 {
 #define WDG_PATCH_HG ((MT * NT <= 16) ? 2 : 1)
 #endif
 #ifndef WDG_PATCH_DEPTH
-#define WDG_PATCH_DEPTH ((LSTM == 2) ? 3 : 2)      // weight stages in flight (register sets): deep for the latency-bound recurrent step (LSTM == 2)
+#define WDG_PATCH_DEPTH (LSTM ? 3 : 2)             // weight stages in flight (register sets): deep for the latency-bound recurrent step
 #endif
 #if WDG_PATCH_LB2
 #define WDG_PATCH_BOUNDS __launch_bounds__(256, 2)
@@ -111,9 +112,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
 
     const wdg_srd srdA = p.in16 ? wdg_make_srd(reinterpret_cast<const wdg_h16<FMT>*>(p.A) + (long long)img * p.imgStrideA)
                                 : wdg_make_srd(p.A + (long long)img * p.imgStrideA);
-    const wdg_srd srdB = wdg_make_srd(p.B);
-    // (LSTM == 2) the weight tensor exactly: requests past its end return zeros by the hardware's range check, no select
-    const wdg_srd srdBx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.Ncols * p.ldB * 2, 0x00020000);
+    const wdg_srd srdB = wdg_make_srd(p.B);          // (2 GiB window: byte offsets with bit 31 set are out of range and return zeros)
 
     // ---- per-lane fragment bases (LDS slots) and output pixels
     const int FW = 1 << p.fw_shift, FH = 16 >> p.fw_shift;
@@ -128,12 +127,38 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         opix[a] = p.shufC ? ((oy0 + oyl) * p.shufK) * (p.Wo * p.shufK) + (ox0 + oxl) * p.shufK : (oy0 + oyl) * p.Wo + ox0 + oxl;
     }
 
-    const int nks = p.flat ? (p.nent + 3) >> 2 : p.kh * p.kw * p.kcn;            // K-steps per chunk
-    const int nstage = (nks + 1) >> 1;
     const int npatch = p.CK8 * p.PH * p.PW;
     const int dummy_slot = p.CK8 * p.pitch;         // one spare slot behind the patch takes the stores of the tail threads
-    const int bj = t & 7, bh = bj >> 2, bq = bj & 3;
+    const int bj = t & 7;                           // this thread's weight slot of a stage: K-step bj >> 2, channel group bj & 3
     float* outImg = p.Out + (long long)img * p.imgStrideO;
+
+    // ---- K-step tables, behind the patch in LDS: entry e = 4 * (K-step of the chunk) + (channel group q of the K-step's 32
+    // reduction indices).  tabT: slot offset inside the patch of that (tap, channel group) — what a lane of quarter lq = q adds to
+    // its fragment bases; tabK: element offset inside a weight row (without the chunk's first channel).  A K-step walks the taps
+    // with kcn K-steps of 4 channel groups each, or (flat: 24 / 40 channels) the flattened (tap, channel group) list 4 entries
+    // at a time.  Entries that do not exist (channel group past the chunk, K-step past the end — the table covers the stages the
+    // pipeline requests beyond the last) read patch slot 0 against zero weights (offset out of the descriptor's range).
+    int* tabT = reinterpret_cast<int*>(ldsP + dummy_slot + 1);
+    int* tabK = tabT + p.ntab;
+    for (int e = t; e < p.ntab; e += 256) {
+        const int ks = e >> 2, q = e & 3;
+        int tap, g8, koff;
+        bool ok;
+        if (p.flat) {
+            tap = (int)wdg_fastdiv_do((unsigned)e, p.div_ck);
+            g8 = e - tap * p.CK8;
+            ok = e < p.nent;
+            koff = 8 * e;
+        } else {
+            tap = (int)wdg_fastdiv_do((unsigned)ks, p.div_kcn);
+            g8 = (ks - tap * p.kcn) * 4 + q;
+            ok = tap < p.kh * p.kw && g8 < p.CK8;
+            koff = tap * p.Cin_p + g8 * 8;
+        }
+        const int ky = (int)wdg_fastdiv_do((unsigned)tap, p.div_kw), kx = tap - ky * p.kw;
+        tabT[e] = ok ? (((ky << p.sshift) + (kx & (s - 1))) * p.PWs) + (kx >> p.sshift) + g8 * p.pitch : 0;
+        tabK[e] = (ok && !(DBG & 1)) ? koff : 0x40000000;
+    }
 
     // ---- channel tiles of this workgroup: one, or (ntn_blk > 1: a patch that holds every channel, shallow reductions) several
     // against the same resident patch
@@ -147,14 +172,14 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- this thread's weight slots of a stage: j = (K-step of the stage, channel group q), column n
-    int b_row[B_LOADS];        // element offset of row n, or -1
+    unsigned b_off[B_LOADS];   // byte offset of weight row n (columns past the layer's last: row 0 — their accumulators are never stored)
     int b_slot[B_LOADS];       // LDS slot inside a stage
 #pragma unroll
     for (int r = 0; r < B_LOADS; ++r) {
         const int n = (t >> 3) + 32 * r;
         const int ng = n0 + n;
         const int wrow = p.gate_F ? (ng & 3) * p.gate_F + (ng >> 2) : ng;
-        b_row[r] = (ng < p.Ncols) ? wrow * p.ldB : -1;
+        b_off[r] = (ng < p.Ncols) ? (unsigned)(wrow * p.ldB) << 1 : 0u;
         b_slot[r] = bj * BN + (n ^ bj);
     }
 
@@ -183,6 +208,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     };
     for (int ck = 0; ck < p.nchunk; ++ck) {
         __syncthreads();                             // every wave is done with the previous chunk's patch, weight stages and epilogue tiles
+                                                     // (first chunk: the K-step tables are complete)
         // ---- patch chunk: global fp32 -> 16-bit -> LDS, PU slots (2 x 16-byte loads each) per thread in flight
         constexpr int PU = (MT * NT >= 24) ? 8 : (WDG_PATCH_DEPTH > 2) ? 6 : 10;   // (the 6 x 4 tile has no registers to spare; nor a deep weight pipeline)
         if (p.in16) {
@@ -227,94 +253,31 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             for (int u = 0; u < PU; ++u) ldsP[slot[u]] = wdg_pack_h16<FMT>(v[u][0], v[u][1]);
         }
 
-        // ---- weight stages.  Stage st+2 is fetched into registers while stage st is computed from LDS and stage st+1
-        // (fetched one iteration earlier) is written to the other LDS buffer behind the MFMAs: one barrier per stage, two
-        // stages of load latency budget.  (tap, kc) counters: f* of the stage being fetched, c* of the one being computed.
-        // (requesting them HERE, in front of the weight stream, spills: 48 + 12 more live registers across the reduction loop
-        // put the 3 x 4 tile at 256 registers + 292 bytes of scratch; they are requested in one batch behind the loop instead)
-        int f_kc = 0, f_kx = 0, f_ky = 0;
-        int c_kc = 0, c_kx = 0, c_ky = 0;
+        // ---- weight stages, D register sets deep: stage s + D is requested while stage s is computed from LDS, and stage s + 1 —
+        // requested D - 1 compute stages ago — moves from its registers into the other LDS buffer behind the MFMAs; one barrier
+        // per stage.  The body is branch-free and the same for every layer shape: what a K-step reads — the patch slot offset of its
+        // (tap, channel group) for the lane's quarter lq, the weight-row offset for the thread's slot bj — comes from the two LDS
+        // tables built above (one ds_read each, requested a stage ahead), not from counters with carries, divisions and
+        // validity selects in the loop (round 5: ~80 vector + ~25 scalar instructions and a dozen branches per K-step of 16
+        // MFMAs — SQ_INSTS_VALU 105 M against 21 M MFMAs on the generator's first layer, profiles/r06a_pmc_infer_bf16.txt; the
+        // branches also cost the compiler its exact count of outstanding loads, hence s_waitcnt vmcnt(0) in front of every
+        // stage).  The stage count is rounded up to a multiple of D: table entries past the end hold an out-of-range weight
+        // offset (zeros, no memory traffic) and patch slot 0.
         constexpr int D = WDG_PATCH_DEPTH;
+        const unsigned kb0 = (unsigned)(ck * p.CK8) * 16u;          // this chunk's first channel group, in bytes of a weight row
         u32x4 rb[D][B_LOADS];
-        auto advance = [&](int& kc, int& kx, int& ky) {
-            if (++kc == p.kcn) {
-                kc = 0;
-                if (++kx == p.kw) { kx = 0; ++ky; }
-            }
-        };
-        int f_ks = 0, c_ks = 0;                       // D > 2: K-step counters of the branch-free forms
-        auto fetch_stage = [&](u32x4 (&r_)[B_LOADS]) {
-            // the two K-steps of the stage; this thread serves K-step bh, channel group bq
-            bool kok;
-            int koff;
-            if constexpr (D > 2) {
-                // LSTM == 2: 3 x 3 taps, stride 1, ONE chunk of 16 channel groups (kcn = 4), whole column tiles — every shape
-                // parameter a constant, so a trip of the stage loop is straight-line code: no counters with carries, no
-                // flat / tap-major fork, no validity selects (the compiler turns those into exec-masked branches, and at every
-                // join its wait-count bookkeeping gives up the exact number of outstanding requests).  Requests past the last
-                // stage stay inside the buffer descriptor's range or read zeros; their stages are never multiplied.
-                const int ks = f_ks + bh;
-                f_ks += 2;
-                kok = true;
-                koff = (ks >> 2) * p.Cin_p + ((ks & 3) * 4 + bq) * 8;
-            } else if (p.flat) {
-                // (f_kc counts K-steps) entry j = (tap, group) = 4 * K-step + bq; the weights' reduction index of entry j is 8 * j
-                const int j = 4 * (f_kc + bh) + bq;
-                f_kc += 2;
-                kok = j < p.nent && !(DBG & 1);
-                koff = 8 * j;
-            } else {
-                const int kc0 = f_kc, kx0 = f_kx, ky0 = f_ky;
-                advance(f_kc, f_kx, f_ky);
-                const int kc1 = f_kc, kx1 = f_kx, ky1 = f_ky;
-                advance(f_kc, f_kx, f_ky);
-                const int kc = bh ? kc1 : kc0, kx = bh ? kx1 : kx0, ky = bh ? ky1 : ky0;
-                const int g8 = kc * 4 + bq;              // channel group inside the chunk
-                kok = ky < p.kh && g8 < p.CK8 && !(DBG & 1);
-                koff = (ky * p.kw + kx) * p.Cin_p + (ck * p.CK8 + g8) * 8;
-            }
-            if constexpr (D > 2) {
+        auto ldk = [&](int f) { return ((unsigned)tabK[8 * f + bj] << 1) + kb0; };
+        auto fetch_stage = [&](u32x4 (&r_)[B_LOADS], unsigned kq) {
 #pragma unroll
-                for (int r = 0; r < B_LOADS; ++r)
-                    r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdBx, (int)((unsigned)(b_row[r] + koff) << 1), 0, 0);
-                return;
-            }
-#pragma unroll
-            for (int r = 0; r < B_LOADS; ++r)
-                r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB, (kok && b_row[r] >= 0) ? (int)((unsigned)(b_row[r] + koff) << 1) : (int)WDG_SRD_OOB, 0, 0);
+            for (int r = 0; r < B_LOADS; ++r) r_[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB, (int)(b_off[r] + kq), 0, 0);
         };
         auto store_stage = [&](const u32x4 (&r_)[B_LOADS], int buf) {
             h16x8* sB = ldsB + buf * 8 * BN;
 #pragma unroll
             for (int r = 0; r < B_LOADS; ++r) sB[b_slot[r]] = __builtin_bit_cast(h16x8, r_[r]);
         };
-        // the slot offset of a K-step's tap and channel group for this lane (K-steps past the end: offset 0, their weights are zero;
-        // lanes whose channel group is past the chunk read group 0 for the same reason)
-        auto tap_offset = [&]() {
-            if constexpr (D > 2) {
-                const int ks = c_ks++;
-                const int tap = ks >> 2, g8 = (ks & 3) * 4 + lq;
-                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;            // tap / 3 for tap < 9
-                return ky * p.PWs + kx + g8 * p.pitch;
-            }
-            if (p.flat) {
-                // this lane group's own (tap, channel group) entry; entries past the end read slot 0 (their weights are zero)
-                const int j = 4 * c_kc + lq;
-                ++c_kc;
-                const int tap = (int)wdg_fastdiv_do((unsigned)j, p.div_ck), g8 = j - tap * p.CK8;
-                const int ky = (int)wdg_fastdiv_do((unsigned)tap, p.div_kw), kx = tap - ky * p.kw;
-                const int o = (((ky << p.sshift) + (kx & (s - 1))) * p.PWs) + (kx >> p.sshift) + g8 * p.pitch;
-                return j < p.nent ? o : 0;
-            }
-            const int g8 = c_kc * 4 + lq;
-            const int o = (((c_ky << p.sshift) + (c_kx & (s - 1))) * p.PWs) + (c_kx >> p.sshift) + (g8 < p.CK8 ? g8 : 0) * p.pitch;
-            const int r = c_ky < p.kh ? o : 0;
-            advance(c_kc, c_kx, c_ky);
-            return r;
-        };
-        auto compute_stage = [&](int buf) {
+        auto compute_stage = [&](int buf, int off0, int off1) {
             const h16x8* sB = ldsB + buf * 8 * BN;
-            const int off0 = tap_offset(), off1 = tap_offset();
             // both K-steps' fragments are requested before the first MFMA where the registers allow it (the 6 x 4 tile: one at a time)
             constexpr int HG = WDG_PATCH_HG;
 #pragma unroll
@@ -361,47 +324,25 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 }
             }
         };
-        // Weight pipeline, D register sets deep: stage s + D is requested while stage s is computed, and stage s + 1 — requested
-        // D - 1 compute stages ago — moves from its registers into the other LDS buffer behind the MFMAs; one barrier per stage.
-        // D = 2 (rounds 2-3) left ONE compute stage (~0.2 us of MFMAs at one or two waves per SIMD) between a request and its
-        // use against an L2 round trip of ~0.8 us: the stage loop of the recurrent step ran at the round trip, ~0.9 us per stage
-        // whatever the memory traffic (profiles/r04l_step16_skeletons.txt, r04m_chain_floor.txt)
         const bool bar = !(DBG & 32);
-        if constexpr (D == 2) {
-            fetch_stage(rb[0]);
-            if (nstage > 1) fetch_stage(rb[1]);
-            store_stage(rb[0], 0);
-            __syncthreads();
-            for (int st = 0; st < nstage; st += 2) {
-                if (st + 2 < nstage) fetch_stage(rb[0]);
-                compute_stage(0);
-                if (st + 1 < nstage) store_stage(rb[1], 1);
+#pragma unroll
+        for (int i = 0; i < D; ++i) fetch_stage(rb[i], ldk(i));
+        store_stage(rb[0], 0);
+        unsigned kq = ldk(D);                                       // weight offset of the next stage to request
+        int t0 = tabT[lq], t1 = tabT[4 + lq];                       // patch offsets of the next stage to compute (its two K-steps)
+        __syncthreads();
+        for (int st = 0; st < p.npad; st += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int sc = st + u;
+                fetch_stage(rb[u], kq);                             // stage sc + D (rb[u]'s stage sc is in LDS already)
+                kq = ldk(sc + D + 1);
+                const int o0 = t0, o1 = t1;
+                t0 = tabT[8 * (sc + 1) + lq];
+                t1 = tabT[8 * (sc + 1) + 4 + lq];
+                compute_stage((D & 1) ? (sc & 1) : (u & 1), o0, o1);
+                store_stage(rb[(u + 1) % D], (D & 1) ? ((sc + 1) & 1) : ((u + 1) & 1));
                 if (bar) __syncthreads();
-                if (st + 1 < nstage) {
-                    if (st + 3 < nstage) fetch_stage(rb[1]);
-                    compute_stage(1);
-                    if (st + 2 < nstage) store_stage(rb[0], 0);
-                    if (bar) __syncthreads();
-                }
-            }
-        } else {
-            // branch-free body, D stages per trip: with the requests behind `if`s the compiler's wait-count bookkeeping loses the
-            // exact number of outstanding loads at every join and waits for (nearly) all of them — including the requests it has
-            // just issued.  The stage count is rounded up to a multiple of D instead: requests past the end are out of range
-            // (zeros, no memory traffic), their stages multiply the patch's slot 0 by zero weights.
-            const int npad = (nstage + D - 1) / D * D;
-#pragma unroll
-            for (int i = 0; i < D; ++i) fetch_stage(rb[i]);
-            store_stage(rb[0], 0);
-            __syncthreads();
-            for (int st = 0; st < npad; st += D) {
-#pragma unroll
-                for (int u = 0; u < D; ++u) {
-                    fetch_stage(rb[u]);                                     // stage st + u + D (rb[u]'s stage st + u is in LDS already)
-                    compute_stage((st + u) & 1);
-                    store_stage(rb[(u + 1) % D], (st + u + 1) & 1);
-                    if (bar) __syncthreads();
-                }
             }
         }
     }
@@ -578,11 +519,10 @@ static int patch_shapes(const WdgPatchView& g, WdgPatchCfg* c) {
 }
 
 static int g_patch_lstm_small = 1;       // the recurrent step on the smallest tile shape (tuning key patch_lstm_small)
-static int g_patch_lstm_deep = 1;        // recurrent step: the specialised deep-pipeline instantiation (patch_lstm_small value 4 clears, 8 sets)
 static int g_patch_lstm_bn = 0;          // recurrent step: channel tile forced to 64 / 128 (0 = the general rule); patch_lstm_small values >= 64
 void wdg_patch_h16_set_lstm_small(int v) {
     if (v >= 64) g_patch_lstm_bn = v;
-    else if (v == 4 || v == 8) g_patch_lstm_deep = v == 8;
+    else if (v == 4 || v == 8) return;       // (rounds 4-5: selected a specialised deep-pipeline instantiation; every instantiation has that loop now)
     else { g_patch_lstm_small = (v & 1) != 0; if (v & 2) g_patch_lstm_bn = 0; }
 }
 // small_first: the candidate shapes from the smallest — the per-timestep recurrent convolution has few pixel tiles (48 of 8 x 24 on
@@ -709,7 +649,15 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     p.div_pw = wdg_fastdiv_make((unsigned)p.PW);
     const long long blocks = tiles_px * p.tiles_n;
     if (blocks <= 0 || blocks >= (1LL << 31)) return 1;
-    const size_t lds = (size_t)2 * 8 * BN * 16 + ((size_t)p.CK8 * p.pitch + 1) * 16;   // weight stages + patch
+    {
+        const int depth = lstm ? 3 : 2;                                   // WDG_PATCH_DEPTH of the instantiation launched below
+        const int nks = p.flat ? (p.nent + 3) / 4 : g.kh * g.kw * p.kcn;  // K-steps per chunk
+        const int nstage = (nks + 1) / 2;
+        p.npad = (nstage + depth - 1) / depth * depth;
+        p.ntab = (p.npad + depth + 1) * 8;                                // the pipeline requests stages up to npad + depth
+    }
+    const size_t lds = (size_t)2 * 8 * BN * 16 + ((size_t)p.CK8 * p.pitch + 1) * 16 + (size_t)2 * p.ntab * 4;   // weight stages + patch + K-step tables
+    if (lds > 160 * 1024) return 1;
 #ifdef WDG_PATCH_EXPERIMENTS
     // timing experiments (wrong results by design): bf16, 1 x 16 fragments, 128 channels per tile only
 #define WDG_PATCH_DBG_CASE(D) if (g_patch_dbg == D && fmt == 0 && MT == 4 && BN == 128) return patch_launch<0, 4, 4, false, D>(p, (int)blocks, lds, st)
@@ -722,12 +670,6 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     WDG_PATCH_DBG_LSTM(3); WDG_PATCH_DBG_LSTM(80); WDG_PATCH_DBG_LSTM(83); WDG_PATCH_DBG_LSTM(87); WDG_PATCH_DBG_LSTM(119);
 #undef WDG_PATCH_DBG_LSTM
 #endif
-    // the recurrent step's deep-pipeline instantiation: 3 x 3, stride 1, one chunk of 16 channel groups, whole column tiles, and a
-    // stage count that is a multiple of its pipeline depth (18 stages, depth 3)
-    const bool lstm_deep = lstm && g_patch_lstm_deep && MT == 3 && BN == 128 && g.kh == 3 && g.kw == 3 && g.stride == 1 && p.CK8 == 16 &&
-                           p.nchunk == 1 && !p.flat && g.Ncols % BN == 0;
-    if (lstm_deep && fmt == 0) return patch_launch<0, 3, 4, false, 0, 2>(p, (int)blocks, lds, st);
-    if (lstm_deep && fmt == 1) return patch_launch<1, 3, 4, false, 0, 2>(p, (int)blocks, lds, st);
 #define WDG_PATCH_CASE(F, M, N)                                                                        \
     if (fmt == F && MT == M && BN == 32 * N)                                                           \
         return lstm ? patch_launch<F, M, N, false, 0, 1>(p, (int)blocks, lds, st)                     \

@@ -448,6 +448,17 @@ class HipOps:
 
     supports_weight_slices = True
 
+    def weight_slices_ok(self, x, dy_slice, pk, g):
+        """Can conv_dgrad_slice / conv_wgrad_slice run this layer on a channel range of width dy_slice.shape[-1]?
+        wdg_conv_plan_create_sliced accepts only geometries whose three directions run on the implicit-GEMM kernels (it
+        returns WDG_ERR_ARG where the halo / thin kernels would be picked: stride 1, 3x3, few channels, large maps); the
+        caller then keeps the full-width conv_wgrad / conv_dgrad."""
+        try:
+            self._plan(x, dy_slice, pk.cin, dy_slice.shape[-1], g, w_ld=pk.cout)
+            return True
+        except native.NativeError:
+            return False
+
     def conv_dgrad_slice(self, dy, pk, n0, n1, dx, g, accumulate=False):
         """dx (+)= conv_transpose(dy, W[..., n0:n1]) for a channel RANGE of the layer's output: dy is the [.., n0:n1] view of the
         output-gradient tensor, pk the pack of the FULL layer (wdg_conv_plan_create_sliced).  A ConvLSTM2D at n_timesteps = 1 has

@@ -483,6 +483,10 @@ class ConvLSTM:
         # gradient's reduction is skipped (channel ranges [0, F) and [2F, 4F) of the gate tensor: HipOps.conv_dgrad_slice)
         live = T == 1 and F % 4 == 0 and getattr(o, "supports_weight_slices", False) and not getattr(o, "split_mode", False) \
             and os.environ.get("WDG_LSTM_LIVE_GATES", "1") != "0"
+        if live and hasattr(o, "weight_slices_ok"):
+            # (both range widths: F for the input gate, 2F for candidate + output gate; layers that would run on the halo / thin
+            # kernels cannot be sliced and keep the full-width calls below)
+            live = o.weight_slices_ok(x, self.dgates[..., :F], self.pkx, self.g) and o.weight_slices_ok(x, self.dgates[..., 2 * F:], self.pkx, self.g)
         if need_wgrad:
             def weight_grads():
                 # (the bias gradient — the column sums of dgates, 453 MB at batch 8 x T 24 — rides on the input kernel's weight
