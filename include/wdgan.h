@@ -664,6 +664,11 @@ int wdg_philox_normal(float* out, int ldo, const float* add, int lda, int64_t P,
 int wdg_input_assemble_supported(int CI, int CN, int ld);
 int wdg_input_assemble(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, float* out, int ld, int64_t rows,
                        int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, wdg_stream stream);
+/* The same for B of the Bo batch slots of a larger time-major buffer — destination row (t * Bo + b0 + b) * XY + r; image source,
+ * Philox counters and values exactly those of wdg_input_assemble on the dense [T' * B * XY, ld] view.  One predict() group of 16
+ * tiles with its own noise draw (api.py:132-137) inside a forward pass that carries several groups. */
+int wdg_input_assemble_slots(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, float* out, int ld, int64_t rows,
+                             int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, int Bo, int b0, wdg_stream stream);
 /* U[0,1) for the interpolation coefficients eps (ganbase.py:30). */
 int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, wdg_stream stream);
 

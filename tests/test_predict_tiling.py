@@ -103,6 +103,31 @@ def test_predict_array_gpu(hip_ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_predict_array_groups_per_launch_gpu(hip_ops, monkeypatch, precision):
+    """Two predict() groups of 16 tiles per forward pass (the default, WDG_PREDICT_GROUPS=2) against one group per pass: every
+    group keeps its own noise draw at its own place in the generator's stream (LazyGroupNoise, wdg_input_assemble_slots) and
+    tiles are independent in inference mode, so the blended fields are the same bits — including a launch whose second group
+    is short (50 tiles = 3 groups + 2 tiles -> launches of (16, 16) and (16, 2 + 14 padding))."""
+    from downscaling.engine import runtime
+    import downscaling.api as api
+    runtime.set_ops(hip_ops)
+    rng = np.random.default_rng(2)
+    fields = rng.standard_normal((48, 400, 400, 3)).astype(np.float32)
+    fields[..., 2] = fields[..., 2] * 800 + 1500
+    outs = []
+    for per in ("1", "2", "3"):
+        monkeypatch.setenv("WDG_PREDICT_GROUPS", per)
+        network = api.get_network(allow_random_init=True, random_seed=21)
+        network.generator.inference_precision = precision
+        out, cnt = api.predict_array(fields, overlap_factor=0.05, network=network, return_count=True)
+        assert network.noise_generator.prng.offset == 4 * (16 * 24 * 96 * 96 * 20 // 4)      # four draws of a full group, whatever the launches
+        outs.append(out)
+    assert int((cnt > 0).sum()) > 0 and np.isfinite(outs[0][cnt > 0]).all()
+    assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_tiling_kernels_gpu():
     """csrc/tiling.hip against the literal expressions of the driver (api.py:117-129 tile gather + np.nanmean / np.nanstd
     normalisation; api.py:139-150 cropped sum / count), NaNs in the field, overlapping tiles inside one group."""

@@ -755,7 +755,9 @@ extern "C" int wdg_philox_normal(float* out, int ldo, const float* add, int lda,
 template <int CI, int CN, int LD>
 __global__ void __launch_bounds__(256) wdg_input_assemble_kernel(const float* __restrict__ image, long long img_stride_b, long long img_stride_t,
                                                                  float* __restrict__ out, long long rows, int B, int XY, uint64_t seed,
-                                                                 uint64_t offset, float stdv) {
+                                                                 uint64_t offset, float stdv, int Bo, int b0) {
+    // (Bo, b0: the rows are written for batch slots [b0, b0 + B) of a time-major buffer of Bo slots — row (t * Bo + b0 + b) * XY + r;
+    // the image source and the Philox counters are those of the dense B-slot view)
     static_assert(CN % 4 == 0 && LD % 4 == 0 && CI + CN <= LD, "whole Philox blocks and whole 16-byte stores per pixel");
     for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < rows; row += (long long)gridDim.x * 256) {
         const long long tb = row / XY;
@@ -782,7 +784,7 @@ __global__ void __launch_bounds__(256) wdg_input_assemble_kernel(const float* __
                 v[CI + 4 * k + 2 * h + 1] = stdv * (rad * sinf(ang));
             }
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(out + row * LD);
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (((long long)t * Bo + b0 + b) * XY + r) * LD);
 #pragma unroll
         for (int q = 0; q < LD / 4; ++q) dst[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     }
@@ -799,7 +801,22 @@ extern "C" int wdg_input_assemble(const float* image, int64_t img_stride_b, int6
     WDG_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
     if (rows == 0) return WDG_OK;
     hipLaunchKernelGGL((wdg_input_assemble_kernel<3, 20, 24>), dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, image,
-                       (long long)img_stride_b, (long long)img_stride_t, out, (long long)rows, B, XY, seed, offset, std);
+                       (long long)img_stride_b, (long long)img_stride_t, out, (long long)rows, B, XY, seed, offset, std, B, 0);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// The same for B of the Bo batch slots of a larger time-major buffer (slots [b0, b0 + B)): image, Philox counters and values are
+// exactly those of wdg_input_assemble on the dense [T' * B * XY, ld] view; only the destination row changes.  One predict()
+// group of 16 tiles (its own noise draw) inside a forward pass that carries several groups — api.predict_array.
+extern "C" int wdg_input_assemble_slots(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, float* out, int ld, int64_t rows,
+                                        int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, int Bo, int b0, wdg_stream stream) {
+    WDG_CHECK_ARG(image && out && rows >= 0 && B > 0 && XY > 0 && rows % ((int64_t)B * XY) == 0 && b0 >= 0 && b0 + B <= Bo, "bad argument");
+    WDG_CHECK_ARG(wdg_input_assemble_supported(CI, CN, ld), "unsupported channel counts (3 + 20 in 24)");
+    WDG_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
+    if (rows == 0) return WDG_OK;
+    hipLaunchKernelGGL((wdg_input_assemble_kernel<3, 20, 24>), dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, image,
+                       (long long)img_stride_b, (long long)img_stride_t, out, (long long)rows, B, XY, seed, offset, std, Bo, b0);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

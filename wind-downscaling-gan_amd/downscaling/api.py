@@ -12,7 +12,7 @@ from pathlib import Path
 
 import numpy as np
 
-from downscaling.data.data_generator import FlexibleNoiseGenerator
+from downscaling.data.data_generator import FlexibleNoiseGenerator, LazyGroupNoise
 from downscaling.gan import train, metrics
 from downscaling.gan.ganbase import GAN
 from downscaling.gan.models import make_generator, make_discriminator
@@ -232,31 +232,54 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     num_groups = math.ceil(tensors.shape[0] / group_size)
     lap('tiles_and_normalisation')
     rank, world = (sync.rank, sync.world_size) if sync is not None else (0, 1)
+    # The groups of 16 tiles (api.py:132) are the unit of the reference's NOISE DRAWS, not of the launches here: `per` of this
+    # rank's groups share one forward pass — every kernel of the pass carries `per` times the rows for the same weight traffic,
+    # and the 24 recurrent steps (a dependent chain of launches that 16 tiles cannot fill the chip with) run once for all of
+    # them.  Each group still takes its own draw from the generator's stream, in group order (LazyGroupNoise), and inference
+    # treats every tile independently, so the result is the one of group-by-group calls.  WDG_PREDICT_GROUPS=1 restores those.
+    per = max(1, int(os.environ.get('WDG_PREDICT_GROUPS', '2')))
+    mine = list(range(rank, num_groups, world))
+    per = min(per, max(1, len(mine)))
     with torch.no_grad():
-        for t in range(rank, num_groups, world):
-            tensor = tensors[t * group_size:(t + 1) * group_size, ...]
-            n_real = tensor.shape[0]
-            if n_real < group_size and num_groups > 1:
-                # a short last group runs at the resident batch size (zero tiles behind the real ones, their outputs unused):
-                # inference treats every tile independently, and the generator keeps its buffers, plans and graph
-                tensor = torch.cat([tensor, tensor.new_zeros((group_size - n_real,) + tuple(tensor.shape[1:]))], dim=0)
+        for c0 in range(0, len(mine), per):
+            chunk = mine[c0:c0 + per]
+            parts, kparts, n_real = [], [], []
+            for t in chunk:
+                tensor = tensors[t * group_size:(t + 1) * group_size, ...]
+                n_real.append(tensor.shape[0])
+                if tensor.shape[0] < group_size and num_groups > 1:
+                    # a short last group runs at the resident batch size (zero tiles behind the real ones, their outputs unused):
+                    # inference treats every tile independently, and the generator keeps its buffers, plans and graph
+                    tensor = torch.cat([tensor, tensor.new_zeros((group_size - tensor.shape[0],) + tuple(tensor.shape[1:]))], dim=0)
+                parts.append(tensor)
+            gsz = parts[0].shape[0]                                                # 16, or the tile count of a single short group
+            if len(parts) < per:
+                # a short last launch runs at the resident batch size too: zero groups behind the real ones, no draws for them
+                parts += [parts[0].new_zeros(parts[0].shape)] * (per - len(parts))
+            tensor = parts[0] if per == 1 else torch.cat(parts, dim=0)
             # fresh noise per group (api.py:136), drawn by the generator model straight into its input buffer
-            # (FlexibleNoiseGenerator.lazy: stream order (time, tile, x, y, channel) for the batch size of the call)
-            noise = network.noise_generator.lazy(bs=tensor.shape[0], channels=NOISE_CHANNELS)
-            lap('noise')
-            pred = gen([tensor, noise])                                            # stays on the device (api.py:137)
-            lap('generator')
-            if native_tiles and pred.dtype == torch.float32:
-                ops.tiles_blend(pred.contiguous(), keys4[t * group_size:(t + 1) * group_size].contiguous(), n_real, acc, cnt, 2)
+            # (stream order (time, tile, x, y, channel) for the batch size of the group's call, the groups one after the other)
+            if per == 1:
+                noise = network.noise_generator.lazy(bs=gsz, channels=NOISE_CHANNELS)
             else:
-                for j, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):
-                    r = _tile_lat_index(sy)[2:-2]                                  # api.py:148: descending, contiguous
-                    ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
-                    rs, cs = slice(int(r[-1]), int(r[0]) + 1), slice(sx + 2, sx + IMG_SIZE - 2)
-                    acc[ts, rs, cs] += pred[j][:, 2:-2, 2:-2].flip(1).double()
-                    cnt[ts, rs, cs] += 1
-            lap('blend')
-            print(f'Predicted {(t + 1) / num_groups:.0%}')
+                noise = LazyGroupNoise(network.noise_generator, len(chunk), gsz, network.noise_generator.noise_shape, NOISE_CHANNELS,
+                                       network.noise_generator.std, pad_groups=per)
+            lap('noise')
+            pred_all = gen([tensor, noise])                                        # stays on the device (api.py:137)
+            lap('generator')
+            for j, t in enumerate(chunk):
+                pred = pred_all[j * gsz:(j + 1) * gsz]
+                if native_tiles and pred.dtype == torch.float32:
+                    ops.tiles_blend(pred.contiguous(), keys4[t * group_size:(t + 1) * group_size].contiguous(), n_real[j], acc, cnt, 2)
+                else:
+                    for i, (sx, sy, k) in enumerate(keys[t * group_size:(t + 1) * group_size]):
+                        r = _tile_lat_index(sy)[2:-2]                              # api.py:148: descending, contiguous
+                        ts = slice(k * SEQUENCE_LENGTH, (k + 1) * SEQUENCE_LENGTH)
+                        rs, cs = slice(int(r[-1]), int(r[0]) + 1), slice(sx + 2, sx + IMG_SIZE - 2)
+                        acc[ts, rs, cs] += pred[i][:, 2:-2, 2:-2].flip(1).double()
+                        cnt[ts, rs, cs] += 1
+                lap('blend')
+                print(f'Predicted {(t + 1) / num_groups:.0%}')
     cnt2d = np.zeros((plan['ntimeseq'], pixels_lat, pixels_lon), dtype=np.int32)   # every rank: the global count (one map per sequence)
     for (sx, sy, k) in keys:
         r = _tile_lat_index(sy)[2:-2]

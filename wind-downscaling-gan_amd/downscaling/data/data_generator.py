@@ -68,6 +68,46 @@ class LazyMemberNoise(object):
                 g.prng.assemble_at(img_j[:, t:t + 1], rows_all[r0:r0 + rows], self.tiles, X * Y, C, self.std, t * (rows * C // 4))
 
 
+class LazyGroupNoise(object):
+    """Pending draws of ONE FlexibleNoiseGenerator for `groups` consecutive calls of `tiles` tiles each, run as one forward pass of
+    batch groups * tiles: batch slots [g * tiles, (g + 1) * tiles) take exactly the values the g-th of `groups` successive
+    `lazy(bs=tiles)` draws would have had — element order (time, tile, x, y, channel) inside a group, the groups one after the
+    other in the stream — so api.predict's result does not depend on how many of its groups of 16 (api.py:132) share a launch."""
+
+    is_lazy_noise = True
+
+    def __init__(self, generator, groups, tiles, noise_shape, channels, std, pad_groups=None):
+        """pad_groups >= groups: the forward pass runs pad_groups * tiles batch slots; the slots behind the real groups get no
+        draw (their outputs are unused) and the generator's stream does not advance for them."""
+        self.generator, self.groups, self.tiles, self.std = generator, int(groups), int(tiles), std
+        self.slots = max(self.groups, int(pad_groups or 0))
+        self.shape = (self.slots * self.tiles, noise_shape[1], noise_shape[2], noise_shape[3], channels)
+
+    def _walk(self, fn):
+        B, T, X, Y, C = self.shape
+        rows = self.tiles * X * Y                       # one timestep of one group: a contiguous row block of the time-major view
+        assert (rows * C) % 4 == 0                      # whole Philox blocks per timestep
+        prng = self.generator.prng
+        for g in range(self.groups):
+            base = prng.reserve(T * rows * C)           # the group's place in the stream (= one lazy(bs=tiles) draw)
+            for t in range(T):
+                fn(g, t, (t * B + g * self.tiles) * X * Y, rows, base + t * (rows * C // 4))
+
+    def fill(self, view2d):
+        B, T, X, Y, C = self.shape
+        assert view2d.shape[0] == T * B * X * Y and view2d.shape[1] == C
+        self._walk(lambda g, t, r0, rows, off: self.generator.prng.normal_at(view2d[r0:r0 + rows], self.std, off))
+
+    def fill_with_image(self, rows_all, image):
+        """As fill, with the image written in the same pass (see LazyNoise.fill_with_image)."""
+        B, T, X, Y, C = self.shape
+        assert rows_all.shape[0] == T * B * X * Y and tuple(image.shape[:4]) == (B, T, X, Y)
+        n, prng = self.tiles, self.generator.prng
+        assert (n * X * Y * C) % 4 == 0
+        for g in range(self.groups):
+            prng.assemble_slots_at(image[g * n:(g + 1) * n], rows_all, n, X * Y, C, self.std, prng.reserve(T * n * X * Y * C), B, g * n)
+
+
 class FlexibleNoiseGenerator(object):
     def __init__(self, noise_shape, std=1, random_seed=None, rank=0):
         self.noise_shape = noise_shape

@@ -1311,6 +1311,17 @@ class HipOps:
         native.check(self.lib.wdg_input_assemble(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo, rows_out.shape[0],
                                                  B, XY, cn, seed & (2**64 - 1), offset, std, self.stream), "input_assemble")
 
+    def input_assemble_slots(self, image, rows_all, B, XY, cn, seed, offset, std, Bo, b0):
+        """input_assemble for batch slots [b0, b0 + B) of the Bo slots of rows_all [T' * Bo * XY, ld]: the values of the dense
+        B-slot call, written to rows (t * Bo + b0 + b) * XY + r (wdg_input_assemble_slots)."""
+        assert image.dim() == 5 and image.stride(4) == 1 and image.stride(3) == image.shape[4] and image.stride(2) == image.shape[3] * image.shape[4]
+        po, ldo = _v2(rows_all)
+        Tn = image.shape[1]
+        assert rows_all.shape[0] == Tn * Bo * XY and image.shape[0] == B
+        native.check(self.lib.wdg_input_assemble_slots(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo, Tn * B * XY,
+                                                       B, XY, cn, seed & (2**64 - 1), offset, std, int(Bo), int(b0), self.stream),
+                     "input_assemble_slots")
+
     def philox_uniform(self, out, seed, offset):
         native.check(self.lib.wdg_philox_uniform(out.data_ptr(), out.numel(), seed & (2**64 - 1), offset, self.stream), "philox_uniform")
 

@@ -57,6 +57,18 @@ class PhiloxSource:
         """[image | noise | 0] into whole rows of the generator's input buffer; the noise is normal_at's stream at `offset`."""
         self.ops.input_assemble(image, rows_out, B, XY, cn, self.seed, offset, float(std))
 
+    def assemble_slots_at(self, image, rows_all, B, XY, cn, std, offset, Bo, b0):
+        """assemble_at for batch slots [b0, b0 + B) of a time-major buffer of Bo slots (HipOps.input_assemble_slots); backends
+        without it get one assemble_at per timestep (each timestep's rows of the group are one contiguous block)."""
+        fn = getattr(self.ops, "input_assemble_slots", None)
+        if fn is not None:
+            fn(image, rows_all, B, XY, cn, self.seed, offset, float(std), Bo, b0)
+            return
+        rows = B * XY
+        for t in range(image.shape[1]):
+            r0 = (t * Bo + b0) * XY
+            self.assemble_at(image[:, t:t + 1], rows_all[r0:r0 + rows], B, XY, cn, std, offset + t * (rows * cn // 4))
+
     def uniform_at(self, vec, offset):
         self.ops.philox_uniform(vec, self.seed, offset)
 
