@@ -466,6 +466,20 @@ def child_legs(headline_ms):
     except Exception as exc:          # a leg must never cost the headline line
         out["dp_path_one_rank"] = {"error": repr(exc)}
     try:
+        # the same with every collective replaced by a stand-in kernel that occupies the chip as the 8-rank collective would
+        # (engine/trainer.py DistSync, WDG_DP_PROXY=1): what RCCL's own stream — a fifth busy queue — and 8-rank SyncBN latencies
+        # would do to the four-queue schedule, measurable on one GPU
+        j = run(["--steps", "6", "--warmup", "2"], {"WDG_DIST_ALWAYS": "1", "WDG_DP_PROXY": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29573"})
+        base = out.get("dp_path_one_rank", {}).get("ms_per_step")
+        out["dp_fifth_queue_proxy"] = {
+            "ms_per_step": j["ms_per_step"], "dp_fifth_queue_proxy_ms": (j["ms_per_step"] - base) if base else None,
+            "vs_headline_ms": j["ms_per_step"] / headline_ms, "proxy": j.get("rccl", {}).get("proxy"),
+            "note": "one-rank group, collectives replaced by wdg_dp_proxy launches: each flat-gradient all-reduce = 16 workgroups on a "
+                    "fifth stream moving 2 * 7/8 of the buffer and lasting its ring time at 150 GB/s per link; each SyncBN / metric "
+                    "all-reduce = a 10 us wait on the calling stream.  dp_fifth_queue_proxy_ms = this step - dp_path_one_rank's"}
+    except Exception as exc:
+        out["dp_fifth_queue_proxy"] = {"error": repr(exc)}
+    try:
         j = run(["--size", "96", "--timesteps", "24", "--batch", "8", "--steps", "5", "--warmup", "2"], {})
         out["train_T24_S96_b8"] = {
             "tile_timesteps_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
@@ -562,6 +576,9 @@ def rccl_evidence(dist, gan, world, rank, dev):
             "d_grad_allreduce_bytes": nb, "allreduce_ms": times[len(times) // 2], "allreduce_ms_min": times[0],
             "allreduce_busbw_gbps": (2.0 * (world - 1) / world * nb / (times[len(times) // 2] * 1e-3) * 1e-9) if world > 1 else None,
             "sync_bn": bool(getattr(gan.engine.gen, "sync", None) is not None),
+            "proxy": dict(gan.engine.sync.proxy_log, ranks=gan.engine.sync.proxy_ranks, link_gbps=gan.engine.sync.proxy_link_gbps,
+                          small_us=gan.engine.sync.proxy_small_us, blocks=gan.engine.sync.proxy_blocks)
+            if getattr(gan.engine.sync, "_proxy", False) else None,
             "note": "3 discriminator (34.2 MB) + 1 generator (7.2 MB) flat-gradient all-reduces per step, started asynchronously and "
                     "overlapped with the next network's forward; SyncBN adds 10 tiny fp64 [2C] all-reduces per generator pass"}
 

@@ -685,6 +685,14 @@ int wdg_adam_tf(float* p, const float* g, float* m, float* v, int64_t n, float l
  * weight-gradient launch instead of being zero-filled (ganbase.py:39,50: a fresh tape per update). */
 int wdg_zero_ranges(float* base, const int64_t* begin_end, int n, wdg_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement only (no reference counterpart): a stand-in for a collective's kernel on a one-GPU box.  `blocks` workgroups copy
+ * `bytes` from src (wrapping around src_bytes) to dst and then idle until min_us microseconds have passed since the kernel
+ * started — what a link-bound RCCL ring all-reduce on its own stream looks like to the rest of the chip.  bytes = 0: only the
+ * wait (a latency-bound small collective).  engine/trainer.py DistSync with WDG_DP_PROXY=1; bench.py dp_fifth_queue_proxy.
+ * ------------------------------------------------------------------------------------------ */
+int wdg_dp_proxy(const void* src, void* dst, int64_t src_bytes, int64_t bytes, int blocks, float min_us, wdg_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

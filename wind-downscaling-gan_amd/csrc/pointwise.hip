@@ -911,3 +911,31 @@ extern "C" int wdg_patch_scatter(const float* dpatch, float* dx, int lddx, int64
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
+
+// ---- stand-in for a collective's kernel on a one-GPU box (measurement only; engine/trainer.py DistSync, WDG_DP_PROXY=1) ------------
+// What an RCCL ring all-reduce looks like to the REST of the chip: a few persistent workgroups on a stream of their own that move
+// 2 (N - 1) / N of the buffer and otherwise wait for their peers.  `blocks` workgroups copy `bytes` from src (wrapping around its
+// `src_bytes`) to dst, then idle (s_sleep) until `min_us` microseconds have passed since the kernel started: the duration of a
+// link-bound transfer (34.2 MB of discriminator gradients: 2 * 7/8 * 34.2 MB at ~150 GB/s = 0.4 ms).  bytes = 0: only the wait
+// (a latency-bound small collective: SyncBN's [2C] statistics, ~10 us).
+__global__ void __launch_bounds__(256) wdg_dp_proxy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n16,
+                                                           long long src16, long long min_ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();          // 100 MHz
+    f32x4 keep = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        const f32x4 v = src[i % src16];
+        dst[i % src16] = v;
+        keep += v;
+    }
+    if (keep[0] == 1.2345e-30f) dst[0] = keep;                                  // (keeps the loads)
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < min_ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int wdg_dp_proxy(const void* src, void* dst, int64_t src_bytes, int64_t bytes, int blocks, float min_us, wdg_stream stream) {
+    WDG_CHECK_ARG(blocks > 0 && blocks <= 1024 && bytes >= 0 && min_us >= 0.f && min_us < 1e5f, "bad argument");
+    WDG_CHECK_ARG(bytes == 0 || (src && dst && src_bytes >= 16 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0), "bad buffers");
+    hipLaunchKernelGGL(wdg_dp_proxy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), (long long)(bytes / 16), (long long)(bytes ? src_bytes / 16 : 1), (long long)(min_us * 100.f));
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}

@@ -167,6 +167,7 @@ SIGNATURES = {
     "wdg_philox_normal": (i32, [c_fp, i32, c_fp, i32, i64, i32, u64, u64, f32, c_fp]),
     "wdg_input_assemble_supported": (i32, [i32, i32, i32]),
     "wdg_input_assemble": (i32, [c_fp, i64, i64, i32, c_fp, i32, i64, i32, i32, i32, u64, u64, f32, c_fp]),
+    "wdg_dp_proxy": (i32, [c_fp, c_fp, i64, i64, i32, f32, c_fp]),
     "wdg_input_assemble_slots": (i32, [c_fp, i64, i64, i32, c_fp, i32, i64, i32, i32, i32, u64, u64, f32, i32, i32, c_fp]),
     "wdg_philox_uniform": (i32, [c_fp, i64, u64, u64, c_fp]),
     "wdg_adam_tf": (i32, [c_fp, c_fp, c_fp, c_fp, i64, f32, f32, f32, f32, f32, c_fp]),

@@ -110,12 +110,57 @@ class DistSync:
             warnings.warn("WDG_DIST_NOOP=1: collectives are skipped (timing experiment only, results are not a training step)",
                           RuntimeWarning)
 
+        # measurement switch (bench.py dp_fifth_queue_proxy, one rank only): every collective is replaced by a stand-in kernel
+        # that occupies the chip the way the 8-rank collective would (wdg_dp_proxy) — the large gradient all-reduces as 16
+        # workgroups on a stream of their own (the FIFTH busy queue beside main / generator / real / generated) moving
+        # 2 * 7/8 of the buffer and lasting what the ring needs at ~150 GB/s per xGMI link; the small blocking ones (SyncBN
+        # statistics, metrics) as a ~10 us wait on the calling stream.  Results are those of a one-rank group (identity).
+        self._proxy = os.environ.get("WDG_DP_PROXY", "0") == "1"
+        if self._proxy:
+            if self.world_size > 1:
+                raise RuntimeError("WDG_DP_PROXY=1 is a one-rank measurement switch (it replaces the collectives by stand-in kernels)")
+            self.active = True
+            self._proxy_stream = self._proxy_scratch = None
+            self.proxy_ranks = int(os.environ.get("WDG_DP_PROXY_RANKS", "8"))
+            self.proxy_link_gbps = float(os.environ.get("WDG_DP_PROXY_GBPS", "150"))
+            self.proxy_small_us = float(os.environ.get("WDG_DP_PROXY_SMALL_US", "10"))
+            self.proxy_blocks = int(os.environ.get("WDG_DP_PROXY_BLOCKS", "16"))
+            self.proxy_log = {"large": 0, "small": 0, "large_bytes": 0}
+
+    def _proxy_large(self, t):
+        from downscaling.engine import native
+        lib = native.load()
+        cur = torch.cuda.current_stream(t.device)
+        if self._proxy_stream is None:
+            self._proxy_stream = torch.cuda.Stream(device=t.device)
+        nb = t.numel() * t.element_size()
+        if self._proxy_scratch is None or self._proxy_scratch.numel() < nb:
+            self._proxy_scratch = torch.empty(nb, dtype=torch.uint8, device=t.device)
+        n = self.proxy_ranks
+        moved = int(2 * (n - 1) / n * nb) // 16 * 16
+        s = self._proxy_stream
+        s.wait_stream(cur)
+        native.check(lib.wdg_dp_proxy(t.data_ptr(), self._proxy_scratch.data_ptr(), nb // 16 * 16, moved, self.proxy_blocks,
+                                      moved / (self.proxy_link_gbps * 1e3), s.cuda_stream), "dp_proxy")
+        ev = torch.cuda.Event()
+        ev.record(s)
+        self.proxy_log["large"] += 1
+        self.proxy_log["large_bytes"] += moved
+        return lambda: torch.cuda.current_stream(t.device).wait_event(ev)
+
+    def _proxy_small(self, t):
+        from downscaling.engine import native
+        native.check(native.load().wdg_dp_proxy(None, None, 0, 0, 1, self.proxy_small_us, torch.cuda.current_stream(t.device).cuda_stream), "dp_proxy")
+        self.proxy_log["small"] += 1
+
     def all_reduce_sum_async(self, t):
         """Start the all-reduce and return a zero-argument `finish()`; the collective runs on RCCL's own stream, so
         kernels enqueued on the compute stream before `finish()` overlap with it (`finish` makes the compute stream
         wait for the result)."""
         if self._noop:
             return lambda: None
+        if self._proxy and t.is_cuda:
+            return self._proxy_large(t)
         if self._stage and t.is_cuda:
             self.all_reduce_sum(t)          # host-staged test path: nothing to overlap
             return lambda: None
@@ -124,6 +169,10 @@ class DistSync:
 
     def all_reduce_sum(self, t):
         if self._noop:
+            return
+        if self._proxy:
+            if t.is_cuda:
+                self._proxy_small(t)
             return
         if self._stage and t.is_cuda:
             h = t.cpu()
