@@ -64,6 +64,15 @@ struct WdgPatchH16 {
     wdg_fastdiv div_tn, div_tx, div_ty, div_ck, div_pw;
 };
 
+#ifndef WDG_PATCH_PROF
+#define WDG_PATCH_PROF 0              // measurement builds: shader-clock totals per phase, summed over the workgroups (wdg_patch_prof)
+#endif
+#if WDG_PATCH_PROF
+__device__ unsigned long long patch_prof[8];
+#define PP_MARK(k) do { __builtin_amdgcn_s_waitcnt(0xc07f); const long long now_ = (long long)__builtin_amdgcn_s_memtime(); pp[k] += now_ - pp_last; pp_last = now_; } while (0)
+#else
+#define PP_MARK(k) do {} while (0)
+#endif
 // MT fragments of 16 pixels per wave (2 waves along the pixels), NT 16-channel tiles per wave (2 waves along the channels)
 // compile-time experiment knobs (tools/build_variants.sh)
 #ifndef WDG_PATCH_LB2
@@ -89,6 +98,9 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     h16x8* ldsB = reinterpret_cast<h16x8*>(smem_raw);              // [2 stages][8 planes][BN]
     h16x8* ldsP = ldsB + 2 * 8 * BN;                                // [CK8][pitch] patch
 
+#if WDG_PATCH_PROF
+    long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lq = lane >> 4;
@@ -160,6 +172,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         tabK[e] = (ok && !(DBG & 1)) ? koff : 0x40000000;
     }
 
+    PP_MARK(0);                                      // index arithmetic + K-step tables
     // ---- channel tiles of this workgroup: one, or (ntn_blk > 1: a patch that holds every channel, shallow reductions) several
     // against the same resident patch
     // (NLOOP is a template parameter: the single-tile kernels keep their register allocation)
@@ -253,6 +266,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             for (int u = 0; u < PU; ++u) ldsP[slot[u]] = wdg_pack_h16<FMT>(v[u][0], v[u][1]);
         }
 
+        PP_MARK(1);                                  // chunk barrier + patch: requests, conversion, LDS stores
         // ---- weight stages, D register sets deep: stage s + D is requested while stage s is computed from LDS, and stage s + 1 —
         // requested D - 1 compute stages ago — moves from its registers into the other LDS buffer behind the MFMAs; one barrier
         // per stage.  The body is branch-free and the same for every layer shape: what a K-step reads — the patch slot offset of its
@@ -331,6 +345,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         unsigned kq = ldk(D);                                       // weight offset of the next stage to request
         int t0 = tabT[lq], t1 = tabT[4 + lq];                       // patch offsets of the next stage to compute (its two K-steps)
         __syncthreads();
+        PP_MARK(2);                                  // first weight stages requested, stage 0 in LDS, patch visible
         for (int st = 0; st < p.npad; st += D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
@@ -345,6 +360,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 if (bar) __syncthreads();
             }
         }
+        PP_MARK(3);                                  // the stage loop
     }
 
     // ---- epilogue.  Lane (li, lq) holds channels 4*lq .. 4*lq+3 of pixel li of every fragment and stores them directly,
@@ -462,7 +478,26 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         }
     }
     }   // channel tiles
+#if WDG_PATCH_PROF
+    PP_MARK(4);                                      // epilogue: constants, activation, stores issued
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    PP_MARK(5);                                      // ... and completed (vmcnt(0))
+    if (t == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&patch_prof[k], (unsigned long long)pp[k]);
+        atomicAdd(&patch_prof[7], 1ull);
+    }
+#endif
 }
+#if WDG_PATCH_PROF
+extern "C" int wdg_patch_prof(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(patch_prof), sizeof(patch_prof)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(patch_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 static int g_patch_h16 = 1;
