@@ -269,6 +269,15 @@ int wdg_conv_fwd_h16_gates(const wdg_conv_plan* plan, const float* x, const void
 int wdg_convlstm_step_h16(const wdg_conv_plan* plan, const float* h_prev, const void* wF16, const float* gates_x,
                           const float* c_prev, float* c_out, int ldc, float* h_out, int ldh, int F, int fmt,
                           wdg_stream stream);
+/* The same two with activations in the 16-bit operand format (see wdg_conv_fwd_h16_act16): x16 / h_prev16 != 0: the layer input /
+ * the previous hidden state holds 16-bit elements of `fmt` (plan strides in elements); h_out16: a copy of h_t in that format
+ * [pixel][ldh16] — additional (h_out != NULL) or the only one (h_out == NULL).  The readers of h in inference (the next step,
+ * the next convolution) round it to the operand format while staging: the same bits, half the bytes.  models.py:45 */
+int wdg_conv_fwd_h16_gates_x16(const wdg_conv_plan* plan, const void* x, int x16, const void* wF16, const float* bias, float* gates,
+                               int F, int fmt, wdg_stream stream);
+int wdg_convlstm_step_h16x(const wdg_conv_plan* plan, const void* h_prev, int h_prev16, const void* wF16, const float* gates_x,
+                           const float* c_prev, float* c_out, int ldc, float* h_out, int ldh, void* h_out16, int ldh16, int F, int fmt,
+                           wdg_stream stream);
 int wdg_conv_dgrad_f16(const wdg_conv_plan* plan, const float* dy, const void* wD16, const float* bias,
                        const float* affine, float* dx, int act, float slope, int accumulate, wdg_stream stream);
 int wdg_conv_halo_fwd_f16(const wdg_conv_plan* plan, const float* x, const void* wF16, const float* bias,

@@ -390,6 +390,37 @@ extern "C" int wdg_convlstm_step_h16(const wdg_conv_plan* pl, const float* h_pre
     return rc;
 }
 
+// The same two with the hidden state / the layer input in the 16-bit operand format (see "activations in the 16-bit operand format"
+// below): x16 != 0: x holds 16-bit elements; h_prev16 / h_out16: the state the step reads / an additional (h_out != NULL) or the only
+// (h_out == NULL) copy of the state it writes — what the next step and the next layer round h to while staging it.
+extern "C" int wdg_conv_fwd_h16_gates_x16(const wdg_conv_plan* pl, const void* x, int x16, const void* wF16, const float* bias, float* y,
+                                          int F, int fmt, wdg_stream stream) {
+    WDG_CHECK_ARG(pl && x && wF16 && y && wdg_convlstm_h16_supported(pl, F), "not supported for this geometry");
+    WDG_CHECK_ARG(!x16 || pl->g.ldx % 8 == 0, "16-bit input: pixel stride a multiple of 8 elements");
+    WdgPatchGates gx;
+    memset(&gx, 0, sizeof(gx));
+    gx.F = F;
+    const int rc = wdg_patch_h16_launch(pl, 0, reinterpret_cast<const float*>(x), wF16, bias, nullptr, y, 0, 0.f, 0, fmt, (hipStream_t)stream, &gx, 0, x16);
+    WDG_CHECK_ARG(rc != 1, "patch kernel refused the geometry");
+    return rc;
+}
+extern "C" int wdg_convlstm_step_h16x(const wdg_conv_plan* pl, const void* h_prev, int h_prev16, const void* wF16, const float* gates_x,
+                                      const float* c_prev, float* c_out, int ldc, float* h_out, int ldh, void* h_out16, int ldh16, int F, int fmt,
+                                      wdg_stream stream) {
+    WDG_CHECK_ARG(pl && wF16 && gates_x && c_out && (h_out || h_out16) && wdg_convlstm_h16_supported(pl, F), "not supported for this geometry");
+    WDG_CHECK_ARG(ldc >= F && (!h_out || ldh >= F) && (!h_out16 || ldh16 >= F) && (h_prev != nullptr) == (c_prev != nullptr), "bad argument");
+    WDG_CHECK_ARG(!h_prev16 || pl->g.ldx % 8 == 0, "16-bit state: pixel stride a multiple of 8 elements");
+    WdgPatchGates gx;
+    memset(&gx, 0, sizeof(gx));
+    gx.F = F; gx.gates_x = gates_x; gx.c_prev = c_prev; gx.c_out = c_out; gx.ldc = ldc; gx.h_out = h_out; gx.ldh = ldh;
+    gx.h16_out = h_out16; gx.ldh16 = ldh16;
+    gx.skip_k = h_prev == nullptr;
+    const int rc = wdg_patch_h16_launch(pl, 0, h_prev ? reinterpret_cast<const float*>(h_prev) : gates_x, wF16, nullptr, nullptr, h_out, 0, 0.f, 0, fmt,
+                                        (hipStream_t)stream, &gx, 0, h_prev ? h_prev16 : 0);
+    WDG_CHECK_ARG(rc != 1, "patch kernel refused the geometry (16-bit state: whole 128-column tiles, aligned rows)");
+    return rc;
+}
+
 // ---- activations in the 16-bit operand format between two 16-bit layers --------------------------------------------------
 // A layer of the inference-precision forward rounds its input to the operand format while staging it.  When every reader of a
 // tensor is such a layer, the PRODUCER can store it rounded: the values multiplied are the same bits, the tensor has half the

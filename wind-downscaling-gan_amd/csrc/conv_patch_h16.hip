@@ -52,6 +52,9 @@ struct WdgPatchH16 {
     const float* c_prev;       // previous cell state [pixel][ldc] or NULL (zero)
     float* c_out;              // new cell state; Out receives h
     int ldc;
+    void* h16_out;             // LSTM step: optional copy of h in the 16-bit operand format [pixel][ldh16] (what the next step and the next
+    int ldh16;                 // layer would round h to while staging it: the same bits, half the bytes; Out may then be NULL)
+    int lstm_vec;              // LSTM step, NT = 4: whole column tiles, 16-byte aligned c / h rows -> the transposed 16-byte epilogue
     int mt;                    // fragments per wave (host side: picks the instantiation)
     int fw_shift, tfx;         // fragment width 1 << fw_shift (16 or 4), fragments per fragment-row of the tile
     int TH, TW, PH, PW, PWs, pitch;   // tile, patch, columns per parity plane, slots per channel-group plane
@@ -89,6 +92,23 @@ __device__ unsigned long long patch_prof[8];
 #else
 #define WDG_PATCH_BOUNDS __launch_bounds__(256)
 #endif
+// 4 x 4 transpose between a lane's four registers and the four lanes li, li + 16, li + 32, li + 48 (one lane per quarter lq):
+// afterwards register j of quarter lq holds what register lq of quarter j held.  v_permlane32_swap exchanges the upper half of
+// its first operand with the lower half of its second (register bit 1 <-> lane bit 5), v_permlane16_swap the odd 16-lane rows of
+// the first with the even rows of the second (register bit 0 <-> lane bit 4).
+__device__ __forceinline__ void wdg_tr4(float (&v)[4]) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    unsigned u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = __builtin_bit_cast(unsigned, v[j]);
+    u32x2 r = __builtin_amdgcn_permlane32_swap(u[0], u[2], false, false); u[0] = r[0]; u[2] = r[1];
+    r = __builtin_amdgcn_permlane32_swap(u[1], u[3], false, false); u[1] = r[0]; u[3] = r[1];
+    r = __builtin_amdgcn_permlane16_swap(u[0], u[1], false, false); u[0] = r[0]; u[1] = r[1];
+    r = __builtin_amdgcn_permlane16_swap(u[2], u[3], false, false); u[2] = r[0]; u[3] = r[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(float, u[j]);
+}
+
 template <int FMT, int MT, int NT, bool NLOOP, int DBG = 0, int LSTM = 0>
 __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) {
     typedef wdg_h16x8<FMT> h16x8;
@@ -203,6 +223,31 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     auto load_cell_inputs = [&]() {
         if constexpr (LSTM) {
             const int nw0_ = n0 + wn * (BN / 2);
+            if constexpr (NT == 4) {
+                if (p.lstm_vec) {
+                    // the quarter's four consecutive features of the previous cell state in ONE 16-byte request per fragment, handed to
+                    // the lanes that hold those features' gates by the lane transpose (instead of NT 4-byte requests)
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
+                        float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (p.c_prev && !(DBG & 64)) {
+                            const f32x4 q = *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.ldc + (nw0_ >> 2) + 4 * lq);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) c4[j] = q[j];
+                        }
+                        wdg_tr4(c4);
+#pragma unroll
+                        for (int b = 0; b < NT; ++b) {
+                            cp[b][a] = c4[b];
+                            gx[b][a] = (DBG & 64) ? (f32x4){0.1f, 0.2f, 0.3f, 0.4f}
+                                                  : *reinterpret_cast<const f32x4*>(p.gates_x + pix * (4 * p.gate_F) + nw0_ + b * 16 + 4 * lq);
+                        }
+                    }
+                    gx_loaded = true;
+                    return;
+                }
+            }
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int n = nw0_ + b * 16 + 4 * lq;
@@ -376,8 +421,44 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
         // the previous tile's stores (possible aliases): NT dependent round trips — 12 of the step's 35 us on their own
         // (profiles/r04m_chain_floor.txt: 14.7 us for a step without its K loop against 3.1 us without the epilogue's memory traffic)
         if (!gx_loaded) load_cell_inputs();
+        bool vec_done = false;
+        if constexpr (NT == 4) {
+            if (p.lstm_vec) {
+                // a lane's four column tiles hold features f0 + 4 b + lq of its pixel (b = tile): after the lane transpose quarter lq
+                // holds the four CONSECUTIVE features f0 + 4 lq .. + 3 — c and h leave as 16-byte stores (24 four-byte stores per lane
+                // before), h optionally also / only in the 16-bit operand format for its readers
+                const int f0 = (nw0 >> 2) + 4 * lq;
+                wdg_h16<FMT>* h16 = reinterpret_cast<wdg_h16<FMT>*>(p.h16_out);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
+                for (int a = 0; a < MT; ++a) {
+                    const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
+                    float cn[4], hv[4];
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        const f32x4 z = acc[a][b] + gx[b][a];
+                        const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
+                        const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
+                        const float gc = wdg_tanh(z[2]);
+                        const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
+                        cn[b] = gi * gc + gf * cp[b][a];
+                        hv[b] = go * wdg_tanh(cn[b]);
+                    }
+                    wdg_tr4(cn);
+                    wdg_tr4(hv);
+                    if constexpr (DBG & 16) { if (cn[0] == 123.456f) p.c_out[pix * p.ldc + f0] = cn[0]; continue; }
+                    *reinterpret_cast<f32x4*>(p.c_out + pix * p.ldc + f0) = (f32x4){cn[0], cn[1], cn[2], cn[3]};
+                    if (p.Out) *reinterpret_cast<f32x4*>(outImg + (long long)opix[a] * p.ldO + f0) = (f32x4){hv[0], hv[1], hv[2], hv[3]};
+                    if (h16) {
+                        typedef wdg_h16<FMT> h16x4 __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<h16x4*>(h16 + pix * p.ldh16 + f0) =
+                            (h16x4){(wdg_h16<FMT>)hv[0], (wdg_h16<FMT>)hv[1], (wdg_h16<FMT>)hv[2], (wdg_h16<FMT>)hv[3]};
+                    }
+                }
+                vec_done = true;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < (vec_done ? 0 : NT); ++b) {
             const int n = nw0 + b * 16 + 4 * lq;
             if (n >= p.Ncols) continue;
             const int f = n >> 2;
@@ -633,7 +714,6 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
                          const float* affine, float* y, int act, float slope, int accumulate, int fmt, hipStream_t st,
                          const WdgPatchGates* gx, int out16, int in16) {
     if (out16 && (gx || accumulate)) return 1;
-    if (in16 && gx && gx->c_out) return 1;           // (the recurrent step keeps its fp32 hidden state)
     const bool shuffle = transposed1x1 == 2;
     if (transposed1x1 == 1 && (pl->g.kh != 1 || pl->g.kw != 1 || pl->g.stride != 1 || pl->g.pad_h || pl->g.pad_w)) return 1;
     if (shuffle && (pl->g.kh != pl->g.kw || pl->g.stride != pl->g.kh || pl->g.kh < 2 || pl->g.pad_h || pl->g.pad_w || pl->g.Cin % 4 ||
@@ -661,6 +741,8 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
         if (lstm) {
             p.gates_x = gx->gates_x; p.c_prev = gx->c_prev; p.c_out = gx->c_out; p.ldc = gx->ldc;
             p.Out = gx->h_out; p.ldO = gx->ldh; p.imgStrideO = (long long)g.Ho * g.Wo * gx->ldh;
+            p.h16_out = gx->h16_out; p.ldh16 = gx->ldh16;
+            if (!gx->h_out && !gx->h16_out) return 1;
             if (gx->skip_k) p.nchunk = 0;            // t = 0: h_{-1} = 0, the recurrent convolution contributes nothing
         }
     }
@@ -669,8 +751,15 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     // 64-channel tiles when the map is small (the per-timestep recurrent convolution) or the layer is narrow
     const long long tiles_px = (long long)g.n_img * p.tiles_x * p.tiles_y;
     const bool narrow = g.Ncols <= 64 || tiles_px * ((g.Ncols + 127) / 128) < (long long)g.cus * 3 / 2;
-    const int BN = (lstm && g_patch_lstm_bn) ? g_patch_lstm_bn : narrow ? 64 : 128;
+    const bool h16_state = lstm && (gx->h16_out || !gx->h_out);       // (written by the transposed epilogue of the 128-column tile only)
+    const int BN = h16_state ? 128 : (lstm && g_patch_lstm_bn) ? g_patch_lstm_bn : narrow ? 64 : 128;
     p.tiles_n = (g.Ncols + BN - 1) / BN;
+    if (lstm) {
+        const bool al16 = !((uintptr_t)gx->c_out & 15) && !((uintptr_t)gx->c_prev & 15) && !((uintptr_t)gx->h_out & 15) && !((uintptr_t)gx->h16_out & 7) &&
+                          !((uintptr_t)gx->gates_x & 15);
+        p.lstm_vec = BN == 128 && g.Ncols % BN == 0 && gx->ldc % 4 == 0 && (!gx->h_out || gx->ldh % 4 == 0) && (!gx->h16_out || gx->ldh16 % 4 == 0) && al16;
+        if (!p.lstm_vec && (gx->h16_out || !gx->h_out)) return 1;        // (the 16-bit copy of h is written by the transposed epilogue only)
+    }
     p.ntn_blk = 1;
     if (g_patch_nloop && !lstm && p.nchunk == 1 && p.tiles_n > 1 && tiles_px >= 4LL * g.cus) { p.ntn_blk = p.tiles_n; p.tiles_n = 1; }
     p.div_tn = wdg_fastdiv_make((unsigned)p.tiles_n);

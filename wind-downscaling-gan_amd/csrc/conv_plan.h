@@ -135,9 +135,11 @@ struct WdgPatchGates {
     const float* c_prev;
     float* c_out;
     int ldc;
-    float* h_out;
+    float* h_out;              // fp32 h [pixel][ldh], or NULL when only the 16-bit copy is wanted
     int ldh;
     int skip_k;
+    void* h16_out;             // optional: h in the 16-bit operand format [pixel][ldh16]
+    int ldh16;
 };
 int wdg_patch_h16_eligible_s(const wdg_conv_plan* pl);
 int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float* x, const void* w16, const float* bias,

@@ -727,6 +727,10 @@ class HipOps:
     def convlstm16_gates(self, x, pk, bias, gates, g, F, fmt="bf16"):
         """Input part of the gates for all timesteps, gate columns interleaved (the layout the step kernel reads)."""
         plan, _, _ = self._plan(x, gates, pk.cin, pk.cout, g)
+        if self._is16(x, fmt):           # the layer input in the operand format (written that way by its producer)
+            native.check(self.lib.wdg_conv_fwd_h16_gates_x16(plan, x.data_ptr(), 1, pk.half(fmt)[0].data_ptr(), _ptr(bias), gates.data_ptr(),
+                                                             F, 0 if fmt == "bf16" else 1, self.stream), "conv_fwd_h16_gates_x16")
+            return
         native.check(self.lib.wdg_conv_fwd_h16_gates(plan, x.data_ptr(), pk.half(fmt)[0].data_ptr(), _ptr(bias), gates.data_ptr(),
                                                      F, 0 if fmt == "bf16" else 1, self.stream), "conv_fwd_h16_gates")
 
@@ -735,6 +739,14 @@ class HipOps:
         plan, _, _ = self._plan(h_out if h_prev is None else h_prev, gates_t, pk.cin, pk.cout, g)
         _, ldc, _ = _v4(c_out)
         _, ldh, _ = _v4(h_out)
+        if self._is16(h_out, fmt):
+            # the hidden state ONLY in the operand format: its readers in inference (the next step, the next convolution) round it
+            # to that format while staging — the same bits, half the bytes read, no fp32 copy written
+            assert h_prev is None or self._is16(h_prev, fmt)
+            native.check(self.lib.wdg_convlstm_step_h16x(plan, _ptr(h_prev), 1, pk.half(fmt)[0].data_ptr(), gates_t.data_ptr(), _ptr(c_prev),
+                                                         c_out.data_ptr(), ldc, None, 0, h_out.data_ptr(), ldh, F, 0 if fmt == "bf16" else 1,
+                                                         self.stream), "convlstm_step_h16x")
+            return
         native.check(self.lib.wdg_convlstm_step_h16(plan, _ptr(h_prev), pk.half(fmt)[0].data_ptr(), gates_t.data_ptr(), _ptr(c_prev),
                                                     c_out.data_ptr(), ldc, h_out.data_ptr(), ldh, F, 0 if fmt == "bf16" else 1,
                                                     self.stream), "convlstm_step_h16")
@@ -777,6 +789,12 @@ class HipOps:
     def act16_upconv_in_ok(self, x_low, pk_up):
         """The fused upsample kernel reads x_low in the 16-bit operand format."""
         return bool(self.act16 and self._upconv_fused16_layer_ok(pk_up) and x_low.shape[3] == pk_up.cout and _v4(x_low)[1] % 8 == 0)
+
+    def act16_lstm_ok(self, x, gates, pk_x, pk_h, g, F):
+        """Would the 16-bit ConvLSTM (convlstm16_gates / convlstm16_step) take its input AND keep its hidden state in the operand
+        format?  (The state is written by the 128-column tile's transposed epilogue: whole tiles, 16-byte rows.)"""
+        return bool(self.act16 and (4 * F) % 128 == 0 and _v4(x)[1] % 8 == 0 and F % 8 == 0 and
+                    self.convlstm16_supported(x[:1], gates[:1], pk_h, g, F) and self.convlstm16_supported(x, gates, pk_x, g, F))
 
     def act16_conv_ok(self, x, y, pk, g, transposed, in16, out16):
         """Would conv_fwd_bf16 (transposed False) / conv_dgrad_bf16 (True) take x / y in the 16-bit operand format?  x, y: tensors

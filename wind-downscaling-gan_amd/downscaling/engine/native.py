@@ -51,6 +51,8 @@ SIGNATURES = {
     "wdg_convlstm_h16_supported": (i32, [c_fp, i32]),
     "wdg_conv_fwd_h16_gates": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, c_fp]),
     "wdg_convlstm_step_h16": (i32, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
+    "wdg_conv_fwd_h16_gates_x16": (i32, [c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, c_fp]),
+    "wdg_convlstm_step_h16x": (i32, [c_fp, c_fp, i32, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
     "wdg_tiles_gather_normalise": (i32, [c_fp, i32, i32, i32, c_fp, i32, i32, i32, c_fp, c_fp, i32, c_fp, c_fp]),
     "wdg_tiles_blend": (i32, [c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
     "wdg_split_bf16x3": (i32, [c_fp, c_fp, i64, c_fp]),

@@ -268,9 +268,9 @@ class GeneratorNet(_Net):
             # the upsample block — the largest tensor of the forward — and (below) the 16 channels between the last two layers.
             cat2 = b["cat2"]
             key = "cat2_" + f
+            ok = getattr(self.ops, "act16_conv_ok", None)
             if key not in b:
                 b[key] = None
-                ok = getattr(self.ops, "act16_conv_ok", None)
                 if ok is not None and self.ops.act16 and cat2.shape[3] % 8 == 0 and self.F4p % 8 == 0:
                     c16 = self.ops.zeros(*cat2.shape, dtype=self.ops.H16_DTYPES[f])
                     if ok(b["x0"], c16[..., self.F4p:], self.c0.pk, self.c0.g, False, 0, 1) and \
@@ -281,11 +281,33 @@ class GeneratorNet(_Net):
             if b[key] is not None and self.ops.act16:
                 cat2 = b[key]
                 res2 = cat2[..., self.F4p:]
+            # ... and the quarter-resolution tensors: the [c5 | c2] concatenation (read by the ConvLSTM's gate convolution and by c7)
+            # and the ConvLSTM's hidden state (read by its next step and by c5) — every reader a 16-bit layer
+            cat4, hbuf = b["cat4"], b["h"]
+            key4 = "cat4_" + f
+            if key4 not in b:
+                b[key4] = b["h_" + f] = None
+                okl = getattr(self.ops, "act16_lstm_ok", None)
+                if ok is None:
+                    ok = getattr(self.ops, "act16_conv_ok", None)
+                if ok is not None and okl is not None and self.ops.act16 and cat4.shape[3] % 8 == 0 and (F // 2) % 8 == 0 and F % 8 == 0 \
+                        and T > 1 and os.environ.get("WDG_ACT16_QUARTER", "1") != "0":
+                    c16 = self.ops.zeros(*cat4.shape, dtype=self.ops.H16_DTYPES[f])
+                    h16 = self.ops.zeros(*hbuf.shape, dtype=self.ops.H16_DTYPES[f])
+                    self.lstm._buffers(hbuf.shape[0], hbuf.shape[1], hbuf.shape[2])
+                    if ok(res2, c16[..., F // 2:], self.c2.pk, self.c2.g, False, int(res2.dtype != self.ops.dtype), 1) and \
+                            okl(c16[..., F // 2:], self.lstm.gates, self.lstm.pkx, self.lstm.pkh, self.lstm.g, F) and \
+                            ok(h16, c16[..., :F // 2], self.c5.pk, self.c5.g, False, 1, 1) and \
+                            ok(c16, cat2[..., :self.F4p], self.c7.pk, self.c7.g, True, 1, int(cat2.dtype != self.ops.dtype)):
+                        b[key4], b["h_" + f] = c16, h16
+            if b[key4] is not None and self.ops.act16:
+                cat4, hbuf = b[key4], b["h_" + f]
+                res4 = cat4[..., F // 2:]
             self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine(), fmt=f)
             self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine(), fmt=f)
-            self.lstm.forward(res4, b["h"], B, T, bf16=True, fmt=f)
-            self.c5.forward_bf16(b["h"], b["cat4"][..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
-            self.c7.forward_bf16(b["cat4"], cat2[..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
+            self.lstm.forward(res4, hbuf, B, T, bf16=True, fmt=f)
+            self.c5.forward_bf16(hbuf, cat4[..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)
+            self.c7.forward_bf16(cat4, cat2[..., :self.F4p], affine=self.bn8.infer_affine(), fmt=f)
             z9 = b["z9"]
             ok16 = getattr(self.ops, "act16_output_conv_ok", None)
             aff10 = self.bn10.infer_affine()
