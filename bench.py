@@ -607,8 +607,7 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true",
                     help="skip the extra single-stream train steps the per-kernel roofline figures are taken from (profiling runs: "
                          "the figures then come from the timed region, whatever its stream schedule)")
-    ap.add_argument("--no-split-leg", action="store_true",
-                    help="skip the extra leg that repeats the timed steps with the implicit-GEMM kernels in bf16-slice mode")
+    ap.add_argument("--no-split-leg", action="store_true", help="(accepted and ignored: the bf16-slice mode was removed in round 6)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp16"], default="fp32", help="gen_fwd only: inference precision")
     ap.add_argument("--workload", choices=["train", "gen_fwd"], default="train",
                     help="train: the headline GAN train step (default); gen_fwd: generator-only forward (inference "
@@ -866,32 +865,6 @@ def main():
         if getattr(ops, "_cstreams_probe", None):
             # how the generator / twin-discriminator streams were placed (HipOps.concurrent_streams: measured, not assumed)
             out["stream_placement"] = dict(ops._cstreams_probe, gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"))
-        if getattr(ops, "split_mode", False):
-            out["dtype"] = "f32 via 3 bf16 slices per operand (6 slice products on bf16 MFMA, fp32 accumulate)"
-        elif headline and world == 1 and not args.no_split_leg and hasattr(ops, "set_split_mode"):
-            # NOT the headline: the same steps with the forward / data-gradient implicit GEMMs computing every fp32 product
-            # from three exact bf16 slices per operand (conv_igemm.hip PIPE 4; fp32-rounding accuracy, all GPU parity tests
-            # pass with it at unchanged tolerances: profiles/r02zz_gpu_tests_split.log).  Reported beside the fp32-MFMA line.
-            try:
-                ops.set_split_mode(True)
-                gan.train_step((low, high))
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    gan.train_step((low, high))
-                barrier()
-                dts = time.perf_counter() - t1
-                out["extra_bf16_slice_mode"] = {
-                    "value": B * T * args.steps / dts, "unit": "samples/s", "ms_per_step": 1e3 * dts / args.steps,
-                    "vs_fp32_mfma_line": (dt / dts),
-                    "arithmetic": "x = x1 + x2 + x3 exactly (8-bit slices of the fp32 significand); a*b ~ a1b1 + a2b1 + a3b1 + a1b2 + a2b2 + a1b3 "
-                                  "on v_mfma_f32_16x16x32_bf16, fp32 accumulate; omitted terms <= 2^-24 relative",
-                    "scope": "wdg_igemm_kernel (forward and data-gradient convolutions); weight-gradient, halo and ConvLSTM kernels stay on fp32 MFMA",
-                    "status": "opt-in (WDG_SPLIT=1 / HipOps.set_split_mode); the headline above is the fp32-MFMA path"}
-            except Exception as exc:      # the extra leg must never cost the headline line
-                out["extra_bf16_slice_mode"] = {"error": repr(exc)}
-            finally:
-                ops.set_split_mode(False)
         if world == 1 and not args.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -108,17 +108,6 @@ int wdg_conv_dgrad(const wdg_conv_plan* plan, const float* dy, const float* wD, 
                    float* dx, int act, float slope, int accumulate,
                    void* ws, size_t ws_bytes, wdg_stream stream);
 
-/* Experimental fp32-from-bf16-slices mode of the implicit-GEMM kernels (wdg_set_tuning("igemm_pipe", 4)): every fp32 operand
- * is the exact sum of three bf16 slices and six slice products on v_mfma_f32_16x16x32_bf16 reproduce the fp32 product to
- * 2^-24 relative.  wdg_split_bf16x3 writes the three slices of n floats as [3][n] bf16 (dst3: 3*n*2 + 16 bytes);
- * wdg_split_register tells the conv entry points that `w32` (a packed weight buffer passed as wF / wD) has the up-to-date
- * slice copy `w3` (NULL: forget it) — unregistered weights are sliced inside the kernel.  The registry is a process-wide map
- * keyed by device address, written and read on the launching thread only (not thread-safe; the Python side re-registers at
- * every use because the allocator recycles addresses).  No reference counterpart (TF
- * computes these convolutions in fp32: gan/models.py:33-70). */
-int wdg_split_bf16x3(const float* src, void* dst3, int64_t n, wdg_stream stream);
-int wdg_split_register(const float* w32, const void* w3, int64_t n);
-
 /* The same two launches as PRODUCERS OF A BatchNormalization INPUT (models.py:33-34, 39-40, 49-50, 55-56: conv ->
  * bias -> LeakyReLU -> BatchNormalization), with the norm's first pass folded into the epilogue:
  *   stats  != NULL (training):  y = act(conv + bias), and the replica slabs stats[stats_rep][2][C] (fp64, zeroed by the
@@ -678,6 +667,11 @@ int wdg_input_assemble(const float* image, int64_t img_stride_b, int64_t img_str
  * tiles with its own noise draw (api.py:132-137) inside a forward pass that carries several groups. */
 int wdg_input_assemble_slots(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, float* out, int ld, int64_t rows,
                              int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, int Bo, int b0, wdg_stream stream);
+/* ... with the rows in the 16-bit operand format of the inference-precision layers (fmt 0 bf16, 1 fp16; out holds 16-bit
+ * elements, ld in elements): the values wdg_input_assemble_slots writes, rounded to nearest even — what the generator's first
+ * 16-bit layer would round them to while staging (wdg_conv_fwd_h16_act16 with in16). */
+int wdg_input_assemble_h16(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, void* out, int ld, int64_t rows,
+                           int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, int fmt, int Bo, int b0, wdg_stream stream);
 /* U[0,1) for the interpolation coefficients eps (ganbase.py:30). */
 int wdg_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, wdg_stream stream);
 

@@ -237,16 +237,32 @@ def test_convlstm16_fused_step_matches_unfused(hip_ops, S, T, F, fmt):
     net.set_image(torch.randn(B, T, S, S, cin, generator=g).to(dev))
     net.set_noise((torch.randn(B, T, S, S, nz, generator=g) * 0.1).to(dev))
     outs = []
-    for fused in (1, 0):
+    b = net.buffers(B)
+    for fused, act16 in ((1, True), (1, False), (0, True)):
         assert hip_ops.lib.wdg_set_tuning(b"lstm16_fused", fused) == 0
+        hip_ops.act16 = act16
         try:
+            b["h"].fill_(7.0)                 # (a route that does not write the fp32 state must not be credited with an older one)
+            if b.get("h_" + fmt) is not None:
+                b["h_" + fmt].fill_(7.0)
             out = net.forward(B, False, precision=fmt).clone()
-            outs.append((out, net.buffers(B)["h"].clone()))
+            outs.append((out, b["h"].clone(), b["h_" + fmt].clone() if b.get("h_" + fmt) is not None else None))
         finally:
             hip_ops.lib.wdg_set_tuning(b"lstm16_fused", 1)
-    x = net.buffers(B)["cat4"][..., F // 2:]
+            hip_ops.act16 = True
+    x = b["cat4"][..., F // 2:]
     assert hip_ops.convlstm16_supported(x, net.lstm.gates, net.lstm.pkx, net.lstm.g, F), "the fused path must be the one tested"
-    assert rel_err(outs[0][1], outs[1][1]) < 2e-5, "hidden states"
+    # (1) the hidden state (and the quarter-resolution activations) kept in the operand format — the default — against the fp32
+    # hand-over: every reader rounds to the operand format while staging, so the state IS the rounded fp32 state and the generator's
+    # output is the same bits
+    if (S, F) == (96, 128):
+        assert outs[0][2] is not None, "the shipped shape keeps the ConvLSTM state in the operand format"
+    if outs[0][2] is not None:
+        assert float(outs[0][1].min()) == 7.0, "... and only there"
+        assert torch.equal(outs[0][2], outs[1][1].to(outs[0][2].dtype)), "16-bit state == rounded fp32 state"
+    assert torch.equal(outs[0][0], outs[1][0]), "same output bits with either hand-over"
+    # (2) fused step against the three-launch form (which keeps fp32 buffers: the switch moves the layer off the 16-bit-state route)
+    assert rel_err(outs[1][1], outs[2][1]) < 2e-5, "hidden states"
     # behind the ConvLSTM every 16-bit layer re-rounds its input: a 1e-7 difference in h flips an occasional operand by one 16-bit
     # ulp (bf16 4e-3, fp16 5e-4 relative), so the outputs agree to a few operand ulps at isolated pixels, not to fp32 noise
-    assert rel_err(outs[0][0], outs[1][0]) < (1e-2 if fmt == "bf16" else 2e-3), "generator output"
+    assert rel_err(outs[1][0], outs[2][0]) < (1e-2 if fmt == "bf16" else 2e-3), "generator output"

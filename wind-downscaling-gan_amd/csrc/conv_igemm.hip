@@ -32,8 +32,6 @@
 struct WdgIgemm {
     const float* A;
     const float* B;
-    const void* B3;        // PIPE 4: B pre-split into three bf16 slices [3][B3_slice] (same element order as B), or NULL
-    long long B3_slice;
     float* Out;
     const float* bias;
     const int4* ktab;  // {a_off, dh, dw, b_off}; b_off < 0 marks a padding entry
@@ -296,140 +294,7 @@ __global__ void __launch_bounds__(256 * KG, (BM == 256 && BN == 32 && PIPE == 3 
         if constexpr (WDG_MFMA_PRIO != 0) __builtin_amdgcn_s_setprio(0);
     };
 
-    if constexpr (PIPE == 4) {
-        // ---- fp32 product from three bf16 terms per operand on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate):
-        //   x = x1 + x2 + x3 EXACTLY (three 8-bit slices of the 24-bit significand, taken by truncation: x1 = x & 0xFFFF0000,
-        //   x2 = (x - x1) & 0xFFFF0000, x3 = x - x1 - x2), every slice product is exact in fp32, and the six products
-        //   a1b1, a2b1, a3b1, a1b2, a2b2, a1b3 leave out only terms of relative size 2^-24 (a2b3, a3b2) and 2^-32 (a3b3):
-        //   the fp32 GEMM to fp32 rounding accuracy at 6 x 16 instead of 8 x 32 MFMA cycles per 16 x 16 x 32 block.
-        // LDS stage: [operand][slice 3][k-octet 4][row] 16-byte slots (8 bf16 = one lane's MFMA operand); a staging thread
-        // owns 4 consecutive k of a row = half a slot per slice (ds_write_b64).  Rows are XOR-swizzled by 2 * octet: the 16
-        // lanes of a write group and of a ds_read_b128 group then fall on distinct banks.
-        typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        u32x2* lds2 = reinterpret_cast<u32x2*>(lds_all);                 // 8-byte units
-        const bf16x8_t* lds16 = reinterpret_cast<const bf16x8_t*>(lds_all);
-        constexpr int A_SLOTS16 = 12 * BM;                                // 16-byte slots of the A tile (3 slices x 4 octets x BM rows)
-        auto split_store = [&](const f32x4& v, int slot_base16, int rows, int row) {
-            // slot = ((slice * 4 + octet) * rows + (row ^ 2 * octet)); this thread's half = kg & 1
-            const int oct = kg >> 1;
-            const int base = (slot_base16 + oct * rows + (row ^ (2 * oct))) * 2 + (kg & 1);
-            unsigned h1[4], h2[4], h3[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x = v[j];
-                const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
-                const float r1 = x - __uint_as_float(b1);
-                const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-                const float r2 = r1 - __uint_as_float(b2);
-                h1[j] = b1; h2[j] = b2; h3[j] = __float_as_uint(r2);
-            }
-            // two bf16 per dword: element j in the low half, j + 1 in the high half
-            lds2[base] = (u32x2){(h1[0] >> 16) | h1[1], (h1[2] >> 16) | h1[3]};
-            lds2[base + 8 * rows] = (u32x2){(h2[0] >> 16) | h2[1], (h2[2] >> 16) | h2[3]};
-            lds2[base + 16 * rows] = (u32x2){(h3[0] >> 16) | (h3[1] & 0xFFFF0000u), (h3[2] >> 16) | (h3[3] & 0xFFFF0000u)};
-        };
-        // B (the weights) arrives pre-split when the host registered a three-slice copy (wdg_split_register): its staging is
-        // then 16-byte copies, slot id = t + 256 r -> octet id & 3 (4 lanes = 64 contiguous bytes of a row), row, slice
-        constexpr int B3_LOADS = (12 * BN + 255) / 256;
-        const bool pre = p.B3 != nullptr;
-        const wdg_srd srdB3 = wdg_make_srd(pre ? p.B3 : (const void*)p.B);
-        const int oct3 = t & 3;
-        u32x4 rb3[B3_LOADS];
-        int b3_off[B3_LOADS], b3_slot[B3_LOADS];
-#pragma unroll
-        for (int r = 0; r < B3_LOADS; ++r) {
-            const int qd = (t >> 2) + 64 * r;
-            const int sl = qd / BN, rown = qd - sl * BN;
-            const bool ok = sl < 3 && n0 + rown < p.Ncols;
-            b3_off[r] = ok ? (int)(sl * p.B3_slice) + (n0 + rown) * p.ldB : -1;
-            b3_slot[r] = sl < 3 ? A_SLOTS16 + (sl * 4 + oct3) * BN + (rown ^ (2 * oct3)) : -1;
-        }
-        const int4* tab3 = p.ktab + ph.tab_off + k4_begin + 2 * oct3;
-        int w3_cur = (pre && nk > 0) ? tab3[0].w : -1;
-        auto load_b3 = [&](int kt) {
-            const int w = w3_cur;
-#pragma unroll
-            for (int r = 0; r < B3_LOADS; ++r)
-                rb3[r] = __builtin_amdgcn_raw_buffer_load_b128(srdB3, (w >= 0 && b3_off[r] >= 0) ? (int)((unsigned)(b3_off[r] + w) << 1) : (int)WDG_SRD_OOB, 0, 0);
-            w3_cur = tab3[(kt + 1 < nk ? kt + 1 : kt) * 8].w;
-        };
-        auto load_a = [&](int kt) {
-            const int4 e = e_cur;
-#pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) {
-                const int ih = a_ih0[i] + e.y, iw = a_iw0[i] + e.z;
-                const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W) && (e.w >= 0);
-                ra[i] = wdg_buffer_load_f32x4(srdA, ok ? (unsigned)(a_off[i] + e.x) << 2 : WDG_SRD_OOB);
-            }
-            e_cur = tab[(kt + 1 < nk ? kt + 1 : kt) * 8];
-        };
-        auto load4 = [&](int kt) {
-            if (pre) {
-                load_a(kt);
-                load_b3(kt);
-            } else {
-                load_tile(kt);
-            }
-        };
-        u32x4* lds16w = reinterpret_cast<u32x4*>(lds_all);
-        auto store_split = [&]() {
-#pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) split_store(ra[i], 0, BM, lrow + 32 * i);
-            if (pre) {
-#pragma unroll
-                for (int r = 0; r < B3_LOADS; ++r)
-                    if (b3_slot[r] >= 0) lds16w[b3_slot[r]] = rb3[r];
-            } else {
-#pragma unroll
-                for (int i = 0; i < B_LOADS; ++i) {
-                    const int row = lrow + 32 * i;
-                    if (32 * (i + 1) <= BN || row < BN) split_store(rb[i], A_SLOTS16, BN, row);
-                }
-            }
-        };
-        const int oq = lane >> 4;                                         // this lane's k-octet
-        auto fragA = [&](int sl, int a) {
-            return lds16[(sl * 4 + oq) * BM + ((wm * (BM / WGM) + a * 16 + (lane & 15)) ^ (2 * oq))];
-        };
-        auto fragB = [&](int sl, int b) {
-            return lds16[A_SLOTS16 + (sl * 4 + oq) * BN + ((wn * (BN / WGN) + b * 16 + (lane & 15)) ^ (2 * oq))];
-        };
-        auto mma = [&](const bf16x8_t (&bw)[NT], const bf16x8_t (&ax)[MT]) {
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[b], ax[a], acc[a][b], 0, 0, 0);
-        };
-        if (nk > 0) {
-            load4(0);
-            store_split();
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            load4(kt + 1 < nk ? kt + 1 : kt);   // unconditional (the last one is redundant)
-            bf16x8_t a1[MT], a2[MT], a3[MT], bw[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) { a1[a] = fragA(0, a); a2[a] = fragA(1, a); a3[a] = fragA(2, a); }
-            // smallest terms first
-#pragma unroll
-            for (int b = 0; b < NT; ++b) bw[b] = fragB(2, b);
-            mma(bw, a1);
-#pragma unroll
-            for (int b = 0; b < NT; ++b) bw[b] = fragB(1, b);
-            mma(bw, a2);
-            mma(bw, a1);
-#pragma unroll
-            for (int b = 0; b < NT; ++b) bw[b] = fragB(0, b);
-            __syncthreads();   // every wave has read this tile: the stage may be overwritten
-            mma(bw, a3);
-            mma(bw, a2);
-            mma(bw, a1);
-            store_split();
-            __syncthreads();
-        }
-    } else if (PIPE == 5) {
+    if constexpr (PIPE == 5) {
         // ---- operands travel global -> LDS directly (LDS-DMA: buffer_load_dwordx4 ... lds), two LDS stages, ONE barrier per K-step.
         // No staging registers (the rotated loop keeps 24-40 of them live between the request and the ds_write, which is why the
         // compiler sinks the requests behind the K-step's MFMAs), no ds_write instructions, and the requests of tile k + 1 are issued
@@ -1856,7 +1721,7 @@ extern "C" int wdg_tuning_epoch(void) { return g_tuning_epoch; }
 extern "C" int wdg_set_tuning(const char* key, int value) {
     ++g_tuning_epoch;          // (callers that cache launch sequences — captured HIP graphs — key them on this)
     if (key && !strcmp(key, "igemm_pipe")) {
-        if (value < 0 || value > 4) return WDG_ERR_ARG;   // 4 = fp32 products from three bf16 slices per operand (PIPE == 4)
+        if (value < 0 || value > 3) return WDG_ERR_ARG;
         g_igemm_pipe = value;
         return WDG_OK;
     }
@@ -2027,45 +1892,9 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     return WDG_ERR_ARG;
 }
 
-// ---- three-slice bf16 copies of weight buffers for PIPE 4 (see the kernel): registered by the host after it filled them
-#include <mutex>
-#include <unordered_map>
-static std::unordered_map<const void*, std::pair<const void*, long long>> g_split_map;
-static std::mutex g_split_mutex;     // the registry may be touched from any host thread (register / unregister / launch look-up)
-extern "C" int wdg_split_register(const float* w32, const void* w3, int64_t n) {
-    WDG_CHECK_ARG(w32 != nullptr && n >= 0, "bad argument");
-    std::lock_guard<std::mutex> lock(g_split_mutex);
-    if (w3) g_split_map[w32] = std::make_pair(w3, (long long)n);
-    else g_split_map.erase(w32);
-    return WDG_OK;
-}
-__global__ void __launch_bounds__(256) wdg_split_bf16x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float x = src[i];
-        const unsigned b1 = __float_as_uint(x) & 0xFFFF0000u;
-        const float r1 = x - __uint_as_float(b1);
-        const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
-        const float r2 = r1 - __uint_as_float(b2);
-        dst[i] = (unsigned short)(b1 >> 16);
-        dst[n + i] = (unsigned short)(b2 >> 16);
-        dst[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
-    }
-}
-// dst3: 3 * n bf16 (+ 16 bytes of slack: the kernel's 16-byte loads may run past a row's last valid octet)
-extern "C" int wdg_split_bf16x3(const float* src, void* dst3, int64_t n, wdg_stream stream) {
-    WDG_CHECK_ARG(src && dst3 && n >= 0, "bad argument");
-    if (n == 0) return WDG_OK;
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL(wdg_split_bf16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst3, (long long)n);
-    WDG_LAUNCH_CHECK();
-    return WDG_OK;
-}
-static void set_b3(WdgIgemm& p, int k_per_tap);
-
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
-    constexpr size_t lds = PIPE == 4 ? (size_t)12 * (BM + BN) * 16     // three bf16 slices per operand: 1.5x the fp32 stage
-                                     : (size_t)((PIPE == 0 || PIPE == 3) ? KG : 2) * 8 * (BM + BN) * sizeof(f32x4);   // (PIPE 5: two stages)
+    constexpr size_t lds = (size_t)((PIPE == 0 || PIPE == 3) ? KG : 2) * 8 * (BM + BN) * sizeof(f32x4);   // (PIPE 5: two stages)
     static_assert(KG == 1 || lds >= (size_t)BM * BN * sizeof(float), "the second group's accumulators fit the two stages");
     static_assert(EPI != 1 || lds >= (size_t)WGM * BN * 2 * sizeof(float), "statistics scratch fits the K-loop stage");
     static_assert(EPI != 3 || lds >= (size_t)BM * 4 * WGN * sizeof(float), "LayerNorm scratch fits the K-loop stage");
@@ -2081,18 +1910,6 @@ static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm&
     hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI, KG>), grid, dim3(block.x * KG), lds, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
-}
-
-// the pre-split copy of p.B, if one is registered and every tap's reduction run is a whole number of octets
-static void set_b3(WdgIgemm& p, int k_per_tap) {
-    p.B3 = nullptr;
-    p.B3_slice = 0;
-    if (g_igemm_pipe != 4 || (k_per_tap & 7)) return;
-    std::lock_guard<std::mutex> lock(g_split_mutex);
-    auto it = g_split_map.find((const void*)p.B);
-    if (it == g_split_map.end()) return;
-    p.B3 = it->second.first;
-    p.B3_slice = it->second.second;
 }
 
 // tiles whose EPI 5 instantiation exists (4 x 1 waves: a row's channels in one wave)
@@ -2165,8 +1982,6 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
     const int dma_bit = (tc.BM == 128 && tc.BN == 64) ? 1 : (tc.BM == 256 && tc.BN <= 32) ? 2 : (tc.BM == 64 && tc.BN == 64) ? 4
                         : (tc.BM == 128 && tc.BN == 128) ? 8 : 16;
     const bool pipe5 = pipe == 3 && (g_igemm_dma & dma_bit) && kg == 1;
-    // the pre-split weight copy pays on the wide tiles (measured: profiles/r02t_per_layer_split.txt); elsewhere the kernel slices B itself
-    if (!(tc.BM >= 128 && (tc.BN == 64 || tc.BN == 128))) p.B3 = nullptr;
     int rc = WDG_OK;
     // fused BatchNorm hooks: only without split-K (the reduce kernel owns the epilogue then; callers fall back to the
     // standalone passes — see conv_fused_bn) and only on the default pipeline
@@ -2177,18 +1992,14 @@ static int launch_igemm(WdgIgemm& p, int nphase, int K4max, int split, void* ws,
         wdg_set_error("igemm: the LayerNorm-backward epilogue needs one column tile of a 4 x 1 wave layout, no split-K, the fp32 pipeline");
         return WDG_ERR_ARG;
     }
-    if (epi == 4 && (split != 1 || nphase != 1 || pipe == 4)) {
+    if (epi == 4 && (split != 1 || nphase != 1)) {
         wdg_set_error("igemm: the ConvLSTM step epilogue needs one phase, no split-K and the fp32 pipeline");
         return WDG_ERR_ARG;
     }
     if (bn_fused) *bn_fused = epi != 0;
 #define WDG_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                              \
     if (tc.BM == BM_ && tc.BN == BN_) {                                                                 \
-        if (pipe == 4 && epi == 1) rc = launch_variant<BM_, BN_, WM_, WN_, 4, 1>(grid, block, st, p);   \
-        else if (pipe == 4 && epi == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 4, 2>(grid, block, st, p); \
-        else if (pipe == 4 && epi == 3) rc = launch_variant<BM_, BN_, WM_, WN_, 4, 3>(grid, block, st, p); \
-        else if (pipe == 4) rc = launch_variant<BM_, BN_, WM_, WN_, 4>(grid, block, st, p);             \
-        else if (epi == 4) {                                                                            \
+        if (epi == 4) {                                                                                 \
             if constexpr (BN_ % 64 == 0 && BM_ <= 128) {                                                \
                 if constexpr (BM_ == BN_) {                                                             \
                     if (kg == 2) rc = launch_variant<BM_, BN_, WM_, WN_, 3, 4, 2>(grid, block, st, p);  \
@@ -2297,7 +2108,6 @@ static int conv_fwd_impl(const wdg_conv_plan* pl, const float* x, const float* w
     WdgIgemm p;
     memset(&p, 0, sizeof(p));
     p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
-    set_b3(p, pl->Cin_p);
     p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
     p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
     p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
@@ -2331,7 +2141,6 @@ static int conv_dgrad_impl(const wdg_conv_plan* pl, const float* dy, const float
     WdgIgemm p;
     memset(&p, 0, sizeof(p));
     p.A = dy; p.B = wD; p.Out = dx; p.bias = bias; p.ktab = pl->d_tab_dgrad;
-    set_b3(p, pl->Cout_p);
     p.imgStrideA = g.img_stride_y; p.imgStrideO = g.img_stride_x;
     p.n_img = g.n_img; p.H = g.Ho; p.W = g.Wo; p.ldA = g.ldy;
     p.Ho = g.H; p.Wo = g.W; p.ldO = g.ldx;
@@ -2368,7 +2177,7 @@ extern "C" int wdg_convlstm_step_gemm_supported(const wdg_conv_plan* pl, int F) 
         return 0;
     if (pl->halo_auto_fwd && pl->halo_fwd_nt) return 0;           // (the halo-tile kernel owns the thin layers: wdg_convlstm_step)
     const TileCfg tc = pick_tile(g.Cout, true, (long long)g.n_img * g.Ho * g.Wo);
-    return tc.BN % 64 == 0 && tc.BM <= 128 && g_igemm_pipe != 4;
+    return tc.BN % 64 == 0 && tc.BM <= 128;
 }
 
 extern "C" int wdg_convlstm_step_gemm(const wdg_conv_plan* pl, const float* h_prev, const float* wF_il, float* gates,
@@ -2424,8 +2233,7 @@ extern "C" int wdg_conv_fwd_ln_strided(const wdg_conv_plan* pl, const float* x, 
         WdgIgemm p;
         memset(&p, 0, sizeof(p));
         p.A = x; p.B = wF; p.Out = y; p.bias = bias; p.ktab = pl->d_tab_fwd;
-        set_b3(p, pl->Cin_p);
-        p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
+            p.imgStrideA = g.img_stride_x; p.imgStrideO = g.img_stride_y;
         p.n_img = g.n_img; p.H = g.H; p.W = g.W; p.ldA = g.ldx;
         p.Ho = g.Ho; p.Wo = g.Wo; p.ldO = g.ldy;
         p.Ncols = g.Cout; p.ldB = pl->taps * pl->Cin_p;

@@ -436,11 +436,11 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
 #pragma unroll
                     for (int b = 0; b < NT; ++b) {
                         const f32x4 z = acc[a][b] + gx[b][a];
-                        const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
-                        const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
+                        const float gi = fminf(fmaxf(__builtin_fmaf(0.2f, z[0], 0.5f), 0.f), 1.f);
+                        const float gf = fminf(fmaxf(__builtin_fmaf(0.2f, z[1], 0.5f), 0.f), 1.f);
                         const float gc = wdg_tanh(z[2]);
-                        const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
-                        cn[b] = gi * gc + gf * cp[b][a];
+                        const float go = fminf(fmaxf(__builtin_fmaf(0.2f, z[3], 0.5f), 0.f), 1.f);
+                        cn[b] = __builtin_fmaf(gi, gc, gf * cp[b][a]);       // (explicit: the same rounding as the per-tile form below)
                         hv[b] = go * wdg_tanh(cn[b]);
                     }
                     wdg_tr4(cn);
@@ -466,11 +466,11 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             for (int a = 0; a < MT; ++a) {
                 const long long pix = (long long)img * p.Ho * p.Wo + opix[a];
                 const f32x4 z = acc[a][b] + gx[b][a];
-                const float gi = fminf(fmaxf(0.2f * z[0] + 0.5f, 0.f), 1.f);
-                const float gf = fminf(fmaxf(0.2f * z[1] + 0.5f, 0.f), 1.f);
+                const float gi = fminf(fmaxf(__builtin_fmaf(0.2f, z[0], 0.5f), 0.f), 1.f);
+                const float gf = fminf(fmaxf(__builtin_fmaf(0.2f, z[1], 0.5f), 0.f), 1.f);
                 const float gc = wdg_tanh(z[2]);
-                const float go = fminf(fmaxf(0.2f * z[3] + 0.5f, 0.f), 1.f);
-                const float cn = gi * gc + gf * cp[b][a];
+                const float go = fminf(fmaxf(__builtin_fmaf(0.2f, z[3], 0.5f), 0.f), 1.f);
+                const float cn = __builtin_fmaf(gi, gc, gf * cp[b][a]);
                 if constexpr (DBG & 16) { if (cn == 123.456f) p.c_out[pix * p.ldc + f] = cn; continue; }
                 p.c_out[pix * p.ldc + f] = cn;
                 outImg[(long long)opix[a] * p.ldO + f] = go * wdg_tanh(cn);

@@ -2,6 +2,7 @@
 // train-step elementwise ops and reductions, Philox noise.  All HBM-bound.
 // Reference call sites are cited per kernel (files under /root/reference/src/downscaling).
 #include "common.h"
+#include "h16.h"
 #include <algorithm>
 
 static inline int ew_blocks(int64_t total, int cap = 16384) {
@@ -752,7 +753,9 @@ extern "C" int wdg_philox_normal(float* out, int ldo, const float* add, int lda,
 // blocks — the SAME counters and values as wdg_philox_normal on the [rows, CN] view (element e = row * CN + c of block
 // offset + e / 4) — the image's CI values gathered from the [batch, time] ordered source, whole 16-byte stores.
 // Rows are time-major: row = (t * B + b) * XY + r.
-template <int CI, int CN, int LD>
+// FMT: -1 fp32 rows; 0 / 1: rows in the bf16 / fp16 operand format of the inference-precision layers (the first layer would
+// round them to it while staging: the same bits, half the bytes — h16.h)
+template <int CI, int CN, int LD, int FMT = -1>
 __global__ void __launch_bounds__(256) wdg_input_assemble_kernel(const float* __restrict__ image, long long img_stride_b, long long img_stride_t,
                                                                  float* __restrict__ out, long long rows, int B, int XY, uint64_t seed,
                                                                  uint64_t offset, float stdv, int Bo, int b0) {
@@ -784,9 +787,19 @@ __global__ void __launch_bounds__(256) wdg_input_assemble_kernel(const float* __
                 v[CI + 4 * k + 2 * h + 1] = stdv * (rad * sinf(ang));
             }
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(out + (((long long)t * Bo + b0 + b) * XY + r) * LD);
+        const long long orow = ((long long)t * Bo + b0 + b) * XY + r;
+        if constexpr (FMT >= 0) {
+            static_assert(LD % 8 == 0, "whole 16-byte stores of eight 16-bit elements");
+            wdg_h16x8<(FMT < 0 ? 0 : FMT)>* dst16 = reinterpret_cast<wdg_h16x8<(FMT < 0 ? 0 : FMT)>*>(out) + orow * (LD / 8);
 #pragma unroll
-        for (int q = 0; q < LD / 4; ++q) dst[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            for (int q = 0; q < LD / 8; ++q)
+                dst16[q] = wdg_pack_h16<(FMT < 0 ? 0 : FMT)>((f32x4){v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3]},
+                                                           (f32x4){v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]});
+        } else {
+            f32x4* dst = reinterpret_cast<f32x4*>(out + orow * LD);
+#pragma unroll
+            for (int q = 0; q < LD / 4; ++q) dst[q] = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
     }
 }
 
@@ -908,6 +921,24 @@ extern "C" int wdg_patch_scatter(const float* dpatch, float* dx, int lddx, int64
     const long long total = (long long)n_img * H * W * (C / 4);
     hipLaunchKernelGGL(wdg_patch_scatter_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dpatch, dx,
                        lddx, (long long)img_stride_dx, H, W, C / 4, k, stride, pad, t, accumulate, total);
+    WDG_LAUNCH_CHECK();
+    return WDG_OK;
+}
+
+// ... with the rows written in the 16-bit operand format (fmt 0 bf16, 1 fp16; out holds 16-bit elements, ld in elements): the input
+// of the inference-precision generator, whose first layer rounds it to that format while staging.
+extern "C" int wdg_input_assemble_h16(const float* image, int64_t img_stride_b, int64_t img_stride_t, int CI, void* out, int ld, int64_t rows,
+                                      int B, int XY, int CN, uint64_t seed, uint64_t offset, float std, int fmt, int Bo, int b0, wdg_stream stream) {
+    WDG_CHECK_ARG(image && out && rows >= 0 && B > 0 && XY > 0 && rows % ((int64_t)B * XY) == 0 && b0 >= 0 && b0 + B <= Bo && (fmt == 0 || fmt == 1), "bad argument");
+    WDG_CHECK_ARG(wdg_input_assemble_supported(CI, CN, ld), "unsupported channel counts (3 + 20 in 24)");
+    WDG_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
+    if (rows == 0) return WDG_OK;
+    if (fmt == 0)
+        hipLaunchKernelGGL((wdg_input_assemble_kernel<3, 20, 24, 0>), dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, image,
+                           (long long)img_stride_b, (long long)img_stride_t, reinterpret_cast<float*>(out), (long long)rows, B, XY, seed, offset, std, Bo, b0);
+    else
+        hipLaunchKernelGGL((wdg_input_assemble_kernel<3, 20, 24, 1>), dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, image,
+                           (long long)img_stride_b, (long long)img_stride_t, reinterpret_cast<float*>(out), (long long)rows, B, XY, seed, offset, std, Bo, b0);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }

@@ -47,8 +47,6 @@ class PackedWeights:
         self._half = {}
         self._hver = 0
         self._bf16_stale = True
-        self._split = {}                 # "wF" / "wD" -> three-slice bf16 copy (HipOps.split_mode), refreshed lazily
-        self._split_stale = {"wF": True, "wD": True}
         self._up4 = None
         self.refresh()
 
@@ -68,28 +66,6 @@ class PackedWeights:
 
     def bf16(self):
         return self.half("bf16")
-
-    def split3(self, which):
-        """Keeps the three-bf16-slice copy of wF / wD (wdg_split_bf16x3) current and registered with the library
-        (wdg_split_register) — HipOps.split_mode only; derived views (as_1x1, column_slice) are sliced inside the kernel."""
-        owner = getattr(self, "_split_owner", None)
-        if owner is not None:            # as_1x1: the same two buffers as its parent
-            return owner.split3(which)
-        src = self.wF if which == "wF" else self.wD
-        lib = self.ops.lib
-        if not hasattr(self, "_split"):
-            # a derived view (column_slice): no copy of its own — and no stale entry of a freed buffer at the same address
-            native.check(lib.wdg_split_register(src.data_ptr(), None, 0), "split_register")
-            return
-        buf = self._split.get(which)
-        if buf is None:
-            buf = torch.zeros(3 * src.numel() + 8, dtype=torch.bfloat16, device=src.device)
-            self._split[which] = buf
-        # (re)registered at every use: the library's map is keyed by address, and addresses are recycled by the allocator
-        native.check(lib.wdg_split_register(src.data_ptr(), buf.data_ptr(), src.numel()), "split_register")
-        if self._split_stale[which]:
-            native.check(lib.wdg_split_bf16x3(src.data_ptr(), buf.data_ptr(), src.numel(), self.ops.stream), "split_bf16x3")
-            self._split_stale[which] = False
 
     def half(self, fmt="bf16"):
         """(wF16, wD16): 16-bit copies (fmt "bf16" or "fp16") of the packed layouts for the inference-precision
@@ -153,7 +129,6 @@ class PackedWeights:
         sub.ops, sub.taps, sub.cin, sub.cout = self.ops, 1, self.taps * self.cin, self.cout
         sub.w = self.w.view(1, 1, self.taps * self.cin, self.cout)
         sub.wF, sub.wD = self.wF, sub.w
-        sub._split_owner = self
         return sub
 
     def column_slice(self, n0, n1):
@@ -166,21 +141,8 @@ class PackedWeights:
         sub._parent, sub._range = self, (n0 * ld, n1 * ld)
         return sub
 
-    def __del__(self):
-        # the library's bf16-slice registry is keyed by device address: drop this object's entries before the allocator
-        # can hand the same address to another buffer (derived views own no entry)
-        try:
-            if getattr(self, "_split", None):
-                for which in self._split:
-                    src = self.wF if which == "wF" else self.wD
-                    self.ops.lib.wdg_split_register(src.data_ptr(), None, 0)
-        except Exception:
-            pass
-
     def mark_stale(self):
         self._bf16_stale = True
-        if hasattr(self, "_split_stale"):
-            self._split_stale["wF"] = self._split_stale["wD"] = True
 
     def refresh(self):
         self.mark_stale()
@@ -266,11 +228,6 @@ class HipOps:
         self._plans = {}
         self._ws = None
         self._sn_scratch = None
-        # fp32 implicit-GEMM products from three bf16 slices per operand (conv_igemm.hip PIPE 4; measurement mode, off by default):
-        # WDG_SPLIT=1 or set_split_mode(True) at any time: the mode is read per launch, plans do not depend on it
-        self.split_mode = False
-        if os.environ.get("WDG_SPLIT", "0") == "1":
-            self.set_split_mode(True)
         self.upconv4 = True   # fused upsample + 5x5 transposed conv through the composite-kernel path
         self.upconv_col = True   # its backward in column form on the low-res grid
         self.z16 = os.environ.get("WDG_Z16", "0") == "1"   # 16-bit inference: the column GEMM's result z in the operand format
@@ -300,8 +257,8 @@ class HipOps:
         `graphs`: the dict that owns the captured graphs — the caller's (a layer's), so the graphs die with the buffers whose
         addresses they hold; without one, a process-wide dict.  Split-K scratch requested while capturing is allocated for
         that graph alone (see _workspace): graphs replayed at the same time on different streams never share scratch."""
-        if not self.chain_graphs or self.split_mode or torch.cuda.is_current_stream_capturing():
-            return fn()               # (split mode refreshes its weight slices lazily on the host path: never from a graph)
+        if not self.chain_graphs or torch.cuda.is_current_stream_capturing():
+            return fn()
         if graphs is None:
             graphs = self._chains
         key = key + (int(self.lib.wdg_tuning_epoch()),)
@@ -435,10 +392,6 @@ class HipOps:
         weight gradients of a backward pass: name "wgrad").  stream: run on THIS stream instead of the named pool stream."""
         return _Fork(self, name, stream)
 
-    def set_split_mode(self, on):
-        self.split_mode = bool(on)
-        native.check(self.lib.wdg_set_tuning(b"igemm_pipe", 4 if on else 3), "set_tuning")
-
     def _plan(self, x, y, cin, cout, g: ConvGeom, w_ld=0):
         px, ldx, isx = _v4(x)
         py, ldy, isy = _v4(y)
@@ -463,7 +416,7 @@ class HipOps:
         """dx (+)= conv_transpose(dy, W[..., n0:n1]) for a channel RANGE of the layer's output: dy is the [.., n0:n1] view of the
         output-gradient tensor, pk the pack of the FULL layer (wdg_conv_plan_create_sliced).  A ConvLSTM2D at n_timesteps = 1 has
         a dead forget gate (c_0 = 0): its quarter of the reduction is skipped this way."""
-        assert pk.cout % 4 == 0 and n0 % 4 == 0 and n1 % 4 == 0 and dy.shape[-1] == n1 - n0 and not self.split_mode
+        assert pk.cout % 4 == 0 and n0 % 4 == 0 and n1 % 4 == 0 and dy.shape[-1] == n1 - n0
         plan, wsb, _ = self._plan(dx, dy, pk.cin, n1 - n0, g, w_ld=pk.cout)
         ws = self._workspace(wsb)
         native.check(self.lib.wdg_conv_dgrad(plan, dy.data_ptr(), pk.wD.data_ptr() + 4 * n0, None, dx.data_ptr(), 0, 0.2,
@@ -517,8 +470,6 @@ class HipOps:
         scaled / shifted per channel (inference-mode BatchNormalization) — see wdg_conv_fwd_bn."""
         plan, wsb, _ = self._plan(x, y, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
-        if self.split_mode:
-            pk.split3("wF")
         if bn_stats is not None or bn_affine is not None:
             assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * ((pk.cout + 3) // 4 * 4)))
             native.check(self.lib.wdg_conv_fwd_bn(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), int(act), slope,
@@ -536,8 +487,6 @@ class HipOps:
         ws = self._workspace(wsb)
         assert z.shape[:3] == y.shape[:3] and z.shape[3] == pk.cout
         _, ldz, isz = _v4(z)            # z may live in a wider buffer (a channel slice of a concatenation)
-        if self.split_mode:
-            pk.split3("wF")
         native.check(self.lib.wdg_conv_fwd_ln_strided(plan, x.data_ptr(), pk.wF.data_ptr(), _ptr(bias), y.data_ptr(), z.data_ptr(),
                                                       ldz, isz, gamma.data_ptr(), beta.data_ptr(), eps, _ptr(mean_rstd), int(act),
                                                       slope, ws.data_ptr(), ws.numel(), self.stream), "conv_fwd_ln")
@@ -547,8 +496,6 @@ class HipOps:
         as in conv_fwd, over the Cin channels this launch writes."""
         plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
         ws = self._workspace(wsb)
-        if self.split_mode:
-            pk.split3("wD")
         if bn_stats is not None or bn_affine is not None:
             assert not accumulate and (bn_stats is None or (bn_stats.dtype == torch.float64 and bn_stats.shape[1] == 2 * ((pk.cin + 3) // 4 * 4)))
             native.check(self.lib.wdg_conv_dgrad_bn(plan, dy.data_ptr(), pk.wD.data_ptr(), _ptr(bias), dx.data_ptr(), int(act), slope,
@@ -628,7 +575,7 @@ class HipOps:
         plan, _, _ = self._plan(h_prev, gates_t, pk.cin, pk.cout, g)
         if self.lib.wdg_convlstm_step_supported(plan, F):
             return True
-        return bool(self.lstm_step_gemm and not self.split_mode and pk.cout == 4 * F and
+        return bool(self.lstm_step_gemm and pk.cout == 4 * F and
                     self.lib.wdg_convlstm_step_gemm_supported(plan, F))
 
     def convlstm_step_prepare(self, h_prev, pk, gates_t, g, F):
@@ -688,7 +635,7 @@ class HipOps:
     def convlstm_pair_supported(self, h16, gates16, pk16, h2, gates2, pk2, g):
         """h16 / gates16 / pk16: one timestep's views and the recurrent pack of the 16-feature layer; h2 / gates2 / pk2: the
         two-feature layer's."""
-        if os.environ.get("WDG_LSTM_PAIR", "1") == "0" or self.split_mode:
+        if os.environ.get("WDG_LSTM_PAIR", "1") == "0":
             return False
         p16, _, _ = self._plan(h16, gates16, pk16.cin, pk16.cout, g)
         p2, _, _ = self._plan(h2, gates2, pk2.cin, pk2.cout, g)
@@ -1326,6 +1273,12 @@ class HipOps:
         (any batch / time strides, pixels dense), the noise = philox_normal(rows_out[:, CI:CI + cn], seed, offset, std)'s stream."""
         assert image.dim() == 5 and image.stride(4) == 1 and image.stride(3) == image.shape[4] and image.stride(2) == image.shape[3] * image.shape[4]
         po, ldo = _v2(rows_out)
+        if rows_out.dtype != torch.float32:      # rows in the 16-bit operand format of the inference-precision layers
+            fmt = {v: k for k, v in self.H16_DTYPES.items()}[rows_out.dtype]
+            native.check(self.lib.wdg_input_assemble_h16(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo,
+                                                         rows_out.shape[0], B, XY, cn, seed & (2**64 - 1), offset, std,
+                                                         0 if fmt == "bf16" else 1, B, 0, self.stream), "input_assemble_h16")
+            return
         native.check(self.lib.wdg_input_assemble(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo, rows_out.shape[0],
                                                  B, XY, cn, seed & (2**64 - 1), offset, std, self.stream), "input_assemble")
 
@@ -1336,6 +1289,12 @@ class HipOps:
         po, ldo = _v2(rows_all)
         Tn = image.shape[1]
         assert rows_all.shape[0] == Tn * Bo * XY and image.shape[0] == B
+        if rows_all.dtype != torch.float32:
+            fmt = {v: k for k, v in self.H16_DTYPES.items()}[rows_all.dtype]
+            native.check(self.lib.wdg_input_assemble_h16(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo, Tn * B * XY,
+                                                         B, XY, cn, seed & (2**64 - 1), offset, std, 0 if fmt == "bf16" else 1, int(Bo), int(b0),
+                                                         self.stream), "input_assemble_h16")
+            return
         native.check(self.lib.wdg_input_assemble_slots(image.data_ptr(), image.stride(0), image.stride(1), image.shape[4], po, ldo, Tn * B * XY,
                                                        B, XY, cn, seed & (2**64 - 1), offset, std, int(Bo), int(b0), self.stream),
                      "input_assemble_slots")

@@ -481,7 +481,7 @@ class ConvLSTM:
         o, F = self.ops, self.F
         # n_timesteps = 1: dgates of the forget gate = dc * c_0 * hs' = 0 -> its quarter of the weight gradient and of the data
         # gradient's reduction is skipped (channel ranges [0, F) and [2F, 4F) of the gate tensor: HipOps.conv_dgrad_slice)
-        live = T == 1 and F % 4 == 0 and getattr(o, "supports_weight_slices", False) and not getattr(o, "split_mode", False) \
+        live = T == 1 and F % 4 == 0 and getattr(o, "supports_weight_slices", False) \
             and os.environ.get("WDG_LSTM_LIVE_GATES", "1") != "0"
         if live and hasattr(o, "weight_slices_ok"):
             # (both range widths: F for the input gate, 2F for candidate + output gate; layers that would run on the halo / thin

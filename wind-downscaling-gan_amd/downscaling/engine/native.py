@@ -55,8 +55,6 @@ SIGNATURES = {
     "wdg_convlstm_step_h16x": (i32, [c_fp, c_fp, i32, c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, c_fp, i32, i32, i32, c_fp]),
     "wdg_tiles_gather_normalise": (i32, [c_fp, i32, i32, i32, c_fp, i32, i32, i32, c_fp, c_fp, i32, c_fp, c_fp]),
     "wdg_tiles_blend": (i32, [c_fp, i32, c_fp, i32, i32, i32, i32, i32, i32, c_fp, c_fp, c_fp]),
-    "wdg_split_bf16x3": (i32, [c_fp, c_fp, i64, c_fp]),
-    "wdg_split_register": (i32, [c_fp, c_fp, i64]),
     "wdg_conv_plan_create": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom)]),
     "wdg_conv_plan_create_sliced": (i32, [C.POINTER(C.c_void_p), C.POINTER(ConvGeom), i32]),
     "wdg_conv_plan_destroy": (i32, [C.c_void_p]),
@@ -169,6 +167,7 @@ SIGNATURES = {
     "wdg_philox_normal": (i32, [c_fp, i32, c_fp, i32, i64, i32, u64, u64, f32, c_fp]),
     "wdg_input_assemble_supported": (i32, [i32, i32, i32]),
     "wdg_input_assemble": (i32, [c_fp, i64, i64, i32, c_fp, i32, i64, i32, i32, i32, u64, u64, f32, c_fp]),
+    "wdg_input_assemble_h16": (i32, [c_fp, i64, i64, i32, c_fp, i32, i64, i32, i32, i32, u64, u64, f32, i32, i32, i32, c_fp]),
     "wdg_dp_proxy": (i32, [c_fp, c_fp, i64, i64, i32, f32, c_fp]),
     "wdg_input_assemble_slots": (i32, [c_fp, i64, i64, i32, c_fp, i32, i64, i32, i32, i32, u64, u64, f32, i32, i32, c_fp]),
     "wdg_philox_uniform": (i32, [c_fp, i64, u64, u64, c_fp]),

@@ -184,6 +184,7 @@ class GeneratorNet(_Net):
     def set_image(self, image):
         """image [B,T,S,S,in] -> channels [0:in] of the concatenated input buffer (models.py:28)."""
         b = self.buffers(image.shape[0])
+        b["x0_src"] = None
         self.to_time_major(image, b["x0"])
 
     def set_noise(self, noise):
@@ -196,10 +197,33 @@ class GeneratorNet(_Net):
 
     def input_rows(self, B):
         """[T*B*S*S, ld] view of the whole input buffer ([image | noise | zero alignment channels] per pixel, time-major rows)."""
+        self.buffers(B)["x0_src"] = None
         return v2(self.buffers(B)["x0"])
+
+    def input_rows16(self, B, fmt):
+        """The same view of the input buffer in the 16-bit operand format `fmt` — what the first layer of the inference-precision
+        forward rounds the input to while staging; a caller that assembles the input on the device (HipOps.input_assemble) can
+        write it there directly.  None when that forward would not read it (no 16-bit first layer for this shape / WDG_ACT16=0).
+        The caller marks the buffer as the current input with `mark_input16`."""
+        b = self.buffers(B)
+        key = "x0_" + fmt
+        if key not in b:
+            b[key] = None
+            ok = getattr(self.ops, "act16_conv_ok", None)
+            x0 = b["x0"]
+            if ok is not None and self.ops.act16 and x0.shape[3] % 8 == 0 and os.environ.get("WDG_ACT16_INPUT", "1") != "0":
+                x16 = self.ops.zeros(*x0.shape, dtype=self.ops.H16_DTYPES[fmt])
+                if ok(x16, b["cat2"][..., self.F4p:], self.c0.pk, self.c0.g, False, 1, 0) and \
+                        ok(x16, b["cat2"][..., self.F4p:], self.c0.pk, self.c0.g, False, 1, 1):
+                    b[key] = x16
+        return v2(b[key]) if b[key] is not None and self.ops.act16 else None
+
+    def mark_input16(self, B, fmt):
+        self.buffers(B)["x0_src"] = fmt
 
     def noise_view(self, B):
         """[T*B*S*S, noise_channels] view of the input buffer: noise can be generated in place."""
+        self.buffers(B)["x0_src"] = None
         return v2(self.buffers(B)["x0"][..., self.in_channels:self.cin])
 
     # ---- inference forward as a HIP graph ----------------------------------------------------------------
@@ -219,7 +243,7 @@ class GeneratorNet(_Net):
         # weights version + prep epoch: a training-mode forward (SN power iteration, no optimizer step) rewrites w and the
         # packed fp32 layouts in place, but the 16-bit copies / composite kernels are reconverted lazily on the HOST path
         # only — a graph captured before must not be replayed on them
-        key = (B, precision, self.params.version, self._prep.epoch if self._prep is not None else 0)
+        key = (B, precision, self.params.version, self._prep.epoch if self._prep is not None else 0, self.buffers(B).get("x0_src"))
         entry = graphs.get(key)
         if entry is None:
             # capture pays off only for repeated calls: the first two forwards of a configuration run eagerly (they also
@@ -300,10 +324,15 @@ class GeneratorNet(_Net):
                             ok(h16, c16[..., :F // 2], self.c5.pk, self.c5.g, False, 1, 1) and \
                             ok(c16, cat2[..., :self.F4p], self.c7.pk, self.c7.g, True, 1, int(cat2.dtype != self.ops.dtype)):
                         b[key4], b["h_" + f] = c16, h16
-            if b[key4] is not None and self.ops.act16:
+            # (decided per call: wdg_set_tuning switches such as lstm16_fused / patch_h16 move the ConvLSTM off the route that keeps
+            # its state in the operand format)
+            if b[key4] is not None and self.ops.act16 and \
+                    self.ops.act16_lstm_ok(b[key4][..., F // 2:], self.lstm.gates, self.lstm.pkx, self.lstm.pkh, self.lstm.g, F):
                 cat4, hbuf = b[key4], b["h_" + f]
                 res4 = cat4[..., F // 2:]
-            self.c0.forward_bf16(b["x0"], res2, affine=self.bn1.infer_affine(), fmt=f)
+            # the input itself, when its producer wrote it in the operand format (input_rows16 / mark_input16)
+            x0 = b["x0_" + f] if b.get("x0_src") == f and b.get("x0_" + f) is not None and self.ops.act16 else b["x0"]
+            self.c0.forward_bf16(x0, res2, affine=self.bn1.infer_affine(), fmt=f)
             self.c2.forward_bf16(res2, res4, affine=self.bn3.infer_affine(), fmt=f)
             self.lstm.forward(res4, hbuf, B, T, bf16=True, fmt=f)
             self.c5.forward_bf16(hbuf, cat4[..., :F // 2], affine=self.bn6.infer_affine(), fmt=f)

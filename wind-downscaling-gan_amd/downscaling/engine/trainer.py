@@ -160,6 +160,8 @@ class DistSync:
         if self._noop:
             return lambda: None
         if self._proxy and t.is_cuda:
+            if os.environ.get("WDG_DP_PROXY_LARGE", "1") == "0":       # (A/B: only the small blocking stand-ins)
+                return lambda: None
             return self._proxy_large(t)
         if self._stage and t.is_cuda:
             self.all_reduce_sum(t)          # host-staged test path: nothing to overlap

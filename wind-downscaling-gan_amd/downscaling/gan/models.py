@@ -153,16 +153,23 @@ class Generator(_Model):
         assert tuple(image.shape[1:]) == (net.T, net.S, net.S, net.in_channels), image.shape
         assert tuple(noise.shape) == (B, net.T, net.S, net.S, net.noise_channels), noise.shape
         ok = getattr(ops, "input_assemble_ok", None)
+        precision = precision or ("fp32" if training else self.inference_precision)
         if lazy and hasattr(noise, "fill_with_image") and image.is_contiguous() and image.dtype == ops.dtype and ok is not None and \
                 ok(net.in_channels, net.noise_channels, net.buffers(B)["x0"].shape[-1]):
-            noise.fill_with_image(net.input_rows(B), image)      # [image | noise | 0] in one pass, the same Philox stream
+            rows16 = net.input_rows16(B, precision) if precision in ("bf16", "fp16") and hasattr(net, "input_rows16") else None
+            if rows16 is not None:
+                # inference precision: the first layer rounds the input to its operand format while staging — assembled in that
+                # format it is the same bits and half the bytes, written once
+                noise.fill_with_image(rows16, image)
+                net.mark_input16(B, precision)
+            else:
+                noise.fill_with_image(net.input_rows(B), image)  # [image | noise | 0] in one pass, the same Philox stream
         else:
             net.set_image(image)
             if lazy:
                 noise.fill(net.noise_view(B))
             else:
                 net.set_noise(noise)
-        precision = precision or ("fp32" if training else self.inference_precision)
         if training or not self.graph_inference:
             out_tm = net.forward(B, bool(training), precision=precision)
         else:
