@@ -547,6 +547,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                     for (int r = 0; r < 4; ++r) v[r] = wdg_lrelu(v[r], p.slope);
                 }
                 if (p.affine) v = v * sc4 + sh4;
+                if constexpr (DBG & 128) { if (v[0] == 123.456f) *reinterpret_cast<f32x4*>(dst) = v; continue; }   // (timing: the arithmetic without the store traffic)
                 if (full) {
                     if (p.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = v;
@@ -786,7 +787,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
     // timing experiments (wrong results by design): bf16, 1 x 16 fragments, 128 channels per tile only
 #define WDG_PATCH_DBG_CASE(D) if (g_patch_dbg == D && fmt == 0 && MT == 4 && BN == 128) return patch_launch<0, 4, 4, false, D>(p, (int)blocks, lds, st)
     WDG_PATCH_DBG_CASE(1); WDG_PATCH_DBG_CASE(2); WDG_PATCH_DBG_CASE(4); WDG_PATCH_DBG_CASE(8); WDG_PATCH_DBG_CASE(12);
-    WDG_PATCH_DBG_CASE(16); WDG_PATCH_DBG_CASE(32); WDG_PATCH_DBG_CASE(3); WDG_PATCH_DBG_CASE(15);
+    WDG_PATCH_DBG_CASE(16); WDG_PATCH_DBG_CASE(32); WDG_PATCH_DBG_CASE(3); WDG_PATCH_DBG_CASE(15); WDG_PATCH_DBG_CASE(128); WDG_PATCH_DBG_CASE(131);
 #undef WDG_PATCH_DBG_CASE
     // ... and of the recurrent step (bf16, 4 x 24 tiles, 128 channels per tile); bit 6: no gate / cell-state loads in the epilogue
 #define WDG_PATCH_DBG_LSTM(D) if (lstm && g_patch_dbg == D && fmt == 0 && MT == 3 && BN == 128) return patch_launch<0, 3, 4, false, D, 1>(p, (int)blocks, lds, st)
