@@ -355,10 +355,10 @@ def other_config_legs(dev, ops):
     # ---- configs[3]: the shipped network G(96, T=24); one predict() group of 16 tiles, bf16 operands
     network = api.get_network(allow_random_init=True, random_seed=5)
     gen = network.generator
-    # (api.predict_array's default: TWO predict() groups of 16 tiles per forward pass, each with its own noise draw — the group of 16
+    # (api.predict_array runs SEVERAL predict() groups of 16 tiles per forward pass, each with its own noise draw — the group of 16
     # is the reference's noise-draw unit, api.py:132-137, not the launch unit; ms below is per group of 16)
     from downscaling.data.data_generator import LazyGroupNoise
-    gpl = max(1, int(os.environ.get("WDG_PREDICT_GROUPS", "2")))
+    gpl = api.groups_per_forward(4)                          # (4 of a field's groups in one forward pass)
     tiles = torch.randn(16 * gpl, api.SEQUENCE_LENGTH, api.IMG_SIZE, api.IMG_SIZE, 3, device=dev)
     gen.inference_precision = "bf16"
     ngen = network.noise_generator

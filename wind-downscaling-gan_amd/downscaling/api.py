@@ -159,6 +159,20 @@ def _tile_lat_index(sy):
     return np.arange(IMG_SIZE, 0, -1)
 
 
+def groups_per_forward(n_groups):
+    """How many of a rank's groups of 16 tiles share one forward pass: WDG_PREDICT_GROUPS when set, else the count in 2..5 that
+    leaves the fewest padding groups in the last launch (the larger on ties) — 15 groups run as 3 x 5, 8 as 2 x 4, 7 as 2 x 4
+    with one padding group.  Measured on the shipped generator (bf16, per group of 16): 2.57 ms alone, 2.37 in pairs, 2.30 in
+    fours (profiles/r06x_ab_weight_lds_dma_neutral.txt): the 24 recurrent steps are a dependent chain of launches that 16 tiles
+    cannot fill the chip with."""
+    env = os.environ.get('WDG_PREDICT_GROUPS')
+    if env:
+        return max(1, min(int(env), max(1, n_groups)))
+    if n_groups <= 5:
+        return max(1, n_groups)
+    return min(range(2, 6), key=lambda p: ((-n_groups) % p, -p))
+
+
 def predict_array(fields, overlap_factor=0.05, network=None, return_count=False, sync=None, timings=None, out=None):
     """Array core of predict (api.py:96-151).  fields: (time, lat, lon, 3) float array with channels
     [u10, v10, elevation in metres].  Returns (ntimeseq*24, lat, lon, 2) with NaN where no tile
@@ -236,10 +250,9 @@ def predict_array(fields, overlap_factor=0.05, network=None, return_count=False,
     # rank's groups share one forward pass — every kernel of the pass carries `per` times the rows for the same weight traffic,
     # and the 24 recurrent steps (a dependent chain of launches that 16 tiles cannot fill the chip with) run once for all of
     # them.  Each group still takes its own draw from the generator's stream, in group order (LazyGroupNoise), and inference
-    # treats every tile independently, so the result is the one of group-by-group calls.  WDG_PREDICT_GROUPS=1 restores those.
-    per = max(1, int(os.environ.get('WDG_PREDICT_GROUPS', '2')))
+    # treats every tile independently, so the result is the one of group-by-group calls (groups_per_forward: WDG_PREDICT_GROUPS=1).
     mine = list(range(rank, num_groups, world))
-    per = min(per, max(1, len(mine)))
+    per = groups_per_forward(len(mine))
     with torch.no_grad():
         for c0 in range(0, len(mine), per):
             chunk = mine[c0:c0 + per]
