@@ -172,6 +172,7 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     // pipeline requests beyond the last) read patch slot 0 against zero weights (offset out of the descriptor's range).
     int* tabT = reinterpret_cast<int*>(ldsP + dummy_slot + 1);
     int* tabK = tabT + p.ntab;
+    float* cst = reinterpret_cast<float*>(tabK + p.ntab);          // [3][BN] epilogue constants of the current channel tile
     for (int e = t; e < p.ntab; e += 256) {
         const int ks = e >> 2, q = e & 3;
         int tap, g8, koff;
@@ -267,6 +268,24 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
     for (int ck = 0; ck < p.nchunk; ++ck) {
         __syncthreads();                             // every wave is done with the previous chunk's patch, weight stages and epilogue tiles
                                                      // (first chunk: the K-step tables are complete)
+        if constexpr (!LSTM) {
+            if (ck == 0) {
+                // ---- epilogue constants of this channel tile -> LDS: bias | scale | shift per column (columns past the layer's last:
+                // 0 | 1 | 0), published by the barrier behind the patch.  The epilogue used to fetch them from global memory per column
+                // tile — twelve scalar loads behind validity branches, each with its own wait, four tiles in sequence: most of the
+                // 14,000 clocks a workgroup of the first layer spent between its last MFMA and its last store
+                // (profiles/r06f_patch_phases.txt).
+                const int naff = p.shufC ? p.shufC : p.Ncols;
+                for (int c = t; c < BN; c += 256) {
+                    const int n = n0 + c;
+                    const bool on = n < p.Ncols;
+                    const int nb = p.gate_F ? (n & 3) * p.gate_F + (n >> 2) : p.shufC ? n % p.shufC : n;
+                    cst[c] = (on && p.bias) ? p.bias[nb] : 0.f;
+                    cst[BN + c] = (on && p.affine) ? p.affine[nb] : 1.f;
+                    cst[2 * BN + c] = (on && p.affine) ? p.affine[naff + nb] : 0.f;
+                }
+            }
+        }
         // ---- patch chunk: global fp32 -> 16-bit -> LDS, PU slots (2 x 16-byte loads each) per thread in flight
         constexpr int PU = (MT * NT >= 24) ? 8 : (WDG_PATCH_DEPTH > 2) ? 6 : 10;   // (the 6 x 4 tile has no registers to spare; nor a deep weight pipeline)
         if (p.in16) {
@@ -486,15 +505,9 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
             const int stap = p.shufC ? n / p.shufC : 0;
             const int nch = p.shufC ? n - stap * p.shufC : n;                       // (shufC % 4 == 0: a quad stays inside one tap)
             const int spix = p.shufC ? (stap / p.shufK) * (p.Wo * p.shufK) + stap % p.shufK : 0;
-            const int naff = p.shufC ? p.shufC : p.Ncols;
-            f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4 = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4 = bias4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.Ncols) {
-                    const int nb = p.gate_F ? r * p.gate_F + (n >> 2) : nch + r;    // (interleaved gate columns: n % 4 == 0)
-                    if (p.bias) bias4[r] = p.bias[nb];
-                    if (p.affine) { sc4[r] = p.affine[nb]; sh4[r] = p.affine[naff + nb]; }
-                }
+            const int nl = n - n0;                                                  // column inside the workgroup's channel tile
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(cst + nl), sc4 = *reinterpret_cast<const f32x4*>(cst + BN + nl),
+                        sh4 = *reinterpret_cast<const f32x4*>(cst + 2 * BN + nl);
             if (p.out16) {
                 // 16-bit result (column count a multiple of 16; no accumulate).  A lane's four channels are 8 bytes — stores of
                 // that width ran at 0.6x the rate and made the 16-bit z slower than the fp32 one.  So the column tiles go in pairs:
@@ -511,14 +524,8 @@ __global__ void WDG_PATCH_BOUNDS wdg_conv_patch_h16_kernel(const WdgPatchH16 p) 
                 const bool odd = lq & 1;
                 const int nst = nw0 + (b + (odd ? 1 : 0)) * 16 + 8 * (lq >> 1);
                 const int nst_ch = p.shufC ? nst - stap * p.shufC : nst;
-                f32x4 bias4b = (f32x4){0.f, 0.f, 0.f, 0.f}, sc4b = (f32x4){1.f, 1.f, 1.f, 1.f}, sh4b = bias4b;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + 16 + r < p.Ncols) {
-                        const int nb = nch + 16 + r;
-                        if (p.bias) bias4b[r] = p.bias[nb];
-                        if (p.affine) { sc4b[r] = p.affine[nb]; sh4b[r] = p.affine[naff + nb]; }
-                    }
+                const f32x4 bias4b = *reinterpret_cast<const f32x4*>(cst + nl + 16), sc4b = *reinterpret_cast<const f32x4*>(cst + BN + nl + 16),
+                            sh4b = *reinterpret_cast<const f32x4*>(cst + 2 * BN + nl + 16);
 #pragma unroll
                 for (int a = 0; a < MT; ++a) {
                     f32x4 v0 = acc[a][b] + bias4, v1 = acc[a][b + 1] + bias4b;
@@ -781,7 +788,7 @@ int wdg_patch_h16_launch(const wdg_conv_plan* pl, int transposed1x1, const float
         p.npad = (nstage + depth - 1) / depth * depth;
         p.ntab = (p.npad + depth + 1) * 8;                                // the pipeline requests stages up to npad + depth
     }
-    const size_t lds = (size_t)2 * 8 * BN * 16 + ((size_t)p.CK8 * p.pitch + 1) * 16 + (size_t)2 * p.ntab * 4;   // weight stages + patch + K-step tables
+    const size_t lds = (size_t)2 * 8 * BN * 16 + ((size_t)p.CK8 * p.pitch + 1) * 16 + (size_t)2 * p.ntab * 4 + (size_t)3 * BN * 4;   // weight stages + patch + K-step tables + epilogue constants
     if (lds > 160 * 1024) return 1;
 #ifdef WDG_PATCH_EXPERIMENTS
     // timing experiments (wrong results by design): bf16, 1 x 16 fragments, 128 channels per tile only
