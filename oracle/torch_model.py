@@ -291,9 +291,9 @@ def weighted_loss(value, sample_weight):
     (a scalar for train.py:11-12) times the per-sample weights, reduced SUM_OVER_BATCH_SIZE — sum(value * sw) / numel.
     No weights: the value itself.  ganbase.py:44,67."""
     if sample_weight is None:
-        return value
+        return value if value.numel() <= 1 else value.reshape(-1).sum() / value.numel()
     sw = torch.as_tensor(sample_weight, dtype=value.dtype).reshape(-1)
-    w = value * sw
+    w = value.reshape(-1) * sw if value.numel() > 1 else value * sw
     return w.sum() / w.numel()
 
 

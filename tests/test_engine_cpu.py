@@ -169,6 +169,31 @@ def _wasserstein_again(real_output, fake_output):
     return fake_output.mean() - real_output.mean()
 
 
+def _per_sample_hinge(real_output, fake_output):
+    """A compiled loss that returns one value PER SAMPLE ([B]): Keras weights it elementwise and reduces SUM_OVER_BATCH_SIZE."""
+    return (torch.relu(1.0 - real_output) + torch.relu(1.0 + fake_output)).reshape(-1)
+
+
+def test_per_sample_custom_loss_is_weighted_elementwise(ops):
+    """a per-sample loss vector with non-uniform sample weights is sum(loss_b * sw_b) / B (compute_weighted_loss), not
+    loss * mean(sw); without weights it is the mean.  Engine (coupled critic path) against the autograd restatement."""
+    B, cin, nz, ch, S, T = 2, 3, 2, 2, 12, 1
+    for sw in (torch.tensor([0.25, 1.75], dtype=torch.float64), None):
+        gen = GeneratorNet(ops, S, cin, nz, ch, T, feature_channels=32, seed=5)
+        disc = DiscriminatorNet(ops, S, S, cin, ch, T, feature_channels=8, seed=6)
+        gw, dw = randomize(gen, 21), randomize(disc, 22)
+        eng = GanEngine(gen, disc, PhiloxSource(ops, seed=99), noise_std=0.1, n_critic=1)
+        draws = Draws(eng.noise.seed, B, T, S, nz, ch, 0.1)
+        low, _, high = _inputs(B, T, S, cin, nz, ch, seed=40)
+        res = eng.train_step(low, high, AdamTF(1e-4, 0.5, 0.9, 0.1), AdamTF(4e-4, 0.5, 0.9, 0.1), d_loss_fn=_per_sample_hinge, sample_weight=sw)
+        ref = TM.train_step(gw, dw, low, high, draws, TM.AdamTF(1e-4), TM.AdamTF(4e-4), n_critic=1, d_loss_fn=_per_sample_hinge, sample_weight=sw)
+        for k in ("d_loss", "_d_loss_train", "d_gradient_param"):
+            assert rel_err(res[k], ref[k]) < 1e-7, (k, sw)
+        got = weights64(disc)
+        for k in dw:
+            assert rel_err(got[k], dw[k]) < 1e-7, (k, sw)
+
+
 @pytest.mark.parametrize("loss", [_wasserstein_again, _relativistic], ids=["wasserstein_as_custom", "relativistic_hinge"])
 def test_train_step_with_custom_discriminator_loss(ops, loss):
     """GAN.compile(discriminator_loss=<any callable>) (ganbase.py:44-45 calls compiled_loss(real_output, fake_output)): the

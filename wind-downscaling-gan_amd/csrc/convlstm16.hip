@@ -18,6 +18,7 @@
 #include "convlstm2.h"
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 namespace {
 constexpr int L_TH = 4, L_TW = 32;                 // output tile
@@ -142,7 +143,13 @@ bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, 
     return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f | (uintptr_t)g | (uintptr_t)h) & 15) == 0;
 }
 int lds_opt_in() {
-    static bool done = false;
+    // per device (the attribute belongs to the function ON a device) and safe against a concurrent first call from another host thread
+    static std::mutex mtx;
+    static bool done_dev[64] = {};
+    int dev = 0;
+    WDG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mtx);
+    bool& done = done_dev[dev & 63];
     if (!done) {
         WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_lstm16_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_LDS));
         WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_lstm16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_LDS));

@@ -55,10 +55,11 @@ class _Net:
     # again: once the LayerNorm backward moved into the data gradients and the second stages got short, the weight gradients are
     # what is left to run beside the data-gradient chain — 64.2 / 64.0 -> 63.6 / 63.3 ms, same box, alternating
     # (profiles/r05x_ab_step_wgrad_stream.txt).  WDG_WGRAD_STREAM=0 disables.
-    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "1") == "1"
+    # (parsed as documented: 0 = off, 2 = only the small ones, anything else = on)
+    wgrad_stream = os.environ.get("WDG_WGRAD_STREAM", "1") not in ("0", "2")
     # WDG_WGRAD_STREAM=2: only the weight gradients flagged `small` (the discriminator's 27 x 27 / 8 x 8 / 2 x 2 blocks: launches of
     # 25-45 TFLOP/s that leave most of the chip idle beside an equally small data-gradient chain)
-    wgrad_stream_small = os.environ.get("WDG_WGRAD_STREAM", "0") == "2"
+    wgrad_stream_small = os.environ.get("WDG_WGRAD_STREAM", "1") == "2"
 
     def _wgrad(self, fn, joins, small=False):
         """Runs `fn` (the weight-gradient launches of one layer) on the "wgrad" side stream, after everything enqueued so far

@@ -304,7 +304,19 @@ class GanEngine:
         per_var = st.seg_out if st.seg_scale is None else st.seg_out * st.seg_scale.to(st.seg_out.dtype)
         return per_var.mean() * (scale * scale)
 
-    def _critic_coupled(self, d_loss_fn, B, real, fake, noisy, sw_mean, low):
+    @staticmethod
+    def _compiled_loss(value, sample_weight, sw_mean):
+        """What Keras' `compiled_loss(y_true, y_pred, sample_weight)` makes of a plain-function loss (compute_weighted_loss,
+        SUM_OVER_BATCH_SIZE): a scalar value times the mean weight; a per-sample vector weighted ELEMENTWISE, summed, divided by its
+        element count (oracle/torch_model.py::weighted_loss)."""
+        if value.numel() <= 1:
+            return value.reshape(()) * sw_mean
+        v = value.reshape(-1)
+        if sample_weight is not None:
+            v = v * torch.as_tensor(sample_weight, dtype=v.dtype, device=v.device).reshape(-1)
+        return v.sum() / v.numel()
+
+    def _critic_coupled(self, d_loss_fn, B, real, fake, noisy, sw_mean, low, sample_weight=None):
         """Real + generated pass of one critic iteration for an arbitrary compiled loss d_loss_fn(real_output,
         fake_output) (ganbase.py:41-46).  The built-in Wasserstein loss is separable, so its real pass is differentiated
         before the generated pass runs; a general loss needs both score vectors first.  The real pass therefore runs on
@@ -329,7 +341,7 @@ class GanEngine:
         fake_scores = disc.forward(B, training=True).clone()                                  # :43
         r = real_scores.detach().clone().requires_grad_(True)
         f = fake_scores.detach().clone().requires_grad_(True)
-        loss = d_loss_fn(r.view(B, 1), f.view(B, 1)) * sw_mean                                # :44 compiled_loss
+        loss = self._compiled_loss(d_loss_fn(r.view(B, 1), f.view(B, 1)), sample_weight, sw_mean)   # :44 compiled_loss
         gr, gf = torch.autograd.grad(loss, (r, f), allow_unused=True)
         gr = torch.zeros_like(r) if gr is None else gr
         gf = torch.zeros_like(f) if gf is None else gf
@@ -376,6 +388,12 @@ class GanEngine:
             twin.wgrad_side = twin2.wgrad_side = gs if tw.startswith("gs") else None
             if os.environ.get("WDG_WGRAD_STREAM_G", "1") == "1":
                 gen.wgrad_side = ds               # the generator's backward runs when the real-pass stream has nothing to do
+        else:
+            # (two-network / one-network schedules: the generator keeps the pool's side stream, and a twin does not fork its weight
+            # gradients onto the stream this network's already use — each fork / join would make one network wait for the other's)
+            gen.wgrad_side = None
+            if twin is not None:
+                twin.wgrad_stream = False
 
         def start_real_pass(o_r):
             """The three discriminator passes of an iteration on TWO networks (this one and its twin: own variables and
@@ -537,7 +555,7 @@ class GanEngine:
             gradient_reg = self.GAMMA * ((gnorm - 1.0) ** 2).mean()               # :37  (a constant w.r.t. D's weights)
             disc.params.zero_grad()
             if d_loss_fn is not None:
-                loss_value, real_mean, fake_mean = self._critic_coupled(d_loss_fn, B, real, fake, noisy, sw_mean, low)
+                loss_value, real_mean, fake_mean = self._critic_coupled(d_loss_fn, B, real, fake, noisy, sw_mean, low, sample_weight)
                 disc_loss = loss_value + gradient_reg                             # :44-45 (regularization_losses)
                 dscale = self._reduce_and_step(disc, d_opt)                       # :46-47
                 continue
@@ -599,7 +617,7 @@ class GanEngine:
         if d_loss_fn is None:
             d_loss = (fake_mean - real_mean) * sw_mean                            # :67, train.py:11-12
         else:
-            d_loss = d_loss_fn(real_scores.view(B, 1), fake_scores.view(B, 1)) * sw_mean    # :67 compiled_loss = the custom callable
+            d_loss = self._compiled_loss(d_loss_fn(real_scores.view(B, 1), fake_scores.view(B, 1)), sample_weight, sw_mean)    # :67 compiled_loss = the custom callable
         return self._reduce_metrics({
             "g_loss": -fake_mean,
             "g_disc_loss": gen_disc_loss,
