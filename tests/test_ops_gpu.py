@@ -594,6 +594,9 @@ def test_conv_layernorm_fused(case, hip_ops, ref_ops):
 LNB_CASES = [
     # name, n, H, W, cin (= channels of dx), cout, k, s, p, c0, C   (the LayerNorm group is channels [c0, c0 + C) of dx)
     ("d_block0_group16_of_32", 3, 96, 96, 32, 64, 7, 3, 1, 16, 16),     # 256x32 tile, 9 phases: the norm of the low + high branch (models.py:105)
+    ("d_block0_full_map", 2, 256, 256, 32, 64, 7, 3, 1, 16, 16),         # dgrad_patch_s3.hip: 11 x 11 tiles of 8 x 8 bases, ragged last tiles
+    ("d_block0_same_pad_all32", 2, 50, 77, 32, 64, 7, 3, 3, 0, 32),      # 'same' padding, all 32 channels one group, H != W
+    ("d_block0_valid_group8", 2, 64, 40, 32, 64, 7, 3, 0, 8, 8),         # no padding, a group inside one channel tile
     ("d_block1_64ch", 3, 31, 31, 64, 128, 7, 3, 1, 0, 64),               # 128x64 tile on 4 x 1 waves
     ("d_block1_64ch_big", 4, 84, 84, 64, 128, 7, 3, 1, 0, 64),
     ("d_block2_128ch_tile64x128", 8, 27, 27, 128, 256, 7, 3, 1, 0, 128),  # 64x64 tiling -> the 64x128 tile of the fused route
@@ -649,6 +652,17 @@ def test_conv_dgrad_layernorm_backward_fused(case, par, hip_ops, ref_ops):
         ops.conv_dgrad_lnbwd(cv(dy), ops.pack_weights(cv(w)), dx2, ConvGeom(k, k, s_, p_), cv(y), cv(mr), cv(gamma), c0, C, 0.2,
                              h["dg"], h["db"], h["dbias"], h["ws"])
         assert rel_err(h["dg"], 2 * r["dg"] - start[0]) < 5 * TOL and rel_err(dx2, r["dx"]) < TOL
+    if name.startswith("d_block0"):
+        # the result does not depend on the route: the patch kernel (default) against the implicit-GEMM epilogue
+        ops, cv = hip_ops, (lambda t: t.float().to(dev).contiguous())
+        assert ops.lib.wdg_set_tuning(b"dgrad_s3", 0) == 0
+        try:
+            dx3 = ops.zeros(n, H, W, cin)
+            ops.conv_dgrad_lnbwd(cv(dy), ops.pack_weights(cv(w)), dx3, ConvGeom(k, k, s_, p_), cv(y), cv(mr), cv(gamma), c0, C, 0.2,
+                                 None, None, None, None)
+        finally:
+            ops.lib.wdg_set_tuning(b"dgrad_s3", 1)
+        assert rel_err(dx3, h["dx"]) < 1e-5 and not torch.equal(dx3, h["dx"])      # (different reduction order: close, not identical)
 
 
 @pytest.mark.parametrize("B,T,npix,C,par", [(4, 1, 4, 512, True), (3, 2, 9, 64, True), (2, 3, 1, 256, False), (32, 1, 4, 512, True)])
