@@ -4,10 +4,11 @@
 # output), its in-kernel phase clocks.   bash tools/ab_dgrad_s3.sh <tag>
 TAG=${1:-r06}; OUT=gpurun_out/${TAG}_dgrad_s3.txt
 {
-echo "# routes (HIP events, 20 launches each; patch_s3 = dgrad_patch_s3.hip, igemm = wdg_igemm_kernel<256,32> epilogue 5 / 6)"
+echo "# every python process starts with 60 untimed launches (clocks: a cold first case measures 60 us more)
+# routes (HIP events, 20 launches each; patch_s3 = dgrad_patch_s3.hip, igemm = wdg_igemm_kernel<256,32> epilogue 5 / 6)"
 python3 tools/bench_dgrad_s3.py 32 20 2>/dev/null | grep route
 echo "# occupancy: LDS padded by k KB (1 + 256 * (k + 1)): 0 = three workgroups per CU, 7 = two (the default pads to 54 KB), 70 = one"
-WDG_S3_ROUTES=257,2049,18177 python3 tools/bench_dgrad_s3.py 32 20 2>/dev/null | grep route
+WDG_S3_ROUTES=257,2049,18177,257,2049 python3 tools/bench_dgrad_s3.py 32 20 2>/dev/null | grep route
 echo "# skeletons at two workgroups per CU (-DWDG_S3_SKELETONS; bits: 1 no weight refills, 2 no dy fragment reads, 4 no epilogue, 8 no DMA of the norm's input)"
 WDG_LIB=$PWD/gpurun_variants/libwdgan_s3skel.so WDG_S3_ROUTES=1,3,5,9,17,25,27,31 python3 tools/bench_dgrad_s3.py 32 20 2>/dev/null | grep route
 echo "# skeletons at three workgroups per CU"

@@ -23,13 +23,15 @@ dg, db, dbias = (torch.zeros(16, device=dev) for _ in range(3))
 ws = ops.lnbwd_scratch(16)
 dx = ops.zeros(n, H, W, 32)
 flops = 2.0 * 49 * 32 * 64 * n * Ho * Ho
+warm = False
 routes = [int(v) for v in os.environ.get("WDG_S3_ROUTES", "1,0").split(",")]      # 1 + 2 * DBG: skeletons of a -DWDG_S3_SKELETONS build
 for route in routes:
     assert ops.lib.wdg_set_tuning(b"dgrad_s3", route) == 0
-    for par in ((True, False) if route < 2 else (False,)):
+    for par in ((True, False) if route < 2 else ((True,) if ((route >> 1) & 127) in (16, 48) else (False,))):
         args = (dg, db, dbias, ws) if par else (None, None, None, None)
-        for _ in range(3):
+        for _ in range(3 if warm else 60):          # (the first case also warms the clocks up: cold, a 470 us launch measures 530)
             ops.conv_dgrad_lnbwd(dy, pk, dx, g, y, mr, gamma, 16, 16, 0.2, *args)
+        warm = True
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())

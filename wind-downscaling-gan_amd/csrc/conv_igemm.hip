@@ -2289,15 +2289,13 @@ extern "C" int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* pl, const float* dy, co
     WDG_CHECK_ARG(c0 >= 0 && C > 0 && c0 % 4 == 0 && C % 4 == 0 && c0 + C <= g.Cin, "bad channel group");
     WDG_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ldy_act % 4 == 0 && ldy_act >= C, "y / gamma alignment");
     const bool want_par = dgamma || dbeta || dbias;
-    if (g_dgrad_lnbwd && (!want_par || par_ws) && wdg_dgrad_s3_ok(pl, c0, C, ldy_act) && ws && ws_bytes >= wdg_dgrad_s3_ws_bytes(pl) &&
+    if (g_dgrad_lnbwd && wdg_dgrad_s3_ok(pl, c0, C, ldy_act) && ws && ws_bytes >= wdg_dgrad_s3_ws_bytes(pl) &&
         ((uintptr_t)ws & 15) == 0) {
         // 7 x 7 stride-3 32 -> 64: the dy patch of a 24 x 24 block of dx pixels in LDS, all nine residue classes in one workgroup (dgrad_patch_s3.hip)
         WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)mean_rstd & 7) == 0,
                       "dy / wD / dx must be 16-byte aligned");
-        const int rc = wdg_dgrad_s3_launch(pl, dy, wD, dx, y, ldy_act, img_stride_act, mean_rstd, gamma, c0, C, act_slope, want_par ? par_ws : nullptr,
-                                           WDG_LNB_REP, ws, (hipStream_t)stream);
-        if (rc != WDG_OK || !want_par) return rc;
-        return wdg_lnb_finish(par_ws, WDG_LNB_REP, C, dgamma, dbeta, dbias, (hipStream_t)stream);
+        return wdg_dgrad_s3_launch(pl, dy, wD, dx, y, ldy_act, img_stride_act, mean_rstd, gamma, c0, C, act_slope, dgamma, dbeta, dbias, ws,
+                                   (hipStream_t)stream);
     }
     bool fuse = g_dgrad_lnbwd && !(pl->halo_auto_dgrad && pl->halo_dgrad_nt) && g_igemm_pipe == 3 && (!want_par || par_ws);
     TileCfg tc_force = {0, 0};

@@ -80,7 +80,7 @@ bool wdg_dgrad_s3_ok(const wdg_conv_plan* pl, int c0, int C, int ldy_act);
 size_t wdg_dgrad_s3_ws_bytes(const wdg_conv_plan* pl);
 #if defined(__HIPCC__)
 int wdg_dgrad_s3_launch(const wdg_conv_plan* pl, const float* dy, const float* wD, float* dx, const float* y, int ldy_act,
-                        int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope, float* par, int rep,
+                        int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope, float* dgamma, float* dbeta, float* dbias,
                         void* ws, hipStream_t stream);
 #endif
 

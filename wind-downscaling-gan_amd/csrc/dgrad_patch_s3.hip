@@ -20,16 +20,15 @@
 //     LDS by DMA, requested a whole class ahead.
 // Algorithmic work of a launch: 2 * 49 * 32 * 64 flops per dy pixel; tile padding (bases 86 -> 88 per axis on the 256 x 256 map) 4.7 %.
 //
-// Measured (32 images of 256 x 256, profiles/r06ad_dgrad_s3.txt): input-gradient-only launch 452-465 us = 0.62-0.64 of the fp32 peak
-// (implicit GEMM 497-499), with parameter gradients 512-523 (520); whole training step -0.7 .. -1.1 ms on three boxes
-// (profiles/r06ad_ab_tune_dgrad_s3.txt).  Where the rest goes, from the skeletons and in-kernel clocks of the same file:
-//   * MFMAs alone (no weights, no epilogue, no DMA): 375 us = 0.77 — the practical ceiling of this reduction shape (no fp32 MFMA
-//     kernel of this library exceeds 0.80 of the nominal peak);
-//   * every per-wave serial phase costs about twice its own length: with two waves per SIMD the other wave alone issues an MFMA
-//     every ~49 clocks (clocks of the one-workgroup-per-CU run), not every 32-40.  Prologue (patch fill + barrier) 15 % of a wave's
-//     life, epilogue 10 %, DMA requests 7 %;
-//   * three workgroups per CU are SLOWER than two (530 vs 464 us; one: 483): the weight stream (401 KB per workgroup, every line
-//     an L1 miss) queues up — launch-to-first-MFMA 111 k clocks against 38 k and 18 k.  The launch pads its LDS request to two per CU.
+// Measured (32 images of 256 x 256, clocks warm, profiles/r06ae_dgrad_s3.txt): input-gradient-only launch 445-447 us = 0.645 of the
+// fp32 peak (implicit GEMM 497 = 0.58), with parameter gradients 461 incl. the pack and finish kernels (521); whole training step
+// -0.65 .. -1.1 ms on three boxes (profiles/r06ae_ab_tune_dgrad_s3.txt).  Where the rest goes, from the skeletons and in-kernel clocks:
+//   * MFMAs alone (no weights, no epilogue, no DMA): 373 us = 0.77 — the practical ceiling of this reduction shape (no fp32 MFMA
+//     kernel of this library exceeds 0.81 of the nominal peak); without epilogue and DMA 400, without weight requests 414;
+//   * a wave's serial phases — prologue (patch fill + barrier) 16 % of its life, epilogue 10 %, DMA requests 7 % — are covered by ONE
+//     other wave per SIMD, which alone issues an MFMA every ~49 clocks (clocks of the one-workgroup-per-CU run), not every 32-40;
+//   * three workgroups per CU are SLOWER than two (472 vs 444 us; one: 480): the weight stream (401 KB per workgroup, every line
+//     an L1 miss) queues up — launch-to-first-MFMA 114 k clocks against 38 k and 20 k.  The launch pads its LDS request to two per CU.
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
@@ -57,7 +56,7 @@ struct WdgDgS3 {
     const float* y;        // the producer's LayerNorm input (pre-norm, post-activation), [img][H][W][ldY]
     const float* stats;    // {mean, rstd} per dx pixel
     const float* gamma;
-    float* par;            // replica slabs [rep][3][32] or null
+    float* par;            // per-workgroup sums [ntiles][3][32] (dgamma, dbeta, dbias shares by dx channel) or null
     long long imgStrideDy, imgStrideDx, imgStrideY;
     int ldDy, ldDx, ldY, ldB;
     int H, W, Ho, Wo, pad_h, pad_w;
@@ -96,12 +95,40 @@ __device__ __forceinline__ unsigned wdg_s3_role_classes(int role) { return role 
 // Weights in fragment order: chunk ((tap * 2 + bt) * 4 + g) * 64 + lane holds W[tap][ci = 16 bt + (lane & 15)][co = 16 g + 4 (lane >> 4) .. + 3],
 // so a wave's A-fragment request is 1 KB of consecutive bytes (eight full lines).  Read from the [tap][ci][co] layout directly the
 // same request touches 16 lines for 64 bytes each, and the 8 requests per wave and tap cost the kernel 86 us of its 505
-// (profiles/r06ad_dgrad_s3.txt).  401 KB per launch, rebuilt by every call: the weights change every step.
+// (profiles/r06ae_dgrad_s3.txt).  401 KB per launch, rebuilt by every call: the weights change every step.
 __global__ void __launch_bounds__(256) wdg_dgrad_s3_pack_kernel(const float* __restrict__ wD, int ldB, f32x4* __restrict__ wS) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 49 * 2 * 4 * 64) return;
     const int lane = idx & 63, g = (idx >> 6) & 3, bt = (idx >> 8) & 1, tap = idx >> 9;
     wS[idx] = *reinterpret_cast<const f32x4*>(wD + (long long)(tap * 32 + 16 * bt + (lane & 15)) * ldB + 16 * g + 4 * (lane >> 4));
+}
+
+// [rows][3][32] (one row per workgroup of the launch) -> dgamma / dbeta / dbias of the group's C channels (accumulated; any may be null): one block of 1024 threads per
+// (quantity, channel), four independent partial sums per thread — the rows are 384 bytes apart, every load its own round trip, and a
+// serial walk (256 threads x 15 dependent loads) took 3 x as long
+__global__ void __launch_bounds__(1024) wdg_dgrad_s3_finish_kernel(const float* __restrict__ part, int ntiles /* rows */, int c0, int C, float* dgamma,
+                                                                   float* dbeta, float* dbias) {
+    __shared__ float red[16];
+    const int which = blockIdx.x / C, c = blockIdx.x - which * C;
+    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dbias;
+    if (!dst) return;
+    const float* src = part + which * 32 + c0 + c;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    for (int i = threadIdx.x; i < ntiles; i += 4096) {
+        v0 += src[(size_t)i * 96];
+        if (i + 1024 < ntiles) v1 += src[(size_t)(i + 1024) * 96];
+        if (i + 2048 < ntiles) v2 += src[(size_t)(i + 2048) * 96];
+        if (i + 3072 < ntiles) v3 += src[(size_t)(i + 3072) * 96];
+    }
+    const float v = wdg_wave_sum((v0 + v1) + (v2 + v3));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        dst[c] += t;
+    }
 }
 
 template <bool PAR, int DBG = 0>
@@ -231,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) wdg_dgrad_s3_kernel(const WdgDgS3 p) {
     // at the start of a class the queue holds [first tap's weights: 8 | epilogue stores: 8 | DMA of the norm's input: C / 4 + 2]:
     // the fragment a step needs is the OLDEST entry, but the compiler's count for the loop (its states merged over the back
     // edges) is the steady one, vmcnt(6) — which there means "the stores have been acknowledged and the DMA has come back from
-    // HBM": measured 44 + 15 us apart and 95 us together of a 505 us launch (profiles/r06ad_dgrad_s3.txt).  Counted by hand:
+    // HBM": measured 44 + 15 us apart and 95 us together of a 505 us launch (profiles/r06ae_dgrad_s3.txt).  Counted by hand:
     //   steady step g: newer than its pair = the 3 pairs requested since -> vmcnt(6);
     //   first tap of a class, step g: (3 - g) pairs of this tap + 8 stores + >= 3 DMA requests + g refills -> vmcnt(17)
     //   (the wave's first class has no stores in front: its first tap's weights are requested in front of the patch fill and waited
@@ -378,9 +405,20 @@ __global__ void __launch_bounds__(256, 2) wdg_dgrad_s3_kernel(const WdgDgS3 p) {
         atomicAdd(&s3_prof[7], 1ull);
     }
 #endif
-    if constexpr (PAR) {
+    if constexpr (PAR && DBG == 48) {
+        // (skeleton: the per-lane sums stay alive through one never-taken store; no row sums, no barrier, no final stores)
+        float keep = 0.f;
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep += pg[bt][r][0] + pg[bt][r][1] + pg[bt][r][2];
+        if (keep == 12345.678f) p.par[t] = keep;
+    }
+    if constexpr (PAR && DBG != 48) {
         if (!p.par) return;
-        // the 16 pixels of a lane row meet in DPP row sums, the four waves in LDS: one atomic per (workgroup, channel, quantity)
+        // The 16 pixels of a lane row meet in DPP row sums, the four waves in LDS; the workgroup then stores ITS row [3][32] of the
+        // scratch (plain stores, summed by wdg_dgrad_s3_finish_kernel — not float atomics into shared slabs: the sums are the
+        // same bits on every run).  (A row per wave, without the barrier: 4 us less here, 14 us more in the finish kernel.)
 #pragma unroll
         for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
@@ -391,11 +429,7 @@ __global__ void __launch_bounds__(256, 2) wdg_dgrad_s3_kernel(const WdgDgS3 p) {
                     if (li == 0) red[wv * 96 + q * 32 + bt * 16 + 4 * lq + r] = sq;
                 }
         __syncthreads();
-        if (t < 96) {
-            const int which = t >> 5, n = (t & 31) - p.c0;
-            if (n >= 0 && n < p.C)
-                atomicAdd(p.par + ((size_t)(blockIdx.x % (unsigned)p.rep) * 3 + which) * p.C + n, red[t] + red[96 + t] + red[192 + t] + red[288 + t]);
-        }
+        if (t < 96 && !(DBG & 16)) p.par[(size_t)tile * 96 + t] = (red[t] + red[96 + t]) + (red[192 + t] + red[288 + t]);
     }
 }
 
@@ -424,31 +458,39 @@ bool wdg_dgrad_s3_ok(const wdg_conv_plan* pl, int c0, int C, int ldy_act) {
            (int64_t)g.Ho * g.Wo * g.ldy * 4 < (int64_t)1 << 31;     // (32-bit byte offsets into one image of the norm's input)
 }
 
-// scratch of the route (the weights in fragment order); 0: the plan's layer is not this kernel's
+constexpr size_t WDG_S3_WS_WEIGHTS = (size_t)49 * 32 * 64 * 4;
+// workgroups of a launch: 8 x 8 blocks of base positions b = (i + pad) div 3 over the dx map
+static int wdg_s3_tiles(const wdg_conv_geom& g, int* tiles_w, int* tiles_img) {
+    const int nb_h = (g.H - 1 + g.pad_h) / 3 - g.pad_h / 3 + 1, nb_w = (g.W - 1 + g.pad_w) / 3 - g.pad_w / 3 + 1;
+    const int th = (nb_h + 7) / 8, tw = (nb_w + 7) / 8;
+    if (tiles_w) *tiles_w = tw;
+    if (tiles_img) *tiles_img = th * tw;
+    return th * tw * g.n_img;
+}
+// scratch of the route; 0: the plan's layer is not this kernel's
 size_t wdg_dgrad_s3_ws_bytes(const wdg_conv_plan* pl) {
     const wdg_conv_geom& g = pl->g;
-    return (g.kh == 7 && g.kw == 7 && g.stride == 3 && g.Cin == 32 && g.Cout == 64) ? (size_t)49 * 32 * 64 * 4 : 0;
+    if (!(g.kh == 7 && g.kw == 7 && g.stride == 3 && g.Cin == 32 && g.Cout == 64 && g.pad_h >= 0 && g.pad_w >= 0)) return 0;
+    return WDG_S3_WS_WEIGHTS + (size_t)wdg_s3_tiles(g, nullptr, nullptr) * 96 * 4;     // the weights in fragment order + the workgroups' parameter sums
 }
 
 int wdg_dgrad_s3_launch(const wdg_conv_plan* pl, const float* dy, const float* wD, float* dx, const float* y, int ldy_act,
-                        int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope, float* par, int rep,
+                        int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope, float* dgamma, float* dbeta, float* dbias,
                         void* ws, hipStream_t stream) {
     const wdg_conv_geom& g = pl->g;
     WdgDgS3 p;
-    p.dy = dy; p.wD = wD; p.wS = reinterpret_cast<const f32x4*>(ws); p.dx = dx; p.y = y; p.stats = mean_rstd; p.gamma = gamma; p.par = par;
+    p.dy = dy; p.wD = wD; p.wS = reinterpret_cast<const f32x4*>(ws); p.dx = dx; p.y = y; p.stats = mean_rstd; p.gamma = gamma;
+    const bool par = dgamma || dbeta || dbias;
+    p.par = par ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WDG_S3_WS_WEIGHTS) : nullptr;
     p.imgStrideDy = g.img_stride_y; p.imgStrideDx = g.img_stride_x; p.imgStrideY = img_stride_act;
     p.ldDy = g.ldy; p.ldDx = g.ldx; p.ldY = ldy_act; p.ldB = pl->w_ld ? pl->w_ld : pl->Cout_p;
     p.H = g.H; p.W = g.W; p.Ho = g.Ho; p.Wo = g.Wo; p.pad_h = g.pad_h; p.pad_w = g.pad_w;
     p.bmin_h = g.pad_h / 3; p.bmin_w = g.pad_w / 3;
-    const int nb_h = (g.H - 1 + g.pad_h) / 3 - p.bmin_h + 1, nb_w = (g.W - 1 + g.pad_w) / 3 - p.bmin_w + 1;
-    const int tiles_h = (nb_h + 7) / 8;
-    p.tiles_w = (nb_w + 7) / 8;
-    p.tiles_img = tiles_h * p.tiles_w;
-    p.ntiles = p.tiles_img * g.n_img;
-    p.rep = rep; p.c0 = c0; p.C = C; p.slope = act_slope;
+    p.ntiles = wdg_s3_tiles(g, &p.tiles_w, &p.tiles_img);
+    p.rep = 0; p.c0 = c0; p.C = C; p.slope = act_slope;
     // TWO workgroups per CU, not the three the kernel's own 47 KB would allow: with three the weight stream (401 KB per workgroup, every
-    // line a miss of the CU's L1) queues up — in-kernel clocks: 28 us from launch to the first MFMA of a wave against 7 with one workgroup
-    // per CU — and the launch takes 498 us instead of 454-464 (one per CU: 539; profiles/r06ad_dgrad_s3.txt).  The request is
+    // line a miss of the CU's L1) queues up — in-kernel clocks: 114 k clocks from launch to the first MFMA of a wave against 38 k with two and
+    // 20 k with one workgroup per CU — and the launch takes 472 us instead of 444 (one per CU: 480; profiles/r06ae_dgrad_s3.txt).  The request is
     // padded to 54 KB; wdg_set_tuning("dgrad_s3", 1 + 256 * k) sets the padding to k KB instead (measurement).
     size_t lds_bytes = (size_t)PATCH_SLOTS * 16 + 4 * 3 * 32 * 4 + 4 * (64 * (size_t)C + 128) * 4;
     if (g_dgrad_s3 >> 8) lds_bytes += (size_t)((g_dgrad_s3 >> 8) - 1) * 1024;
@@ -460,11 +502,17 @@ int wdg_dgrad_s3_launch(const wdg_conv_plan* pl, const float* dy, const float* w
     const int dbg = (g_dgrad_s3 >> 1) & 127;
 #define WDG_S3_CASE(D) if (dbg == D) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<false, D>), dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }
     WDG_S3_CASE(1) WDG_S3_CASE(2) WDG_S3_CASE(4) WDG_S3_CASE(8) WDG_S3_CASE(12) WDG_S3_CASE(13) WDG_S3_CASE(15)
+    if (dbg == 16 && par) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<true, 16>), dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }   // 16: parameter sums without their final stores
+    if (dbg == 48 && par) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<true, 48>), dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }   // 48: ... and without the final reduction
 #endif
     if (par)
         hipLaunchKernelGGL(wdg_dgrad_s3_kernel<true>, dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p);
     else
         hipLaunchKernelGGL(wdg_dgrad_s3_kernel<false>, dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p);
     WDG_LAUNCH_CHECK();
+    if (par) {
+        hipLaunchKernelGGL(wdg_dgrad_s3_finish_kernel, dim3(3 * C), dim3(1024), 0, stream, p.par, p.ntiles, c0, C, dgamma, dbeta, dbias);
+        WDG_LAUNCH_CHECK();
+    }
     return WDG_OK;
 }
