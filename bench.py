@@ -133,8 +133,11 @@ class ConvTimer:
         def conv_dgrad_lnbwd(dy, pk, dx, g, *a, **k):
             # data gradient -> LayerNorm + LeakyReLU backward of the producer in one call (epilogues 5 / 6 of wdg_igemm_kernel):
             # the convolution's FLOPs, timed with its fused norm backward
-            timed(ops.conv_kernel_label("dgrad", dx, dy, pk, g) + " +LNbwd", flops(dx, dy, pk, g), orig_dgrad_ln, dy, pk, dx, g, *a,
-                  layer=geom("dgrad+LNbwd", dx, dy, pk, g), **k)
+            # (or wdg_dgrad_s3_kernel, the patch kernel of the 7x7 stride-3 32 -> 64 layer, with its weight repack and — with
+            # parameter gradients — its finish kernel)
+            route = ops.conv_dgrad_lnbwd_route(dy, pk, dx, g, a[0], a[3], a[4], a[6] is not None or a[7] is not None or a[8] is not None)
+            name = "wdg_dgrad_s3_kernel" if route == 2 else ops.conv_kernel_label("dgrad", dx, dy, pk, g)
+            timed(name + " +LNbwd", flops(dx, dy, pk, g), orig_dgrad_ln, dy, pk, dx, g, *a, layer=geom("dgrad+LNbwd", dx, dy, pk, g), **k)
 
         ops.conv_dgrad_lnbwd = conv_dgrad_lnbwd
         orig_fwd_ln = ops.conv_fwd_ln

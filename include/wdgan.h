@@ -136,11 +136,16 @@ int wdg_conv_dgrad_bn(const wdg_conv_plan* plan, const float* dy, const float* w
  * par_ws: zero-initialised scratch of wdg_conv_dgrad_lnbwd_par_floats(C) floats (needed with parameter gradients; the call
  * leaves it zeroed).  One launch where an implicit-GEMM tile owns complete pixels — the norm's two reductions then run on the
  * accumulators and the standalone pass over dz (read dz + y, write dpre) disappears —, wdg_conv_dgrad + wdg_ln_bwd
- * otherwise: the results do not depend on the route. */
+ * otherwise: the results do not depend on the route.  The 7 x 7 stride-3 layer with 32 input and 64 output channels (the
+ * discriminator's first block, models.py:105-116) runs on a kernel of its own, csrc/dgrad_patch_s3.hip: the dy patch of a
+ * 24 x 24 block of dx pixels in LDS, all nine residue classes of the stride in one workgroup; its parameter sums are the same
+ * bits on every run (no atomics) and it does not touch par_ws.  wdg_conv_dgrad_lnbwd_route tells which one a call would take
+ * (profiling labels): 0 data gradient + wdg_ln_bwd, 1 implicit-GEMM epilogue, 2 the patch kernel. */
 int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* plan, const float* dy, const float* wD, float* dx, const float* y, int ldy_act,
                          int64_t img_stride_act, const float* mean_rstd, const float* gamma, int c0, int C, float act_slope,
                          float* dgamma, float* dbeta, float* dbias, float* par_ws, void* ws, size_t ws_bytes, wdg_stream stream);
 int64_t wdg_conv_dgrad_lnbwd_par_floats(int C);
+int wdg_conv_dgrad_lnbwd_route(const wdg_conv_plan* plan, int c0, int C, int ldy_act, int with_param_grads, size_t ws_bytes);
 
 /* conv -> bias -> LeakyReLU -> LayerNormalization in one call (the discriminator's blocks, models.py:113-116, 122-125,
  * 134-136; the shortcut branch, tf_utils.py:29-31; the encoder, autoencoder.py:27-30):

@@ -14,9 +14,11 @@ python3 - "$ROOT/$OUT/${TAG}_infer_group_${PREC}_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-print("kernel time per forward (7 forwards) %.3f ms" % (tot / 7e6))
+# forwards in the trace = launches of a kernel that runs once per forward (warm-ups + timed repetitions of tools/prof_infer_group.py)
+nf = max([int(r['Calls']) for r in rows if 'wdg_upconv_fused_h16_kernel' in r['Name'] or 'wdg_conv_thin16_h16_kernel' in r['Name']] or [7])
+print("kernel time per forward (%d forwards in the trace) %.3f ms" % (nf, tot / nf / 1e6))
 for r in rows[:12]:
-    print("%8.3f ms/fwd %5d x %8.1f us  %s" % (float(r['TotalDurationNs']) / 7e6, int(r['Calls']) // 7, float(r['AverageNs']) / 1e3, r['Name'][:110]))
+    print("%8.3f ms/fwd %5d x %8.1f us  %s" % (float(r['TotalDurationNs']) / nf / 1e6, int(r['Calls']) // nf, float(r['AverageNs']) / 1e3, r['Name'][:110]))
 PY
 [ "$MODE" = trace ] && exit 0
 i=0

@@ -13,7 +13,9 @@ CSRC = ROOT / "wind-downscaling-gan_amd" / "csrc"
 ROLE = [
     (r"wdg_igemm_kernel<128, 128", "implicit-GEMM conv fwd / dgrad, 128x128 tile (G: 8x8s2 23->128, 4x4s2, 3x3 128->512 gates; D: wide layers)"),
     (r"wdg_igemm_kernel<128, 64", "implicit GEMM 128x64 (D 7x7s3 32->64 fwd + LN; G 3x3 128->64)"),
-    (r"wdg_igemm_kernel<256, 32", "implicit GEMM 256x32 (D 7x7s3 data gradient + LN backward; 1x1 column GEMMs of the upsample block)"),
+    (r"wdg_dgrad_s3_kernel", "D 7x7s3 32->64 data gradient + LayerNorm backward below it: dy patch in LDS, nine residue classes per workgroup"),
+    (r"wdg_dgrad_s3_(pack|finish)_kernel", "its weights in fragment order / its parameter sums"),
+    (r"wdg_igemm_kernel<256, 32", "implicit GEMM 256x32 (1x1 column GEMMs of the upsample block; thin data gradients)"),
     (r"wdg_igemm_kernel<256, 16", "implicit GEMM 256x16 (thin data gradients)"),
     (r"wdg_igemm_kernel<64, 64", "implicit GEMM 64x64, LDS-DMA loop (D's small maps 29^2 .. 3^2)"),
     (r"wdg_igemm_kernel<128, 80", "implicit GEMM 128x80 (G 16->160 layer)"),

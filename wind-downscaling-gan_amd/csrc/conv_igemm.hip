@@ -2277,6 +2277,30 @@ extern "C" int wdg_conv_dgrad(const wdg_conv_plan* pl, const float* dy, const fl
 }
 
 
+// which way a wdg_conv_dgrad_lnbwd call goes: 0 data gradient + wdg_ln_bwd, 1 the implicit-GEMM epilogue (tc_force: its tile when
+// not the default one), 2 the patch kernel of dgrad_patch_s3.hip (ws_bytes: the caller's scratch; 0 rules it out)
+static int dgrad_lnbwd_route(const wdg_conv_plan* pl, int c0, int C, int ldy_act, bool /*with_par*/, bool par_ok, size_t ws_bytes, TileCfg* tc_force) {
+    const wdg_conv_geom& g = pl->g;
+    if (g_dgrad_lnbwd && ws_bytes && wdg_dgrad_s3_ok(pl, c0, C, ldy_act) && ws_bytes >= wdg_dgrad_s3_ws_bytes(pl)) return 2;
+    bool fuse = g_dgrad_lnbwd && !(pl->halo_auto_dgrad && pl->halo_dgrad_nt) && g_igemm_pipe == 3 && par_ok;
+    if (fuse && pl->dgrad_split > 1) {
+        fuse = g.Cin % 4 == 0 && g.Cin <= 1024;                        // second stage: wdg_igemm_reduce_lnbwd_kernel
+    } else if (fuse) {
+        long long Mmax = 0;
+        for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g.n_img * ph.Pa * ph.Pb);
+        TileCfg tc = pick_tile(g.Cin, true, Mmax);
+        if (tc.BM == 64 && tc.BN == 64 && g.Cin == 128 && (g_dgrad_lnbwd & 2)) tc = *tc_force = TileCfg{64, 128};   // a 128-channel row in one wave
+        fuse = lnb_tile_ok(tc) && g.Cin <= tc.BN;
+    }
+    return fuse ? 1 : 0;
+}
+
+extern "C" int wdg_conv_dgrad_lnbwd_route(const wdg_conv_plan* pl, int c0, int C, int ldy_act, int with_param_grads, size_t ws_bytes) {
+    if (!pl) return -1;
+    TileCfg tc = {0, 0};
+    return dgrad_lnbwd_route(pl, c0, C, ldy_act, with_param_grads != 0, true, ws_bytes, &tc);
+}
+
 // Data gradient of a convolution whose INPUT tensor (channels [c0, c0 + C) of it) was produced by conv -> bias -> LeakyReLU -> LayerNormalization:
 // dx = dgrad(dy), then the LayerNorm + LeakyReLU backward applied to those channels of dx IN PLACE (dx[..., c0:c0+C] becomes the gradient
 // w.r.t. the producer's pre-activation), with dgamma / dbeta / dbias accumulated when given.  One launch where an implicit-GEMM tile owns
@@ -2289,25 +2313,16 @@ extern "C" int wdg_conv_dgrad_lnbwd(const wdg_conv_plan* pl, const float* dy, co
     WDG_CHECK_ARG(c0 >= 0 && C > 0 && c0 % 4 == 0 && C % 4 == 0 && c0 + C <= g.Cin, "bad channel group");
     WDG_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ldy_act % 4 == 0 && ldy_act >= C, "y / gamma alignment");
     const bool want_par = dgamma || dbeta || dbias;
-    if (g_dgrad_lnbwd && wdg_dgrad_s3_ok(pl, c0, C, ldy_act) && ws && ws_bytes >= wdg_dgrad_s3_ws_bytes(pl) &&
-        ((uintptr_t)ws & 15) == 0) {
+    TileCfg tc_force = {0, 0};
+    const int route = dgrad_lnbwd_route(pl, c0, C, ldy_act, want_par && par_ws, !want_par || par_ws, ws_bytes, &tc_force);
+    if (route == 2 && ws && ((uintptr_t)ws & 15) == 0) {
         // 7 x 7 stride-3 32 -> 64: the dy patch of a 24 x 24 block of dx pixels in LDS, all nine residue classes in one workgroup (dgrad_patch_s3.hip)
         WDG_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wD & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)mean_rstd & 7) == 0,
                       "dy / wD / dx must be 16-byte aligned");
         return wdg_dgrad_s3_launch(pl, dy, wD, dx, y, ldy_act, img_stride_act, mean_rstd, gamma, c0, C, act_slope, dgamma, dbeta, dbias, ws,
                                    (hipStream_t)stream);
     }
-    bool fuse = g_dgrad_lnbwd && !(pl->halo_auto_dgrad && pl->halo_dgrad_nt) && g_igemm_pipe == 3 && (!want_par || par_ws);
-    TileCfg tc_force = {0, 0};
-    if (fuse && pl->dgrad_split > 1) {
-        fuse = g.Cin % 4 == 0 && g.Cin <= 1024;                        // second stage: wdg_igemm_reduce_lnbwd_kernel
-    } else if (fuse) {
-        long long Mmax = 0;
-        for (auto& ph : pl->ph_dgrad) Mmax = std::max(Mmax, (long long)g.n_img * ph.Pa * ph.Pb);
-        TileCfg tc = pick_tile(g.Cin, true, Mmax);
-        if (tc.BM == 64 && tc.BN == 64 && g.Cin == 128 && (g_dgrad_lnbwd & 2)) tc = tc_force = TileCfg{64, 128};   // a 128-channel row in one wave
-        fuse = lnb_tile_ok(tc) && g.Cin <= tc.BN;
-    }
+    const bool fuse = route >= 1 && (route == 1 || dgrad_lnbwd_route(pl, c0, C, ldy_act, false, !want_par || par_ws, 0, &tc_force) == 1);
     if (!fuse) {
         int rc = conv_dgrad_impl(pl, dy, wD, nullptr, dx, 0, 0.f, 0, nullptr, ws, ws_bytes, stream);
         if (rc != WDG_OK) return rc;

@@ -519,6 +519,13 @@ class HipOps:
                                                    gamma.data_ptr(), int(c0), int(C), float(act_slope), _ptr(dgamma), _ptr(dbeta), _ptr(dbias),
                                                    _ptr(par_ws), ws.data_ptr(), ws.numel(), self.stream), "conv_dgrad_lnbwd")
 
+    def conv_dgrad_lnbwd_route(self, dy, pk, dx, g, y, c0, C, with_param_grads=True):
+        """Which kernels a conv_dgrad_lnbwd call launches (profiling labels): 0 data gradient + ln_bwd, 1 the implicit-GEMM
+        epilogue, 2 the 7x7 stride-3 patch kernel (csrc/dgrad_patch_s3.hip)."""
+        plan, wsb, _ = self._plan(dx, dy, pk.cin, pk.cout, g)
+        _, ldy, _ = _v4(y)
+        return int(self.lib.wdg_conv_dgrad_lnbwd_route(plan, int(c0), int(C), ldy, int(bool(with_param_grads)), self._workspace(wsb).numel()))
+
     def lnbwd_scratch(self, C):
         return self.zeros(int(self.lib.wdg_conv_dgrad_lnbwd_par_floats(int(C))))
 

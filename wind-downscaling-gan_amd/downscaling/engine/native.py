@@ -66,6 +66,7 @@ SIGNATURES = {
     "wdg_conv_dgrad_bn": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, f32, c_fp, i32, c_fp, c_fp, szt, c_fp]),
     "wdg_conv_dgrad_lnbwd": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp, i32, i32, f32, c_fp, c_fp, c_fp, c_fp, c_fp, szt, c_fp]),
     "wdg_conv_dgrad_lnbwd_par_floats": (i64, [i32]),
+    "wdg_conv_dgrad_lnbwd_route": (i32, [C.c_void_p, i32, i32, i32, i32, szt]),
     "wdg_conv_fwd_ln": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, f32, c_fp, i32, f32, c_fp, szt, c_fp]),
     "wdg_conv_fwd_ln_strided": (i32, [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i64, c_fp, c_fp, f32, c_fp, i32, f32, c_fp, szt, c_fp]),
     "wdg_upconv_fwd": (i32, [C.c_void_p, c_fp, i32, i64, c_fp, c_fp, c_fp, i32, f32, c_fp]),
