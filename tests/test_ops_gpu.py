@@ -665,6 +665,41 @@ def test_conv_dgrad_layernorm_backward_fused(case, par, hip_ops, ref_ops):
         assert rel_err(dx3, h["dx"]) < 1e-5 and not torch.equal(dx3, h["dx"])      # (different reduction order: close, not identical)
 
 
+def test_conv_dgrad_layernorm_backward_routes_and_repeatability(hip_ops):
+    """wdg_conv_dgrad_lnbwd_route names the kernels a call launches: the 7x7 stride-3 32 -> 64 layer goes to the patch kernel
+    (csrc/dgrad_patch_s3.hip), whose parameter sums — plain stores + a fixed-order finish kernel, no atomics — are the same bits on
+    every run; the other fused layers stay in the implicit-GEMM epilogue; with the patch kernel switched off so does that layer."""
+    from downscaling.engine.hipops import ConvGeom
+    ops, dev = hip_ops, hip_ops.device
+    gen = torch.Generator().manual_seed(5)
+
+    def make(n, H, cin, cout, C):
+        Ho = (H + 2 - 7) // 3 + 1
+        dy = torch.randn(n, Ho, Ho, cout, generator=gen).to(dev)
+        pk = ops.pack_weights((torch.randn(7, 7, cin, cout, generator=gen) / 50).to(dev))
+        y = torch.randn(n, H, H, C, generator=gen).to(dev)
+        mr = torch.stack([y.mean(-1).reshape(-1), 1.0 / torch.sqrt(y.var(-1, unbiased=False).reshape(-1) + 1e-3)], 1).contiguous()
+        return dy, pk, ops.zeros(n, H, H, cin), y, mr, (torch.rand(C, generator=gen) + 0.5).to(dev)
+
+    g = ConvGeom(7, 7, 3, 1)
+    dy, pk, dx, y, mr, gamma = make(3, 96, 32, 64, 16)
+    assert ops.conv_dgrad_lnbwd_route(dy, pk, dx, g, y, 16, 16) == 2
+    runs = []
+    for _ in range(3):
+        grads = [torch.zeros(16, device=dev) for _ in range(3)]
+        ops.conv_dgrad_lnbwd(dy, pk, dx, g, y, mr, gamma, 16, 16, 0.2, *grads, ops.lnbwd_scratch(16))
+        runs.append([t.clone() for t in grads] + [dx.clone()])
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+    assert ops.lib.wdg_set_tuning(b"dgrad_s3", 0) == 0
+    try:
+        assert ops.conv_dgrad_lnbwd_route(dy, pk, dx, g, y, 16, 16) == 1
+    finally:
+        ops.lib.wdg_set_tuning(b"dgrad_s3", 1)
+    dy2, pk2, dx2, y2, _, _ = make(2, 31, 64, 128, 64)
+    assert ops.conv_dgrad_lnbwd_route(dy2, pk2, dx2, g, y2, 0, 64) == 1
+
+
 @pytest.mark.parametrize("B,T,npix,C,par", [(4, 1, 4, 512, True), (3, 2, 9, 64, True), (2, 3, 1, 256, False), (32, 1, 4, 512, True)])
 def test_dense_head_backward_through_layernorm(B, T, npix, C, par, hip_ops, ref_ops):
     """wdg_dense_gap_bwd_ln: Dense(1) + GlobalAveragePooling backward (models.py:137-140) chained with the backward of the
