@@ -131,15 +131,32 @@ __global__ void __launch_bounds__(1024) wdg_dgrad_s3_finish_kernel(const float* 
     }
 }
 
+#ifndef WDG_S3_PAIR
+#define WDG_S3_PAIR 0                 // experiment (-DWDG_S3_PAIR=1): two tiles per workgroup of 8 waves, the waves of one role paired on a
+                                      // SIMD so that their weight requests meet in L1 — correct, and SLOWER: 513 us against 449
+                                      // (profiles/r06ae_dgrad_s3.txt)
+#endif
 template <bool PAR, int DBG = 0>
-__global__ void __launch_bounds__(256, 2) wdg_dgrad_s3_kernel(const WdgDgS3 p) {
+__global__ void __launch_bounds__(WDG_S3_PAIR ? 512 : 256, WDG_S3_PAIR ? 1 : 2) wdg_dgrad_s3_kernel(const WdgDgS3 p) {
 #if WDG_S3_PROF
     long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_last = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    extern __shared__ f32x4 lds[];
-    float* const red = reinterpret_cast<float*>(lds + PATCH_SLOTS);      // [4 waves][3][32], then the waves' norm-input buffers
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 15, lq = lane >> 4;
+    extern __shared__ f32x4 lds_all[];
+#if WDG_S3_PAIR
+    // two tiles per workgroup: waves w and w + 4 take the same role on the same SIMD and request the same weights within a step of
+    // each other — the second request meets the first in the CU's L1 (or its miss queue) instead of going to L2 again
+    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    f32x4* const lds = lds_all + sub * (PATCH_SLOTS + (4 * 3 * 32 + 4 * (64 * p.C + 128)) / 4);
+    const int t = threadIdx.x & 255;
+    const int tile2 = 2 * wdg_xcd_remap(blockIdx.x, gridDim.x) + sub;
+    const int tile = tile2 < p.ntiles ? tile2 : p.ntiles - 1;          // (an odd tile count: the last half repeats its neighbour's work, same values)
+#else
+    f32x4* const lds = lds_all;
+    const int t = threadIdx.x;
     const int tile = wdg_xcd_remap(blockIdx.x, gridDim.x);
+#endif
+    float* const red = reinterpret_cast<float*>(lds + PATCH_SLOTS);      // [4 waves][3][32], then the waves' norm-input buffers
+    const int lane = t & 63, wv = t >> 6, li = lane & 15, lq = lane >> 4;
     const int img = tile / p.tiles_img;
     const int trem = tile - img * p.tiles_img;
     const int ty = trem / p.tiles_w, tx = trem - ty * p.tiles_w;
@@ -155,7 +172,11 @@ __global__ void __launch_bounds__(256, 2) wdg_dgrad_s3_kernel(const WdgDgS3 p) {
 
     // Wave role, decorrelated over the workgroups that share a CU (their tile numbers differ by multiples of the CU count: a plain
     // (wave + tile) rotation hands one SIMD the same role — the same 13-tap share and the same epilogue times — from all of them)
+#if WDG_S3_PAIR
+    const int role = __builtin_amdgcn_readfirstlane((wv + __builtin_popcount((unsigned)tile2 >> 1)) & 3);    // (the same for both halves)
+#else
     const int role = __builtin_amdgcn_readfirstlane((wv + __builtin_popcount((unsigned)tile)) & 3);
+#endif
     // weights in fragment order: lane (li, lq) of A tile bt holds ci = 16 bt + li, co = 16 g + 4 lq .. + 3
     const f32x4* const wl = p.wS + lane;
     auto wtap_ptr = [&](int cls, int tt) -> const f32x4* {
@@ -495,20 +516,34 @@ int wdg_dgrad_s3_launch(const wdg_conv_plan* pl, const float* dy, const float* w
     size_t lds_bytes = (size_t)PATCH_SLOTS * 16 + 4 * 3 * 32 * 4 + 4 * (64 * (size_t)C + 128) * 4;
     if (g_dgrad_s3 >> 8) lds_bytes += (size_t)((g_dgrad_s3 >> 8) - 1) * 1024;
     else lds_bytes = std::max(lds_bytes, (size_t)54 * 1024);
+#if WDG_S3_PAIR
+    lds_bytes = 2 * ((size_t)PATCH_SLOTS * 16 + 4 * 3 * 32 * 4 + 4 * (64 * (size_t)C + 128) * 4);
+    const dim3 s3_grid((unsigned)((p.ntiles + 1) / 2)), s3_block(512);
+    {
+        static bool done = false;
+        if (!done) {
+            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_dgrad_s3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_dgrad_s3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            done = true;
+        }
+    }
+#else
+    const dim3 s3_grid((unsigned)p.ntiles), s3_block(256);
+#endif
     hipLaunchKernelGGL(wdg_dgrad_s3_pack_kernel, dim3(49 * 2 * 4 * 64 / 256), dim3(256), 0, stream, wD, p.ldB, reinterpret_cast<f32x4*>(ws));
 #ifdef WDG_S3_SKELETONS
     // measurement builds only (tools/ab_dgrad_s3_skeletons.sh): wdg_set_tuning("dgrad_s3", 1 + 2 * DBG) runs the input-gradient-only
     // kernel with parts removed — 1: no weight refills, 2: no dy fragment reads, 4: no epilogue, 8: no DMA of the norm's input
     const int dbg = (g_dgrad_s3 >> 1) & 127;
-#define WDG_S3_CASE(D) if (dbg == D) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<false, D>), dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }
+#define WDG_S3_CASE(D) if (dbg == D) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<false, D>), s3_grid, s3_block, lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }
     WDG_S3_CASE(1) WDG_S3_CASE(2) WDG_S3_CASE(4) WDG_S3_CASE(8) WDG_S3_CASE(12) WDG_S3_CASE(13) WDG_S3_CASE(15)
-    if (dbg == 16 && par) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<true, 16>), dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }   // 16: parameter sums without their final stores
-    if (dbg == 48 && par) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<true, 48>), dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }   // 48: ... and without the final reduction
+    if (dbg == 16 && par) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<true, 16>), s3_grid, s3_block, lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }   // 16: parameter sums without their final stores
+    if (dbg == 48 && par) { hipLaunchKernelGGL((wdg_dgrad_s3_kernel<true, 48>), s3_grid, s3_block, lds_bytes, stream, p); WDG_LAUNCH_CHECK(); return WDG_OK; }   // 48: ... and without the final reduction
 #endif
     if (par)
-        hipLaunchKernelGGL(wdg_dgrad_s3_kernel<true>, dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p);
+        hipLaunchKernelGGL(wdg_dgrad_s3_kernel<true>, s3_grid, s3_block, lds_bytes, stream, p);
     else
-        hipLaunchKernelGGL(wdg_dgrad_s3_kernel<false>, dim3((unsigned)p.ntiles), dim3(256), lds_bytes, stream, p);
+        hipLaunchKernelGGL(wdg_dgrad_s3_kernel<false>, s3_grid, s3_block, lds_bytes, stream, p);
     WDG_LAUNCH_CHECK();
     if (par) {
         hipLaunchKernelGGL(wdg_dgrad_s3_finish_kernel, dim3(3 * C), dim3(1024), 0, stream, p.par, p.ntiles, c0, C, dgamma, dbeta, dbias);
