@@ -184,7 +184,10 @@ __global__ void __launch_bounds__(WDG_S3_PAIR ? 512 : 256, WDG_S3_PAIR ? 1 : 2) 
         const int jy = tt / ntx, jx = tt - jy * ntx;
         return wl + ((ry + 3 * jy) * 7 + rx + 3 * jx) * 512;
     };
-#define WDG_S3_LOAD(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(dst) : "v"(ptr) : "memory")
+#ifndef WDG_S3_WPOL
+#define WDG_S3_WPOL ""                // cache-policy modifiers of the weight requests (experiment: " nt", " sc1", " sc0 sc1")
+#endif
+#define WDG_S3_LOAD(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF WDG_S3_WPOL : "=v"(dst) : "v"(ptr) : "memory")
     // the wave's first tap: requested here, in front of the patch fill, waited for behind the barrier
     f32x4 af[2][4];
     const unsigned role_cls = wdg_s3_role_classes(role);
