@@ -1714,6 +1714,7 @@ static int g_igemm_dma = 4;        // wdg_set_tuning("igemm_dma", mask): tiles t
 // bit 1: a 64 x 128 tile (a 128-channel row in one wave) where the plain launch would take 64 x 64 tiles — measured SLOWER on the 27 x 27 map
 // of the discriminator's third block (137 us against 101 + 15 us for the 64 x 64 launch + the standalone pass: matrix pipe busy 0.38 at
 // 1.4 workgroups per CU, profiles/r05k_pmc_summary.csv) and off
+static int g_igemm_pad_kb[4] = {0, 0, 0, 0};      // (see launch_variant) BN 32, 64, 80 / 160, 128
 static int g_dgrad_lnbwd = 1;
 static int g_ln_wave = 1;     // wdg_set_tuning("ln_wave", 0/1): the 128 x 64 tile's LayerNorm epilogue on 4 x 1 waves (in-wave reductions)
 static int g_igemm_kg2 = 1;   // wdg_set_tuning("igemm_kg2", 0/1): in-workgroup split of the reduction for the ConvLSTM step epilogue
@@ -1807,6 +1808,11 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
         g_igemm_dma = value;
         return WDG_OK;
     }
+    if (key && !strncmp(key, "igemm_pad", 9)) {
+        const int bn = atoi(key + 9);
+        g_igemm_pad_kb[bn == 32 ? 0 : bn == 64 ? 1 : bn == 128 ? 3 : 2] = value;
+        return WDG_OK;
+    }
     if (key && !strcmp(key, "dgrad_s3")) {
         wdg_dgrad_s3_set(value);        // 0: the 7 x 7 stride-3 32 -> 64 data gradient back on the implicit-GEMM route
         return WDG_OK;
@@ -1897,6 +1903,10 @@ extern "C" int wdg_set_tuning(const char* key, int value) {
     return WDG_ERR_ARG;
 }
 
+// wdg_set_tuning("igemm_pad<BN>", k): k KB added to the LDS request of the implicit-GEMM tiles with BN columns — fewer resident
+// workgroups per CU (measurement: the patch data-gradient kernel is faster with two per CU than with three)
+static int igemm_pad_slot(int bn) { return bn == 32 ? 0 : bn == 64 ? 1 : bn == 128 ? 3 : 2; }
+
 template <int BM, int BN, int WGM, int WGN, int PIPE, int EPI = 0, int KG = 1>
 static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm& p) {
     constexpr size_t lds = (size_t)((PIPE == 0 || PIPE == 3) ? KG : 2) * 8 * (BM + BN) * sizeof(f32x4);   // (PIPE 5: two stages)
@@ -1912,7 +1922,16 @@ static int launch_variant(dim3 grid, dim3 block, hipStream_t st, const WdgIgemm&
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI, KG>), grid, dim3(block.x * KG), lds, st, p);
+    const size_t pad = (size_t)g_igemm_pad_kb[igemm_pad_slot(BN)] * 1024;
+    if (pad) {
+        static bool attr_pad = false;
+        if (!attr_pad) {
+            WDG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI, KG>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_pad = true;
+        }
+    }
+    hipLaunchKernelGGL((wdg_igemm_kernel<BM, BN, WGM, WGN, PIPE, EPI, KG>), grid, dim3(block.x * KG), lds + pad, st, p);
     WDG_LAUNCH_CHECK();
     return WDG_OK;
 }
